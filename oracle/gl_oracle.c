@@ -1,0 +1,617 @@
+/*
+ * gl_oracle.c -- CPU oracle (TEST INFRASTRUCTURE, see gl_oracle.h).
+ *
+ * Plain-C restatement of the reference's JavaScript algorithms.  Nothing in
+ * pil2-stark-js_amd/ (the product) links or calls this file.
+ */
+#include "gl_oracle.h"
+#include "poseidon_gl_constants.h"
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef unsigned __int128 u128;
+#define GL_P 0xFFFFFFFF00000001ull
+
+static int g_threads = 1;
+void or_set_threads(int n) { g_threads = n < 1 ? 1 : n; }
+int  or_get_threads(void) { return g_threads; }
+
+/* ------------------------------------------------------------------ field
+ * src/helpers/f3g.js:47-104 (add/sub/mul are `% p` on BigInt there; the
+ * results are the canonical representatives, which is what these return). */
+uint64_t or_add(uint64_t a, uint64_t b) {
+    u128 s = (u128)a + b;
+    if (s >= GL_P) s -= GL_P;
+    return (uint64_t)s;
+}
+uint64_t or_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : GL_P - b + a; }  /* f3g.js:60-62 */
+static inline uint64_t neg1(uint64_t a) { return a ? GL_P - a : 0; }               /* f3g.js:73-79 */
+
+uint64_t or_mul(uint64_t a, uint64_t b) {
+    /* (a*b) % p, f3g.js:82-86, using 2^64 = 2^32-1 and 2^96 = -1 (mod p). */
+    u128 m = (u128)a * b;
+    uint64_t lo = (uint64_t)m, hi = (uint64_t)(m >> 64);
+    uint64_t hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
+    uint64_t t0 = lo - hh;
+    if (lo < hh) t0 -= 0xFFFFFFFFull;           /* borrow: add p (= subtract 2^32-1 mod 2^64) */
+    uint64_t t1 = hl * 0xFFFFFFFFull;
+    uint64_t t2 = t0 + t1;
+    if (t2 < t1) t2 += 0xFFFFFFFFull;           /* carry: 2^64 = 2^32-1 */
+    if (t2 >= GL_P) t2 -= GL_P;
+    return t2;
+}
+
+uint64_t or_exp(uint64_t base, uint64_t e) {    /* f3g.js:295-315 */
+    uint64_t r = 1;
+    while (e) { if (e & 1) r = or_mul(r, base); base = or_mul(base, base); e >>= 1; }
+    return r;
+}
+uint64_t or_inv(uint64_t a) { return or_exp(a, GL_P - 2); }   /* f3g.js:174-188 (same value as ext. Euclid) */
+
+/* roots of unity: f3g.js:40 + fft/fft.js:39-50: w[32] given, w[k] = w[k+1]^2 */
+static uint64_t g_w[33], g_wi[33];
+static int g_w_ready = 0;
+static void init_roots(void) {
+    if (g_w_ready) return;
+    g_w[32] = 7277203076849721926ull;
+    g_wi[32] = or_inv(g_w[32]);
+    for (int n = 31; n >= 0; n--) { g_w[n] = or_mul(g_w[n + 1], g_w[n + 1]); g_wi[n] = or_mul(g_wi[n + 1], g_wi[n + 1]); }
+    g_w_ready = 1;
+}
+uint64_t or_root(int bits) { init_roots(); return g_w[bits]; }
+uint64_t or_root_inv(int bits) { init_roots(); return g_wi[bits]; }
+
+/* cubic extension, x^3 = x + 1: f3g.js:94-102 */
+void or3_mul(const uint64_t a[3], const uint64_t b[3], uint64_t r[3]) {
+    uint64_t A = or_mul(or_add(a[0], a[1]), or_add(b[0], b[1]));
+    uint64_t B = or_mul(or_add(a[0], a[2]), or_add(b[0], b[2]));
+    uint64_t C = or_mul(or_add(a[1], a[2]), or_add(b[1], b[2]));
+    uint64_t D = or_mul(a[0], b[0]);
+    uint64_t E = or_mul(a[1], b[1]);
+    uint64_t F = or_mul(a[2], b[2]);
+    uint64_t G = or_sub(D, E);
+    uint64_t r0 = or_sub(or_add(C, G), F);
+    uint64_t r1 = or_sub(or_sub(or_sub(or_add(A, C), E), E), D);
+    uint64_t r2 = or_sub(B, G);
+    r[0] = r0; r[1] = r1; r[2] = r2;
+}
+static void add3(const uint64_t a[3], const uint64_t b[3], uint64_t r[3]) {
+    r[0] = or_add(a[0], b[0]); r[1] = or_add(a[1], b[1]); r[2] = or_add(a[2], b[2]);
+}
+/* f3g.js:136-172 */
+void or3_inv(const uint64_t a[3], uint64_t r[3]) {
+    uint64_t aa = or_mul(a[0], a[0]), ac = or_mul(a[0], a[2]), ba = or_mul(a[1], a[0]);
+    uint64_t bb = or_mul(a[1], a[1]), bc = or_mul(a[1], a[2]), cc = or_mul(a[2], a[2]);
+    uint64_t aaa = or_mul(aa, a[0]), aac = or_mul(aa, a[2]), abc = or_mul(ba, a[2]), abb = or_mul(ba, a[1]);
+    uint64_t acc = or_mul(ac, a[2]), bbb = or_mul(bb, a[1]), bcc = or_mul(bc, a[2]), ccc = or_mul(cc, a[2]);
+    /* t = -aaa -2aac +3abc + abb - acc - bbb + bcc - ccc */
+    uint64_t t = neg1(aaa);
+    t = or_sub(t, aac); t = or_sub(t, aac);
+    t = or_add(t, abc); t = or_add(t, abc); t = or_add(t, abc);
+    t = or_add(t, abb); t = or_sub(t, acc); t = or_sub(t, bbb); t = or_add(t, bcc); t = or_sub(t, ccc);
+    uint64_t tinv = or_inv(t);
+    /* i1 = (-aa -2ac + bc + bb - cc)*tinv ; i2 = (ba - cc)*tinv ; i3 = (-bb + ac + cc)*tinv */
+    uint64_t i1 = neg1(aa);
+    i1 = or_sub(i1, ac); i1 = or_sub(i1, ac); i1 = or_add(i1, bc); i1 = or_add(i1, bb); i1 = or_sub(i1, cc);
+    uint64_t i2 = or_sub(ba, cc);
+    uint64_t i3 = or_add(or_add(neg1(bb), ac), cc);
+    r[0] = or_mul(i1, tinv); r[1] = or_mul(i2, tinv); r[2] = or_mul(i3, tinv);
+}
+
+/* f3g.js:370-385 */
+void or_batch_inverse(const uint64_t *a, uint64_t n, uint64_t *r) {
+    if (!n) return;
+    uint64_t *tmp = (uint64_t *)malloc(n * 8);
+    tmp[0] = a[0];
+    for (uint64_t i = 1; i < n; i++) tmp[i] = or_mul(tmp[i - 1], a[i]);
+    uint64_t z = or_inv(tmp[n - 1]);
+    for (uint64_t i = n - 1; i > 0; i--) { r[i] = or_mul(z, tmp[i - 1]); z = or_mul(z, a[i]); }
+    r[0] = z;
+    free(tmp);
+}
+void or3_batch_inverse(const uint64_t *a, uint64_t n, uint64_t *r) {
+    if (!n) return;
+    uint64_t *tmp = (uint64_t *)malloc(n * 24);
+    memcpy(tmp, a, 24);
+    for (uint64_t i = 1; i < n; i++) or3_mul(tmp + 3 * (i - 1), a + 3 * i, tmp + 3 * i);
+    uint64_t z[3];
+    or3_inv(tmp + 3 * (n - 1), z);
+    for (uint64_t i = n - 1; i > 0; i--) {
+        uint64_t ai[3] = { a[3 * i], a[3 * i + 1], a[3 * i + 2] };   /* r may alias a */
+        or3_mul(z, tmp + 3 * (i - 1), r + 3 * i);
+        or3_mul(z, ai, z);
+    }
+    r[0] = z[0]; r[1] = z[1]; r[2] = z[2];
+    free(tmp);
+}
+
+/* ------------------------------------------------------------------ scalar NTT
+ * src/helpers/fft/fft.js:118-163: bit-reverse copy, then DIT stages s=1..bits
+ * with twiddle w = winc^j, winc = w[s].  (The twiddles are read from a table
+ * of w[nBits]^j instead of a running product; same field values.) */
+static uint32_t bitrev(uint32_t x, int bits) {
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    x = (x >> 16) | (x << 16);
+    return bits ? x >> (32 - bits) : 0;
+}
+
+static void fft_core(uint64_t *buf, int nBits, const uint64_t *tw /* w[nBits]^j, j<n/2 */) {
+    uint64_t n = 1ull << nBits;
+    for (int s = 1; s <= nBits; s++) {
+        uint64_t m = 1ull << s, md2 = m >> 1, tstep = n >> s;
+        for (uint64_t k = 0; k < n; k += m) {
+            for (uint64_t j = 0; j < md2; j++) {
+                uint64_t t = or_mul(tw[j * tstep], buf[k + j + md2]);
+                uint64_t u = buf[k + j];
+                buf[k + j] = or_add(u, t);
+                buf[k + j + md2] = or_sub(u, t);
+            }
+        }
+    }
+}
+
+static uint64_t *make_twiddles(int nBits) {
+    uint64_t h = nBits ? (1ull << (nBits - 1)) : 1;
+    uint64_t *tw = (uint64_t *)malloc(h * 8);
+    uint64_t w = or_root(nBits), r = 1;
+    for (uint64_t j = 0; j < h; j++) { tw[j] = r; r = or_mul(r, w); }
+    return tw;
+}
+
+static void fft_tw(uint64_t *p, int nBits, uint64_t stride, const uint64_t *tw, uint64_t *buf) {
+    uint64_t n = 1ull << nBits;
+    for (uint64_t i = 0; i < n; i++) buf[bitrev((uint32_t)i, nBits)] = p[i * stride];
+    fft_core(buf, nBits, tw);
+    for (uint64_t i = 0; i < n; i++) p[i * stride] = buf[i];
+}
+static void ifft_tw(uint64_t *p, int nBits, uint64_t stride, const uint64_t *tw, uint64_t *buf) {
+    /* fft.js:165-174: q = fft(p); res[(n-i)%n] = q[i]/n */
+    uint64_t n = 1ull << nBits;
+    for (uint64_t i = 0; i < n; i++) buf[bitrev((uint32_t)i, nBits)] = p[i * stride];
+    fft_core(buf, nBits, tw);
+    uint64_t ninv = or_inv(n % GL_P);
+    for (uint64_t i = 0; i < n; i++) p[((n - i) % n) * stride] = or_mul(buf[i], ninv);
+}
+
+void or_fft(uint64_t *p, int nBits, uint64_t stride) {
+    if (nBits == 0) return;                     /* fft.js:119 */
+    uint64_t *tw = make_twiddles(nBits), *buf = (uint64_t *)malloc(8ull << nBits);
+    fft_tw(p, nBits, stride, tw, buf);
+    free(tw); free(buf);
+}
+void or_ifft(uint64_t *p, int nBits, uint64_t stride) {
+    if (nBits == 0) return;                     /* fft(p) returns p for length<=1; /n with n=1 is identity */
+    uint64_t *tw = make_twiddles(nBits), *buf = (uint64_t *)malloc(8ull << nBits);
+    ifft_tw(p, nBits, stride, tw, buf);
+    free(tw); free(buf);
+}
+
+/* src/helpers/polutils.js:18-30 (shift = true) */
+void or_extend_pol(const uint64_t *p, int nBits, int extBits, uint64_t *out) {
+    uint64_t n = 1ull << nBits, en = n << extBits;
+    memcpy(out, p, n * 8);
+    or_ifft(out, nBits, 1);
+    uint64_t r = 1;
+    for (uint64_t i = 0; i < n; i++) { out[i] = or_mul(out[i], r); r = or_mul(r, 7); }   /* polMulAxi, polutils.js:1-7 */
+    for (uint64_t i = n; i < en; i++) out[i] = 0;
+    or_fft(out, nBits + extBits, 1);
+}
+
+/* ------------------------------------------------------------------ multi-column operators
+ * src/helpers/fft/fft_p.js:178-302.  The reference tiles these over worker
+ * threads; its own tests (test/fft_p.test.js:47-229) define the result as the
+ * per-column F.fft / F.ifft / extendPol, which is what is computed here. */
+typedef void (*col_fn)(uint64_t *, int, uint64_t, const uint64_t *, uint64_t *);
+static void cols_apply(const uint64_t *src, uint64_t nPols, int nBits, uint64_t *dst, col_fn fn) {
+    uint64_t n = 1ull << nBits;
+    if (dst != src) memcpy(dst, src, n * nPols * 8);
+    if (nBits == 0) return;
+    uint64_t *tw = make_twiddles(nBits);
+#pragma omp parallel num_threads(g_threads)
+    {
+        uint64_t *buf = (uint64_t *)malloc(n * 8);
+#pragma omp for schedule(dynamic, 1)
+        for (uint64_t c = 0; c < nPols; c++) fn(dst + c, nBits, nPols, tw, buf);
+        free(buf);
+    }
+    free(tw);
+}
+void or_fft_cols(const uint64_t *src, uint64_t nPols, int nBits, uint64_t *dst) { cols_apply(src, nPols, nBits, dst, fft_tw); }
+void or_ifft_cols(const uint64_t *src, uint64_t nPols, int nBits, uint64_t *dst) { cols_apply(src, nPols, nBits, dst, ifft_tw); }
+
+void or_interpolate(const uint64_t *src, uint64_t nPols, int nBits, uint64_t *dst, int nBitsExt) {
+    /* fft_p.js:187-297 == per column extendPol (test/fft_p.test.js:82-118) */
+    uint64_t n = 1ull << nBits, en = 1ull << nBitsExt;
+    uint64_t *tw = make_twiddles(nBits), *twe = make_twiddles(nBitsExt);
+    uint64_t ninv = or_inv(n % GL_P);
+#pragma omp parallel num_threads(g_threads)
+    {
+        uint64_t *col = (uint64_t *)malloc(en * 8), *buf = (uint64_t *)malloc(en * 8);
+#pragma omp for schedule(dynamic, 1)
+        for (uint64_t c = 0; c < nPols; c++) {
+            for (uint64_t i = 0; i < n; i++) col[i] = src[i * nPols + c];
+            if (nBits) ifft_tw(col, nBits, 1, tw, buf);
+            (void)ninv;
+            uint64_t r = 1;
+            for (uint64_t i = 0; i < n; i++) { col[i] = or_mul(col[i], r); r = or_mul(r, 7); }
+            for (uint64_t i = n; i < en; i++) col[i] = 0;
+            if (nBitsExt) fft_tw(col, nBitsExt, 1, twe, buf);
+            for (uint64_t i = 0; i < en; i++) dst[i * nPols + c] = col[i];
+        }
+        free(col); free(buf);
+    }
+    free(tw); free(twe);
+}
+
+/* ------------------------------------------------------------------ Poseidon-12
+ * Un-optimised 30-round form, src/helpers/glwasm.js:216-426: per round add the
+ * 12 round constants (:535-627), x^7 on all lanes for rounds 0-3 and 26-29 and
+ * on lane 0 otherwise (:377-384, :695-757), then the MDS matrix
+ * circ(17,15,41,16,2,28,13,13,39,18,34,20)+diag(8,0..) (:428-440).
+ * Equal, mod p, to the optimised form in hash/poseidon/poseidon.js:57-108
+ * (checked by the KATs and random vectors in tests/golden/poseidon.json). */
+static const uint64_t MCIRC[12] = { 17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20 };
+static inline uint64_t reduce128(u128 x) {
+    uint64_t lo = (uint64_t)x, hi = (uint64_t)(x >> 64);
+    uint64_t hh = hi >> 32, hl = hi & 0xFFFFFFFFull;
+    uint64_t t0 = lo - hh;
+    if (lo < hh) t0 -= 0xFFFFFFFFull;
+    uint64_t t1 = hl * 0xFFFFFFFFull;
+    uint64_t t2 = t0 + t1;
+    if (t2 < t1) t2 += 0xFFFFFFFFull;
+    if (t2 >= GL_P) t2 -= GL_P;
+    return t2;
+}
+static inline uint64_t pow7(uint64_t a) {
+    uint64_t a2 = or_mul(a, a), a3 = or_mul(a2, a), a4 = or_mul(a2, a2);
+    return or_mul(a3, a4);
+}
+static void poseidon_perm(uint64_t st[12]) {
+    for (int r = 0; r < 30; r++) {
+        for (int i = 0; i < 12; i++) st[i] = or_add(st[i], ORACLE_POSEIDON_C[r * 12 + i]);
+        if (r < 4 || r >= 26) { for (int i = 0; i < 12; i++) st[i] = pow7(st[i]); }
+        else st[0] = pow7(st[0]);
+        uint64_t o[12];
+        for (int i = 0; i < 12; i++) {
+            u128 acc = 0;
+            for (int j = 0; j < 12; j++) acc += (u128)st[j] * MCIRC[(j - i + 12) % 12];
+            if (i == 0) acc += (u128)st[0] * 8;
+            o[i] = reduce128(acc);
+        }
+        memcpy(st, o, sizeof o);
+    }
+}
+void or_poseidon(const uint64_t in[8], const uint64_t cap[4], uint64_t *out, int nOut) {
+    uint64_t st[12];
+    for (int i = 0; i < 8; i++) st[i] = in[i] % GL_P;      /* F.e(): poseidon.js:65-67 */
+    for (int i = 0; i < 4; i++) st[8 + i] = cap ? cap[i] % GL_P : 0;
+    poseidon_perm(st);
+    for (int i = 0; i < nOut; i++) out[i] = st[i];
+}
+
+/* src/helpers/hash/linearhash/linearhash.js:22-41 */
+static void linear_hash_plain(const uint64_t *v, uint64_t width, uint64_t out[4]) {
+    uint64_t st[4] = { 0, 0, 0, 0 };
+    if (width <= 4) { for (uint64_t i = 0; i < width; i++) st[i] = v[i]; memcpy(out, st, 32); return; }
+    for (uint64_t i = 0; i < width; i += 8) {
+        uint64_t in[8] = { 0 };
+        uint64_t n = width - i < 8 ? width - i : 8;
+        memcpy(in, v + i, n * 8);
+        or_poseidon(in, st, st, 4);
+    }
+    memcpy(out, st, 32);
+}
+/* src/helpers/hash/linearhash/linearhash_gpu.js:30-66 ("splitLinearHash"; glwasm.js:879-1087) */
+static void linear_hash_split(const uint64_t *v, uint64_t width, uint64_t out[4]) {
+    if (width <= 4) { linear_hash_plain(v, width, out); return; }
+    uint64_t batch = (width + 3) / 4; if (batch < 8) batch = 8;
+    uint64_t hashes[16 * 4]; uint64_t nh = 0;
+    for (uint64_t b = 0; b < width; b += batch) {
+        uint64_t size = width - b < batch ? width - b : batch;
+        linear_hash_plain(v + b, size, hashes + nh); nh += 4;
+    }
+    if (nh <= 4) { memcpy(out, hashes, 32); return; }
+    linear_hash_plain(hashes, nh, out);
+}
+void or_linear_hash(const uint64_t *vals, uint64_t width, int split, uint64_t out[4]) {
+    if (split) linear_hash_split(vals, width, out); else linear_hash_plain(vals, width, out);
+}
+
+/* merklehash_p.js:28-42 (_getNNodes(height*4)) */
+uint64_t or_merkle_num_nodes(uint64_t height) {
+    uint64_t n = height * 4;
+    uint64_t nextN = ((n - 1) / 8 + 1) * 4;
+    uint64_t acc = nextN * 2;
+    while (n > 4) {
+        n = nextN;
+        nextN = ((n - 1) / 8 + 1) * 4;
+        if (n > 4) acc += nextN * 2; else acc += 4;
+    }
+    return acc;
+}
+/* merklehash_p.js:44-133; worker merklehash_worker.js:37-117 */
+void or_merkelize(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes) {
+    memset(nodes, 0, or_merkle_num_nodes(height) * 8);
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+    for (uint64_t i = 0; i < height; i++) or_linear_hash(elems + i * width, width, split, nodes + 4 * i);
+    uint64_t pIn = 0, n64 = height * 4;
+    uint64_t nextN64 = ((n64 - 1) / 8 + 1) * 4;
+    uint64_t pOut = pIn + nextN64 * 2;
+    while (n64 > 4) {
+        uint64_t nOps = nextN64 / 4;
+#pragma omp parallel for num_threads(g_threads) schedule(static)
+        for (uint64_t i = 0; i < nOps; i++) or_poseidon(nodes + pIn + 8 * i, NULL, nodes + pOut + 4 * i, 4);
+        n64 = nextN64;
+        nextN64 = ((n64 - 1) / 8 + 1) * 4;
+        pIn = pOut;
+        pOut = pIn + nextN64 * 2;
+    }
+}
+/* merklehash_p.js:142-168 */
+int or_group_proof(const uint64_t *nodes, uint64_t height, uint64_t idx, uint64_t *siblings) {
+    uint64_t offset = 0, n = height * 4; int lvl = 0;
+    while (n > 4) {
+        uint64_t si = (idx ^ 1) * 4;
+        memcpy(siblings + 4 * lvl, nodes + offset + si, 32);
+        uint64_t nextN = ((n - 1) / 8 + 1) * 4;
+        offset += nextN * 2; n = nextN; idx >>= 1; lvl++;
+    }
+    return lvl;
+}
+/* merklehash_p.js:170-210 */
+void or_root_from_proof(const uint64_t *vals, uint64_t width, int split, uint64_t idx,
+                        const uint64_t *siblings, int nLevels, uint64_t root[4]) {
+    uint64_t v[4];
+    or_linear_hash(vals, width, split, v);
+    for (int l = 0; l < nLevels; l++) {
+        uint64_t in[8];
+        if ((idx & 1) == 0) { memcpy(in, v, 32); memcpy(in + 4, siblings + 4 * l, 32); }
+        else { memcpy(in, siblings + 4 * l, 32); memcpy(in + 4, v, 32); }
+        or_poseidon(in, NULL, v, 4);
+        idx >>= 1;
+    }
+    memcpy(root, v, 32);
+}
+
+/* ------------------------------------------------------------------ transcript
+ * src/helpers/transcript/transcript.js:2-85 */
+void or_transcript_init(or_transcript *t) { memset(t, 0, sizeof *t); }
+static void tr_update(or_transcript *t) {                 /* :40-47 */
+    while (t->nPending < 8) t->pending[t->nPending++] = 0;
+    or_poseidon(t->pending, t->state, t->out, 12);
+    t->nOut = 12; t->outPos = 0; t->nPending = 0;
+    memcpy(t->state, t->out, 32);
+}
+void or_transcript_put(or_transcript *t, const uint64_t *a, uint64_t n) {   /* :30-38, :49-57 */
+    for (uint64_t i = 0; i < n; i++) {
+        t->nOut = 0; t->outPos = 0;
+        t->pending[t->nPending++] = a[i];
+        if (t->nPending == 8) {
+            or_poseidon(t->pending, t->state, t->out, 12);
+            t->nOut = 12; t->outPos = 0; t->nPending = 0;
+            memcpy(t->state, t->out, 32);
+        }
+    }
+}
+uint64_t or_transcript_get1(or_transcript *t) {            /* :22-28 */
+    if (t->outPos >= t->nOut) tr_update(t);
+    return t->out[t->outPos++];
+}
+void or_transcript_get_field(or_transcript *t, uint64_t r[3]) { for (int i = 0; i < 3; i++) r[i] = or_transcript_get1(t); }
+void or_transcript_get_state(or_transcript *t, uint64_t r[4]) { if (t->nPending > 0) tr_update(t); memcpy(r, t->state, 32); }
+void or_transcript_get_permutations(or_transcript *t, int n, int nBits, uint64_t *res) {   /* :59-84 */
+    int totalBits = n * nBits;
+    int nFields = (totalBits - 1) / 63 + 1;
+    uint64_t *fields = (uint64_t *)malloc(8 * (size_t)nFields);
+    for (int i = 0; i < nFields; i++) fields[i] = or_transcript_get1(t);
+    int curField = 0, curBit = 0;
+    for (int i = 0; i < n; i++) {
+        uint64_t a = 0;
+        for (int j = 0; j < nBits; j++) {
+            if ((fields[curField] >> curBit) & 1) a += 1ull << j;
+            if (++curBit == 63) { curBit = 0; curField++; }
+        }
+        res[i] = a;
+    }
+    free(fields);
+}
+
+/* ------------------------------------------------------------------ FRI
+ * src/stark/fri.js:22-81.  F.ifft on extension elements is component-wise
+ * because the twiddles are base-field (f3g.js:87-90). */
+uint64_t or_fri_shift_inv(int bits0, int bitsPrev) {       /* fri.js:31-36 */
+    uint64_t s = or_inv(7);
+    if (bitsPrev >= 0) for (int j = 0; j < bits0 - bitsPrev; j++) s = or_mul(s, s);
+    return s;
+}
+void or_fri_fold(const uint64_t *pol, int polBits, int outBits, uint64_t shiftInv,
+                 const uint64_t challenge[3], uint64_t *out) {
+    uint64_t pol2N = 1ull << outBits, nX = (1ull << polBits) >> outBits;
+    int xBits = polBits - outBits;
+    uint64_t wi = or_inv(or_root(polBits));
+    uint64_t *sinvs = (uint64_t *)malloc(pol2N * 8);
+    { uint64_t s = shiftInv; for (uint64_t g = 0; g < pol2N; g++) { sinvs[g] = s; s = or_mul(s, wi); } }   /* fri.js:45,60 */
+#pragma omp parallel num_threads(g_threads)
+    {
+        uint64_t *ppar = (uint64_t *)malloc(nX * 24);
+#pragma omp for schedule(static)
+        for (uint64_t g = 0; g < pol2N; g++) {
+            for (uint64_t i = 0; i < nX; i++) memcpy(ppar + 3 * i, pol + 3 * (i * pol2N + g), 24);   /* :51-54 */
+            for (int c = 0; c < 3; c++) or_ifft(ppar + c, xBits, 3);                                  /* :55 */
+            uint64_t r = 1;                                                                          /* :56 polMulAxi */
+            for (uint64_t i = 0; i < nX; i++) {
+                for (int c = 0; c < 3; c++) ppar[3 * i + c] = or_mul(ppar[3 * i + c], r);
+                r = or_mul(r, sinvs[g]);
+            }
+            uint64_t res[3] = { ppar[3 * (nX - 1)], ppar[3 * (nX - 1) + 1], ppar[3 * (nX - 1) + 2] };   /* :58 evalPol, polutils.js:9-16 */
+            for (uint64_t i = nX - 1; i-- > 0;) { or3_mul(res, challenge, res); add3(res, ppar + 3 * i, res); }
+            memcpy(out + 3 * g, res, 24);
+        }
+        free(ppar);
+    }
+    free(sinvs);
+}
+/* fri.js:187-202 getTransposedBuffer */
+void or_fri_transpose(const uint64_t *pol, int polBits, int transposeBits, uint64_t *out) {
+    uint64_t n = 1ull << polBits, w = 1ull << transposeBits, h = n / w;
+    for (uint64_t i = 0; i < w; i++)
+        for (uint64_t j = 0; j < h; j++) memcpy(out + (i * h + j) * 3, pol + (j * w + i) * 3, 24);
+}
+
+/* ------------------------------------------------------------------ STARK step helpers */
+void or_build_x(int nBits, uint64_t shift, uint64_t *x) {  /* stark_gen_helpers.js:111-116 (shift=1), :139-144 (shift=7) */
+    uint64_t v = shift, w = or_root(nBits);
+    for (uint64_t i = 0; i < (1ull << nBits); i++) { x[i] = v; v = or_mul(v, w); }
+}
+void or_build_zhinv(int nBits, int nBitsExt, uint64_t *out) {   /* polutils.js:39-55, stark=true */
+    int eb = nBitsExt - nBits; uint64_t extN = 1ull << nBitsExt, ext = 1ull << eb;
+    uint64_t w = 1, sn = 7;
+    for (int i = 0; i < nBits; i++) sn = or_mul(sn, sn);
+    for (uint64_t i = 0; i < ext; i++) { out[i] = or_inv(or_sub(or_mul(sn, w), 1)); w = or_mul(w, or_root(eb)); }
+    for (uint64_t i = ext; i < extN; i++) out[i] = out[i % ext];
+}
+void or_build_one_row_zerofier_inv(int nBits, int nBitsExt, uint64_t rowIndex, uint64_t *out) {   /* polutils.js:57-71 */
+    uint64_t extN = 1ull << nBitsExt;
+    uint64_t *zh = (uint64_t *)malloc(extN * 8);
+    or_build_zhinv(nBits, nBitsExt, zh);
+    uint64_t root = or_exp(or_root(nBits), rowIndex), w = 1;
+    for (uint64_t i = 0; i < extN; i++) {
+        uint64_t x = or_mul(7, w);
+        out[i] = or_mul(or_sub(x, root), zh[i]);
+        w = or_mul(w, or_root(nBitsExt));
+    }
+    or_batch_inverse(out, extN, zh);           /* element-wise F.inv in the reference; same values */
+    memcpy(out, zh, extN * 8);
+    free(zh);
+}
+void or_build_frame_zerofier(int nBits, int nBitsExt, uint64_t offMin, uint64_t offMax, uint64_t *out) {   /* polutils.js:74-102 */
+    uint64_t extN = 1ull << nBitsExt, N = 1ull << nBits, nr = offMin + offMax;
+    uint64_t *roots = (uint64_t *)malloc((nr ? nr : 1) * 8);
+    for (uint64_t i = 0; i < offMin; i++) roots[i] = or_exp(or_root(nBits), i);
+    for (uint64_t i = 0; i < offMax; i++) roots[offMin + i] = or_exp(or_root(nBits), N - i - 1);
+    uint64_t w = 1;
+    for (uint64_t i = 0; i < extN; i++) {
+        uint64_t zi = 1, x = or_mul(7, w);
+        for (uint64_t j = 0; j < nr; j++) zi = or_mul(zi, or_sub(x, roots[j]));
+        out[i] = zi;
+        w = or_mul(w, or_root(nBitsExt));
+    }
+    free(roots);
+}
+void or_compute_q_split(const uint64_t *qq1, int nBits, int nBitsExt, int qDim, int qDeg, uint64_t *qq2) {   /* stark_gen_helpers.js:179-190 */
+    uint64_t N = 1ull << nBits, extN = 1ull << nBitsExt;
+    memset(qq2, 0, extN * (uint64_t)qDim * qDeg * 8);
+    uint64_t shiftIn = or_exp(or_inv(7), N), curS = 1;
+    for (int p = 0; p < qDeg; p++) {
+        for (uint64_t i = 0; i < N; i++)
+            for (int k = 0; k < qDim; k++)
+                qq2[i * qDim * qDeg + (uint64_t)qDim * p + k] = or_mul(qq1[(uint64_t)p * N * qDim + i * qDim + k], curS);
+        curS = or_mul(curS, shiftIn);
+    }
+}
+void or_x_div_x_sub_xi(int nBitsExt, const uint64_t xi[3], uint64_t nOpen, uint64_t iOpen, uint64_t *out) {   /* stark_gen_helpers.js:302-322 */
+    uint64_t extN = 1ull << nBitsExt;
+    uint64_t *den = (uint64_t *)malloc(extN * 24);
+    uint64_t x = 7, w = or_root(nBitsExt);
+    for (uint64_t k = 0; k < extN; k++) {       /* F.sub(scalar, triple): f3g.js:66 */
+        den[3 * k] = or_sub(x, xi[0]); den[3 * k + 1] = neg1(xi[1]); den[3 * k + 2] = neg1(xi[2]);
+        x = or_mul(x, w);
+    }
+    or3_batch_inverse(den, extN, den);
+    x = 7;
+    for (uint64_t k = 0; k < extN; k++) {
+        for (int c = 0; c < 3; c++) out[3 * (k * nOpen + iOpen) + c] = or_mul(den[3 * k + c], x);
+        x = or_mul(x, w);
+    }
+    free(den);
+}
+void or_lev(int nBits, const uint64_t xi[3], uint64_t *lev) {   /* stark_gen_helpers.js:216-231; xi = challenge*w^opening/shift */
+    uint64_t N = 1ull << nBits;
+    lev[0] = 1; lev[1] = 0; lev[2] = 0;
+    for (uint64_t k = 1; k < N; k++) or3_mul(lev + 3 * (k - 1), xi, lev + 3 * k);
+    for (int c = 0; c < 3; c++) or_ifft(lev + c, nBits, 3);
+}
+void or_eval_pol_at(const uint64_t *buf, uint64_t size, uint64_t offset, int dim, int nBits, int extendBits,
+                    const uint64_t *lev, uint64_t r[3]) {       /* stark_gen_helpers.js:250-264 */
+    uint64_t N = 1ull << nBits, acc[3] = { 0, 0, 0 };
+    for (uint64_t k = 0; k < N; k++) {
+        const uint64_t *v = buf + (k << extendBits) * size + offset;
+        uint64_t t[3];
+        if (dim == 1) { for (int c = 0; c < 3; c++) t[c] = or_mul(v[0], lev[3 * k + c]); }
+        else or3_mul(v, lev + 3 * k, t);
+        add3(acc, t, acc);
+    }
+    memcpy(r, acc, 24);
+}
+
+/* ------------------------------------------------------------------ expression evaluator
+ * src/prover/prover_helpers.js:31-45 (row loop), :83-107 (ops), :109-259 (operands);
+ * mixed-dimension arithmetic: src/helpers/f3g.js:47-104. */
+static void glx_load(const glx_ref *r, const glx_ctx *ctx, uint64_t i, const uint64_t *tmp, uint64_t v[3]) {
+    const uint64_t *p;
+    if (r->kind == GLX_TMP) p = tmp + 3ull * r->index;
+    else if (r->kind == GLX_SCALAR) p = ctx->scalars + r->index;
+    else {
+        const glx_section *s = &ctx->sections[r->section];
+        uint64_t mask = (1ull << ctx->nBits) - 1;
+        uint64_t row = (i + (uint64_t)((int64_t)r->prime * (int64_t)(1ll << ctx->primeShift))) & mask;   /* evalMap: (i+next)%N */
+        p = s->ptr + row * s->width + r->index;
+    }
+    v[0] = p[0];
+    if (r->dim == 3) { v[1] = p[1]; v[2] = p[2]; } else { v[1] = 0; v[2] = 0; }
+}
+int or_eval_program(const glx_program *prog, const glx_ctx *ctx, uint64_t rowBegin, uint64_t rowEnd) {
+    int bad = 0;
+#pragma omp parallel num_threads(g_threads)
+    {
+        uint64_t *tmp = (uint64_t *)calloc(3ull * (prog->nTmp ? prog->nTmp : 1), 8);
+#pragma omp for schedule(static)
+        for (uint64_t i = rowBegin; i < rowEnd; i++) {
+            for (uint32_t k = 0; k < prog->nOps; k++) {
+                const glx_op *op = &prog->ops[k];
+                uint64_t a[3], b[3] = { 0, 0, 0 }, r[3];
+                int da = op->src[0].dim, db = 1;
+                glx_load(&op->src[0], ctx, i, tmp, a);
+                if (op->op != GLX_OP_COPY) { glx_load(&op->src[1], ctx, i, tmp, b); db = op->src[1].dim; }
+                switch (op->op) {
+                case GLX_OP_ADD:    /* f3g.js:47-58: scalar+triple touches component 0 only */
+                    r[0] = or_add(a[0], b[0]);
+                    if (da == 3 && db == 3) { r[1] = or_add(a[1], b[1]); r[2] = or_add(a[2], b[2]); }
+                    else if (da == 3) { r[1] = a[1]; r[2] = a[2]; } else { r[1] = b[1]; r[2] = b[2]; }
+                    break;
+                case GLX_OP_SUB:    /* f3g.js:60-71 */
+                    r[0] = or_sub(a[0], b[0]);
+                    if (da == 3 && db == 3) { r[1] = or_sub(a[1], b[1]); r[2] = or_sub(a[2], b[2]); }
+                    else if (da == 3) { r[1] = a[1]; r[2] = a[2]; } else { r[1] = neg1(b[1]); r[2] = neg1(b[2]); }
+                    break;
+                case GLX_OP_MUL:    /* f3g.js:82-103 */
+                    if (da == 3 && db == 3) or3_mul(a, b, r);
+                    else if (da == 3) { r[0] = or_mul(a[0], b[0]); r[1] = or_mul(a[1], b[0]); r[2] = or_mul(a[2], b[0]); }
+                    else { r[0] = or_mul(a[0], b[0]); r[1] = or_mul(a[0], b[1]); r[2] = or_mul(a[0], b[2]); }
+                    break;
+                case GLX_OP_COPY: r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; break;
+                default: bad = 1; r[0] = r[1] = r[2] = 0;
+                }
+                const glx_ref *d = &op->dest;
+                uint64_t *q;
+                if (d->kind == GLX_TMP) q = tmp + 3ull * d->index;
+                else if (d->kind == GLX_SEC) {
+                    const glx_section *s = &ctx->sections[d->section];
+                    uint64_t mask = (1ull << ctx->nBits) - 1;
+                    uint64_t row = (i + (uint64_t)((int64_t)d->prime * (int64_t)(1ll << ctx->primeShift))) & mask;
+                    q = s->ptr + row * s->width + d->index;
+                } else { bad = 1; continue; }
+                q[0] = r[0];
+                if (d->dim == 3) { q[1] = r[1]; q[2] = r[2]; }
+            }
+        }
+        free(tmp);
+    }
+    return bad ? -1 : 0;
+}

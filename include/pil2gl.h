@@ -1,0 +1,144 @@
+/*
+ * pil2gl.h -- C ABI of the MI355X (gfx950) STARK proving hot path for pil2-stark-js.
+ *
+ * One shared library (pil2-stark-js_amd/lib/libpil2gl.so), plain pointers and
+ * sizes, no C++/torch types.  Each entry point replaces one JavaScript-level
+ * operator of the reference (cited per function, paths relative to the
+ * reference checkout); the Node.js addon (pil2-stark-js_amd/addon) and the
+ * Python ctypes binding (pil2-stark-js_amd/python/pil2gl) are thin wrappers
+ * over exactly these symbols.  INTEGRATION.md shows the reference-side binding.
+ *
+ * Conventions
+ *  - Field elements are canonical little-endian u64 in [0,p), p = 2^64-2^32+1.
+ *    Outputs are always canonical.  (The reference's WASM kernel may leave a
+ *    digest word in [p,2^64), equal mod p -- src/helpers/glwasm.js:196-210;
+ *    its JS twin src/helpers/hash/poseidon/poseidon.js is canonical, and so is this library.)
+ *  - Matrices are row-major: element (row r, col c) at r*nCols + c
+ *    (src/witness/witnessCalculator.js:113-141, src/helpers/fft/fft_worker.js:53-56).
+ *  - Extension-field elements are 3 consecutive u64 (src/helpers/f3g.js:5-9).
+ *  - Functions without suffix take HOST pointers (copy in, compute on the GPU,
+ *    copy out): drop-in for the reference's BigUint64Array/BigBuffer calls.
+ *    Functions with suffix _dev take DEVICE pointers (hipMalloc / pil2gl_dev_alloc /
+ *    torch tensor.data_ptr()) plus a hipStream_t passed as void* (NULL = default
+ *    stream); they enqueue work and do not synchronise, so buffers can stay
+ *    resident in HBM across the prover's steps.
+ *  - Every function returns 0 on success, a negative PIL2GL_E* code otherwise;
+ *    pil2gl_last_error() describes the failure (the reference throws Error /
+ *    rejects the Promise; the addon converts the code back into a JS exception).
+ *  - The library has no CPU fallback: without a HIP device every compute entry
+ *    point fails with PIL2GL_ENODEV.
+ *  - Calls are not thread-safe against each other (the reference issues them
+ *    sequentially from one JS thread: src/prover/prover.js, `await` on every step).
+ */
+#pragma once
+#include <stdint.h>
+#include "pil2gl_expr.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PIL2GL_OK        0
+#define PIL2GL_EINVAL   -1      /* bad argument (the reference would throw / assert) */
+#define PIL2GL_ENODEV   -2      /* no usable HIP device */
+#define PIL2GL_ENOMEM   -3      /* device or host allocation failed */
+#define PIL2GL_EHIP     -4      /* a HIP runtime call failed */
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int         pil2gl_init(int device);            /* select device, upload tables; idempotent */
+void        pil2gl_shutdown(void);
+const char *pil2gl_last_error(void);
+int         pil2gl_version(void);
+int         pil2gl_device_info(char *name, uint32_t nameLen, uint32_t *numCUs, uint64_t *totalMem);
+
+/* ---- device buffers (for hosts without their own HIP allocator, e.g. Node) ---- */
+int pil2gl_dev_alloc(uint64_t nWords, uint64_t **out);
+int pil2gl_dev_free(uint64_t *p);
+int pil2gl_dev_zero(uint64_t *p, uint64_t nWords, void *stream);
+int pil2gl_dev_upload(uint64_t *dst, const uint64_t *hostSrc, uint64_t nWords);
+int pil2gl_dev_download(uint64_t *hostDst, const uint64_t *src, uint64_t nWords);
+int pil2gl_sync(void *stream);
+
+/* ---- NTT / LDE: src/helpers/fft/fft_p.js -------------------------------- */
+/* interpolate(buffSrc,nPols,nBits,buffDst,nBitsExt)  fft_p.js:187-297:
+ * per column, coefficients = iNTT_N(col), c_k *= 7^k, zero-pad to 2^nBitsExt, NTT ->
+ * evaluations on the coset 7*<w_E> in natural order (== extendPol, polutils.js:18-30). */
+int pil2gl_interpolate(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt);
+int pil2gl_interpolate_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt, void *stream);
+/* fft / ifft (buffSrc,nPols,nBits,buffDst)  fft_p.js:178-184: in-order multi-column NTT / iNTT,
+ * root F.w[nBits]; ifft = fft, index j -> (n-j) mod n, times 1/n (fft/fft.js:165-174). src may equal dst. */
+int pil2gl_fft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst);
+int pil2gl_ifft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst);
+int pil2gl_fft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, void *stream);
+int pil2gl_ifft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, void *stream);
+
+/* ---- Poseidon / linear hash / Merkle tree -------------------------------- */
+/* WASM export poseidon(pIn,nIn,pCap,nCap,pOut,nOut)  src/helpers/glwasm.js:216-426;
+ * JS twin poseidon(inputs[8],capacity[4],nOuts)  hash/poseidon/poseidon.js:57.
+ * `count` independent permutations: in = count x 8, cap = count x 4 (NULL = zeros), out = count x nOut. */
+int pil2gl_poseidon(const uint64_t *in, const uint64_t *cap, uint64_t count, uint32_t nOut, uint64_t *out);
+int pil2gl_poseidon_dev(const uint64_t *in, const uint64_t *cap, uint64_t count, uint32_t nOut, uint64_t *out, void *stream);
+/* worker linearHash(buffIn,width,st_i,st_n,splitLinearHash)  merklehash_worker.js:37-82
+ * (= WASM multiLinearHash glwasm.js:1124-1218 / multiLinearHashGPU :1089-1122, with the
+ * width<=4 raw copy of merklehash_worker.js:42-49): out = height x 4 digests. */
+int pil2gl_linear_hash_rows(const uint64_t *in, uint64_t width, uint64_t height, int split, uint64_t *out);
+int pil2gl_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64_t height, int split, uint64_t *out, void *stream);
+/* WASM merkelizeLevel(pIn,nOps,pOut)  glwasm.js:1220-1254: out[i] = Poseidon(in[8i..8i+7], cap=0)[0..3] */
+int pil2gl_merkelize_level(const uint64_t *in, uint64_t nOps, uint64_t *out);
+int pil2gl_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint64_t *out, void *stream);
+/* MerkleHash._getNNodes(height*4)  merklehash_p.js:28-42: u64 words of tree.nodes */
+uint64_t pil2gl_merkle_num_nodes(uint64_t height);
+/* MerkleHash.merkelize(buff,width,height)  merklehash_p.js:44-133: nodes[0..4*height) = leaf digests,
+ * then each level padded to an even node count with zero digests; root = last 4 words (:224-226). */
+int pil2gl_merkelize(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes);
+int pil2gl_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes, void *stream);
+/* MerkleHash.getGroupProof(tree,idx)  merklehash_p.js:142-168: copies row idx (width words) to hostVals
+ * and the sibling digest of every level (nLevels x 4 words) to hostSiblings; returns nLevels in *nLevels.
+ * elems/nodes are DEVICE pointers (the tree stays in HBM); synchronises. */
+int pil2gl_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height,
+                           uint64_t idx, uint64_t *hostVals, uint64_t *hostSiblings, uint32_t *nLevels);
+
+/* ---- FRI: src/stark/fri.js ------------------------------------------------ */
+/* FRI.fold(step>0, pol, challenge)  fri.js:22-61: pol has 2^polBits extension elements, out 2^outBits;
+ * shiftInv = (1/7)^(2^(steps[0].nBits - polBits)) (fri.js:31-36, computed by the caller). */
+int pil2gl_fri_fold(const uint64_t *pol, uint32_t polBits, uint32_t outBits, uint64_t shiftInv,
+                    const uint64_t challenge[3], uint64_t *out);
+int pil2gl_fri_fold_dev(const uint64_t *pol, uint32_t polBits, uint32_t outBits, uint64_t shiftInv,
+                        const uint64_t challenge[3], uint64_t *out, void *stream);
+/* getTransposedBuffer(pol, trasposeBits)  fri.js:187-202 */
+int pil2gl_fri_transpose(const uint64_t *pol, uint32_t polBits, uint32_t transposeBits, uint64_t *out);
+int pil2gl_fri_transpose_dev(const uint64_t *pol, uint32_t polBits, uint32_t transposeBits, uint64_t *out, void *stream);
+
+/* ---- STARK step helpers: src/stark/stark_gen_helpers.js, src/helpers/polutils.js ---- */
+/* x_n / x_ext tables  stark_gen_helpers.js:111-116,139-144: x[i] = shift * w[nBits]^i */
+int pil2gl_build_x_dev(uint32_t nBits, uint64_t shift, uint64_t *x, void *stream);
+/* buildZhInv(stark=true)  polutils.js:39-55 */
+int pil2gl_build_zhinv_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t *out, void *stream);
+/* buildOneRowZerofierInv(stark=true)  polutils.js:57-71 */
+int pil2gl_build_one_row_zerofier_inv_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t rowIndex, uint64_t *out, void *stream);
+/* buildFrameZerofierInv(stark=true)  polutils.js:74-102 (product of (x-root), not inverted) */
+int pil2gl_build_frame_zerofier_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t offsetMin, uint64_t offsetMax, uint64_t *out, void *stream);
+/* computeQStark split/scale  stark_gen_helpers.js:179-190: qq2[i][p*qDim+k] = qq1[p*N+i][k] * (7^-N)^p, rows >= N zero */
+int pil2gl_compute_q_split_dev(const uint64_t *qq1, uint32_t nBits, uint32_t nBitsExt, uint32_t qDim, uint32_t qDeg, uint64_t *qq2, void *stream);
+/* computeFRIStark xDivXSubXi  stark_gen_helpers.js:293-322: out[3*(k*nOpen+iOpen)+c] = (x_k / (x_k - xi))_c */
+int pil2gl_x_div_x_sub_xi_dev(uint32_t nBitsExt, const uint64_t xi[3], uint64_t nOpen, uint64_t iOpen, uint64_t *out, void *stream);
+/* computeEvalsStark  stark_gen_helpers.js:216-264: lev = ifft_N(xi^k) (extension, N x 3);
+ * evals[e] = sum_k v_e[k << extendBits] * lev[k] for nEvals columns described by (buffer, width, offset, dim). */
+int pil2gl_build_lev_dev(uint32_t nBits, const uint64_t xi[3], uint64_t *lev, void *stream);
+typedef struct { const uint64_t *buf; uint64_t width; uint64_t offset; uint32_t dim; uint32_t levIndex; } pil2gl_eval_desc;
+int pil2gl_compute_evals_dev(const pil2gl_eval_desc *descs, uint32_t nEvals, uint32_t nBits, uint32_t extendBits,
+                             const uint64_t *const *levs, uint32_t nLevs, uint64_t *hostEvals /* nEvals x 3 */, void *stream);
+
+/* ---- expression evaluator: src/prover/prover_helpers.js:23-259 ------------- */
+/* callCalculateExps / calculateExps: run the op-list on every row of the domain.  Section pointers in
+ * ctx are DEVICE pointers; prog/ctx structs themselves are host memory (copied at launch). */
+int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *ctx, void *stream);
+
+/* ---- diagnostics used by the parity tests ---------------------------------- */
+/* element-wise a*b, a+b, a-b on the device (n elements, host pointers) */
+int pil2gl_selftest_field(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *add, uint64_t *sub);
+/* extension a*b and 1/a on the device (n triples) */
+int pil2gl_selftest_ext(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *inv);
+
+#ifdef __cplusplus
+}
+#endif

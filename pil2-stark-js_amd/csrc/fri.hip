@@ -1,0 +1,322 @@
+// FRI folding and the element-wise STARK step helpers (Goldilocks cubic extension), gfx950.
+//
+// Replaces src/stark/fri.js:22-81,187-202 (fold, getTransposedBuffer) and the serial BigInt loops
+// of src/stark/stark_gen_helpers.js:104-160,179-190,216-264,293-322 and src/helpers/polutils.js:39-102.
+#include "common.h"
+#include "gl_field.cuh"
+#include <vector>
+
+using namespace gl;
+
+namespace {
+
+__device__ __forceinline__ u64 pow256(const u64 *__restrict__ T, u32 e) {
+    u64 r = T[e & 255];
+    r = mul_lazy(r, T[256 + ((e >> 8) & 255)]);
+    r = mul_lazy(r, T[512 + ((e >> 16) & 255)]);
+    return mul(r, T[768 + (e >> 24)]);
+}
+__device__ __forceinline__ u64 root_pow(const u64 *__restrict__ T, u32 logM, u32 e) { return logM ? pow256(T, e << (32 - logM)) : 1; }
+
+__device__ __forceinline__ E3 ld3(const u64 *p) { return { { p[0], p[1], p[2] } }; }
+__device__ __forceinline__ void st3(u64 *p, const E3 &v) { p[0] = v.v[0]; p[1] = v.v[1]; p[2] = v.v[2]; }
+
+// fri.js:45-60 after the group iNTT: out[g] = sum_i coef[i][g] * (sinv_g * challenge)^i, sinv_g = shiftInv * wi^g.
+// coef is the nX x (pol2N*3) matrix of iNTT'd groups (row i, column g): lanes walk consecutive g.
+__global__ void fri_horner_kernel(const u64 *__restrict__ coef, u32 polBits, u32 outBits, u64 shiftInv, E3 challenge,
+                                  const u64 *__restrict__ powWi, u64 *__restrict__ out) {
+    const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 pol2N = 1ull << outBits, nX = 1ull << (polBits - outBits);
+    if (g >= pol2N) return;
+    const u64 sinv = mul(shiftInv, root_pow(powWi, polBits, (u32)g));
+    const E3 Y = e3_scale(challenge, sinv);
+    E3 acc = ld3(coef + ((nX - 1) * pol2N + g) * 3);                 // polutils.js:9-16 evalPol
+    for (u64 i = nX - 1; i-- > 0;) acc = e3_add(e3_mul(acc, Y), ld3(coef + (i * pol2N + g) * 3));
+    st3(out + 3 * g, acc);
+}
+
+// fri.js:187-202: out[(i*h + j)] = pol[j*w + i]
+__global__ void fri_transpose_kernel(const u64 *__restrict__ pol, u32 polBits, u32 tBits, u64 *__restrict__ out) {
+    const u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;       // output element index
+    const u64 n = 1ull << polBits;
+    if (o >= n) return;
+    const u64 h = n >> tBits;
+    const u64 i = o / h, j = o - i * h;
+    st3(out + 3 * o, ld3(pol + 3 * ((j << tBits) + i)));
+}
+
+__global__ void build_x_kernel(u32 nBits, u64 shift, const u64 *__restrict__ powW, u64 *__restrict__ x) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1ull << nBits)) return;
+    x[i] = mul(shift, root_pow(powW, nBits, (u32)i));
+}
+__global__ void periodic_kernel(const u64 *__restrict__ tab, u64 period, u64 n, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = tab[i % period];
+}
+
+// Montgomery batch inversion of CH consecutive values per thread
+template <int CH>
+__device__ __forceinline__ void batch_inv(u64 v[CH]) {
+    u64 pre[CH];
+    u64 acc = 1;
+#pragma unroll
+    for (int i = 0; i < CH; i++) { pre[i] = acc; acc = mul(acc, v[i]); }
+    u64 z = inv(acc);
+#pragma unroll
+    for (int i = CH - 1; i >= 0; i--) { u64 t = mul(z, pre[i]); z = mul(z, v[i]); v[i] = t; }
+}
+
+// polutils.js:57-71: out[i] = 1 / ((x_i - root) * ZhInv[i]) = zh[i % ext] / (x_i - root), zh = 1/ZhInv
+__global__ void one_row_zerofier_kernel(u32 nBitsExt, u64 root, const u64 *__restrict__ zh, u64 ext,
+                                        const u64 *__restrict__ powW, u64 *__restrict__ out) {
+    constexpr int CH = 8;
+    const u64 i0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * CH;
+    const u64 n = 1ull << nBitsExt;
+    if (i0 >= n) return;
+    u64 v[CH];
+#pragma unroll
+    for (int k = 0; k < CH; k++) { u64 i = i0 + k < n ? i0 + k : i0; v[k] = sub(mul(7, root_pow(powW, nBitsExt, (u32)i)), root); }
+    batch_inv<CH>(v);
+#pragma unroll
+    for (int k = 0; k < CH; k++) if (i0 + k < n) out[i0 + k] = mul(v[k], zh[(i0 + k) % ext]);
+}
+// polutils.js:74-102: out[i] = prod_j (x_i - roots[j])
+__global__ void frame_zerofier_kernel(u32 nBitsExt, const u64 *__restrict__ roots, u32 nRoots, const u64 *__restrict__ powW, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1ull << nBitsExt)) return;
+    const u64 x = mul(7, root_pow(powW, nBitsExt, (u32)i));
+    u64 zi = 1;
+    for (u32 j = 0; j < nRoots; j++) zi = mul(zi, sub(x, roots[j]));
+    out[i] = zi;
+}
+// stark_gen_helpers.js:179-190
+__global__ void q_split_kernel(const u64 *__restrict__ qq1, u32 nBits, u32 nBitsExt, u32 qDim, u32 qDeg,
+                               const u64 *__restrict__ sPow /* (7^-N)^p */, u64 *__restrict__ qq2) {
+    const u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 W = (u64)qDim * qDeg, N = 1ull << nBits;
+    if (o >= (W << nBitsExt)) return;
+    const u64 i = o / W, r = o - i * W;
+    if (i >= N) { qq2[o] = 0; return; }
+    const u64 p = r / qDim, k = r - p * qDim;
+    qq2[o] = mul(qq1[(p * N + i) * qDim + k], sPow[p]);
+}
+// stark_gen_helpers.js:302-322: (x_k - xi)^-1 * x_k with F.sub(scalar, triple) (f3g.js:66)
+__global__ void x_div_x_sub_xi_kernel(u32 nBitsExt, E3 xi, u64 nOpen, u64 iOpen, const u64 *__restrict__ powW, u64 *__restrict__ out) {
+    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1ull << nBitsExt)) return;
+    const u64 x = mul(7, root_pow(powW, nBitsExt, (u32)k));
+    E3 den = { { sub(x, xi.v[0]), neg(xi.v[1]), neg(xi.v[2]) } };
+    st3(out + 3 * (k * nOpen + iOpen), e3_scale(e3_inv(den), x));
+}
+// stark_gen_helpers.js:216-229: lev[k] = xi^k; xiPow[b] = xi^(2^b)
+__global__ void lev_pow_kernel(u32 nBits, const u64 *__restrict__ xiPow, u64 *__restrict__ lev) {
+    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (1ull << nBits)) return;
+    E3 acc = { { 1, 0, 0 } };
+    for (u32 b = 0; b < nBits; b++) if ((k >> b) & 1) acc = e3_mul(acc, ld3(xiPow + 3 * b));
+    st3(lev + 3 * k, acc);
+}
+// stark_gen_helpers.js:250-264: partial[e][blk] = sum over this block's k of v_e[k << eb] * lev[k]
+__global__ void evals_partial_kernel(pil2gl_eval_desc d, const u64 *__restrict__ lev, u32 nBits, u32 eb, u64 *__restrict__ partial) {
+    __shared__ u64 red[256 * 3];
+    const u64 N = 1ull << nBits;
+    E3 acc = { { 0, 0, 0 } };
+    for (u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x; k < N; k += (u64)gridDim.x * blockDim.x) {
+        const u64 *v = d.buf + (k << eb) * d.width + d.offset;
+        const E3 l = ld3(lev + 3 * k);
+        acc = e3_add(acc, d.dim == 1 ? e3_scale(l, v[0]) : e3_mul(ld3(v), l));
+    }
+    red[threadIdx.x * 3] = acc.v[0]; red[threadIdx.x * 3 + 1] = acc.v[1]; red[threadIdx.x * 3 + 2] = acc.v[2];
+    __syncthreads();
+    for (u32 s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) for (int c = 0; c < 3; c++) red[threadIdx.x * 3 + c] = add(red[threadIdx.x * 3 + c], red[(threadIdx.x + s) * 3 + c]);
+        __syncthreads();
+    }
+    if (threadIdx.x < 3) partial[(u64)blockIdx.x * 3 + threadIdx.x] = red[threadIdx.x];
+}
+__global__ void evals_final_kernel(const u64 *__restrict__ partial, u32 nBlocks, u32 nEvals, u64 *__restrict__ out) {
+    const u32 e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nEvals * 3) return;
+    const u32 ev = e / 3, c = e % 3;
+    u64 acc = 0;
+    for (u32 b = 0; b < nBlocks; b++) acc = add(acc, partial[((u64)ev * nBlocks + b) * 3 + c]);
+    out[e] = acc;
+}
+
+inline unsigned nblk(u64 n, u32 t = 256) { return (unsigned)((n + t - 1) / t); }
+
+}  // namespace
+
+using namespace pil2gl;
+
+extern "C" {
+
+int pil2gl_fri_fold_dev(const uint64_t *pol, uint32_t polBits, uint32_t outBits, uint64_t shiftInv,
+                        const uint64_t challenge[3], uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (!pol || !out || !challenge) return fail(PIL2GL_EINVAL, "null buffer");
+    if (outBits > polBits || polBits > 27) return fail(PIL2GL_EINVAL, "Invalid polynomial size");
+    hipStream_t st = as_stream(stream);
+    const u64 n = 1ull << polBits;
+    u64 *coef;
+    P2_TRY(scratch(1, 3 * n, &coef));
+    // group iNTT (fri.js:51-55): pol is an nX x (pol2N*3) row-major matrix, transform along its rows' index
+    P2_TRY(ntt_launch(pol, 3ull << outBits, polBits - outBits, coef, true, st));
+    E3 ch = { { challenge[0], challenge[1], challenge[2] } };
+    fri_horner_kernel<<<nblk(1ull << outBits), 256, 0, st>>>(coef, polBits, outBits, shiftInv, ch, tables().powWi, out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+int pil2gl_fri_transpose_dev(const uint64_t *pol, uint32_t polBits, uint32_t transposeBits, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (!pol || !out) return fail(PIL2GL_EINVAL, "null buffer");
+    if (transposeBits > polBits || polBits > 31) return fail(PIL2GL_EINVAL, "Invalid polynomial size");
+    fri_transpose_kernel<<<nblk(1ull << polBits), 256, 0, as_stream(stream)>>>(pol, polBits, transposeBits, out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+static int host3(const uint64_t *in, u64 nIn, uint64_t *out, u64 nOut, int (*fn)(const u64 *, u64 *, void *), void *arg) {
+    P2_TRY(ensure_init());
+    u64 *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (nIn + nOut + 1) * 8));
+    int rc = PIL2GL_OK;
+    hipError_t e = hipMemcpy(d, in, nIn * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
+    if (rc == PIL2GL_OK) rc = fn(d, d + nIn, arg);
+    if (rc == PIL2GL_OK) { e = hipMemcpy(out, d + nIn, nOut * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
+    (void)hipFree(d);
+    return rc;
+}
+struct FoldArgs { u32 polBits, outBits; u64 shiftInv; const u64 *ch; };
+int pil2gl_fri_fold(const uint64_t *pol, uint32_t polBits, uint32_t outBits, uint64_t shiftInv, const uint64_t challenge[3], uint64_t *out) {
+    if (outBits > polBits || polBits > 27) return fail(PIL2GL_EINVAL, "Invalid polynomial size");
+    FoldArgs a = { polBits, outBits, shiftInv, challenge };
+    return host3(pol, 3ull << polBits, out, 3ull << outBits,
+                 [](const u64 *i, u64 *o, void *p) { FoldArgs *a = (FoldArgs *)p; return pil2gl_fri_fold_dev(i, a->polBits, a->outBits, a->shiftInv, a->ch, o, nullptr); }, &a);
+}
+int pil2gl_fri_transpose(const uint64_t *pol, uint32_t polBits, uint32_t transposeBits, uint64_t *out) {
+    if (transposeBits > polBits || polBits > 31) return fail(PIL2GL_EINVAL, "Invalid polynomial size");
+    u32 a[2] = { polBits, transposeBits };
+    return host3(pol, 3ull << polBits, out, 3ull << polBits,
+                 [](const u64 *i, u64 *o, void *p) { u32 *a = (u32 *)p; return pil2gl_fri_transpose_dev(i, a[0], a[1], o, nullptr); }, a);
+}
+
+// ---- STARK step helpers ----
+int pil2gl_build_x_dev(uint32_t nBits, uint64_t shift, uint64_t *x, void *stream) {
+    P2_TRY(ensure_init());
+    if (nBits > 31) return fail(PIL2GL_EINVAL, "nBits too large");
+    build_x_kernel<<<nblk(1ull << nBits), 256, 0, as_stream(stream)>>>(nBits, shift, tables().powW, x);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+// zh[i] = 7^N * w_ext^i - 1 for i < 2^eb (polutils.js:44-51); inv = its inverse
+static void zh_table(u32 nBits, u32 nBitsExt, std::vector<u64> &zh, bool inverted) {
+    u32 eb = nBitsExt - nBits;
+    u64 sn = 7;
+    for (u32 i = 0; i < nBits; i++) sn = h_mul(sn, sn);
+    u64 w = 1, we = h_root(eb);
+    zh.resize(1ull << eb);
+    for (u64 i = 0; i < zh.size(); i++) { u64 z = h_sub(h_mul(sn, w), 1); zh[i] = inverted ? h_inv(z) : z; w = h_mul(w, we); }
+}
+static int upload_small(const std::vector<u64> &h, u32 slot, u64 **d, hipStream_t st) {
+    P2_TRY(scratch(slot, h.size() ? h.size() : 1, d));
+    // pageable-host async copies are staged by the runtime before returning, so `h` may go out of scope
+    HIP_TRY(hipMemcpyAsync(*d, h.data(), h.size() * 8, hipMemcpyHostToDevice, st));
+    return PIL2GL_OK;
+}
+
+int pil2gl_build_zhinv_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (nBitsExt < nBits || nBitsExt > 31 || nBitsExt - nBits > 20) return fail(PIL2GL_EINVAL, "bad domain sizes");
+    std::vector<u64> zh; zh_table(nBits, nBitsExt, zh, true);
+    u64 *d; P2_TRY(upload_small(zh, 2, &d, as_stream(stream)));
+    periodic_kernel<<<nblk(1ull << nBitsExt), 256, 0, as_stream(stream)>>>(d, zh.size(), 1ull << nBitsExt, out);
+    KERNEL_CHECK();
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));       // scratch slot 2 is reused by the next helper call
+    return PIL2GL_OK;
+}
+int pil2gl_build_one_row_zerofier_inv_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t rowIndex, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (nBitsExt < nBits || nBitsExt > 31 || nBitsExt - nBits > 20) return fail(PIL2GL_EINVAL, "bad domain sizes");
+    std::vector<u64> zh; zh_table(nBits, nBitsExt, zh, false);
+    u64 *d; P2_TRY(upload_small(zh, 2, &d, as_stream(stream)));
+    u64 root = h_pow(h_root(nBits), rowIndex);
+    one_row_zerofier_kernel<<<nblk(((1ull << nBitsExt) + 7) / 8), 256, 0, as_stream(stream)>>>(nBitsExt, root, d, zh.size(), tables().powW, out);
+    KERNEL_CHECK();
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return PIL2GL_OK;
+}
+int pil2gl_build_frame_zerofier_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t offsetMin, uint64_t offsetMax, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (nBitsExt < nBits || nBitsExt > 31 || offsetMin + offsetMax > 4096) return fail(PIL2GL_EINVAL, "bad frame zerofier arguments");
+    std::vector<u64> roots;
+    u64 w = h_root(nBits), N = 1ull << nBits;
+    for (u64 i = 0; i < offsetMin; i++) roots.push_back(h_pow(w, i));
+    for (u64 i = 0; i < offsetMax; i++) roots.push_back(h_pow(w, N - i - 1));
+    u64 *d; P2_TRY(upload_small(roots, 2, &d, as_stream(stream)));
+    frame_zerofier_kernel<<<nblk(1ull << nBitsExt), 256, 0, as_stream(stream)>>>(nBitsExt, d, (u32)roots.size(), tables().powW, out);
+    KERNEL_CHECK();
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return PIL2GL_OK;
+}
+int pil2gl_compute_q_split_dev(const uint64_t *qq1, uint32_t nBits, uint32_t nBitsExt, uint32_t qDim, uint32_t qDeg, uint64_t *qq2, void *stream) {
+    P2_TRY(ensure_init());
+    if (!qq1 || !qq2) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nBitsExt < nBits || nBitsExt > 31 || !qDim || !qDeg || ((u64)qDeg << nBits) > (1ull << nBitsExt)) return fail(PIL2GL_EINVAL, "bad q split arguments");
+    std::vector<u64> sp(qDeg);
+    u64 shiftIn = h_pow(h_inv(7), 1ull << nBits), cur = 1;
+    for (u32 p = 0; p < qDeg; p++) { sp[p] = cur; cur = h_mul(cur, shiftIn); }
+    u64 *d; P2_TRY(upload_small(sp, 2, &d, as_stream(stream)));
+    q_split_kernel<<<nblk(((u64)qDim * qDeg) << nBitsExt), 256, 0, as_stream(stream)>>>(qq1, nBits, nBitsExt, qDim, qDeg, d, qq2);
+    KERNEL_CHECK();
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return PIL2GL_OK;
+}
+int pil2gl_x_div_x_sub_xi_dev(uint32_t nBitsExt, const uint64_t xi[3], uint64_t nOpen, uint64_t iOpen, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (!xi || !out || iOpen >= nOpen || nBitsExt > 31) return fail(PIL2GL_EINVAL, "bad xDivXSubXi arguments");
+    E3 x = { { xi[0], xi[1], xi[2] } };
+    x_div_x_sub_xi_kernel<<<nblk(1ull << nBitsExt), 256, 0, as_stream(stream)>>>(nBitsExt, x, nOpen, iOpen, tables().powW, out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+int pil2gl_build_lev_dev(uint32_t nBits, const uint64_t xi[3], uint64_t *lev, void *stream) {
+    P2_TRY(ensure_init());
+    if (!xi || !lev || nBits > 27) return fail(PIL2GL_EINVAL, "bad LEv arguments");
+    std::vector<u64> xp(3 * (nBits ? nBits : 1));
+    u64 cur[3] = { xi[0], xi[1], xi[2] };
+    for (u32 b = 0; b < nBits; b++) { xp[3 * b] = cur[0]; xp[3 * b + 1] = cur[1]; xp[3 * b + 2] = cur[2]; h_e3_mul(cur, cur, cur); }
+    u64 *d; P2_TRY(upload_small(xp, 2, &d, as_stream(stream)));
+    lev_pow_kernel<<<nblk(1ull << nBits), 256, 0, as_stream(stream)>>>(nBits, d, lev);
+    KERNEL_CHECK();
+    P2_TRY(ntt_launch(lev, 3, nBits, lev, true, as_stream(stream)));       // F.ifft on triples: component-wise
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return PIL2GL_OK;
+}
+int pil2gl_compute_evals_dev(const pil2gl_eval_desc *descs, uint32_t nEvals, uint32_t nBits, uint32_t extendBits,
+                             const uint64_t *const *levs, uint32_t nLevs, uint64_t *hostEvals, void *stream) {
+    P2_TRY(ensure_init());
+    if (!nEvals) return PIL2GL_OK;
+    if (!descs || !levs || !hostEvals) return fail(PIL2GL_EINVAL, "null buffer");
+    hipStream_t st = as_stream(stream);
+    const u32 nBlocks = (u32)std::min<u64>(256, ((1ull << nBits) + 255) / 256);
+    u64 *partial, *res;
+    P2_TRY(scratch(3, (u64)nEvals * nBlocks * 3 + (u64)nEvals * 3, &partial));
+    res = partial + (u64)nEvals * nBlocks * 3;
+    for (u32 e = 0; e < nEvals; e++) {
+        if (descs[e].levIndex >= nLevs || (descs[e].dim != 1 && descs[e].dim != 3)) return fail(PIL2GL_EINVAL, "bad eval descriptor %u", e);
+        evals_partial_kernel<<<nBlocks, 256, 0, st>>>(descs[e], levs[descs[e].levIndex], nBits, extendBits, partial + (u64)e * nBlocks * 3);
+    }
+    KERNEL_CHECK();
+    evals_final_kernel<<<nblk(nEvals * 3), 256, 0, st>>>(partial, nBlocks, nEvals, res);
+    KERNEL_CHECK();
+    HIP_TRY(hipMemcpyAsync(hostEvals, res, (u64)nEvals * 24, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return PIL2GL_OK;
+}
+
+}  // extern "C"

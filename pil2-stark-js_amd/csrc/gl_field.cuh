@@ -1,0 +1,114 @@
+// Goldilocks field (p = 2^64 - 2^32 + 1) and its cubic extension for gfx950 device code.
+//
+// Arithmetic spec: src/helpers/f3g.js:47-172 of the reference (canonical results).
+// gfx950 has no 64-bit integer multiplier: a 64x64->128 product is four
+// v_mad_u64_u32, and the reduction uses 2^64 = 2^32 - 1, 2^96 = -1 (mod p), i.e.
+// only adds/subs -- no Montgomery form is needed for this prime.
+//
+// Two value classes are used:
+//   canonical  [0, p)      -- everything stored to memory
+//   lazy       [0, 2^64)   -- any representative; cheaper to produce, accepted by mul()/add_lazy()
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gl {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+static constexpr u64 P = 0xFFFFFFFF00000001ull;
+static constexpr u64 EPS = 0xFFFFFFFFull;           // 2^64 mod p
+
+__device__ __forceinline__ u64 canon(u64 a) { return a >= P ? a - P : a; }
+
+// canonical + canonical -> canonical
+__device__ __forceinline__ u64 add(u64 a, u64 b) {
+    u64 s = a + b;
+    // a,b < p: the true sum is < 2p < 2^65; on carry or s >= p subtract p once (== add EPS mod 2^64)
+    return (s < a || s >= P) ? s + EPS : s;
+}
+// canonical - canonical -> canonical
+__device__ __forceinline__ u64 sub(u64 a, u64 b) {
+    u64 d = a - b;
+    return (a < b) ? d - EPS : d;                    // borrow: add p (== subtract EPS mod 2^64)
+}
+__device__ __forceinline__ u64 neg(u64 a) { return a ? P - a : 0; }
+
+// lazy + lazy -> lazy
+__device__ __forceinline__ u64 add_lazy(u64 a, u64 b) {
+    u64 s = a + b;
+    if (s < a) {                                     // wrapped: add 2^64 mod p
+        s += EPS;
+        if (s < EPS) s += EPS;                       // (only possible for non-canonical inputs)
+    }
+    return s;
+}
+
+// 128-bit (hi,lo) -> lazy
+__device__ __forceinline__ u64 reduce128_lazy(u64 lo, u64 hi) {
+    u64 hh = hi >> 32, hl = hi & EPS;
+    u64 t0 = lo - hh;
+    if (lo < hh) t0 -= EPS;                          // borrow: + p
+    u64 t1 = (hl << 32) - hl;                        // hl * (2^32 - 1)
+    u64 t2 = t0 + t1;
+    if (t2 < t1) t2 += EPS;                          // carry: 2^64 = EPS; cannot wrap again (t1 <= 2^64 - 2^33 + 1)
+    return t2;
+}
+
+// any u64 x any u64 -> lazy
+__device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
+    return reduce128_lazy(a * b, __umul64hi(a, b));
+}
+// any x any -> canonical
+__device__ __forceinline__ u64 mul(u64 a, u64 b) { return canon(mul_lazy(a, b)); }
+__device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }
+
+__device__ inline u64 pow(u64 base, u64 e) {
+    u64 r = 1;
+    while (e) { if (e & 1) r = mul(r, base); base = mul(base, base); e >>= 1; }
+    return r;
+}
+__device__ inline u64 inv(u64 a) { return pow(a, P - 2); }
+
+// ---- cubic extension, x^3 = x + 1 (f3g.js:94-102) ----
+struct E3 { u64 v[3]; };
+
+__device__ __forceinline__ E3 e3_add(const E3 &a, const E3 &b) { return { { add(a.v[0], b.v[0]), add(a.v[1], b.v[1]), add(a.v[2], b.v[2]) } }; }
+__device__ __forceinline__ E3 e3_sub(const E3 &a, const E3 &b) { return { { sub(a.v[0], b.v[0]), sub(a.v[1], b.v[1]), sub(a.v[2], b.v[2]) } }; }
+__device__ __forceinline__ E3 e3_scale(const E3 &a, u64 s) { return { { mul(a.v[0], s), mul(a.v[1], s), mul(a.v[2], s) } }; }
+__device__ __forceinline__ E3 e3_mul(const E3 &a, const E3 &b) {
+    u64 A = mul(add(a.v[0], a.v[1]), add(b.v[0], b.v[1]));
+    u64 B = mul(add(a.v[0], a.v[2]), add(b.v[0], b.v[2]));
+    u64 C = mul(add(a.v[1], a.v[2]), add(b.v[1], b.v[2]));
+    u64 D = mul(a.v[0], b.v[0]);
+    u64 E = mul(a.v[1], b.v[1]);
+    u64 F = mul(a.v[2], b.v[2]);
+    u64 G = sub(D, E);
+    E3 r;
+    r.v[0] = sub(add(C, G), F);
+    r.v[1] = sub(sub(sub(add(A, C), E), E), D);
+    r.v[2] = sub(B, G);
+    return r;
+}
+// f3g.js:136-172
+__device__ inline E3 e3_inv(const E3 &x) {
+    u64 a = x.v[0], b = x.v[1], c = x.v[2];
+    u64 aa = mul(a, a), ac = mul(a, c), ba = mul(b, a), bb = mul(b, b), bc = mul(b, c), cc = mul(c, c);
+    u64 aaa = mul(aa, a), aac = mul(aa, c), abc = mul(ba, c), abb = mul(ba, b);
+    u64 acc = mul(ac, c), bbb = mul(bb, b), bcc = mul(bc, c), ccc = mul(cc, c);
+    u64 t = neg(aaa);
+    t = sub(t, aac); t = sub(t, aac);
+    t = add(t, abc); t = add(t, abc); t = add(t, abc);
+    t = add(t, abb); t = sub(t, acc); t = sub(t, bbb); t = add(t, bcc); t = sub(t, ccc);
+    u64 ti = inv(t);
+    u64 i1 = neg(aa);
+    i1 = sub(i1, ac); i1 = sub(i1, ac); i1 = add(i1, bc); i1 = add(i1, bb); i1 = sub(i1, cc);
+    u64 i2 = sub(ba, cc);
+    u64 i3 = add(add(neg(bb), ac), cc);
+    return { { mul(i1, ti), mul(i2, ti), mul(i3, ti) } };
+}
+
+__device__ __forceinline__ u32 bitrev32(u32 x, u32 bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
+
+}  // namespace gl

@@ -1,0 +1,217 @@
+// Poseidon linear hash of rows and Merkle tree construction (Goldilocks), gfx950.
+//
+// Replaces src/helpers/hash/merklehash/merklehash_p.js:44-133 (merkelize), its worker
+// merklehash_worker.js:37-117 and the WASM exports multiLinearHash / multiLinearHashGPU /
+// merkelizeLevel / poseidon of src/helpers/glwasm.js:216-426,879-1254.
+// Leaf rule: src/helpers/hash/linearhash/linearhash.js:22-41; split rule: linearhash_gpu.js:30-66.
+//
+// One permutation per lane: the work is integer-ALU bound (about 600 64-bit modular
+// multiplication equivalents per permutation against 96 bytes of traffic), so the kernels only
+// need "not stupid" memory access: a row's 8-element chunk is 64 contiguous bytes per lane.
+#include "common.h"
+#include "poseidon_gl.cuh"
+#include <algorithm>
+
+using namespace gl;
+
+namespace {
+
+// sponge over `width` consecutive words (linearhash.js:29-40); width > 4
+__device__ __forceinline__ void sponge(const u64 *__restrict__ v, u32 width, u64 digest[4]) {
+    u64 st[12];
+    st[8] = st[9] = st[10] = st[11] = 0;
+    for (u32 i = 0; i < width; i += 8) {
+        const u32 n = min(8u, width - i);
+#pragma unroll
+        for (u32 j = 0; j < 8; j++) st[j] = j < n ? v[i + j] : 0;
+        poseidon_perm(st);
+        st[8] = st[0]; st[9] = st[1]; st[10] = st[2]; st[11] = st[3];
+    }
+    digest[0] = st[8]; digest[1] = st[9]; digest[2] = st[10]; digest[3] = st[11];
+}
+__device__ __forceinline__ void linear_hash_plain(const u64 *__restrict__ v, u32 width, u64 digest[4]) {
+    if (width <= 4) {                               // linearhash.js:22-28, merklehash_worker.js:42-49
+#pragma unroll
+        for (u32 j = 0; j < 4; j++) digest[j] = j < width ? v[j] : 0;
+        return;
+    }
+    sponge(v, width, digest);
+}
+
+__global__ void __launch_bounds__(256) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int split, u64 *__restrict__ out) {
+    const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= height) return;
+    const u64 *v = in + row * width;
+    u64 d[4];
+    if (!split || width <= 4) {
+        linear_hash_plain(v, (u32)width, d);
+    } else {                                        // linearhash_gpu.js:30-66, glwasm.js:879-1087
+        u32 w = (u32)width;
+        u32 batch = max(8u, (w + 3) / 4);
+        u64 hs[16];
+        u32 nh = 0;
+        for (u32 b = 0; b < w; b += batch) { linear_hash_plain(v + b, min(batch, w - b), hs + nh); nh += 4; }
+        if (nh <= 4) { d[0] = hs[0]; d[1] = hs[1]; d[2] = hs[2]; d[3] = hs[3]; }
+        else sponge(hs, nh, d);
+    }
+    u64 *o = out + 4 * row;
+    o[0] = d[0]; o[1] = d[1]; o[2] = d[2]; o[3] = d[3];
+}
+
+// glwasm.js:1220-1254: out[i] = Poseidon(in[8i..8i+7], capacity 0)[0..3]
+__global__ void __launch_bounds__(256) merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nOps) return;
+    u64 st[12];
+#pragma unroll
+    for (int j = 0; j < 8; j++) st[j] = in[8 * i + j];
+    st[8] = st[9] = st[10] = st[11] = 0;
+    poseidon_perm(st);
+    u64 *o = out + 4 * i;
+    o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];
+}
+
+// batch of independent permutations (glwasm.js:216 `poseidon`, hash/poseidon/poseidon.js:57)
+__global__ void __launch_bounds__(256) poseidon_batch_kernel(const u64 *__restrict__ in, const u64 *__restrict__ cap, u64 count, u32 nOut, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    u64 st[12];
+#pragma unroll
+    for (int j = 0; j < 8; j++) st[j] = canon(in[8 * i + j]);          // F.e(): poseidon.js:65-67
+#pragma unroll
+    for (int j = 0; j < 4; j++) st[8 + j] = cap ? canon(cap[4 * i + j]) : 0;
+    poseidon_perm(st);
+    for (u32 j = 0; j < nOut; j++) out[(u64)nOut * i + j] = st[j];
+}
+
+}  // namespace
+
+using namespace pil2gl;
+
+extern "C" {
+
+uint64_t pil2gl_merkle_num_nodes(uint64_t height) {        // merklehash_p.js:28-42 with n = height*4
+    if (height == 0) return 0;
+    uint64_t n = height * 4;
+    uint64_t nextN = ((n - 1) / 8 + 1) * 4;
+    uint64_t acc = nextN * 2;
+    while (n > 4) {
+        n = nextN;
+        nextN = ((n - 1) / 8 + 1) * 4;
+        if (n > 4) acc += nextN * 2; else acc += 4;
+    }
+    return acc;
+}
+
+int pil2gl_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64_t height, int split, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (height == 0) return PIL2GL_OK;
+    if (!out || (!in && width)) return fail(PIL2GL_EINVAL, "null buffer");
+    if (width >= (1ull << 31)) return fail(PIL2GL_EINVAL, "row width too large");
+    u64 blocks = (height + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
+    linear_hash_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(in, width, height, split, out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+int pil2gl_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (nOps == 0) return PIL2GL_OK;
+    if (!in || !out) return fail(PIL2GL_EINVAL, "null buffer");
+    merkle_level_kernel<<<(unsigned)((nOps + 255) / 256), 256, 0, as_stream(stream)>>>(in, nOps, out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+int pil2gl_poseidon_dev(const uint64_t *in, const uint64_t *cap, uint64_t count, uint32_t nOut, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (count == 0) return PIL2GL_OK;
+    if (!in || !out) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nOut < 1 || nOut > 12) return fail(PIL2GL_EINVAL, "nOut must be 1..12");
+    poseidon_batch_kernel<<<(unsigned)((count + 255) / 256), 256, 0, as_stream(stream)>>>(in, cap, count, nOut, out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+int pil2gl_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes, void *stream) {
+    P2_TRY(ensure_init());
+    if (height == 0) return fail(PIL2GL_EINVAL, "height must be > 0");
+    if (!nodes || (!elems && width)) return fail(PIL2GL_EINVAL, "null buffer");
+    hipStream_t st = as_stream(stream);
+    // merklehash_p.js:49: nodes is a fresh (zeroed) BigUint64Array; the zero padding of odd levels relies on it
+    HIP_TRY(hipMemsetAsync(nodes, 0, pil2gl_merkle_num_nodes(height) * 8, st));
+    P2_TRY(pil2gl_linear_hash_rows_dev(elems, width, height, split, nodes, stream));
+    // merklehash_p.js:87-103 (offsets in u64 words instead of bytes)
+    u64 pIn = 0, n64 = height * 4;
+    u64 nextN64 = ((n64 - 1) / 8 + 1) * 4;
+    u64 pOut = pIn + nextN64 * 2;
+    while (n64 > 4) {
+        P2_TRY(pil2gl_merkelize_level_dev(nodes + pIn, nextN64 / 4, nodes + pOut, stream));
+        n64 = nextN64;
+        nextN64 = ((n64 - 1) / 8 + 1) * 4;
+        pIn = pOut;
+        pOut = pIn + nextN64 * 2;
+    }
+    return PIL2GL_OK;
+}
+
+int pil2gl_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height,
+                           uint64_t idx, uint64_t *hostVals, uint64_t *hostSiblings, uint32_t *nLevels) {
+    P2_TRY(ensure_init());
+    if (idx >= height) return fail(PIL2GL_EINVAL, "Out of range");      // merklehash_p.js:143
+    if (width) HIP_TRY(hipMemcpy(hostVals, elems + idx * width, width * 8, hipMemcpyDeviceToHost));
+    u64 offset = 0, n = height * 4;
+    uint32_t lvl = 0;
+    while (n > 4) {                                                      // merklehash_p.js:154-167
+        u64 si = (idx ^ 1) * 4;
+        HIP_TRY(hipMemcpy(hostSiblings + 4 * lvl, nodes + offset + si, 32, hipMemcpyDeviceToHost));
+        u64 nextN = ((n - 1) / 8 + 1) * 4;
+        offset += nextN * 2; n = nextN; idx >>= 1; lvl++;
+    }
+    if (nLevels) *nLevels = lvl;
+    return PIL2GL_OK;
+}
+
+// ---- host-pointer forms ----
+static int with_dev(const uint64_t *hIn, u64 nIn, const uint64_t *hIn2, u64 nIn2, uint64_t *hOut, u64 nOut,
+                    int (*fn)(const u64 *, const u64 *, u64 *, void *), void *arg) {
+    P2_TRY(ensure_init());
+    u64 *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (nIn + nIn2 + nOut + 1) * 8));
+    int rc = PIL2GL_OK;
+    hipError_t e = hipSuccess;
+    if (nIn) e = hipMemcpy(d, hIn, nIn * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nIn2) e = hipMemcpy(d + nIn, hIn2, nIn2 * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
+    if (rc == PIL2GL_OK) rc = fn(d, nIn2 ? d + nIn : nullptr, d + nIn + nIn2, arg);
+    if (rc == PIL2GL_OK && nOut) { e = hipMemcpy(hOut, d + nIn + nIn2, nOut * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
+    (void)hipFree(d);
+    return rc;
+}
+struct LhArgs { u64 width, height; int split; };
+struct PsArgs { u64 count; u32 nOut; };
+
+int pil2gl_linear_hash_rows(const uint64_t *in, uint64_t width, uint64_t height, int split, uint64_t *out) {
+    LhArgs a = { width, height, split };
+    return with_dev(in, width * height, nullptr, 0, out, height * 4,
+                    [](const u64 *i, const u64 *, u64 *o, void *p) { LhArgs *a = (LhArgs *)p; return pil2gl_linear_hash_rows_dev(i, a->width, a->height, a->split, o, nullptr); }, &a);
+}
+int pil2gl_merkelize_level(const uint64_t *in, uint64_t nOps, uint64_t *out) {
+    return with_dev(in, nOps * 8, nullptr, 0, out, nOps * 4,
+                    [](const u64 *i, const u64 *, u64 *o, void *p) { return pil2gl_merkelize_level_dev(i, *(u64 *)p, o, nullptr); }, &nOps);
+}
+int pil2gl_poseidon(const uint64_t *in, const uint64_t *cap, uint64_t count, uint32_t nOut, uint64_t *out) {
+    if (nOut < 1 || nOut > 12) return fail(PIL2GL_EINVAL, "nOut must be 1..12");
+    PsArgs a = { count, nOut };
+    return with_dev(in, count * 8, cap, cap ? count * 4 : 0, out, count * nOut,
+                    [](const u64 *i, const u64 *c, u64 *o, void *p) { PsArgs *a = (PsArgs *)p; return pil2gl_poseidon_dev(i, c, a->count, a->nOut, o, nullptr); }, &a);
+}
+int pil2gl_merkelize(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes) {
+    if (height == 0) return fail(PIL2GL_EINVAL, "height must be > 0");
+    LhArgs a = { width, height, split };
+    return with_dev(elems, width * height, nullptr, 0, nodes, pil2gl_merkle_num_nodes(height),
+                    [](const u64 *i, const u64 *, u64 *o, void *p) { LhArgs *a = (LhArgs *)p; return pil2gl_merkelize_dev(i, a->width, a->height, a->split, o, nullptr); }, &a);
+}
+
+}  // extern "C"

@@ -1,0 +1,397 @@
+// Multi-column Goldilocks NTT / iNTT / LDE on a row-major rows x C matrix (gfx950).
+//
+// Replaces src/helpers/fft/fft_p.js:178-302 (interpolate / fft / ifft) of the reference, whose
+// result is, per column, F.fft / F.ifft / extendPol (test/fft_p.test.js:47-229).
+//
+// Design (not the reference's block/transposition scheme):
+//  * A transform of 2^n rows is cut into passes of k <= 10 index bits.  One workgroup owns a
+//    tile of 2^k rows (stride 2^lo rows) x S column slots in LDS, runs the k radix-2 stages
+//    there, and applies the inter-pass twiddle w_(2^(lo+k))^(b*j) from a per-tile LDS table that
+//    is shared by all columns of the tile.  All passes are in place.
+//  * Forward/inverse transforms run decimation-in-frequency (natural in -> bit-reversed out);
+//    the last pass scatters rows to their bit-reversed index so the caller sees natural order.
+//  * interpolate (LDE) never reorders anything: iNTT as DIF leaves coefficient m at row
+//    bitrev(m); the "mid" kernel finishes the iNTT on a contiguous tile, multiplies coefficient m
+//    by (7*w_E^j)^m / N for each of the 2^b cosets j and immediately runs the first k stages of a
+//    decimation-in-time NTT (bit-reversed in -> natural out), writing coset j's tile to rows
+//    (pos << b) + j of dst.  dst is then just an N x (C*2^b) matrix on which the remaining DIT
+//    passes run in place.  Extended row i = 8k+j is coset point 7*w_E^(8k+j): natural order.
+//  * Rows are contiguous in memory, so a tile row is one contiguous segment of Wc*8 bytes
+//    (or several adjacent rows when C is small): every global access is a coalesced segment.
+#include "common.h"
+#include "gl_field.cuh"
+#include <stdlib.h>
+#include <algorithm>
+
+using namespace gl;
+
+namespace {
+
+__device__ __forceinline__ u64 pow256(const u64 *__restrict__ T, u32 e) {
+    u64 r = T[e & 255];
+    r = mul_lazy(r, T[256 + ((e >> 8) & 255)]);
+    r = mul_lazy(r, T[512 + ((e >> 16) & 255)]);
+    return mul(r, T[768 + (e >> 24)]);
+}
+// w_(2^logM)^e for the root whose pow256 table is T (1 <= logM <= 32, e < 2^logM)
+__device__ __forceinline__ u64 root_pow(const u64 *__restrict__ T, u32 logM, u32 e) { return pow256(T, e << (32 - logM)); }
+
+// k radix-2 stages on tile[2^k][S] (column x), Gentleman-Sande: natural in -> bit-reversed out
+__device__ __forceinline__ void dif_stages(u64 *tile, const u64 *TW, u32 k, u32 S, u32 x, u32 y, u32 by) {
+    const u32 half = 1u << (k - 1);
+    for (int s = (int)k - 1; s >= 0; s--) {
+        const u32 h = 1u << s;
+        for (u32 j = y; j < half; j += by) {
+            u32 off = j & (h - 1);
+            u32 p = ((j >> s) << (s + 1)) + off;
+            u64 a = tile[p * S + x], b = tile[(p + h) * S + x];
+            tile[p * S + x] = add(a, b);
+            tile[(p + h) * S + x] = mul(sub(a, b), TW[off << (k - 1 - s)]);
+        }
+        __syncthreads();
+    }
+}
+// Cooley-Tukey: bit-reversed in -> natural out
+__device__ __forceinline__ void dit_stages(u64 *tile, const u64 *TW, u32 k, u32 S, u32 x, u32 y, u32 by) {
+    const u32 half = 1u << (k - 1);
+    for (u32 s = 0; s < k; s++) {
+        const u32 h = 1u << s;
+        for (u32 j = y; j < half; j += by) {
+            u32 off = j & (h - 1);
+            u32 p = ((j >> s) << (s + 1)) + off;
+            u64 a = tile[p * S + x], b = mul(tile[(p + h) * S + x], TW[off << (k - 1 - s)]);
+            tile[p * S + x] = add(a, b);
+            tile[(p + h) * S + x] = sub(a, b);
+        }
+        __syncthreads();
+    }
+}
+
+struct PassParams {
+    const u64 *src; u64 *dst;
+    const u64 *tw;                  // pow256 table of the transform's 2^32-th root (forward or inverse)
+    u64 C;                          // matrix columns
+    u64 tStride, gStride, hiStride; // words between tile rows / slot groups / tiles along the outer index
+    u64 scale;                      // 0: none; else every output is multiplied by it (1/N of an inverse transform)
+    u32 k, logM, hasTw, dit;
+    u32 Wc, nbT;                    // tile slots S = nbT*Wc : nbT adjacent groups x Wc columns
+    u32 nColChunks, nGroupTiles;
+    u32 n, scatter;                 // scatter: store row bitrev_n(g*2^k + t) (lo = 0 pass of a natural-order transform)
+};
+
+__global__ void ntt_pass_kernel(PassParams P) {
+    extern __shared__ u64 lds[];
+    const u32 k = P.k, K = 1u << k, S = blockDim.x, by = blockDim.y;
+    const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
+    u64 *tile = lds, *TW = tile + ((size_t)S << k), *TWO = TW + (K > 1 ? K / 2 : 1);
+
+    u32 bid = blockIdx.x;
+    const u32 cc = bid % P.nColChunks; bid /= P.nColChunks;
+    const u32 gt = bid % P.nGroupTiles;
+    const u32 hi = bid / P.nGroupTiles;
+    const u32 gi = x / P.Wc, ci = x - gi * P.Wc;
+    const u64 c = (u64)cc * P.Wc + ci;
+    const bool valid = c < P.C;
+    const u64 g = (u64)gt * P.nbT + gi;
+    const u64 base = (u64)hi * P.hiStride + g * P.gStride + c;
+
+    for (u32 j = tid; j < K / 2; j += nth) TW[j] = root_pow(P.tw, k, j);
+    if (P.hasTw) {
+        for (u32 idx = tid; idx < P.nbT * K; idx += nth) {
+            u32 b = gt * P.nbT + (idx >> k);
+            u64 v = root_pow(P.tw, P.logM, b * bitrev32(idx & (K - 1), k));
+            if (P.scale) v = mul(v, P.scale);
+            TWO[idx] = v;
+        }
+    }
+    __syncthreads();
+    for (u32 t = y; t < K; t += by) {
+        u64 v = valid ? P.src[base + (u64)t * P.tStride] : 0;
+        if (P.dit && P.hasTw) v = mul(v, TWO[gi * K + t]);
+        tile[t * S + x] = v;
+    }
+    __syncthreads();
+    if (P.dit) dit_stages(tile, TW, k, S, x, y, by); else dif_stages(tile, TW, k, S, x, y, by);
+    if (!valid) return;
+    for (u32 t = y; t < K; t += by) {
+        u64 v = tile[t * S + x];
+        if (P.hasTw) { if (!P.dit) v = mul(v, TWO[gi * K + t]); }
+        else if (P.scale) v = mul(v, P.scale);
+        u64 addr = P.scatter ? (u64)bitrev32((u32)(g * K + t), P.n) * P.C + c : base + (u64)t * P.tStride;
+        P.dst[addr] = v;
+    }
+}
+
+struct LdeParams {
+    const u64 *src; u64 *dst;
+    const u64 *twi, *twf, *pow7;    // pow256 tables: inverse root, forward root, coset shift 7
+    u64 C, ninv;
+    u32 n, k, extBits;
+    u32 Wc, G, nColChunks;
+};
+
+// Finishes the iNTT on bits [0,k), scales by the coset factors and starts the forward NTT (see header).
+template <int EPT>
+__global__ void lde_mid_kernel(LdeParams P) {
+    extern __shared__ u64 lds[];
+    const u32 k = P.k, K = 1u << k, S = blockDim.x, by = blockDim.y;
+    const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
+    u64 *tile = lds, *TWi = tile + ((size_t)S << k), *TWf = TWi + K / 2, *Sc = TWf + K / 2, *Uc = Sc + (size_t)P.G * K;
+
+    u32 bid = blockIdx.x;
+    const u32 cc = bid % P.nColChunks;
+    const u32 gt = bid / P.nColChunks;
+    const u32 gi = x / P.Wc, ci = x - gi * P.Wc;
+    const u64 c = (u64)cc * P.Wc + ci;
+    const bool valid = c < P.C;
+    const u64 g = (u64)gt * P.G + gi;               // index of this slot's 2^k-row block
+    const u64 base = g * K * P.C + c;
+
+    for (u32 j = tid; j < K / 2; j += nth) { TWi[j] = root_pow(P.twi, k, j); TWf[j] = root_pow(P.twf, k, j); }
+    for (u32 idx = tid; idx < P.G * K; idx += nth) {
+        u32 pos = (gt * P.G + (idx >> k)) * K + (idx & (K - 1));
+        u32 m = bitrev32(pos, P.n);                 // this row holds coefficient m of the column polynomial
+        Sc[idx] = mul(P.ninv, pow256(P.pow7, m));   // 7^m / N              (coset j = 0)
+        Uc[idx] = root_pow(P.twf, P.n + P.extBits, m);   // w_E^m : step from coset j to j+1
+    }
+    for (u32 t = y; t < K; t += by) tile[t * S + x] = valid ? P.src[base + (u64)t * P.C] : 0;
+    __syncthreads();
+    dif_stages(tile, TWi, k, S, x, y, by);
+    u64 coef[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) { u32 t = y + i * by; coef[i] = t < K ? tile[t * S + x] : 0; }
+    __syncthreads();
+    const u32 nCosets = 1u << P.extBits;
+    for (u32 j = 0; j < nCosets; j++) {
+#pragma unroll
+        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[t * S + x] = mul(coef[i], Sc[gi * K + t]); }
+        __syncthreads();
+        dit_stages(tile, TWf, k, S, x, y, by);
+        if (valid) {
+#pragma unroll
+            for (int i = 0; i < EPT; i++) {
+                u32 t = y + i * by;
+                if (t < K) P.dst[(((g * K + t) << P.extBits) + j) * P.C + c] = tile[t * S + x];
+            }
+        }
+        for (u32 idx = tid; idx < P.G * K; idx += nth) Sc[idx] = mul(Sc[idx], Uc[idx]);
+        __syncthreads();
+    }
+}
+
+__global__ void copy_rows_kernel(const u64 *src, u64 *dst, u64 nWords) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nWords) dst[i] = src[i];
+}
+__global__ void broadcast_row_kernel(const u64 *src, u64 *dst, u64 C, u64 rows) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * C) dst[i] = src[i % C];
+}
+
+// ---------------------------------------------------------------- host-side planning
+using namespace pil2gl;
+
+u32 env_u32(const char *name, u32 dflt) { const char *s = getenv(name); return s ? (u32)atoi(s) : dflt; }
+u32 pow2floor(u64 v) { u32 r = 1; while ((u64)r * 2 <= v) r *= 2; return r; }
+
+struct Geom { u32 Wc, nbT, nColChunks, S, by; };
+// tile slots for 2^k rows: at most maxElems u64 in LDS, S*by = up to nThreads threads
+Geom make_geom(u32 k, u64 C, u64 totalGroups, u32 maxElems, u32 nThreads) {
+    Geom g;
+    u32 smax = std::min<u32>(256, std::max<u32>(1, maxElems >> k));
+    if (C <= smax) {
+        g.Wc = (u32)C;
+        g.nbT = (u32)std::min<u64>(pow2floor(smax / C), totalGroups);
+        g.nColChunks = 1;
+    } else {
+        u32 chunks = (u32)((C + smax - 1) / smax);
+        g.Wc = (u32)((C + chunks - 1) / chunks);
+        g.nbT = 1;
+        g.nColChunks = (u32)((C + g.Wc - 1) / g.Wc);
+    }
+    g.S = g.Wc * g.nbT;
+    u32 half = k > 0 ? (1u << (k - 1)) : 1;
+    g.by = std::max<u32>(1, std::min<u32>(nThreads / g.S, half));
+    return g;
+}
+
+int set_lds(const void *fn, size_t bytes) {
+    if (bytes > 160 * 1024) return fail(PIL2GL_EINVAL, "tile needs %zu bytes of LDS (>160 KiB)", bytes);
+    if (bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PIL2GL_OK;
+}
+
+// One pass over index bits [lo, lo+k) of a 2^n x C matrix.
+int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit, bool inverse, u64 scale, bool scatter, hipStream_t st) {
+    PassParams P;
+    P.src = src; P.dst = dst;
+    P.tw = inverse ? tables().powWi : tables().powW;
+    P.C = C; P.scale = scale; P.k = k; P.logM = lo + k; P.hasTw = lo > 0; P.dit = dit; P.n = n; P.scatter = scatter;
+    u64 totalGroups;
+    u32 nHi;
+    if (lo > 0) { P.tStride = (C << lo); P.gStride = C; P.hiStride = (C << (lo + k)); totalGroups = 1ull << lo; nHi = 1u << (n - lo - k); }
+    else { P.tStride = C; P.gStride = (C << k); P.hiStride = 0; totalGroups = 1ull << (n - k); nHi = 1; }
+    Geom g = make_geom(k, C, totalGroups, env_u32("PIL2GL_NTT_TILE", 8192), 256);
+    P.Wc = g.Wc; P.nbT = g.nbT; P.nColChunks = g.nColChunks; P.nGroupTiles = (u32)(totalGroups / g.nbT);
+    u64 K = 1ull << k;
+    size_t ldsBytes = 8 * ((size_t)g.S * K + std::max<u64>(1, K / 2) + (P.hasTw ? (size_t)g.nbT * K : 0));
+    P2_TRY(set_lds((const void *)ntt_pass_kernel, ldsBytes));
+    u64 blocks = (u64)nHi * P.nGroupTiles * P.nColChunks;
+    if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
+    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)blocks), dim3(g.S, g.by), ldsBytes, st, P);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+// split `bits` into ceil(bits/kmax) nearly equal passes
+int split_bits(u32 bits, u32 kmax, u32 *ks) {
+    if (bits == 0) return 0;
+    u32 np = (bits + kmax - 1) / kmax, base = bits / np, extra = bits % np;
+    for (u32 i = 0; i < np; i++) ks[i] = base + (i < extra ? 1 : 0);
+    return (int)np;
+}
+
+}  // namespace
+
+namespace pil2gl {
+
+int ntt_launch(const u64 *src, u64 C, u32 n, u64 *dst, bool inverse, hipStream_t st) {
+    if (C == 0) return PIL2GL_OK;
+    u64 N = 1ull << n;
+    if (n == 0) {
+        if (src != dst) HIP_TRY(hipMemcpyAsync(dst, src, C * 8, hipMemcpyDeviceToDevice, st));
+        return PIL2GL_OK;
+    }
+    u32 kmax = std::min<u32>(10, std::max<u32>(1, env_u32("PIL2GL_NTT_KMAX", 10)));
+    u32 ks[32];
+    int np = split_bits(n, kmax, ks);
+    u64 scale = inverse ? h_inv(N % 0xFFFFFFFF00000001ull) : 0;
+    if (np == 1) return launch_pass(src, dst, C, n, 0, n, false, inverse, scale, true, st);
+    u64 *tmp;
+    P2_TRY(scratch(0, N * C, &tmp));
+    u32 lo = n;
+    for (int i = 0; i < np; i++) {
+        lo -= ks[i];
+        const u64 *in = i == 0 ? src : tmp;
+        u64 *out = i == np - 1 ? dst : tmp;
+        P2_TRY(launch_pass(in, out, C, n, lo, ks[i], false, inverse, i == 0 ? scale : 0, i == np - 1, st));
+    }
+    return PIL2GL_OK;
+}
+
+int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st) {
+    if (C == 0) return PIL2GL_OK;
+    u32 eb = nExt - n;
+    u64 N = 1ull << n, E = 1ull << nExt;
+    if (n == 0) {                       // constant polynomial: every coset point evaluates to it
+        broadcast_row_kernel<<<(unsigned)((E * C + 255) / 256), 256, 0, st>>>(src, dst, C, E);
+        KERNEL_CHECK();
+        return PIL2GL_OK;
+    }
+    u32 kmax = std::min<u32>(10, std::max<u32>(1, env_u32("PIL2GL_NTT_KMAX", 10)));
+    u32 nfp = (n + kmax - 1) / kmax;
+    u32 kf = (n + nfp - 1) / nfp;       // bits done by the mid kernel (both directions)
+    // 1. iNTT, decimation in frequency, bits [kf, n) from the top down: src -> tmp, then in place
+    const u64 *coef = src;
+    if (n > kf) {
+        u32 ks[32];
+        int np = split_bits(n - kf, kmax, ks);
+        u64 *tmp;
+        P2_TRY(scratch(0, N * C, &tmp));
+        u32 lo = n;
+        for (int i = 0; i < np; i++) {
+            lo -= ks[i];
+            P2_TRY(launch_pass(i == 0 ? src : tmp, tmp, C, n, lo, ks[i], false, true, 0, false, st));
+        }
+        coef = tmp;
+    }
+    // 2. mid kernel: last kf iNTT stages + coset scaling + first kf NTT stages, tmp -> dst
+    {
+        LdeParams P;
+        P.src = coef; P.dst = dst; P.twi = tables().powWi; P.twf = tables().powW; P.pow7 = tables().pow7;
+        P.C = C; P.ninv = h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb;
+        u64 totalGroups = 1ull << (n - kf);
+        u32 nThreads = env_u32("PIL2GL_LDE_THREADS", 1024);
+        Geom g = make_geom(kf, C, totalGroups, env_u32("PIL2GL_LDE_TILE", 8192), nThreads);
+        P.Wc = g.Wc; P.G = g.nbT; P.nColChunks = g.nColChunks;
+        u64 K = 1ull << kf;
+        size_t ldsBytes = 8 * ((size_t)g.S * K + std::max<u64>(2, K) + 2 * (size_t)g.nbT * K);
+        u32 need = (u32)((K + g.by - 1) / g.by);
+        u64 blocks = (totalGroups / g.nbT) * g.nColChunks;
+        if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
+        dim3 grid((unsigned)blocks), block(g.S, g.by);
+#define LDE_CASE(E_)                                                                              \
+        if (need <= E_) {                                                                         \
+            P2_TRY(set_lds((const void *)lde_mid_kernel<E_>, ldsBytes));                           \
+            hipLaunchKernelGGL(lde_mid_kernel<E_>, grid, block, ldsBytes, st, P);                  \
+        } else
+        LDE_CASE(1) LDE_CASE(2) LDE_CASE(4) LDE_CASE(8) LDE_CASE(16) LDE_CASE(32) LDE_CASE(64)
+        { return fail(PIL2GL_EINVAL, "lde tile too tall for the thread block (need %u rows per thread)", need); }
+#undef LDE_CASE
+        KERNEL_CHECK();
+    }
+    // 3. remaining forward stages, decimation in time, bits [kf, n) from the bottom up, in place on
+    //    dst viewed as N x (C * 2^eb)
+    if (n > kf) {
+        u32 ks[32];
+        int np = split_bits(n - kf, kmax, ks);
+        u32 lo = kf;
+        for (int i = 0; i < np; i++) {
+            P2_TRY(launch_pass(dst, dst, C << eb, n, lo, ks[i], true, false, 0, false, st));
+            lo += ks[i];
+        }
+    }
+    return PIL2GL_OK;
+}
+
+}  // namespace pil2gl
+
+using namespace pil2gl;
+
+static int check_ntt_args(const void *src, const void *dst, uint32_t nBits, uint32_t nBitsExt) {
+    if (!src || !dst) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nBits > 27 || nBitsExt > 27) return fail(PIL2GL_EINVAL, "domain of 2^%u rows is not supported (max 2^27)", nBits > nBitsExt ? nBits : nBitsExt);
+    if (nBitsExt < nBits) return fail(PIL2GL_EINVAL, "nBitsExt (%u) < nBits (%u)", nBitsExt, nBits);
+    return PIL2GL_OK;
+}
+
+extern "C" {
+
+int pil2gl_interpolate_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt, void *stream) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_ntt_args(src, dst, nBits, nBitsExt));
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream));
+}
+int pil2gl_fft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, void *stream) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_ntt_args(src, dst, nBits, nBits));
+    return ntt_launch(src, nPols, nBits, dst, false, as_stream(stream));
+}
+int pil2gl_ifft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, void *stream) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_ntt_args(src, dst, nBits, nBits));
+    return ntt_launch(src, nPols, nBits, dst, true, as_stream(stream));
+}
+
+static int host_wrap(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsOut, int mode) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_ntt_args(src, dst, nBits, nBitsOut));
+    uint64_t nIn = (nPols << nBits), nOut = (nPols << nBitsOut);
+    if (nIn == 0) return PIL2GL_OK;
+    uint64_t *dIn = nullptr, *dOut = nullptr;
+    HIP_TRY(hipMalloc((void **)&dIn, nIn * 8));
+    hipError_t e = hipMalloc((void **)&dOut, nOut * 8);
+    if (e != hipSuccess) { (void)hipFree(dIn); return hip_fail(e, "hipMalloc(dst)"); }
+    int rc = PIL2GL_OK;
+    e = hipMemcpy(dIn, src, nIn * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
+    if (rc == PIL2GL_OK) rc = mode == 0 ? lde_launch(dIn, nPols, nBits, dOut, nBitsOut, 0) : ntt_launch(dIn, nPols, nBits, dOut, mode == 2, 0);
+    if (rc == PIL2GL_OK) { e = hipMemcpy(dst, dOut, nOut * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
+    (void)hipFree(dIn); (void)hipFree(dOut);
+    return rc;
+}
+int pil2gl_interpolate(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt) { return host_wrap(src, nPols, nBits, dst, nBitsExt, 0); }
+int pil2gl_fft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst) { return host_wrap(src, nPols, nBits, dst, nBits, 1); }
+int pil2gl_ifft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst) { return host_wrap(src, nPols, nBits, dst, nBits, 2); }
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Poseidon-12 permutation over Goldilocks for gfx950, one permutation per lane.
+//
+// Spec: the un-optimised 30-round form of the reference's WASM kernel,
+// src/helpers/glwasm.js:216-426 (round constants :535-627; x^7 on all lanes in rounds 0-3 and
+// 26-29, on lane 0 otherwise :377-384; MDS = circ(17,15,41,16,2,28,13,13,39,18,34,20) + diag(8,0,..)
+// :428-440).  It equals, mod p, the optimised JS form hash/poseidon/poseidon.js:57-108.  The dense
+// 64-bit matrices of the optimised form would cost 23 full multiplications per partial round on
+// a machine without a 64-bit multiplier; the circulant form only needs 6-bit constants.
+//
+// Values stay "lazy" (any u64 representative) between rounds; outputs are canonicalised.
+#pragma once
+#include "gl_field.cuh"
+
+namespace gl {
+
+#define POSEIDON_GL_RC_QUAL static __device__
+#include "poseidon_gl_constants.inc"     // POSEIDON_GL_RC[360]: round r, lane i at [12*r+i]
+#undef POSEIDON_GL_RC_QUAL
+
+__device__ __forceinline__ u64 pow7_lazy(u64 x) {
+    u64 x2 = mul_lazy(x, x);
+    u64 x3 = mul_lazy(x2, x);
+    u64 x4 = mul_lazy(x2, x2);
+    return mul_lazy(x3, x4);
+}
+
+// out = M * st with the 6-bit circulant: accumulate the low and high 32-bit halves separately
+// (each sum < 2^32 * 272 < 2^41), recombine to a 97-bit value and reduce once.
+__device__ __forceinline__ void mds_layer(u64 st[12]) {
+    constexpr u32 MC[12] = { 17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20 };
+    u32 lo[12], hi[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) { lo[j] = (u32)st[j]; hi[j] = (u32)(st[j] >> 32); }
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        u64 al = 0, ah = 0;
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const u32 m = MC[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
+            al += (u64)lo[j] * m;
+            ah += (u64)hi[j] * m;
+        }
+        // value = al + ah * 2^32  (< 2^74):  lo64 = al + (ah << 32), hi64 = (ah >> 32) + carry
+        u64 l = al + (ah << 32);
+        u64 h = (ah >> 32) + (l < al ? 1 : 0);
+        st[i] = reduce128_lazy(l, h);
+    }
+}
+
+// in-place permutation; st[] canonical or lazy in, canonical out
+__device__ inline void poseidon_perm(u64 st[12]) {
+#pragma unroll 1
+    for (int r = 0; r < 30; r++) {
+        const bool full = (r < 4) || (r >= 26);
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = add_lazy(st[i], POSEIDON_GL_RC[r * 12 + i]);
+        if (full) {
+#pragma unroll
+            for (int i = 0; i < 12; i++) st[i] = pow7_lazy(st[i]);
+        } else {
+            st[0] = pow7_lazy(st[0]);
+        }
+        mds_layer(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = canon(st[i]);
+}
+
+}  // namespace gl

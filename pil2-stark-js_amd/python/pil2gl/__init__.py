@@ -1,0 +1,409 @@
+"""Python host-side mirror of the reference's L2 operator interface over libpil2gl.so.
+
+Same names, argument order and error behaviour as the JavaScript modules they stand for
+(`interpolate/fft/ifft`: src/helpers/fft/fft_p.js:178-302; `buildMerkleHash`/`MerkleHash`:
+src/helpers/hash/merklehash/merklehash_p.js:12-279; `FRI`: src/stark/fri.js:7-175; `Transcript`:
+src/helpers/transcript/transcript.js), so the parity tests read like the reference's own tests.
+The Node.js binding of the same C ABI lives in ../../js and ../../addon.
+
+Buffers are numpy uint64 arrays (host: copy in / compute on the GPU / copy out) or torch CUDA
+tensors of dtype int64/uint64 (device resident, enqueued on torch's current stream, no sync).
+Every computation runs in the HIP library; nothing falls back to the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Pil2glError, load, call  # noqa: F401
+
+P = 0xFFFFFFFF00000001
+SHIFT = 7
+
+try:  # torch is only plumbing (device memory + streams); the library itself does not need it
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+def _is_dev(b):
+    return torch is not None and isinstance(b, torch.Tensor)
+
+
+def _ptr(b):
+    if b is None:
+        return None
+    if _is_dev(b):
+        if not b.is_cuda:
+            raise Pil2glError("torch tensors must live on the GPU (use numpy arrays for host buffers)")
+        if b.dtype not in (torch.int64, torch.uint64) or not b.is_contiguous():
+            raise Pil2glError("device buffers must be contiguous int64/uint64 tensors")
+        return C.c_void_p(b.data_ptr())
+    if not isinstance(b, np.ndarray) or b.dtype != np.uint64 or not b.flags["C_CONTIGUOUS"]:
+        raise Pil2glError("host buffers must be C-contiguous numpy uint64 arrays")
+    return C.c_void_p(b.ctypes.data)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _same_side(*bufs):
+    dev = [_is_dev(b) for b in bufs if b is not None]
+    if any(dev) and not all(dev):
+        raise Pil2glError("mixing host and device buffers in one call")
+    return bool(dev and dev[0])
+
+
+def init(device=0):
+    call("pil2gl_init", int(device))
+
+
+def device_info():
+    name = C.create_string_buffer(64); cus = C.c_uint32(); mem = C.c_uint64()
+    call("pil2gl_device_info", name, 64, C.byref(cus), C.byref(mem))
+    return name.value.decode(), cus.value, mem.value
+
+
+# ----------------------------------------------------------------------------- fft_p.js
+def _check_len(buf, n, what):
+    if buf is not None and int(np.prod(buf.shape)) < n:
+        raise Pil2glError("%s has %d elements, needs %d" % (what, int(np.prod(buf.shape)), n))
+
+
+def interpolate(buffSrc, nPols, nBits, buffDst, nBitsExt):
+    """fft_p.js:187 interpolate(buffSrc, nPols, nBits, buffDst, nBitsExt); dst is caller-allocated."""
+    _check_len(buffSrc, nPols << nBits, "buffSrc"); _check_len(buffDst, nPols << nBitsExt, "buffDst")
+    if _same_side(buffSrc, buffDst):
+        call("pil2gl_interpolate_dev", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), nBitsExt, _stream())
+    else:
+        call("pil2gl_interpolate", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), nBitsExt)
+
+
+def fft(buffSrc, nPols, nBits, buffDst):
+    """fft_p.js:178"""
+    _check_len(buffSrc, nPols << nBits, "buffSrc"); _check_len(buffDst, nPols << nBits, "buffDst")
+    if _same_side(buffSrc, buffDst):
+        call("pil2gl_fft_dev", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), _stream())
+    else:
+        call("pil2gl_fft", _ptr(buffSrc), nPols, nBits, _ptr(buffDst))
+
+
+def ifft(buffSrc, nPols, nBits, buffDst):
+    """fft_p.js:182"""
+    _check_len(buffSrc, nPols << nBits, "buffSrc"); _check_len(buffDst, nPols << nBits, "buffDst")
+    if _same_side(buffSrc, buffDst):
+        call("pil2gl_ifft_dev", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), _stream())
+    else:
+        call("pil2gl_ifft", _ptr(buffSrc), nPols, nBits, _ptr(buffDst))
+
+
+# ----------------------------------------------------------------------------- poseidon / linear hash
+def poseidon(inputs, capacity=None, nOuts=4):
+    """hash/poseidon/poseidon.js:57 poseidon(inputs[8], capacity[4]?, nOuts=4) -> list of ints"""
+    if len(inputs) != 8:
+        raise Pil2glError("Invalid Input size (must be 8)")
+    if capacity is not None and len(capacity) != 4:
+        raise Pil2glError("Invalid Capacity size (must be 4)")
+    i = np.array([int(v) % P for v in inputs], dtype=np.uint64)
+    c = np.array([int(v) % P for v in capacity], dtype=np.uint64) if capacity is not None else None
+    o = np.zeros(nOuts, np.uint64)
+    call("pil2gl_poseidon", _ptr(i), _ptr(c), 1, nOuts, _ptr(o))
+    return [int(v) for v in o]
+
+
+def poseidon_batch(inp, cap=None, nOuts=4):
+    inp = np.ascontiguousarray(inp, dtype=np.uint64).reshape(-1, 8)
+    if cap is not None:
+        cap = np.ascontiguousarray(cap, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((inp.shape[0], nOuts), np.uint64)
+    call("pil2gl_poseidon", _ptr(inp), _ptr(cap), inp.shape[0], nOuts, _ptr(out))
+    return out
+
+
+def linearHash(buffIn, width, splitLinearHash=False, out=None):
+    """merklehash_worker.js:37 linearHash(buffIn, width, st_i, st_n, splitLinearHash) -> height x 4 digests"""
+    n = int(np.prod(buffIn.shape))
+    height = n // width if width else 0
+    if _is_dev(buffIn):
+        if out is None:
+            out = torch.empty(height * 4, dtype=torch.int64, device=buffIn.device)
+        call("pil2gl_linear_hash_rows_dev", _ptr(buffIn), width, height, int(bool(splitLinearHash)), _ptr(out), _stream())
+    else:
+        if out is None:
+            out = np.zeros(height * 4, np.uint64)
+        call("pil2gl_linear_hash_rows", _ptr(buffIn), width, height, int(bool(splitLinearHash)), _ptr(out))
+    return out
+
+
+def merkelizeLevel(buffIn, out=None):
+    """merklehash_worker.js:86 merkelizeLevel(buffIn, st_i, st_n): 8 words in -> 4 words out per op"""
+    nOps = int(np.prod(buffIn.shape)) // 8
+    if _is_dev(buffIn):
+        if out is None:
+            out = torch.empty(nOps * 4, dtype=torch.int64, device=buffIn.device)
+        call("pil2gl_merkelize_level_dev", _ptr(buffIn), nOps, _ptr(out), _stream())
+    else:
+        if out is None:
+            out = np.zeros(nOps * 4, np.uint64)
+        call("pil2gl_merkelize_level", _ptr(buffIn), nOps, _ptr(out))
+    return out
+
+
+class _LinearHash:
+    """linearhash.js / linearhash_gpu.js: hash(vals) -> [4 ints]"""
+
+    def __init__(self, split):
+        self.split = bool(split)
+
+    def hash(self, vals):
+        flat = []
+        for v in vals:
+            if isinstance(v, (list, tuple, np.ndarray)):
+                flat.extend(int(x) for x in v)
+            else:
+                flat.append(int(v))
+        if not flat:
+            return [0, 0, 0, 0]
+        a = np.array(flat, dtype=np.uint64)
+        return [int(x) for x in linearHash(a, len(flat), self.split)]
+
+
+# ----------------------------------------------------------------------------- merklehash_p.js
+class MerkleHash:
+    """merklehash_p.js:19-279.  `tree` is a dict {elements, nodes, width, height}; elements aliases the
+    caller's buffer (merklehash_p.js:47), nodes is newly allocated on the same side as elements."""
+
+    def __init__(self, splitLinearHash=False):
+        self.splitLinearHash = bool(splitLinearHash)
+        self.lh = _LinearHash(splitLinearHash)
+        load()
+
+    def _getNNodes(self, n):
+        """merklehash_p.js:28 (n = number of u64 words of the leaf level = 4*height)"""
+        return int(load().pil2gl_merkle_num_nodes(n // 4))
+
+    def merkelize(self, buff, width, height):
+        if height <= 0:
+            raise Pil2glError("height must be > 0")
+        _check_len(buff, width * height, "buff")
+        n_nodes = self._getNNodes(height * 4)
+        if _is_dev(buff):
+            nodes = torch.empty(n_nodes, dtype=torch.int64, device=buff.device)
+            call("pil2gl_merkelize_dev", _ptr(buff), width, height, int(self.splitLinearHash), _ptr(nodes), _stream())
+        else:
+            nodes = np.zeros(n_nodes, np.uint64)
+            call("pil2gl_merkelize", _ptr(buff), width, height, int(self.splitLinearHash), _ptr(nodes))
+        return {"elements": buff, "nodes": nodes, "width": width, "height": height}
+
+    def getElement(self, tree, idx, subIdx):
+        return _word(tree["elements"], tree["width"] * idx + subIdx)
+
+    def root(self, tree):
+        n = tree["nodes"]
+        last = n[-4:]
+        if _is_dev(last):
+            last = last.cpu().numpy().view(np.uint64)
+        return [int(v) for v in last]
+
+    def getGroupProof(self, tree, idx):
+        if idx < 0 or idx >= tree["height"]:
+            raise Pil2glError("Out of range")
+        width, height = tree["width"], tree["height"]
+        if _is_dev(tree["nodes"]):
+            vals = np.zeros(max(width, 1), np.uint64); sib = np.zeros((64, 4), np.uint64); nl = C.c_uint32()
+            call("pil2gl_group_proof_dev", _ptr(tree["elements"]), _ptr(tree["nodes"]), width, height, idx,
+                 _ptr(vals), _ptr(sib), C.byref(nl))
+            return [int(v) for v in vals[:width]], [[int(x) for x in s] for s in sib[:nl.value]]
+        el = tree["elements"].reshape(-1)
+        v = [int(x) for x in el[idx * width:(idx + 1) * width]]
+        nodes = tree["nodes"]; mp = []; offset = 0; n = height * 4
+        while n > 4:                                    # merklehash_p.js:154-167
+            si = (idx ^ 1) * 4
+            mp.append([int(x) for x in nodes[offset + si:offset + si + 4]])
+            nextN = ((n - 1) // 8 + 1) * 4
+            offset += nextN * 2; n = nextN; idx >>= 1
+        return v, mp
+
+    def calculateRootFromGroupProof(self, mp, idx, vals):
+        value = self.lh.hash(vals)                      # merklehash_p.js:170-210
+        for sib in mp:
+            if idx & 1 == 0:
+                value = poseidon(list(value) + list(sib))
+            else:
+                value = poseidon(list(sib) + list(value))
+            idx >>= 1
+        return value
+
+    def eqRoot(self, r1, r2):
+        return all(int(a) % P == int(b) % P for a, b in zip(r1, r2))
+
+    def verifyGroupProof(self, root, mp, idx, groupElements):
+        return self.eqRoot(self.calculateRootFromGroupProof(mp, idx, groupElements), root)
+
+    def writeToFile(self, tree, fileName):
+        """merklehash_p.js:228-246: [width u64][height u64][elements][nodes], little-endian u64"""
+        with open(fileName, "wb") as f:
+            np.array([tree["width"], tree["height"]], dtype="<u8").tofile(f)
+            _to_host(tree["elements"]).astype("<u8", copy=False).tofile(f)
+            _to_host(tree["nodes"]).astype("<u8", copy=False).tofile(f)
+
+    def readFromFile(self, fileName, device=None):
+        """merklehash_p.js:248-278"""
+        with open(fileName, "rb") as f:
+            width, height = (int(v) for v in np.fromfile(f, dtype="<u8", count=2))
+            elements = np.fromfile(f, dtype="<u8", count=width * height).astype(np.uint64)
+            nodes = np.fromfile(f, dtype="<u8", count=self._getNNodes(height * 4)).astype(np.uint64)
+        if device is not None:
+            elements = torch.from_numpy(elements.view(np.int64)).to(device)
+            nodes = torch.from_numpy(nodes.view(np.int64)).to(device)
+        return {"elements": elements, "nodes": nodes, "width": width, "height": height}
+
+
+def buildMerkleHash(splitLinearHash=False):
+    """merklehash_p.js:12"""
+    return MerkleHash(splitLinearHash)
+
+
+def _to_host(b):
+    if _is_dev(b):
+        return b.reshape(-1).cpu().numpy().view(np.uint64)
+    return b.reshape(-1)
+
+
+def _word(b, i):
+    if _is_dev(b):
+        return int(b.reshape(-1)[i:i + 1].cpu().numpy().view(np.uint64)[0])
+    return int(b.reshape(-1)[i])
+
+
+# ----------------------------------------------------------------------------- transcript.js
+class Transcript:
+    """transcript.js:2-85 (host-side duplex sponge; every permutation runs through pil2gl_poseidon)"""
+
+    def __init__(self):
+        self.state = [0, 0, 0, 0]
+        self.pending = []
+        self.out = []
+
+    def getState(self):
+        if self.pending:
+            self.updateState()
+        return self.state
+
+    def getField(self):
+        return [self.getFields1(), self.getFields1(), self.getFields1()]
+
+    def getFields1(self):
+        if not self.out:
+            self.updateState()
+        return self.out.pop(0)
+
+    def put(self, a):
+        if isinstance(a, (list, tuple, np.ndarray)):
+            for v in a:
+                self.put(v)
+        else:
+            self._add1(int(a))
+
+    def updateState(self):
+        while len(self.pending) < 8:
+            self.pending.append(0)
+        self.out = poseidon(self.pending, self.state, 12)
+        self.pending = []
+        self.state = self.out[:4]
+
+    def _add1(self, a):
+        self.out = []
+        self.pending.append(a)
+        if len(self.pending) == 8:
+            self.out = poseidon(self.pending, self.state, 12)
+            self.pending = []
+            self.state = self.out[:4]
+
+    def getPermutations(self, n, nBits):
+        totalBits = n * nBits
+        NFields = (totalBits - 1) // 63 + 1
+        fields = [self.getFields1() for _ in range(NFields)]
+        res = []; curField = 0; curBit = 0
+        for _ in range(n):
+            a = 0
+            for j in range(nBits):
+                if (fields[curField] >> curBit) & 1:
+                    a += 1 << j
+                curBit += 1
+                if curBit == 63:
+                    curBit = 0; curField += 1
+            res.append(a)
+        return res
+
+
+# ----------------------------------------------------------------------------- fri.js
+def _inv(a):
+    return pow(int(a), P - 2, P)
+
+
+class FRI:
+    """fri.js:7-105.  Polynomials are (n,3) uint64 arrays / int64 CUDA tensors of extension elements."""
+
+    def __init__(self, starkStruct, MH):
+        if not starkStruct:
+            raise Pil2glError("stark struct not defined")
+        self.inNBits = starkStruct["nBitsExt"]
+        self.maxDegNBits = starkStruct["nBits"]
+        self.nQueries = starkStruct["nQueries"]
+        self.steps = starkStruct["steps"]
+        self.MH = MH
+
+    def fold(self, step, pol, challenge):
+        n = int(np.prod(pol.shape)) // 3
+        polBits = n.bit_length() - 1
+        if step == 0:
+            assert polBits == self.inNBits, "Invalid polynomial size"
+        else:
+            assert (1 << polBits) == n, "Invalid polynomial size"
+        shiftInv = _inv(SHIFT)                          # fri.js:31-36
+        if step > 0:
+            for _ in range(self.steps[0]["nBits"] - self.steps[step - 1]["nBits"]):
+                shiftInv = shiftInv * shiftInv % P
+        outBits = self.steps[step]["nBits"]
+        dev = _is_dev(pol)
+        if step == 0:                                   # fri.js:48-49
+            pol2_e = pol
+        else:
+            ch = np.array([int(c) % P for c in challenge], dtype=np.uint64)
+            if dev:
+                pol2_e = torch.empty((1 << outBits, 3), dtype=torch.int64, device=pol.device)
+                call("pil2gl_fri_fold_dev", _ptr(pol), polBits, outBits, shiftInv, _ptr(ch), _ptr(pol2_e), _stream())
+            else:
+                pol2_e = np.zeros((1 << outBits, 3), np.uint64)
+                call("pil2gl_fri_fold", _ptr(pol), polBits, outBits, shiftInv, _ptr(ch), _ptr(pol2_e))
+        tree = None
+        if step != len(self.steps) - 1:                 # fri.js:64-71
+            nGroupsBits = self.steps[step + 1]["nBits"]
+            nGroups = 1 << nGroupsBits
+            groupSize = (1 << outBits) // nGroups
+            if dev:
+                tb = torch.empty((1 << outBits) * 3, dtype=torch.int64, device=pol.device)
+                call("pil2gl_fri_transpose_dev", _ptr(pol2_e), outBits, nGroupsBits, _ptr(tb), _stream())
+            else:
+                tb = np.zeros((1 << outBits) * 3, np.uint64)
+                call("pil2gl_fri_transpose", _ptr(np.ascontiguousarray(pol2_e)), outBits, nGroupsBits, _ptr(tb))
+            tree = self.MH.merkelize(tb, 3 * groupSize, nGroups)
+            proof = {"root": self.MH.root(tree)}
+        else:                                           # fri.js:72-75
+            proof = [[int(x) for x in row] for row in _to_host(pol2_e).reshape(-1, 3)]
+        return {"pol": pol2_e, "tree": tree, "proof": proof}
+
+    def proofQueries(self, proof, trees, friQueries):
+        """fri.js:83-105"""
+        for step in range(len(self.steps)):
+            proof[step]["polQueries"] = []
+            if step == 0:
+                for q in friQueries:
+                    proof[step]["polQueries"].append([self.MH.getGroupProof(t, q) for t in trees[step]])
+            else:
+                for i in range(len(friQueries)):
+                    friQueries[i] = friQueries[i] % (1 << self.steps[step]["nBits"])
+                for q in friQueries:
+                    proof[step]["polQueries"].append(self.MH.getGroupProof(trees[step], q))

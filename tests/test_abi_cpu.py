@@ -1,0 +1,60 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol include/pil2gl.h declares,
+and refuses to compute without a GPU (no silent fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pil2gl = pytest.importorskip("pil2gl")
+from pil2gl import _lib  # noqa: E402
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "pil2gl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pil2gl_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 40
+    for n in names:
+        assert hasattr(lib, n), "libpil2gl.so does not export " + n
+    # the Python binding binds exactly the declared set
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_expr_struct_layout_matches_header():
+    # include/pil2gl_expr.h: glx_ref 16 bytes, glx_op 56 bytes
+    assert C.sizeof(_lib.GlxRef) == 16 and C.sizeof(_lib.GlxOp) == 56
+    assert C.sizeof(_lib.GlxSection) == 16
+
+
+def test_merkle_num_nodes_host_only(oracle):
+    lib = _lib.load()
+    for h in list(range(1, 70)) + [255, 256, 257, 1 << 20, (1 << 20) + 3]:
+        assert lib.pil2gl_merkle_num_nodes(h) == oracle.merkle_num_nodes(h)
+
+
+def _have_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="only meaningful on a machine without a GPU")
+def test_no_cpu_fallback_without_gpu():
+    a = np.arange(8, dtype=np.uint64)
+    out = np.zeros(16, np.uint64)
+    with pytest.raises(pil2gl.Pil2glError) as e:
+        pil2gl.interpolate(a, 1, 3, out, 4)
+    assert "-2" in str(e.value) or "no HIP device" in str(e.value)
+    with pytest.raises(pil2gl.Pil2glError):
+        pil2gl.buildMerkleHash(False).merkelize(a, 1, 8)

@@ -1,0 +1,408 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle, the golden vectors and the
+reference's own test shapes.  Bit-exact (integer field arithmetic, no tolerance)."""
+import numpy as np
+import pytest
+
+from conftest import golden, H, U, P, rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gl():
+    import pil2gl
+    pil2gl.init(0)
+    return pil2gl
+
+
+# ------------------------------------------------------------------ field
+def test_field_ops_device(gl, oracle):
+    from pil2gl import _lib
+    g = golden("field.json")
+    rows = H(g["mul"])
+    rng = np.random.default_rng(7)
+    a = np.concatenate([np.array([r[0] for r in rows], dtype=np.uint64), rand_field(rng, 4096)])
+    b = np.concatenate([np.array([r[1] for r in rows], dtype=np.uint64), rand_field(rng, 4096)])
+    m = np.zeros_like(a); s = np.zeros_like(a); d = np.zeros_like(a)
+    _lib.call("pil2gl_selftest_field", gl._ptr(a), gl._ptr(b), a.size, gl._ptr(m), gl._ptr(s), gl._ptr(d))
+    for i, r in enumerate(rows):
+        assert (int(m[i]), int(s[i]), int(d[i])) == (r[2], r[3], r[4])
+    for i in range(len(rows), a.size):
+        x, y = int(a[i]), int(b[i])
+        assert int(m[i]) == x * y % P and int(s[i]) == (x + y) % P and int(d[i]) == (x - y) % P
+
+
+def test_ext_ops_device(gl, oracle):
+    from pil2gl import _lib
+    rows = H(golden("field.json")["ext"])
+    a = np.array([r[0] for r in rows], dtype=np.uint64); b = np.array([r[1] for r in rows], dtype=np.uint64)
+    m = np.zeros_like(a); iv = np.zeros_like(a)
+    _lib.call("pil2gl_selftest_ext", gl._ptr(a), gl._ptr(b), a.shape[0], gl._ptr(m), gl._ptr(iv))
+    assert m.tolist() == [r[2] for r in rows] and iv.tolist() == [r[3] for r in rows]
+
+
+# ------------------------------------------------------------------ NTT / LDE  (test/fft_p.test.js shapes + random)
+def _index_matrix(nBits, nPols):
+    return np.ascontiguousarray(np.repeat(np.arange(1 << nBits, dtype=np.uint64)[:, None], nPols, axis=1))
+
+
+@pytest.mark.parametrize("nBits,nPols", [(5, 2), (3, 1), (1, 3), (0, 2), (10, 5), (11, 3), (12, 8), (13, 17), (18, 5)])
+def test_fft_ifft(gl, oracle, nBits, nPols):
+    rng = np.random.default_rng(nBits * 100 + nPols)
+    for a in (_index_matrix(nBits, nPols), rand_field(rng, ((1 << nBits), nPols))):
+        out = np.zeros_like(a)
+        gl.fft(a, nPols, nBits, out)
+        assert (out == oracle.fft_cols(a, nBits)).all()
+        gl.ifft(a, nPols, nBits, out)
+        assert (out == oracle.ifft_cols(a, nBits)).all()
+
+
+@pytest.mark.parametrize("nBits,nPols,extBits", [(3, 1, 1), (18, 5, 1), (5, 2, 3), (1, 1, 1), (0, 3, 2), (4, 100, 3),
+                                                 (10, 8, 3), (11, 8, 3), (12, 3, 2), (14, 9, 3), (16, 8, 3), (7, 33, 0)])
+def test_interpolate(gl, oracle, nBits, nPols, extBits):
+    rng = np.random.default_rng(nBits * 1000 + nPols * 10 + extBits)
+    for a in (_index_matrix(nBits, nPols), rand_field(rng, ((1 << nBits), nPols))):
+        out = np.zeros(((1 << (nBits + extBits)), nPols), np.uint64)
+        gl.interpolate(a, nPols, nBits, out, nBits + extBits)
+        assert (out == oracle.interpolate(a, nBits, nBits + extBits)).all()
+
+
+def test_interpolate_golden_kat(gl):
+    # SURVEY 8(c)(2) / tests/golden/ntt.json "index3" ext 1
+    c = [x for x in golden("ntt.json")["cases"] if x["name"] == "index3"][0]
+    out = np.zeros(16, np.uint64)
+    gl.interpolate(U(c["p"]), 1, 3, out, 4)
+    assert out.tolist() == H(c["ext"]["1"])
+
+
+def test_ntt_three_passes(gl, oracle):
+    # 2^21 rows forces three passes in every direction
+    rng = np.random.default_rng(21)
+    a = rand_field(rng, ((1 << 21), 1))
+    out = np.zeros_like(a)
+    gl.fft(a, 1, 21, out)
+    assert (out == oracle.fft_cols(a, 21)).all()
+    ext = np.zeros(((1 << 22), 1), np.uint64)
+    gl.interpolate(a, 1, 21, ext, 22)
+    assert (ext == oracle.interpolate(a, 21, 22)).all()
+
+
+def test_fft_in_place_and_errors(gl, oracle):
+    rng = np.random.default_rng(3)
+    a = rand_field(rng, (1 << 12, 4)); ref = oracle.fft_cols(a, 12)
+    gl.fft(a, 4, 12, a)
+    assert (a == ref).all()
+    with pytest.raises(gl.Pil2glError):
+        gl.interpolate(a, 4, 12, np.zeros(4 << 11, np.uint64), 11)       # nBitsExt < nBits
+    with pytest.raises(gl.Pil2glError):
+        gl.fft(a, 4, 13, a)                                              # buffer too small
+
+
+# ------------------------------------------------------------------ Poseidon / linear hash / Merkle
+def test_poseidon_kats(gl):
+    g = H(golden("poseidon.json"))
+    assert gl.poseidon([0] * 8) == [0x3c18a9786cb0b359, 0xc4055e3364a246c3, 0x7953db0ab48808f4, 0xc71603f33a1144ca]
+    assert gl.poseidon(list(range(8)), [8, 9, 10, 11]) == [0xd64e1e3efc5b8e9e, 0x53666633020aaa47, 0xd40285597c6a8825, 0x613a4f81e81231d2]
+    assert gl.poseidon([-1] * 8, [-1] * 4) == [0xbe0085cfc57a8357, 0xd95af71847d05c09, 0xcf55a13d33c1c953, 0x95803a74f4530e82]
+    inp = np.array([r[0] for r in g], dtype=np.uint64); cap = np.array([r[1] for r in g], dtype=np.uint64)
+    assert gl.poseidon_batch(inp, cap, 12).tolist() == [r[2] for r in g]
+    with pytest.raises(gl.Pil2glError):
+        gl.poseidon([1, 2, 3])
+
+
+def test_linear_hash_golden(gl):
+    g = golden("linearhash.json")
+    for w, plain, split in H(g["index"]):
+        if w == 0:
+            continue
+        v = np.arange(w, dtype=np.uint64)
+        assert gl.linearHash(v, w, False).tolist() == plain, w
+        assert gl.linearHash(v, w, True).tolist() == split, w
+    for v, plain, split in H(g["random"]):
+        v = np.array(v, dtype=np.uint64)
+        assert gl.linearHash(v, v.size, False).tolist() == plain
+        assert gl.linearHash(v, v.size, True).tolist() == split
+
+
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("N,nPols,idx", [(256, 3, 3), (256, 9, 3), (33, 6, 32), (1 << 18, 10, 33), (2, 9, 1), (1, 5, 0), (1000, 100, 999)])
+def test_merkle_tree(gl, oracle, N, nPols, idx, split):
+    # test/merklehash_p.test.js:19-250: v = i + 1000 j ; merkelize -> getGroupProof -> verifyGroupProof
+    pols = np.ascontiguousarray(np.arange(N, dtype=np.uint64)[:, None] + np.uint64(1000) * np.arange(nPols, dtype=np.uint64)[None, :])
+    MH = gl.buildMerkleHash(split)
+    tree = MH.merkelize(pols, nPols, N)
+    assert (tree["nodes"] == oracle.merkelize(pols, split)).all()
+    groupElements, mp = MH.getGroupProof(tree, idx)
+    assert groupElements == pols[idx].tolist()
+    assert np.array(mp, dtype=np.uint64).reshape(-1, 4).tolist() == oracle.group_proof(tree["nodes"], N, idx).tolist()
+    root = MH.root(tree)
+    assert MH.verifyGroupProof(root, mp, idx, groupElements)
+    bad = list(groupElements); bad[0] ^= 1
+    assert not MH.verifyGroupProof(root, mp, idx, bad)
+    with pytest.raises(gl.Pil2glError):
+        MH.getGroupProof(tree, N)
+
+
+def test_merkle_roots_golden(gl):
+    for N, w, split, root, leaf0, leaf_last in H(golden("merkle.json")):
+        elems = np.ascontiguousarray(np.arange(N, dtype=np.uint64)[:, None] + np.uint64(1000) * np.arange(w, dtype=np.uint64)[None, :])
+        MH = gl.buildMerkleHash(bool(split))
+        tree = MH.merkelize(elems, w, N)
+        assert MH.root(tree) == root
+        assert tree["nodes"][:4].tolist() == leaf0
+
+
+def test_merkle_file_roundtrip(gl, tmp_path):
+    pols = np.ascontiguousarray(np.arange(4096, dtype=np.uint64)[:, None] + np.uint64(1000) * np.arange(10, dtype=np.uint64)[None, :])
+    MH = gl.buildMerkleHash(False)
+    tree = MH.merkelize(pols, 10, 4096)
+    fn = str(tmp_path / "t.consttree")
+    MH.writeToFile(tree, fn)
+    t2 = MH.readFromFile(fn)
+    assert t2["width"] == 10 and t2["height"] == 4096
+    assert (t2["elements"] == pols.reshape(-1)).all() and (t2["nodes"] == tree["nodes"]).all()
+
+
+def test_merkelize_level_and_rows(gl, oracle):
+    rng = np.random.default_rng(5)
+    a = rand_field(rng, 8 * 1000)
+    out = gl.merkelizeLevel(a)
+    for i in (0, 1, 499, 999):
+        assert out[4 * i:4 * i + 4].tolist() == oracle.poseidon(a[8 * i:8 * i + 8], None, 4).tolist()
+    rows = rand_field(rng, (513, 21))
+    d = gl.linearHash(rows, 21, False)
+    for i in (0, 7, 512):
+        assert d[4 * i:4 * i + 4].tolist() == oracle.linear_hash(rows[i], False).tolist()
+
+
+# ------------------------------------------------------------------ transcript + reference proof, through the product
+def test_transcript_golden(gl):
+    for c in golden("transcript.json"):
+        t = gl.Transcript()
+        puts = H(c["put"]); fields = H(c.get("fields", []))
+        t.put(puts[0])
+        if fields:
+            assert t.getField() == fields[0]
+        if len(puts) > 1:
+            t.put(puts[1]); assert t.getField() == fields[1]; assert t.getField() == fields[2]
+        if "perms" in c:
+            n, nb, res = c["perms"]; assert t.getPermutations(n, nb) == res
+        if "state" in c:
+            assert t.getState() == H(c["state"])
+
+
+def test_reference_proof_through_gpu(gl):
+    import test_reference_proof as trp
+    z = trp._ints(golden("ref_compressor_verifier.proof.zkin.json"))
+
+    class _T:                                   # adapt the product Transcript to the replay helper's interface
+        def __init__(self): self.t = gl.Transcript()
+        def put(self, a): self.t.put(np.asarray(a, dtype=np.uint64).reshape(-1).tolist())
+        def get_field(self): return np.array(self.t.getField(), dtype=np.uint64)
+        def get_permutations(self, n, b): return np.array(self.t.getPermutations(n, b), dtype=np.uint64)
+
+    class _O:
+        Transcript = _T
+    ch, fri_steps, queries = trp._replay(_O, z)
+    assert queries == [891, 1628, 1228, 1991, 1856, 415, 833, 296]
+    MH = gl.buildMerkleHash(False)
+    for q, idx in enumerate(queries):
+        for name, root in (("1", z["root1"]), ("2", z["root2"]), ("3", z["root3"]), ("4", z["root4"]), ("C", trp.ROOT_C)):
+            assert MH.verifyGroupProof(root, z["s0_siblings" + name][q], idx, z["s0_vals" + name][q])
+    # FRI fold of the opened groups (fri.js:107-150) on the GPU
+    pol_bits = trp.STEPS[0]
+    for s in (1, 2):
+        out_bits = trp.STEPS[s]
+        sinv0 = pow(pow(7, P - 2, P), 1 << (trp.STEPS[0] - trp.STEPS[s - 1]), P)
+        wi = pow(int(gl_root(pol_bits)), P - 2, P)
+        for q, idx0 in enumerate(queries):
+            idx = idx0 % (1 << out_bits)
+            group = np.array(z["s%d_vals" % s][q], dtype=np.uint64).reshape(-1, 3)
+            out = np.zeros((1, 3), np.uint64)
+            from pil2gl import _lib
+            sinv_g = sinv0 * pow(wi, idx, P) % P
+            ch_ = np.array([int(x) for x in fri_steps[s]], dtype=np.uint64)
+            _lib.call("pil2gl_fri_fold", gl._ptr(group), group.shape[0].bit_length() - 1, 0, sinv_g, gl._ptr(ch_), gl._ptr(out))
+            if s + 1 < len(trp.STEPS):
+                nxt = np.array(z["s%d_vals" % (s + 1)][q], dtype=np.uint64).reshape(-1, 3)
+                assert nxt[idx // (1 << trp.STEPS[s + 1])].tolist() == out[0].tolist()
+            else:
+                assert z["finalPol"][idx] == out[0].tolist()
+        pol_bits = out_bits
+
+
+def gl_root(bits):
+    w = 7277203076849721926
+    for _ in range(32 - bits):
+        w = w * w % P
+    return w
+
+
+# ------------------------------------------------------------------ FRI
+def test_fri_fold_golden(gl, oracle):
+    from pil2gl import _lib
+    for pol_bits, out_bits, bits0, bits_prev, ch, pol, res in H(golden("fri_fold.json")):
+        pol = np.array(pol, dtype=np.uint64); out = np.zeros((1 << out_bits, 3), np.uint64)
+        sinv = oracle.fri_shift_inv(bits0, bits_prev)
+        chn = np.array(ch, dtype=np.uint64)
+        _lib.call("pil2gl_fri_fold", gl._ptr(pol), pol_bits, out_bits, sinv, gl._ptr(chn), gl._ptr(out))
+        assert out.tolist() == res
+
+
+def test_fri_class_fold_and_queries(gl, oracle):
+    # fri.js fold/proofQueries over steps 11/7/3 with trees, against the oracle
+    struct = {"nBits": 10, "nBitsExt": 11, "nQueries": 8, "steps": [{"nBits": 11}, {"nBits": 7}, {"nBits": 3}]}
+    MH = gl.buildMerkleHash(False)
+    fri = gl.FRI(struct, MH)
+    rng = np.random.default_rng(11)
+    pol = rand_field(rng, (1 << 11, 3))
+    cur = pol; prev_bits = None
+    for step in range(3):
+        ch = rand_field(rng, 3)
+        r = fri.fold(step, cur, ch.tolist())
+        out_bits = struct["steps"][step]["nBits"]
+        if step == 0:
+            exp = cur
+        else:
+            exp = oracle.fri_fold(cur, out_bits, oracle.fri_shift_inv(11, prev_bits), ch)
+        assert (np.asarray(r["pol"]) == exp).all()
+        if step < 2:
+            nb = struct["steps"][step + 1]["nBits"]
+            tb = oracle.fri_transpose(exp, nb)
+            nodes = oracle.merkelize(tb.reshape(1 << nb, -1), False)
+            assert (r["tree"]["nodes"] == nodes).all() and r["proof"]["root"] == nodes[-4:].tolist()
+            gp = MH.getGroupProof(r["tree"], 5)
+            assert MH.verifyGroupProof(r["proof"]["root"], gp[1], 5, gp[0])
+        else:
+            assert r["proof"] == exp.tolist()
+        cur = exp; prev_bits = out_bits
+
+
+# ------------------------------------------------------------------ STARK step helpers
+def _dev(gl, n):
+    import torch
+    return torch.zeros(n, dtype=torch.int64, device="cuda")
+
+
+def _host(t):
+    return t.cpu().numpy().view(np.uint64)
+
+
+def test_step_helpers(gl, oracle):
+    from pil2gl import _lib
+    import torch
+    st = None
+    for nb, nbe, zh, first, last, frame in H(golden("zerofiers.json")):
+        o = _dev(gl, 1 << nbe)
+        _lib.call("pil2gl_build_zhinv_dev", nb, nbe, gl._ptr(o), st); assert _host(o).tolist() == zh
+        _lib.call("pil2gl_build_one_row_zerofier_inv_dev", nb, nbe, 0, gl._ptr(o), st); assert _host(o).tolist() == first
+        _lib.call("pil2gl_build_one_row_zerofier_inv_dev", nb, nbe, (1 << nb) - 1, gl._ptr(o), st); assert _host(o).tolist() == last
+        _lib.call("pil2gl_build_frame_zerofier_dev", nb, nbe, 2, 1, gl._ptr(o), st); assert _host(o).tolist() == frame
+    nb, nbe = 9, 12
+    o = _dev(gl, 1 << nbe)
+    _lib.call("pil2gl_build_x_dev", nbe, 7, gl._ptr(o), st); assert (_host(o) == oracle.build_x(nbe, 7)).all()
+    _lib.call("pil2gl_build_one_row_zerofier_inv_dev", nb, nbe, 3, gl._ptr(o), st)
+    assert (_host(o) == oracle.build_one_row_zerofier_inv(nb, nbe, 3)).all()
+    rng = np.random.default_rng(9)
+    # q split (stark_gen_helpers.js:179-190)
+    qdim, qdeg = 3, 2
+    qq1 = rand_field(rng, (1 << nbe, qdim))
+    d1 = torch.from_numpy(qq1.view(np.int64)).cuda(); d2 = _dev(gl, (1 << nbe) * qdim * qdeg)
+    _lib.call("pil2gl_compute_q_split_dev", gl._ptr(d1), nb, nbe, qdim, qdeg, gl._ptr(d2), st)
+    assert (_host(d2).reshape(1 << nbe, -1) == oracle.compute_q_split(qq1, nb, nbe, qdim, qdeg)).all()
+    # xDivXSubXi (stark_gen_helpers.js:293-322), two openings
+    xis = rand_field(rng, (2, 3))
+    d = _dev(gl, (1 << nbe) * 6)
+    for i in range(2):
+        xi = np.ascontiguousarray(xis[i])
+        _lib.call("pil2gl_x_div_x_sub_xi_dev", nbe, gl._ptr(xi), 2, i, gl._ptr(d), st)
+    assert (_host(d).reshape(1 << nbe, 6) == oracle.x_div_x_sub_xi(nbe, xis)).all()
+    # LEv + evals (stark_gen_helpers.js:216-264)
+    xi = rand_field(rng, 3)
+    lev = _dev(gl, (1 << nb) * 3)
+    _lib.call("pil2gl_build_lev_dev", nb, gl._ptr(xi), gl._ptr(lev), st)
+    lev_o = oracle.lev(nb, xi)
+    assert (_host(lev).reshape(-1, 3) == lev_o).all()
+    buf = rand_field(rng, (1 << nbe, 7)); dbuf = torch.from_numpy(buf.view(np.int64)).cuda()
+    descs = (_lib.EvalDesc * 3)()
+    for e, (off, dim) in enumerate([(0, 1), (2, 3), (6, 1)]):
+        descs[e].buf = dbuf.data_ptr(); descs[e].width = 7; descs[e].offset = off; descs[e].dim = dim; descs[e].levIndex = 0
+    import ctypes as C
+    levs = (C.c_void_p * 1)(lev.data_ptr()); res = np.zeros((3, 3), np.uint64)
+    _lib.call("pil2gl_compute_evals_dev", descs, 3, nb, nbe - nb, levs, 1, gl._ptr(res), st)
+    for e, (off, dim) in enumerate([(0, 1), (2, 3), (6, 1)]):
+        assert res[e].tolist() == oracle.eval_pol_at(buf, off, dim, nb, nbe - nb, lev_o).tolist()
+
+
+# ------------------------------------------------------------------ expression evaluator
+def _random_program(rng, n_ops, sections_w, n_scalars, dest_sec):
+    """random straight-line program over (tmp, section, scalar) operands with mixed dims"""
+    from gl_oracle import TMP, SEC, SCALAR
+    ops = []; tmps = []      # (id, dim)
+    def src():
+        k = rng.integers(0, 3 if tmps else 2)
+        if k == 2:
+            i, d = tmps[rng.integers(0, len(tmps))]; return (TMP, d, 0, 0, i)
+        if k == 1:
+            d = 1 if rng.integers(0, 2) else 3
+            return (SCALAR, d, 0, 0, int(rng.integers(0, n_scalars - 3)))
+        s = int(rng.integers(0, len(sections_w) - 1)); d = 3 if (sections_w[s] >= 3 and rng.integers(0, 3) == 0) else 1
+        return (SEC, d, s, int(rng.integers(-2, 3)), int(rng.integers(0, sections_w[s] - d + 1)))
+    for k in range(n_ops):
+        op = ["add", "sub", "mul", "copy"][rng.integers(0, 4)]
+        a = src(); b = src() if op != "copy" else None
+        dim = max(a[1], b[1] if b else 1)
+        tid = len(tmps); tmps.append((tid, dim))
+        ops.append((op, (TMP, dim, 0, 0, tid), a, b))
+    # final: write an ext result into the destination section
+    last3 = [t for t in tmps if t[1] == 3]
+    t = last3[-1] if last3 else tmps[-1]
+    ops.append(("copy", (SEC, t[1], dest_sec, 0, 0), (TMP, t[1], 0, 0, t[0]), None))
+    return ops, len(tmps)
+
+
+@pytest.mark.parametrize("n_ops,prime_shift", [(20, 0), (300, 3)])
+def test_expression_evaluator(gl, oracle, n_ops, prime_shift):
+    import torch
+    import ctypes as C
+    from pil2gl import _lib
+    rng = np.random.default_rng(n_ops)
+    n_bits = 9
+    widths = [5, 9, 1, 3]           # last = destination (f_ext-like, width 3)
+    secs = [rand_field(rng, (1 << n_bits, w)) for w in widths]
+    secs[-1][:] = 0
+    scalars = rand_field(rng, 40)
+    ops, n_tmp = _random_program(rng, n_ops, widths, scalars.size, len(widths) - 1)
+    ref_secs = [s.copy() for s in secs]
+    oracle.eval_program(ops, n_tmp, ref_secs, scalars, n_bits, prime_shift)
+    dsecs = [torch.from_numpy(s.view(np.int64)).cuda() for s in secs]
+    prog = oracle.make_program(ops, n_tmp, struct_op=_lib.GlxOp, struct_prog=_lib.GlxProgram)
+    csecs = (_lib.GlxSection * len(dsecs))()
+    for i, s in enumerate(dsecs):
+        csecs[i].ptr = s.data_ptr(); csecs[i].width = widths[i]
+    ctx = _lib.GlxCtx(n_bits, prime_shift, len(dsecs), scalars.size, csecs, scalars.ctypes.data_as(_lib.u64p))
+    _lib.call("pil2gl_eval_program_dev", C.byref(prog), C.byref(ctx), None)
+    torch.cuda.synchronize()
+    for d, r in zip(dsecs, ref_secs):
+        assert (d.cpu().numpy().view(np.uint64).reshape(r.shape) == r).all()
+
+
+# ------------------------------------------------------------------ device-resident path (buffers stay in HBM)
+def test_device_resident_extend_and_merkelize(gl, oracle):
+    import torch
+    rng = np.random.default_rng(17)
+    nBits, nPols, ext = 12, 8, 3
+    a = rand_field(rng, (1 << nBits, nPols))
+    src = torch.from_numpy(a.view(np.int64)).cuda()
+    dst = torch.empty((1 << (nBits + ext)) * nPols, dtype=torch.int64, device="cuda")
+    gl.interpolate(src, nPols, nBits, dst, nBits + ext)
+    MH = gl.buildMerkleHash(False)
+    tree = MH.merkelize(dst, nPols, 1 << (nBits + ext))
+    torch.cuda.synchronize()
+    e = oracle.interpolate(a, nBits, nBits + ext)
+    assert (dst.cpu().numpy().view(np.uint64).reshape(e.shape) == e).all()
+    nodes = oracle.merkelize(e, False)
+    assert (tree["nodes"].cpu().numpy().view(np.uint64) == nodes).all()
+    assert MH.root(tree) == nodes[-4:].tolist()
+    v, mp = MH.getGroupProof(tree, 4097)
+    assert v == e[4097].tolist() and MH.verifyGroupProof(MH.root(tree), mp, 4097, v)

@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- trace-cells/s of the STARK commit step (extend + merkelize) on MI355X.
+
+One "step" = one pass of the hot path over one synthetic trace that is already resident in HBM:
+  interpolate (LDE, blow-up 8, fft_p.js:187)  ->  merkelize (Poseidon leaves + tree, merklehash_p.js:44)
+i.e. extendAndMerkelize of src/stark/stark_gen_helpers.js:388-412, called through the C ABI
+(libpil2gl.so) by the Python mirror of the reference operators.  Synthetic uniformly random
+Goldilocks trace; inputs, outputs and the tree stay on the device (no PCIe in the timed region).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|NBITSxCOLS]
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same step on its
+own trace (weak scaling, no data-path collective); value = all ranks' cells / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+WORKLOADS = {"c2": (20, 8), "c3": (24, 100)}      # BASELINE.json configs[1], configs[2]
+EXT_BITS = 3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("PIL2GL_BENCH_WORKLOAD", "auto"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", action="store_true", help="splitLinearHash leaves (linearhash_gpu.js)")
+    return ap.parse_args()
+
+
+def make_trace(n_rows, n_cols, seed, device):
+    """uniform canonical Goldilocks elements: hi in [0, 2^32-1), lo in [0, 2^32)  (value < p)"""
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    n = n_rows * n_cols
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    chunk = 1 << 26
+    for o in range(0, n, chunk):
+        m = min(chunk, n - o)
+        hi = torch.randint(0, 0xFFFFFFFF, (m,), dtype=torch.int64, device=device, generator=g)
+        lo = torch.randint(0, 1 << 32, (m,), dtype=torch.int64, device=device, generator=g)
+        out[o:o + m] = (hi << 32) | lo
+    return out
+
+
+def ev_time(fn, iters):
+    """average ms of fn() on torch's current stream (the stream the library launches on), HIP events"""
+    torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def cpu_baseline(n_cols, split):
+    """extend+merkelize by the CPU oracle (a C/OpenMP port of the reference algorithms) on a bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gl_oracle
+    gl_oracle.build()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    gl_oracle.set_threads(cores)
+    n_bits = 14 if n_cols > 16 else 17
+    rng = np.random.default_rng(1)
+
+    def run(nb):
+        a = rng.integers(0, 0xFFFFFFFF00000001, size=(1 << nb, n_cols), dtype=np.uint64)
+        t0 = time.perf_counter()
+        e = gl_oracle.interpolate(a, nb, nb + EXT_BITS)
+        gl_oracle.merkelize(e, split)
+        return time.perf_counter() - t0
+    t = run(n_bits)
+    while t < 4.0 and n_bits < 20:          # grow the sample until it is a few seconds of CPU work
+        n_bits += 1
+        t = run(n_bits)
+    cells = (1 << n_bits) * n_cols
+    return {"value": cells / t, "unit": "trace-cells/s", "cores": cores, "kind": "port",
+            "sample": "extend+merkelize of 2^%d x %d random trace, blow-up 8, OpenMP C oracle, %.1f s" % (n_bits, n_cols, t)}
+
+
+def load_pmc_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/pmc_traffic.json), if any"""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(kernel)
+    except Exception:
+        return None
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    import pil2gl
+    pil2gl.init(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    wl = args.workload
+    if wl == "auto":
+        free, _ = torch.cuda.mem_get_info()
+        wl = "c3" if free > 170e9 else "c2"
+    if wl in WORKLOADS:
+        n_bits, n_cols = WORKLOADS[wl]
+    else:
+        n_bits, n_cols = (int(v) for v in wl.lower().split("x"))
+    N, E = 1 << n_bits, 1 << (n_bits + EXT_BITS)
+
+    src = make_trace(N, n_cols, 0x5EED0000 + rank, dev)
+    dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
+    MH = pil2gl.buildMerkleHash(args.split)
+    nodes = torch.empty(MH._getNNodes(E * 4), dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    import ctypes as C
+
+    def step():
+        pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
+        pil2gl.call("pil2gl_merkelize_dev", pil2gl._ptr(dst), n_cols, E, int(args.split), pil2gl._ptr(nodes), C.c_void_p(stream))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * N * n_cols / (dt / args.steps)
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel timing with HIP events on the launch stream (each call below is exactly one kernel,
+        #      or one kernel family named in DESIGN.md) ----
+        iters = max(1, min(3, args.steps))
+        digests = torch.empty(E * 4, dtype=torch.int64, device=dev)
+        t_leaf = ev_time(lambda: pil2gl.linearHash(dst, n_cols, args.split, digests), iters)
+        t_lde = ev_time(lambda: pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS), iters)
+        lvl = torch.empty(E * 2, dtype=torch.int64, device=dev)
+        t_lvl = ev_time(lambda: pil2gl.merkelizeLevel(digests, lvl), iters)
+        leaf_perms = E * ((n_cols + 7) // 8) if n_cols > 4 else 0
+        if args.split and n_cols > 4:
+            batch = max(8, (n_cols + 3) // 4); nb = (n_cols + batch - 1) // batch
+            leaf_perms = E * (sum((min(batch, n_cols - b * batch) + 7) // 8 if min(batch, n_cols - b * batch) > 4 else 0 for b in range(nb)) + (((4 * nb) + 7) // 8 if nb > 1 else 0))
+        kernels = [
+            {"kernel": "linear_hash_kernel", "ms": t_leaf, "alg_bytes": 8 * E * n_cols + 32 * E, "perms": leaf_perms},
+            {"kernel": "interpolate (ntt_pass_kernel x / lde_mid_kernel)", "ms": t_lde, "alg_bytes": 8 * N * n_cols * (1 + (1 << EXT_BITS))},
+            {"kernel": "merkle_level_kernel (first level)", "ms": t_lvl, "alg_bytes": 32 * E + 16 * E, "perms": E // 2},
+        ]
+        for k in kernels:
+            k["GBps"] = k["alg_bytes"] / k["ms"] / 1e6
+            k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS
+            if "perms" in k:
+                k["Gperm_s"] = k["perms"] / k["ms"] / 1e6
+        dom = max(kernels, key=lambda k: k["ms"])
+        roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": dom["hbm_frac"], "traffic": load_pmc_traffic(dom["kernel"].split(" ")[0]),
+                    "note": "Poseidon hashing is integer-ALU bound (no 64-bit multiplier on gfx950); its HBM fraction is small by nature, see kernels[]"}
+        out = {
+            "metric": "trace-cells/s, STARK commit step (extend+merkelize), GL Poseidon Merkle, blow-up 8",
+            "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, %s linear hash, per GPU" % (n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain"),
+                       "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "GL-Poseidon-12",
+                       "parallelism": "replicas x%d" % world if world > 1 else "single GPU"},
+            "roofline": roofline, "kernels": kernels,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n_cols, args.split)
+            out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

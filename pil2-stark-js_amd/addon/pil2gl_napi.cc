@@ -1,0 +1,195 @@
+// N-API binding of the libpil2gl C ABI (include/pil2gl.h) for Node.js >= 12.17 (N-API 6: BigUint64Array).
+//
+// Thin by design: every export is one C-ABI call on raw pointers.  Host buffers are BigUint64Array
+// (what the reference hands to its workers: fft_p.js:246, merklehash_p.js:70); device buffers are
+// addresses carried as BigInt.  The CommonJS modules in ../js give these the reference's own
+// function names and signatures.  Calls are synchronous (the reference awaits each one anyway).
+#include <node_api.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "pil2gl.h"
+
+#define NAPI_CALL(env, call)                                                         \
+    do { if ((call) != napi_ok) { napi_throw_error(env, nullptr, "N-API call failed: " #call); return nullptr; } } while (0)
+
+static napi_value throw_rc(napi_env env, int rc) {
+    std::string m = "pil2gl error " + std::to_string(rc) + ": " + pil2gl_last_error();
+    napi_throw_error(env, nullptr, m.c_str());
+    return nullptr;
+}
+#define P2(env, call) do { int rc_ = (call); if (rc_ != PIL2GL_OK) return throw_rc(env, rc_); } while (0)
+
+struct Args {
+    napi_env env; size_t argc; napi_value argv[12]; bool ok;
+    Args(napi_env e, napi_callback_info info) : env(e), argc(12), ok(true) {
+        if (napi_get_cb_info(e, info, &argc, argv, nullptr, nullptr) != napi_ok) ok = false;
+    }
+    bool fail(const char *m) { if (ok) napi_throw_type_error(env, nullptr, m); ok = false; return false; }
+    uint64_t u64(size_t i) {                       // Number or BigInt
+        if (!ok || i >= argc) { fail("missing argument"); return 0; }
+        napi_valuetype t; napi_typeof(env, argv[i], &t);
+        if (t == napi_bigint) { uint64_t v = 0; bool lossless; napi_get_value_bigint_uint64(env, argv[i], &v, &lossless); return v; }
+        if (t == napi_number) { double d; napi_get_value_double(env, argv[i], &d); if (d < 0) { fail("negative size"); return 0; } return (uint64_t)d; }
+        if (t == napi_boolean) { bool b; napi_get_value_bool(env, argv[i], &b); return b; }
+        fail("expected a number or BigInt"); return 0;
+    }
+    bool is_nullish(size_t i) {
+        if (i >= argc) return true;
+        napi_valuetype t; napi_typeof(env, argv[i], &t);
+        return t == napi_undefined || t == napi_null;
+    }
+    uint64_t *arr(size_t i, uint64_t minWords, uint64_t *len = nullptr) {   // BigUint64Array
+        if (!ok || i >= argc) { fail("missing buffer argument"); return nullptr; }
+        bool is; napi_is_typedarray(env, argv[i], &is);
+        if (!is) { fail("expected a BigUint64Array"); return nullptr; }
+        napi_typedarray_type ty; size_t n; void *data; napi_value ab; size_t off;
+        napi_get_typedarray_info(env, argv[i], &ty, &n, &data, &ab, &off);
+        if (ty != napi_biguint64_array && ty != napi_bigint64_array) { fail("expected a BigUint64Array"); return nullptr; }
+        if (n < minWords) { fail("buffer too small"); return nullptr; }
+        if (len) *len = n;
+        return (uint64_t *)data;
+    }
+    void *stream(size_t i) { return is_nullish(i) ? nullptr : (void *)(uintptr_t)u64(i); }
+};
+
+static napi_value mk_undefined(napi_env env) { napi_value v; napi_get_undefined(env, &v); return v; }
+static napi_value mk_bigint(napi_env env, uint64_t x) { napi_value v; napi_create_bigint_uint64(env, x, &v); return v; }
+
+#define FN(name) static napi_value name(napi_env env, napi_callback_info info)
+
+FN(Init) { Args a(env, info); int dev = a.is_nullish(0) ? 0 : (int)a.u64(0); if (!a.ok) return nullptr; P2(env, pil2gl_init(dev)); return mk_undefined(env); }
+FN(Shutdown) { pil2gl_shutdown(); return mk_undefined(env); }
+FN(DeviceInfo) {
+    char name[64]; uint32_t cus; uint64_t mem;
+    P2(env, pil2gl_device_info(name, sizeof name, &cus, &mem));
+    napi_value o, v; napi_create_object(env, &o);
+    napi_create_string_utf8(env, name, NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "name", v);
+    napi_create_uint32(env, cus, &v); napi_set_named_property(env, o, "computeUnits", v);
+    napi_set_named_property(env, o, "totalMem", mk_bigint(env, mem));
+    return o;
+}
+
+// ---- device buffers ----
+FN(DevAlloc) { Args a(env, info); uint64_t n = a.u64(0); if (!a.ok) return nullptr; uint64_t *p; P2(env, pil2gl_dev_alloc(n, &p)); return mk_bigint(env, (uint64_t)(uintptr_t)p); }
+FN(DevFree) { Args a(env, info); uint64_t p = a.u64(0); if (!a.ok) return nullptr; P2(env, pil2gl_dev_free((uint64_t *)(uintptr_t)p)); return mk_undefined(env); }
+FN(DevZero) { Args a(env, info); uint64_t p = a.u64(0), off = a.u64(1), n = a.u64(2); if (!a.ok) return nullptr; P2(env, pil2gl_dev_zero((uint64_t *)(uintptr_t)p + off, n, nullptr)); return mk_undefined(env); }
+FN(DevUpload) {      // (devPtr, offsetWords, BigUint64Array)
+    Args a(env, info); uint64_t p = a.u64(0), off = a.u64(1), n = 0; uint64_t *h = a.arr(2, 0, &n); if (!a.ok) return nullptr;
+    P2(env, pil2gl_dev_upload((uint64_t *)(uintptr_t)p + off, h, n)); return mk_undefined(env);
+}
+FN(DevDownload) {    // (BigUint64Array, devPtr, offsetWords)
+    Args a(env, info); uint64_t n = 0; uint64_t *h = a.arr(0, 0, &n); uint64_t p = a.u64(1), off = a.u64(2); if (!a.ok) return nullptr;
+    P2(env, pil2gl_dev_download(h, (uint64_t *)(uintptr_t)p + off, n)); return mk_undefined(env);
+}
+FN(Sync) { P2(env, pil2gl_sync(nullptr)); return mk_undefined(env); }
+
+// ---- NTT ----
+FN(Interpolate) {    // (src, nPols, nBits, dst, nBitsExt)  fft_p.js:187
+    Args a(env, info); uint64_t nPols = a.u64(1); uint32_t nBits = (uint32_t)a.u64(2), nBitsExt = (uint32_t)a.u64(4);
+    if (nBits > 40 || nBitsExt > 40) a.fail("bad size");
+    uint64_t *s = a.arr(0, a.ok ? nPols << nBits : 0), *d = a.arr(3, a.ok ? nPols << nBitsExt : 0); if (!a.ok) return nullptr;
+    P2(env, pil2gl_interpolate(s, nPols, nBits, d, nBitsExt)); return mk_undefined(env);
+}
+static napi_value fft_common(napi_env env, napi_callback_info info, bool inverse) {
+    Args a(env, info); uint64_t nPols = a.u64(1); uint32_t nBits = (uint32_t)a.u64(2);
+    if (nBits > 40) a.fail("bad size");
+    uint64_t *s = a.arr(0, a.ok ? nPols << nBits : 0), *d = a.arr(3, a.ok ? nPols << nBits : 0); if (!a.ok) return nullptr;
+    P2(env, inverse ? pil2gl_ifft(s, nPols, nBits, d) : pil2gl_fft(s, nPols, nBits, d)); return mk_undefined(env);
+}
+FN(Fft) { return fft_common(env, info, false); }
+FN(Ifft) { return fft_common(env, info, true); }
+FN(InterpolateDev) {
+    Args a(env, info); uint64_t s = a.u64(0), nPols = a.u64(1), nBits = a.u64(2), d = a.u64(3), nBitsExt = a.u64(4); if (!a.ok) return nullptr;
+    P2(env, pil2gl_interpolate_dev((const uint64_t *)(uintptr_t)s, nPols, (uint32_t)nBits, (uint64_t *)(uintptr_t)d, (uint32_t)nBitsExt, a.stream(5))); return mk_undefined(env);
+}
+FN(FftDev) {
+    Args a(env, info); uint64_t s = a.u64(0), nPols = a.u64(1), nBits = a.u64(2), d = a.u64(3); if (!a.ok) return nullptr;
+    P2(env, pil2gl_fft_dev((const uint64_t *)(uintptr_t)s, nPols, (uint32_t)nBits, (uint64_t *)(uintptr_t)d, a.stream(4))); return mk_undefined(env);
+}
+FN(IfftDev) {
+    Args a(env, info); uint64_t s = a.u64(0), nPols = a.u64(1), nBits = a.u64(2), d = a.u64(3); if (!a.ok) return nullptr;
+    P2(env, pil2gl_ifft_dev((const uint64_t *)(uintptr_t)s, nPols, (uint32_t)nBits, (uint64_t *)(uintptr_t)d, a.stream(4))); return mk_undefined(env);
+}
+
+// ---- hashing ----
+FN(Poseidon) {       // (in BigUint64Array(8*count), cap BigUint64Array(4*count)|null, count, nOut, out)
+    Args a(env, info); uint64_t count = a.u64(2); uint32_t nOut = (uint32_t)a.u64(3);
+    uint64_t *in = a.arr(0, 8 * count), *cap = a.is_nullish(1) ? nullptr : a.arr(1, 4 * count), *out = a.arr(4, (uint64_t)nOut * count); if (!a.ok) return nullptr;
+    P2(env, pil2gl_poseidon(in, cap, count, nOut, out)); return mk_undefined(env);
+}
+FN(LinearHashRows) { // (in, width, height, split, out)  merklehash_worker.js:37
+    Args a(env, info); uint64_t w = a.u64(1), h = a.u64(2); int split = (int)a.u64(3);
+    uint64_t *in = a.arr(0, w * h), *out = a.arr(4, 4 * h); if (!a.ok) return nullptr;
+    P2(env, pil2gl_linear_hash_rows(in, w, h, split, out)); return mk_undefined(env);
+}
+FN(MerkelizeLevel) { // (in, nOps, out)  merklehash_worker.js:86
+    Args a(env, info); uint64_t n = a.u64(1); uint64_t *in = a.arr(0, 8 * n), *out = a.arr(2, 4 * n); if (!a.ok) return nullptr;
+    P2(env, pil2gl_merkelize_level(in, n, out)); return mk_undefined(env);
+}
+FN(MerkleNumNodes) { Args a(env, info); uint64_t h = a.u64(0); if (!a.ok) return nullptr; napi_value v; napi_create_double(env, (double)pil2gl_merkle_num_nodes(h), &v); return v; }
+FN(Merkelize) {      // (elems, width, height, split, nodes)  merklehash_p.js:44
+    Args a(env, info); uint64_t w = a.u64(1), h = a.u64(2); int split = (int)a.u64(3);
+    uint64_t *el = a.arr(0, w * h), *nodes = a.arr(4, pil2gl_merkle_num_nodes(h)); if (!a.ok) return nullptr;
+    P2(env, pil2gl_merkelize(el, w, h, split, nodes)); return mk_undefined(env);
+}
+FN(MerkelizeDev) {   // (devElems, width, height, split, devNodes)
+    Args a(env, info); uint64_t el = a.u64(0), w = a.u64(1), h = a.u64(2); int split = (int)a.u64(3); uint64_t nodes = a.u64(4); if (!a.ok) return nullptr;
+    P2(env, pil2gl_merkelize_dev((const uint64_t *)(uintptr_t)el, w, h, split, (uint64_t *)(uintptr_t)nodes, a.stream(5))); return mk_undefined(env);
+}
+FN(GroupProofDev) {  // (devElems, devNodes, width, height, idx, vals BigUint64Array(width), siblings BigUint64Array(4*64)) -> nLevels
+    Args a(env, info); uint64_t el = a.u64(0), nodes = a.u64(1), w = a.u64(2), h = a.u64(3), idx = a.u64(4);
+    uint64_t *vals = a.arr(5, w), *sib = a.arr(6, 4 * 64); if (!a.ok) return nullptr;
+    uint32_t nl = 0;
+    P2(env, pil2gl_group_proof_dev((const uint64_t *)(uintptr_t)el, (const uint64_t *)(uintptr_t)nodes, w, h, idx, vals, sib, &nl));
+    napi_value v; napi_create_uint32(env, nl, &v); return v;
+}
+
+// ---- FRI ----
+FN(FriFold) {        // (pol, polBits, outBits, shiftInv, challenge[3], out)  fri.js:22
+    Args a(env, info); uint32_t pb = (uint32_t)a.u64(1), ob = (uint32_t)a.u64(2); uint64_t sinv = a.u64(3);
+    if (pb > 40 || ob > pb) a.fail("Invalid polynomial size");
+    uint64_t *pol = a.arr(0, a.ok ? 3ull << pb : 0), *ch = a.arr(4, 3), *out = a.arr(5, a.ok ? 3ull << ob : 0); if (!a.ok) return nullptr;
+    P2(env, pil2gl_fri_fold(pol, pb, ob, sinv, ch, out)); return mk_undefined(env);
+}
+FN(FriTranspose) {   // (pol, polBits, transposeBits, out)  fri.js:187
+    Args a(env, info); uint32_t pb = (uint32_t)a.u64(1), tb = (uint32_t)a.u64(2);
+    if (pb > 40) a.fail("Invalid polynomial size");
+    uint64_t *pol = a.arr(0, a.ok ? 3ull << pb : 0), *out = a.arr(3, a.ok ? 3ull << pb : 0); if (!a.ok) return nullptr;
+    P2(env, pil2gl_fri_transpose(pol, pb, tb, out)); return mk_undefined(env);
+}
+
+// ---- expression evaluator ----
+// (opsBuf BigUint64Array = packed glx_op[], nOps, nTmp, nBits, primeShift, sectionPtrs BigUint64Array, sectionWidths BigUint64Array, scalars BigUint64Array)
+FN(EvalProgramDev) {
+    Args a(env, info); uint64_t nOps = a.u64(1), nTmp = a.u64(2), nBits = a.u64(3), ps = a.u64(4);
+    uint64_t nSec = 0, nSec2 = 0, nSc = 0;
+    uint64_t *ops = a.arr(0, nOps * (sizeof(glx_op) / 8)), *ptrs = a.arr(5, 0, &nSec), *widths = a.arr(6, 0, &nSec2), *scal = a.arr(7, 0, &nSc);
+    if (a.ok && nSec != nSec2) a.fail("section arrays differ in length");
+    if (!a.ok) return nullptr;
+    std::vector<glx_section> secs(nSec);
+    for (uint64_t i = 0; i < nSec; i++) { secs[i].ptr = (uint64_t *)(uintptr_t)ptrs[i]; secs[i].width = widths[i]; }
+    glx_program prog = { (uint32_t)nOps, (uint32_t)nTmp, (const glx_op *)ops };
+    glx_ctx ctx = { (uint32_t)nBits, (uint32_t)ps, (uint32_t)nSec, (uint32_t)nSc, secs.data(), scal };
+    P2(env, pil2gl_eval_program_dev(&prog, &ctx, nullptr)); return mk_undefined(env);
+}
+
+static napi_value ModuleInit(napi_env env, napi_value exports) {
+    struct { const char *name; napi_callback fn; } fns[] = {
+        { "init", Init }, { "shutdown", Shutdown }, { "deviceInfo", DeviceInfo },
+        { "devAlloc", DevAlloc }, { "devFree", DevFree }, { "devZero", DevZero }, { "devUpload", DevUpload }, { "devDownload", DevDownload }, { "sync", Sync },
+        { "interpolate", Interpolate }, { "fft", Fft }, { "ifft", Ifft },
+        { "interpolateDev", InterpolateDev }, { "fftDev", FftDev }, { "ifftDev", IfftDev },
+        { "poseidon", Poseidon }, { "linearHashRows", LinearHashRows }, { "merkelizeLevel", MerkelizeLevel },
+        { "merkleNumNodes", MerkleNumNodes }, { "merkelize", Merkelize }, { "merkelizeDev", MerkelizeDev }, { "groupProofDev", GroupProofDev },
+        { "friFold", FriFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
+    };
+    for (auto &f : fns) {
+        napi_value v;
+        NAPI_CALL(env, napi_create_function(env, f.name, NAPI_AUTO_LENGTH, f.fn, nullptr, &v));
+        NAPI_CALL(env, napi_set_named_property(env, exports, f.name, v));
+    }
+    return exports;
+}
+NAPI_MODULE(NODE_GYP_MODULE_NAME, ModuleInit)

@@ -312,10 +312,18 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st)
         P.C = C; P.ninv = h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb;
         u64 totalGroups = 1ull << (n - kf);
         u32 nThreads = env_u32("PIL2GL_LDE_THREADS", 1024);
-        Geom g = make_geom(kf, C, totalGroups, env_u32("PIL2GL_LDE_TILE", 8192), nThreads);
-        P.Wc = g.Wc; P.G = g.nbT; P.nColChunks = g.nColChunks;
+        // LDS = tile (S*K) + two local twiddle tables (K) + coset scale tables (2*G*K); narrow matrices
+        // (small C => many row groups per tile) are dominated by the scale tables, so shrink until it fits
         u64 K = 1ull << kf;
+        u32 maxElems = env_u32("PIL2GL_LDE_TILE", 8192);
+        Geom g = make_geom(kf, C, totalGroups, maxElems, nThreads);
         size_t ldsBytes = 8 * ((size_t)g.S * K + std::max<u64>(2, K) + 2 * (size_t)g.nbT * K);
+        while (ldsBytes > 96 * 1024 && g.nbT > 1) {
+            maxElems /= 2;
+            g = make_geom(kf, C, totalGroups, maxElems, nThreads);
+            ldsBytes = 8 * ((size_t)g.S * K + std::max<u64>(2, K) + 2 * (size_t)g.nbT * K);
+        }
+        P.Wc = g.Wc; P.G = g.nbT; P.nColChunks = g.nColChunks;
         u32 need = (u32)((K + g.by - 1) / g.by);
         u64 blocks = (totalGroups / g.nbT) * g.nColChunks;
         if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");

@@ -1,0 +1,67 @@
+// Drop-in for the prover half of src/stark/fri.js: new FRI(starkStruct, MH); fold(step, pol, challenge) ->
+// {pol, tree, proof}; proofQueries(proof, trees, friQueries) (fri.js:7-105).  `pol` is an array of [a,b,c] BigInt
+// triples as in the reference; the fold and the transposition run on the GPU.
+"use strict";
+const { addon } = require("./native.js");
+const P = 0xFFFFFFFF00000001n;
+
+function powmod(b, e) { let r = 1n; b %= P; while (e > 0n) { if (e & 1n) r = r * b % P; b = b * b % P; e >>= 1n; } return r; }
+function pack(pol) { const a = new BigUint64Array(pol.length * 3); for (let i = 0; i < pol.length; i++) { a[3 * i] = pol[i][0]; a[3 * i + 1] = pol[i][1]; a[3 * i + 2] = pol[i][2]; } return a; }
+function unpack(a) { const r = new Array(a.length / 3); for (let i = 0; i < r.length; i++) r[i] = [a[3 * i], a[3 * i + 1], a[3 * i + 2]]; return r; }
+function log2(n) { let b = 0; while ((1 << b) < n) b++; return b; }
+
+class FRI {
+    constructor(starkStruct, MH) {
+        if (!starkStruct) throw new Error("stark struct not defined");
+        this.inNBits = starkStruct.nBitsExt;
+        this.maxDegNBits = starkStruct.nBits;
+        this.nQueries = starkStruct.nQueries;
+        this.steps = starkStruct.steps;
+        this.MH = MH;
+    }
+
+    async fold(step, pol, challenge) {
+        const polBits = log2(pol.length);
+        if (step === 0) { if (polBits !== this.inNBits) throw new Error("Invalid polynomial size"); }
+        else if ((1 << polBits) !== pol.length) throw new Error("Invalid polynomial size");
+        let shiftInv = powmod(7n, P - 2n);                                    // fri.js:31-36
+        if (step > 0) for (let j = 0; j < this.steps[0].nBits - this.steps[step - 1].nBits; j++) shiftInv = shiftInv * shiftInv % P;
+        const outBits = this.steps[step].nBits;
+        let pol2_e, flat;
+        if (step === 0) { pol2_e = pol; flat = null; }                        // fri.js:48-49
+        else {
+            flat = new BigUint64Array(3 * 2 ** outBits);
+            addon.friFold(pack(pol), polBits, outBits, shiftInv, BigUint64Array.from(challenge, BigInt), flat);
+            pol2_e = unpack(flat);
+        }
+        let tree, proof;
+        if (step !== this.steps.length - 1) {                                 // fri.js:64-71
+            const nGroups = 1 << this.steps[step + 1].nBits;
+            const groupSize = (1 << this.steps[step].nBits) / nGroups;
+            const tb = new BigUint64Array(3 * pol2_e.length);
+            addon.friTranspose(flat || pack(pol2_e), outBits, this.steps[step + 1].nBits, tb);
+            tree = await this.MH.merkelize(tb, 3 * groupSize, nGroups);
+            proof = { root: this.MH.root(tree) };
+        } else {
+            proof = pol2_e.slice();
+        }
+        return { pol: pol2_e, tree, proof };
+    }
+
+    proofQueries(proof, trees, friQueries) {                                  // fri.js:83-105
+        for (let step = 0; step < this.steps.length; step++) {
+            proof[step].polQueries = [];
+            if (step === 0) {
+                for (let i = 0; i < friQueries.length; i++) {
+                    const polQuery = [];
+                    for (let j = 0; j < trees[step].length; ++j) polQuery.push(this.MH.getGroupProof(trees[step][j], friQueries[i]));
+                    proof[step].polQueries.push(polQuery);
+                }
+            } else {
+                for (let i = 0; i < friQueries.length; i++) friQueries[i] = friQueries[i] % (1 << this.steps[step].nBits);
+                for (let i = 0; i < friQueries.length; i++) proof[step].polQueries.push(this.MH.getGroupProof(trees[step], friQueries[i]));
+            }
+        }
+    }
+}
+module.exports = FRI;

@@ -1,0 +1,9 @@
+// Entry point: the MI355X implementations of the reference's L2 operator modules, under their own names.
+"use strict";
+module.exports = {
+    native: require("./native.js").addon,
+    fft_p: require("./fft_p.js"),
+    buildMerkleHash: require("./merklehash_p.js"),
+    buildPoseidon: require("./poseidon.js"),
+    FRI: require("./fri.js"),
+};

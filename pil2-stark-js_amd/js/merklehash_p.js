@@ -1,0 +1,123 @@
+// Drop-in for src/helpers/hash/merklehash/merklehash_p.js: `await buildMerkleHash(splitLinearHash)` -> MH with
+// merkelize / getElement / getGroupProof / calculateRootFromGroupProof / verifyGroupProof / eqRoot / root /
+// writeToFile / readFromFile (merklehash_p.js:12-279).  tree = {elements, nodes, width, height}; elements aliases
+// the caller's buffer (:47), nodes is a new BigUint64Array laid out exactly as the reference's (:28-42, :87-103).
+"use strict";
+const fs = require("fs");
+const { addon, isFlat, upload } = require("./native.js");
+const getPoseidon = require("./poseidon.js");
+
+module.exports = async function buildMerkleHash(splitLinearHash = false) {
+    return new MerkleHash(getPoseidon(), splitLinearHash);
+};
+
+class LinearHash {      // linearhash.js / linearhash_gpu.js: hash(vals) -> [4 BigInt]
+    constructor(split) { this.split = split; }
+    hash(vals) {
+        const flat = [];
+        for (let i = 0; i < vals.length; i++) {
+            if (Array.isArray(vals[i])) for (let j = 0; j < vals[i].length; j++) flat.push(vals[i][j]); else flat.push(vals[i]);
+        }
+        if (flat.length === 0) return [0n, 0n, 0n, 0n];
+        const out = new BigUint64Array(4);
+        addon.linearHashRows(BigUint64Array.from(flat, BigInt), flat.length, 1, this.split ? 1 : 0, out);
+        return Array.from(out);
+    }
+}
+
+class MerkleHash {
+    constructor(poseidon, splitLinearHash = false) {
+        this.poseidon = poseidon;
+        this.splitLinearHash = splitLinearHash;
+        this.lh = new LinearHash(splitLinearHash);
+    }
+
+    _getNNodes(n) { return addon.merkleNumNodes(n / 4); }      // merklehash_p.js:28-42, n = 4*height
+
+    async merkelize(buff, width, height) {
+        const tree = { elements: buff, nodes: new BigUint64Array(this._getNNodes(height * 4)), width, height };
+        if (isFlat(buff)) {
+            addon.merkelize(buff, width, height, this.splitLinearHash ? 1 : 0, tree.nodes);
+        } else {
+            const dEl = addon.devAlloc(width * height);
+            let dNodes;
+            try {
+                dNodes = addon.devAlloc(tree.nodes.length);
+                upload(dEl, buff, width * height);
+                addon.merkelizeDev(dEl, width, height, this.splitLinearHash ? 1 : 0, dNodes);
+                addon.devDownload(tree.nodes, dNodes, 0);
+            } finally {
+                addon.devFree(dEl);
+                if (dNodes !== undefined) addon.devFree(dNodes);
+            }
+        }
+        return tree;
+    }
+
+    getElement(tree, idx, subIdx) {
+        const e = tree.elements;
+        return isFlat(e) ? e[tree.width * idx + subIdx] : e.getElement(tree.width * idx + subIdx);
+    }
+
+    getGroupProof(tree, idx) {          // merklehash_p.js:142-168
+        if ((idx < 0) || (idx >= tree.height)) throw new Error("Out of range");
+        const v = new Array(tree.width);
+        for (let i = 0; i < tree.width; i++) v[i] = this.getElement(tree, idx, i);
+        const mp = [];
+        let offset = 0, n = tree.height * 4;
+        while (n > 4) {
+            const si = (idx ^ 1) * 4;
+            mp.push([tree.nodes[offset + si], tree.nodes[offset + si + 1], tree.nodes[offset + si + 2], tree.nodes[offset + si + 3]]);
+            const nextN = (Math.floor((n - 1) / 8) + 1) * 4;
+            offset += nextN * 2; n = nextN; idx = idx >> 1;
+        }
+        return [v, mp];
+    }
+
+    calculateRootFromGroupProof(mp, idx, vals) {    // merklehash_p.js:170-210
+        let value = this.lh.hash(vals);
+        for (let o = 0; o < mp.length; o++) {
+            value = (idx & 1) === 0 ? this.poseidon([...value, ...mp[o]]) : this.poseidon([...mp[o], ...value]);
+            idx = Math.floor(idx / 2);
+        }
+        return value;
+    }
+
+    eqRoot(r1, r2) { for (let k = 0; k < 4; k++) if (BigInt(r1[k]) !== BigInt(r2[k])) return false; return true; }
+    verifyGroupProof(root, mp, idx, groupElements) { return this.eqRoot(this.calculateRootFromGroupProof(mp, idx, groupElements), root); }
+    root(tree) { return [...tree.nodes.slice(-4)]; }
+
+    async writeToFile(tree, fileName) {             // merklehash_p.js:228-246
+        const fd = await fs.promises.open(fileName, "w+");
+        const header = new BigUint64Array(2);
+        header[0] = BigInt(tree.width); header[1] = BigInt(tree.height);
+        await fd.write(new Uint8Array(header.buffer));
+        const MaxBuffSize = 1024 * 1024 * 32;
+        for (const buff of [tree.elements, tree.nodes]) {
+            for (let i = 0; i < buff.length; i += MaxBuffSize) {
+                const sb = buff.slice(i, Math.min(buff.length, i + MaxBuffSize));
+                await fd.write(new Uint8Array(sb.buffer, sb.byteOffset, sb.byteLength));
+            }
+        }
+        await fd.close();
+    }
+
+    async readFromFile(fileName) {                  // merklehash_p.js:248-278 (elements returned as one BigUint64Array)
+        const fd = await fs.promises.open(fileName, "r");
+        const header = new BigUint64Array(2);
+        await fd.read(new Uint8Array(header.buffer), 0, 16, 0);
+        const tree = { width: Number(header[0]), height: Number(header[1]) };
+        tree.elements = new BigUint64Array(tree.width * tree.height);
+        tree.nodes = new BigUint64Array(this._getNNodes(tree.height * 4));
+        let pos = 16;
+        for (const buff of [tree.elements, tree.nodes]) {
+            const b8 = new Uint8Array(buff.buffer, buff.byteOffset, buff.byteLength);
+            const CH = 1 << 28;
+            for (let o = 0; o < b8.length; o += CH) await fd.read(b8, o, Math.min(CH, b8.length - o), pos + o);
+            pos += b8.length;
+        }
+        await fd.close();
+        return tree;
+    }
+}
+module.exports.MerkleHash = MerkleHash;

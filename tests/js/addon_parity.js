@@ -1,0 +1,96 @@
+// GPU parity of the Node.js boundary: the drop-in modules in pil2-stark-js_amd/js (same names and signatures as the
+// reference's fft_p.js / merklehash_p.js / poseidon.js / fri.js) against the committed golden vectors, which were
+// produced by the reference's own modules (oracle/gen_golden.js).  Shapes follow test/fft_p.test.js and
+// test/merklehash_p.test.js.  Usage: node tests/js/addon_parity.js
+"use strict";
+const fs = require("fs");
+const path = require("path");
+const assert = require("assert");
+const root = path.join(__dirname, "..", "..");
+const { fft, ifft, interpolate } = require(path.join(root, "pil2-stark-js_amd/js/fft_p.js"));
+const buildMH = require(path.join(root, "pil2-stark-js_amd/js/merklehash_p.js"));
+const getPoseidon = require(path.join(root, "pil2-stark-js_amd/js/poseidon.js"));
+const FRI = require(path.join(root, "pil2-stark-js_amd/js/fri.js"));
+const G = (n) => JSON.parse(fs.readFileSync(path.join(root, "tests/golden", n)));
+const H = (v) => Array.isArray(v) ? v.map(H) : (typeof v === "string" ? BigInt("0x" + v) : v);
+
+// minimal chunked container with pilcom.BigBuffer's surface, to drive the staged (non-flat) path
+class ChunkedBuffer {
+    constructor(n, chunk = 1000) { this.length = n; this.chunk = chunk; this.bufs = []; for (let o = 0; o < n; o += chunk) this.bufs.push(new BigUint64Array(Math.min(chunk, n - o))); }
+    getElement(i) { return this.bufs[Math.floor(i / this.chunk)][i % this.chunk]; }
+    setElement(i, v) { this.bufs[Math.floor(i / this.chunk)][i % this.chunk] = v; }
+    slice(a, b) { const r = new BigUint64Array(b - a); for (let i = a; i < b; i++) r[i - a] = this.getElement(i); return r; }
+    set(arr, off) { for (let i = 0; i < arr.length; i++) this.setElement(off + i, arr[i]); }
+}
+
+(async () => {
+    // --- fft_p: "Check fft" / "Check interpolate" shapes of test/fft_p.test.js (value = row index) vs per-column goldens
+    const ntt = G("ntt.json");
+    for (const c of ntt.cases) {
+        if (c.nBits < 1) continue;
+        const n = 1 << c.nBits, nPols = 2;
+        const p = H(c.p), buff = new BigUint64Array(n * nPols), out = new BigUint64Array(n * nPols);
+        for (let j = 0; j < n; j++) for (let i = 0; i < nPols; i++) buff[j * nPols + i] = p[j];
+        await fft(buff, nPols, c.nBits, out);
+        const f = H(c.fft); for (let j = 0; j < n; j++) for (let i = 0; i < nPols; i++) assert.strictEqual(out[j * nPols + i], f[j], "fft " + c.name);
+        await ifft(buff, nPols, c.nBits, out);
+        const fi = H(c.ifft); for (let j = 0; j < n; j++) assert.strictEqual(out[j * nPols + 1], fi[j], "ifft " + c.name);
+        for (const eb of Object.keys(c.ext)) {
+            const e = H(c.ext[eb]), ext = new BigUint64Array(e.length * nPols);
+            await interpolate(buff, nPols, c.nBits, ext, c.nBits + Number(eb));
+            for (let j = 0; j < e.length; j++) for (let i = 0; i < nPols; i++) assert.strictEqual(ext[j * nPols + i], e[j], "interpolate " + c.name);
+            // same through a chunked (BigBuffer-like) container
+            const cb = new ChunkedBuffer(n * nPols, 7), co = new ChunkedBuffer(e.length * nPols, 13);
+            cb.set(buff, 0);
+            await interpolate(cb, nPols, c.nBits, co, c.nBits + Number(eb));
+            for (let j = 0; j < e.length; j++) assert.strictEqual(co.getElement(j * nPols), e[j], "interpolate(chunked) " + c.name);
+        }
+    }
+    // --- poseidon KATs (test/poseidon.test.js)
+    const poseidon = getPoseidon();
+    for (const [inp, cap, out] of H(G("poseidon.json"))) assert.deepStrictEqual(poseidon(inp, cap, 12), out);
+    assert.deepStrictEqual(poseidon([0, 0, 0, 0, 0, 0, 0, 0]).map((x) => x.toString(16)), ["3c18a9786cb0b359", "c4055e3364a246c3", "7953db0ab48808f4", "c71603f33a1144ca"]);
+    assert.deepStrictEqual(poseidon([-1, -1, -1, -1, -1, -1, -1, -1], [-1, -1, -1, -1])[0].toString(16), "be0085cfc57a8357");
+    assert.throws(() => poseidon([1, 2, 3]), /Invalid Input size/);
+    // --- merklehash_p: test/merklehash_p.test.js shapes, roots from the golden file
+    for (const [N, w, split, rootG] of H(G("merkle.json"))) {
+        const MH = await buildMH(!!split);
+        const pols = new BigUint64Array(N * w);
+        for (let i = 0; i < N; i++) for (let j = 0; j < w; j++) pols[i * w + j] = BigInt(i + j * 1000);
+        const tree = await MH.merkelize(pols, w, N);
+        assert.deepStrictEqual(MH.root(tree), rootG, `root ${N}x${w} split=${split}`);
+        const idx = Math.min(3, N - 1);
+        const [groupElements, mp] = MH.getGroupProof(tree, idx);
+        assert(MH.verifyGroupProof(MH.root(tree), mp, idx, groupElements));
+        groupElements[0] ^= 1n;
+        assert(!MH.verifyGroupProof(MH.root(tree), mp, idx, groupElements));
+        assert.throws(() => MH.getGroupProof(tree, N), /Out of range/);
+        if (N === 256 && w === 9) {     // chunked container + file round trip
+            const cb = new ChunkedBuffer(N * w, 100); cb.set(pols, 0);
+            const t2 = await MH.merkelize(cb, w, N);
+            assert.deepStrictEqual(MH.root(t2), rootG);
+            const fn = path.join(require("os").tmpdir(), `pil2gl_${process.pid}.consttree`);
+            await MH.writeToFile(tree, fn);
+            const t3 = await MH.readFromFile(fn);
+            fs.unlinkSync(fn);
+            assert.strictEqual(t3.width, w); assert.strictEqual(t3.height, N);
+            assert.deepStrictEqual(Array.from(t3.nodes), Array.from(tree.nodes));
+            assert.deepStrictEqual(Array.from(t3.elements), Array.from(pols));
+        }
+    }
+    // --- FRI.fold vs golden folds (fri.js:22-61), steps chosen so that step 1 folds polBits -> outBits
+    const MHf = await buildMH(false);
+    for (const [polBits, outBits, bits0, , ch, pol, res] of H(G("fri_fold.json"))) {
+        if (bits0 !== polBits) continue;        // FRI class derives shiftInv from steps[0] - steps[step-1]
+        const fri = new FRI({ nBits: polBits - 1, nBitsExt: polBits, nQueries: 4, steps: [{ nBits: polBits }, { nBits: outBits }] }, MHf);
+        const r = await fri.fold(1, pol, ch);
+        assert.deepStrictEqual(r.pol, res, `fold ${polBits}->${outBits}`);
+        assert.deepStrictEqual(r.proof, res);
+        const r0 = await fri.fold(0, pol, ch);  // step 0: identity + tree over transposed groups
+        assert.strictEqual(r0.pol, pol);
+        const nGroups = 1 << outBits, gp = MHf.getGroupProof(r0.tree, nGroups - 1);
+        assert(MHf.verifyGroupProof(r0.proof.root, gp[1], nGroups - 1, gp[0]));
+        for (let j = 0; j < pol.length / nGroups; j++) assert.strictEqual(gp[0][3 * j], pol[j * nGroups + nGroups - 1][0]);
+    }
+    console.log("addon parity OK");
+})().catch((e) => { console.error(e); process.exit(1); });

@@ -1,0 +1,32 @@
+"""The Node.js side of the boundary: addon loads (CPU) and the drop-in JS modules match the goldens (GPU)."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+NODE = shutil.which("node")
+ADDON = os.path.join(ROOT, "pil2-stark-js_amd", "addon", "pil2gl.node")
+
+
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_addon_loads_and_exports():
+    assert os.path.exists(ADDON), "addon not built (make -C pil2-stark-js_amd)"
+    js = ("const m=require(%r);const a=m.native;"
+          "for (const k of ['interpolate','fft','ifft','merkelize','merkelizeLevel','linearHashRows','poseidon','friFold',"
+          "'friTranspose','devAlloc','devFree','devUpload','devDownload','interpolateDev','merkelizeDev','groupProofDev','evalProgramDev'])"
+          " if (typeof a[k] !== 'function') throw new Error('missing '+k);"
+          "if (a.merkleNumNodes(256) !== 2044) throw new Error('merkleNumNodes');"
+          "for (const k of ['fft','ifft','interpolate']) if (typeof m.fft_p[k] !== 'function') throw new Error(k);"
+          "console.log('ok')") % os.path.join(ROOT, "pil2-stark-js_amd", "js", "index.js")
+    out = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_js_modules_match_goldens_on_gpu():
+    out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "addon_parity.js")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "addon parity OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

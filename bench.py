@@ -75,6 +75,7 @@ def cpu_baseline(n_cols, split):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = min(cores, int(os.environ.get("PIL2GL_CPU_THREADS", "16")))      # the GPU box grants a 16-CPU share per GPU
     gl_oracle.set_threads(cores)
     n_bits = 14 if n_cols > 16 else 17
     rng = np.random.default_rng(1)

@@ -136,6 +136,8 @@ int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *ctx, void *s
 /* ---- diagnostics used by the parity tests ---------------------------------- */
 /* element-wise a*b, a+b, a-b on the device (n elements, host pointers) */
 int pil2gl_selftest_field(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *add, uint64_t *sub);
+/* host-only: the op-list after validation and live-range renumbering of temporaries, as the kernel runs it */
+int pil2gl_debug_compact_program(const glx_program *prog, glx_op *outOps, uint32_t *nSlots);
 /* extension a*b and 1/a on the device (n triples) */
 int pil2gl_selftest_ext(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *inv);
 

@@ -58,3 +58,35 @@ def test_no_cpu_fallback_without_gpu():
     assert "-2" in str(e.value) or "no HIP device" in str(e.value)
     with pytest.raises(pil2gl.Pil2glError):
         pil2gl.buildMerkleHash(False).merkelize(a, 1, 8)
+
+
+def test_tmp_compaction_preserves_program(oracle):
+    """host-side live-range renumbering of temporaries (expr.hip) must not change what the program computes"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_parity import _random_program
+    from conftest import rand_field
+    lib = _lib.load()
+    for n_ops in (5, 20, 300, 1500):
+        rng = np.random.default_rng(n_ops)
+        n_bits = 5
+        widths = [5, 9, 1, 3]
+        secs = [rand_field(rng, (1 << n_bits, w)) for w in widths]
+        secs[-1][:] = 0
+        scalars = rand_field(rng, 40)
+        ops, n_tmp = _random_program(rng, n_ops, widths, scalars.size, len(widths) - 1)
+        ref = [s.copy() for s in secs]
+        oracle.eval_program(ops, n_tmp, ref, scalars, n_bits, 0)
+        prog = oracle.make_program(ops, n_tmp, struct_op=_lib.GlxOp, struct_prog=_lib.GlxProgram)
+        out = (_lib.GlxOp * len(ops))(); n_slots = C.c_uint32()
+        assert lib.pil2gl_debug_compact_program(C.byref(prog), out, C.byref(n_slots)) == 0
+        assert n_slots.value <= n_tmp and (n_ops < 100 or n_slots.value < n_tmp // 2)
+        ops2 = []
+        for o in out:
+            def ref_(r):
+                return (r.kind, r.dim, r.section, r.prime, r.index)
+            ops2.append((o.op, ref_(o.dest), ref_(o.src[0]), ref_(o.src[1]) if o.op != 3 else None))
+        got = [s.copy() for s in secs]
+        oracle.eval_program(ops2, max(1, n_slots.value), got, scalars, n_bits, 0)
+        for a, b in zip(got, ref):
+            assert (a == b).all(), n_ops

@@ -231,7 +231,7 @@ int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit,
     u32 nHi;
     if (lo > 0) { P.tStride = (C << lo); P.gStride = C; P.hiStride = (C << (lo + k)); totalGroups = 1ull << lo; nHi = 1u << (n - lo - k); }
     else { P.tStride = C; P.gStride = (C << k); P.hiStride = 0; totalGroups = 1ull << (n - k); nHi = 1; }
-    Geom g = make_geom(k, C, totalGroups, env_u32("PIL2GL_NTT_TILE", 8192), 256);
+    Geom g = make_geom(k, C, totalGroups, env_u32("PIL2GL_NTT_TILE", 4096), 256);
     P.Wc = g.Wc; P.nbT = g.nbT; P.nColChunks = g.nColChunks; P.nGroupTiles = (u32)(totalGroups / g.nbT);
     u64 K = 1ull << k;
     size_t ldsBytes = 8 * ((size_t)g.S * K + std::max<u64>(1, K / 2) + (P.hasTw ? (size_t)g.nbT * K : 0));
@@ -311,11 +311,11 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st)
         P.src = coef; P.dst = dst; P.twi = tables().powWi; P.twf = tables().powW; P.pow7 = tables().pow7;
         P.C = C; P.ninv = h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb;
         u64 totalGroups = 1ull << (n - kf);
-        u32 nThreads = env_u32("PIL2GL_LDE_THREADS", 1024);
+        u32 nThreads = env_u32("PIL2GL_LDE_THREADS", 512);
         // LDS = tile (S*K) + two local twiddle tables (K) + coset scale tables (2*G*K); narrow matrices
         // (small C => many row groups per tile) are dominated by the scale tables, so shrink until it fits
         u64 K = 1ull << kf;
-        u32 maxElems = env_u32("PIL2GL_LDE_TILE", 8192);
+        u32 maxElems = env_u32("PIL2GL_LDE_TILE", 4096);
         Geom g = make_geom(kf, C, totalGroups, maxElems, nThreads);
         size_t ldsBytes = 8 * ((size_t)g.S * K + std::max<u64>(2, K) + 2 * (size_t)g.nbT * K);
         while (ldsBytes > 96 * 1024 && g.nbT > 1) {

@@ -24,8 +24,10 @@ __device__ __forceinline__ u64 pow7_lazy(u64 x) {
     return mul_lazy(x3, x4);
 }
 
-// out = M * st with the 6-bit circulant: accumulate the low and high 32-bit halves separately
-// (each sum < 2^32 * 272 < 2^41), recombine to a 97-bit value and reduce once.
+// out = M * st with the 6-bit circulant.  The low and high 32-bit halves of the 12 lanes are accumulated
+// separately with v_mad_u64_u32 (A = sum lo_j*m, B = sum hi_j*m, both < 2^41); then
+//   A + B*2^32 = A + B_hi*2^64 + B_lo*2^32 = (A + B_hi*(2^32-1)) + B_lo*2^32   (mod p)
+// where the bracket is < 2^42 (one more mad) and B_lo*2^32 only touches the upper word: one carry to fix.
 __device__ __forceinline__ void mds_layer(u64 st[12]) {
     constexpr u32 MC[12] = { 17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20 };
     u32 lo[12], hi[12];
@@ -33,33 +35,39 @@ __device__ __forceinline__ void mds_layer(u64 st[12]) {
     for (int j = 0; j < 12; j++) { lo[j] = (u32)st[j]; hi[j] = (u32)(st[j] >> 32); }
 #pragma unroll
     for (int i = 0; i < 12; i++) {
-        u64 al = 0, ah = 0;
+        u64 A = 0, B = 0;
 #pragma unroll
         for (int j = 0; j < 12; j++) {
             const u32 m = MC[(j - i + 12) % 12] + ((i == 0 && j == 0) ? 8u : 0u);
-            al += (u64)lo[j] * m;
-            ah += (u64)hi[j] * m;
+            A += (u64)lo[j] * m;
+            B += (u64)hi[j] * m;
         }
-        // value = al + ah * 2^32  (< 2^74):  lo64 = al + (ah << 32), hi64 = (ah >> 32) + carry
-        u64 l = al + (ah << 32);
-        u64 h = (ah >> 32) + (l < al ? 1 : 0);
-        st[i] = reduce128_lazy(l, h);
+        const u64 t = (u64)(u32)(B >> 32) * EPS + A;          // < 2^42
+        u32 th;
+        const bool c = __builtin_uadd_overflow((u32)(t >> 32), (u32)B, &th);
+        const u64 r = ((u64)th << 32) | (u32)t;
+        st[i] = c ? r + EPS : r;                               // wrapped once: r is small, cannot wrap again
     }
 }
 
-// in-place permutation; st[] canonical or lazy in, canonical out
+// in-place permutation; st[] canonical or lazy in, canonical out.
+// Rounds 4..25 use the folded constants (one addition per round, see poseidon_gl_constants.inc).
 __device__ inline void poseidon_perm(u64 st[12]) {
 #pragma unroll 1
-    for (int r = 0; r < 30; r++) {
-        const bool full = (r < 4) || (r >= 26);
+    for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = add_lazy(st[i], POSEIDON_GL_RC[r * 12 + i]);
-        if (full) {
+        for (int i = 0; i < 12; i++) st[i] = pow7_lazy(add_lazy_canon(st[i], POSEIDON_GL_RC[r * 12 + i]));
+        mds_layer(st);
+    }
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+        st[0] = pow7_lazy(add_lazy_canon(st[0], POSEIDON_GL_PARTIAL_C0[r]));
+        mds_layer(st);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) st[i] = pow7_lazy(st[i]);
-        } else {
-            st[0] = pow7_lazy(st[0]);
-        }
+        for (int i = 0; i < 12; i++) st[i] = pow7_lazy(add_lazy_canon(st[i], r == 26 ? POSEIDON_GL_RC26F[i] : POSEIDON_GL_RC[r * 12 + i]));
         mds_layer(st);
     }
 #pragma unroll

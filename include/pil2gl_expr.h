@@ -7,7 +7,7 @@
  * (src/prover/prover_helpers.js:31-45 calculateExps, :83-107 compileCode,
  *  :109-150 setRef, :152-218 getRef, :220-259 evalMap).
  * This header is the C form of that op-list.  The JS-side encoder
- * (pil2-stark-js_amd/js/expr_encoder.js) maps every reference operand kind
+ * (pil2-stark-js_amd/js/prover_helpers.js) maps every reference operand kind
  * onto one of three operand classes:
  *
  *   reference ref.type                         -> encoding

@@ -6,4 +6,5 @@ module.exports = {
     buildMerkleHash: require("./merklehash_p.js"),
     buildPoseidon: require("./poseidon.js"),
     FRI: require("./fri.js"),
+    prover_helpers: require("./prover_helpers.js"),
 };

@@ -1,0 +1,103 @@
+// Drop-in for the evaluator entry point of src/prover/prover_helpers.js:
+//   callCalculateExps(stage, code, dom, ctx, parallelExec, useThreads, debug, global)   (prover_helpers.js:23)
+// The op-list `code.code` is encoded into the binary form of include/pil2gl_expr.h and run on the GPU for every
+// row of the domain; operand resolution follows getRef/setRef/evalMap (prover_helpers.js:109-259).
+// ctx buffers (const_n, cm{s}_n/_ext, x_n/x_ext, Zi_ext, xDivXSubXi_ext, q_ext, f_ext) may be BigUint64Array or
+// BigBuffer-like; referenced sections are staged to the device, destinations copied back.
+"use strict";
+const { addon, upload, download } = require("./native.js");
+const P = 0xFFFFFFFF00000001n;
+const OP = { add: 0, sub: 1, mul: 2, copy: 3 };
+const TMP = 0, SEC = 1, SCALAR = 2;
+const e = (a) => { let v = BigInt(a) % P; if (v < 0n) v += P; return v; };
+
+function encode(code, dom, ctx, global) {
+    const info = ctx.pilInfo;
+    const sections = [];            // {name, buf, width, written}
+    const secIndex = new Map();
+    const scalars = [];
+    function section(name, width, zi) {
+        const key = zi === undefined ? name : name + "#" + zi;
+        if (!secIndex.has(key)) { secIndex.set(key, sections.length); sections.push({ name, width, zi, written: false }); }
+        return secIndex.get(key);
+    }
+    function scalar(v) {            // base element or [3] extension element -> word offset
+        const off = scalars.length;
+        if (Array.isArray(v)) { for (const c of v) scalars.push(e(c)); return [off, 3]; }
+        scalars.push(e(v)); return [off, 1];
+    }
+    function cmRef(r) {             // evalMap, prover_helpers.js:220-259
+        const p = info.cmPolsMap[r.id];
+        const st = "cm" + p.stage;
+        return { kind: SEC, dim: p.dim, section: section(st + "_" + dom, info.mapSectionsN[st]), prime: r.prime || 0, index: p.stagePos };
+    }
+    function ref(r, isDest) {
+        switch (r.type) {
+            case "tmp": return { kind: TMP, dim: r.dim, section: 0, prime: 0, index: r.id };
+            case "const": return { kind: SEC, dim: 1, section: section("const_" + dom, info.nConstants), prime: r.prime || 0, index: r.id };
+            case "cm": return cmRef(r);
+            case "q": if (dom !== "ext") throw new Error("Accessing q in domain n");
+                return { kind: SEC, dim: r.dim, section: section("q_ext", info.qDim), prime: 0, index: 0 };
+            case "f": if (dom !== "ext") throw new Error("Accessing q in domain n");
+                return { kind: SEC, dim: 3, section: section("f_ext", 3), prime: 0, index: 0 };
+            case "x": return { kind: SEC, dim: 1, section: section("x_" + dom, 1), prime: 0, index: 0 };
+            case "Zi": {
+                const boundary = info.boundaries[r.boundaryId];
+                const ziIndex = boundary.name === "everyFrame"
+                    ? info.boundaries.findIndex((b) => b.name === "everyFrame" && b.offsetMin === boundary.offsetMin && b.offsetMax === boundary.offsetMax)
+                    : info.boundaries.findIndex((b) => b.name === boundary.name);
+                if (ziIndex === -1) throw new Error("Something went wrong");
+                return { kind: SEC, dim: 1, section: section("Zi_ext", 1, ziIndex), prime: 0, index: 0 };
+            }
+            case "xDivXSubXi": return { kind: SEC, dim: 3, section: section("xDivXSubXi_ext", 3 * info.openingPoints.length), prime: 0, index: 3 * r.id };
+            case "number": { const [o, d] = scalar(BigInt(r.value)); return { kind: SCALAR, dim: d, section: 0, prime: 0, index: o }; }
+            case "public": { const [o, d] = scalar(ctx.publics[r.id]); return { kind: SCALAR, dim: d, section: 0, prime: 0, index: o }; }
+            case "challenge": { const [o] = scalar(ctx.challenges[r.stage - 1][r.stageId]); return { kind: SCALAR, dim: 3, section: 0, prime: 0, index: o }; }
+            case "subproofValue": { const v = global ? ctx.subproofValues[r.subproofId][r.id] : ctx.subproofValues[r.id]; const [o, d] = scalar(v); return { kind: SCALAR, dim: d, section: 0, prime: 0, index: o }; }
+            case "eval": { const [o] = scalar(ctx.evals[r.id]); return { kind: SCALAR, dim: 3, section: 0, prime: 0, index: o }; }
+            default: throw new Error((isDest ? "Invalid reference type set: " : "Invalid reference type get: ") + r.type);
+        }
+    }
+    // glx_op: u32 op, u32 pad, 3 x glx_ref{u8 kind,u8 dim,u16 section,i32 prime,u32 index,u32 pad} = 56 bytes
+    const buf = new ArrayBuffer(code.length * 56), dv = new DataView(buf);
+    const put = (o, r) => { dv.setUint8(o, r.kind); dv.setUint8(o + 1, r.dim); dv.setUint16(o + 2, r.section, true); dv.setInt32(o + 4, r.prime, true); dv.setUint32(o + 8, r.index, true); };
+    let nTmp = 0;
+    for (let j = 0; j < code.length; j++) {
+        const c = code[j], o = j * 56;
+        if (!(c.op in OP)) throw new Error("Invalid op:" + c.op);
+        dv.setUint32(o, OP[c.op], true);
+        const d = ref(c.dest, true);
+        if (d.kind === SCALAR) throw new Error("Invalid reference type set: " + c.dest.type);
+        if (d.kind === SEC) sections[d.section].written = true;
+        put(o + 8, d);
+        put(o + 24, ref(c.src[0], false));
+        if (c.op !== "copy") put(o + 40, ref(c.src[1], false));
+        for (const r of [c.dest, ...c.src]) if (r.type === "tmp") nTmp = Math.max(nTmp, r.id + 1);
+    }
+    return { ops: new BigUint64Array(buf), nOps: code.length, nTmp, sections, scalars: BigUint64Array.from(scalars.length ? scalars : [0n]) };
+}
+
+module.exports.callCalculateExps = async function callCalculateExps(stage, code, dom, ctx, parallelExec, useThreads, debug, global = false) {
+    if (debug) throw new Error("debug (constraint checking) mode is not offloaded; use the reference evaluator");
+    const enc = encode(code.code, dom, ctx, global);
+    const nBits = dom === "n" ? ctx.nBits : ctx.nBitsExt;
+    const rows = 2 ** nBits;
+    const ptrs = new BigUint64Array(enc.sections.length), widths = new BigUint64Array(enc.sections.length), devs = [];
+    try {
+        enc.sections.forEach((s, i) => {
+            const host = ctx[s.name];
+            if (!host) throw new Error("ctx." + s.name + " is not allocated");
+            const n = rows * s.width, base = s.zi === undefined ? 0 : s.zi * rows;
+            const d = addon.devAlloc(n);
+            devs.push(d);
+            if (base === 0 && n === host.length) upload(d, host, n);
+            else addon.devUpload(d, 0, host.slice(base, base + n));
+            ptrs[i] = d; widths[i] = BigInt(s.width);
+        });
+        addon.evalProgramDev(enc.ops, enc.nOps, enc.nTmp, nBits, dom === "n" ? 0 : ctx.extendBits, ptrs, widths, enc.scalars);
+        enc.sections.forEach((s, i) => { if (s.written) download(ctx[s.name], devs[i], rows * s.width); });
+    } finally {
+        for (const d of devs) addon.devFree(d);
+    }
+};
+module.exports.encode = encode;

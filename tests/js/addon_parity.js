@@ -92,5 +92,34 @@ class ChunkedBuffer {
         assert(MHf.verifyGroupProof(r0.proof.root, gp[1], nGroups - 1, gp[0]));
         for (let j = 0; j < pol.length / nGroups; j++) assert.strictEqual(gp[0][3 * j], pol[j * nGroups + nGroups - 1][0]);
     }
+    // --- callCalculateExps: a small op-list over a fake ctx (prover_helpers.js:23-259 operand kinds), checked by BigInt math
+    {
+        const { callCalculateExps } = require(path.join(root, "pil2-stark-js_amd/js/prover_helpers.js"));
+        const P = 0xFFFFFFFF00000001n, nBits = 4, nBitsExt = 6, extN = 64, ext = 4;
+        const ctx = {
+            nBits, nBitsExt, extendBits: 2, publics: [5n], challenges: [[], [[3n, 1n, 4n]]], evals: [], subproofValues: [],
+            pilInfo: { nConstants: 2, qDim: 3, openingPoints: [0, 1], boundaries: [{ name: "everyRow" }], mapSectionsN: { cm1: 3 },
+                cmPolsMap: [{ stage: 1, dim: 1, stagePos: 0 }, { stage: 1, dim: 1, stagePos: 2 }] },
+            const_ext: new BigUint64Array(extN * 2), cm1_ext: new BigUint64Array(extN * 3), x_ext: new BigUint64Array(extN),
+            Zi_ext: new BigUint64Array(extN), q_ext: new BigUint64Array(extN * 3),
+        };
+        for (let i = 0; i < extN; i++) { ctx.const_ext[2 * i + 1] = BigInt(7 * i + 1); ctx.cm1_ext[3 * i] = BigInt(i * i + 3); ctx.cm1_ext[3 * i + 2] = P - BigInt(i + 1); ctx.x_ext[i] = BigInt(1000 + i); ctx.Zi_ext[i] = BigInt(2 * i + 9); }
+        // q = ((cm0' - cm1) * const1 + public0 + x) * Zi * challenge        (cm0' = next row: prime 1)
+        const code = { tmpUsed: 5, code: [
+            { op: "sub", dest: { type: "tmp", id: 0, dim: 1 }, src: [{ type: "cm", id: 0, prime: 1, dim: 1 }, { type: "cm", id: 1, prime: 0, dim: 1 }] },
+            { op: "mul", dest: { type: "tmp", id: 1, dim: 1 }, src: [{ type: "tmp", id: 0, dim: 1 }, { type: "const", id: 1, prime: 0, dim: 1 }] },
+            { op: "add", dest: { type: "tmp", id: 2, dim: 1 }, src: [{ type: "tmp", id: 1, dim: 1 }, { type: "public", id: 0, dim: 1 }] },
+            { op: "add", dest: { type: "tmp", id: 3, dim: 1 }, src: [{ type: "tmp", id: 2, dim: 1 }, { type: "x", dim: 1 }] },
+            { op: "mul", dest: { type: "tmp", id: 4, dim: 1 }, src: [{ type: "tmp", id: 3, dim: 1 }, { type: "Zi", boundaryId: 0, dim: 1 }] },
+            { op: "mul", dest: { type: "q", dim: 3 }, src: [{ type: "tmp", id: 4, dim: 1 }, { type: "challenge", stage: 2, stageId: 0, id: 0, dim: 3 }] },
+        ] };
+        await callCalculateExps(2, code, "ext", ctx, false, false, false);
+        const mod = (a) => ((a % P) + P) % P;
+        for (let i = 0; i < extN; i++) {
+            const nx = (i + ext) % extN;
+            const t = mod(mod(mod(ctx.cm1_ext[3 * nx] - ctx.cm1_ext[3 * i + 2]) * ctx.const_ext[2 * i + 1] + 5n + ctx.x_ext[i]) * ctx.Zi_ext[i]);
+            assert.deepStrictEqual([ctx.q_ext[3 * i], ctx.q_ext[3 * i + 1], ctx.q_ext[3 * i + 2]], [mod(t * 3n), mod(t * 1n), mod(t * 4n)], "callCalculateExps row " + i);
+        }
+    }
     console.log("addon parity OK");
 })().catch((e) => { console.error(e); process.exit(1); });

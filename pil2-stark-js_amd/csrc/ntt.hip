@@ -36,32 +36,65 @@ __device__ __forceinline__ u64 pow256(const u64 *__restrict__ T, u32 e) {
 // w_(2^logM)^e for the root whose pow256 table is T (1 <= logM <= 32, e < 2^logM)
 __device__ __forceinline__ u64 root_pow(const u64 *__restrict__ T, u32 logM, u32 e) { return pow256(T, e << (32 - logM)); }
 
-// k radix-2 stages on tile[2^k][S] (column x), Gentleman-Sande: natural in -> bit-reversed out
+// k stages on tile[2^k][S] (column x), Gentleman-Sande: natural in -> bit-reversed out.
+// Two stages at a time: a lane takes 4 rows into registers (radix-4 step = 4 radix-2 butterflies), which halves
+// the LDS traffic and the barriers; an odd k ends with one radix-2 stage.  The last stage's twiddles are all 1.
 __device__ __forceinline__ void dif_stages(u64 *tile, const u64 *TW, u32 k, u32 S, u32 x, u32 y, u32 by) {
-    const u32 half = 1u << (k - 1);
-    for (int s = (int)k - 1; s >= 0; s--) {
-        const u32 h = 1u << s;
+    int s = (int)k - 1;
+    for (; s >= 1; s -= 2) {                        // stages s (half-span h) and s-1 (half-span h/2)
+        const u32 h = 1u << s, q = h >> 1, quarter = 1u << (k - 2);
+        const bool lastTrivial = (s == 1);
+        for (u32 j = y; j < quarter; j += by) {
+            const u32 off = j & (q - 1);
+            const u32 p = ((j >> (s - 1)) << (s + 1)) + off;
+            u64 a0 = tile[p * S + x], a1 = tile[(p + q) * S + x], a2 = tile[(p + h) * S + x], a3 = tile[(p + h + q) * S + x];
+            const u64 wA = TW[off << (k - 1 - s)], wB = TW[(off + q) << (k - 1 - s)];
+            u64 b0 = add(a0, a2), b2 = mul(sub(a0, a2), wA);
+            u64 b1 = add(a1, a3), b3 = mul(sub(a1, a3), wB);
+            u64 c0 = add(b0, b1), c1 = sub(b0, b1), c2 = add(b2, b3), c3 = sub(b2, b3);
+            if (!lastTrivial) { const u64 wC = TW[off << (k - s)]; c1 = mul(c1, wC); c3 = mul(c3, wC); }
+            tile[p * S + x] = c0; tile[(p + q) * S + x] = c1; tile[(p + h) * S + x] = c2; tile[(p + h + q) * S + x] = c3;
+        }
+        __syncthreads();
+    }
+    if (s == 0) {                                   // odd k: last stage, twiddle 1
+        const u32 half = 1u << (k - 1);
         for (u32 j = y; j < half; j += by) {
-            u32 off = j & (h - 1);
-            u32 p = ((j >> s) << (s + 1)) + off;
-            u64 a = tile[p * S + x], b = tile[(p + h) * S + x];
+            const u32 p = j << 1;
+            u64 a = tile[p * S + x], b = tile[(p + 1) * S + x];
             tile[p * S + x] = add(a, b);
-            tile[(p + h) * S + x] = mul(sub(a, b), TW[off << (k - 1 - s)]);
+            tile[(p + 1) * S + x] = sub(a, b);
         }
         __syncthreads();
     }
 }
-// Cooley-Tukey: bit-reversed in -> natural out
+// Cooley-Tukey: bit-reversed in -> natural out (same two-stages-at-a-time structure; the first stage's twiddles are 1)
 __device__ __forceinline__ void dit_stages(u64 *tile, const u64 *TW, u32 k, u32 S, u32 x, u32 y, u32 by) {
-    const u32 half = 1u << (k - 1);
-    for (u32 s = 0; s < k; s++) {
-        const u32 h = 1u << s;
+    u32 s = 0;
+    if (k & 1) {                                    // odd k: first stage alone, twiddle 1
+        const u32 half = 1u << (k - 1);
         for (u32 j = y; j < half; j += by) {
-            u32 off = j & (h - 1);
-            u32 p = ((j >> s) << (s + 1)) + off;
-            u64 a = tile[p * S + x], b = mul(tile[(p + h) * S + x], TW[off << (k - 1 - s)]);
+            const u32 p = j << 1;
+            u64 a = tile[p * S + x], b = tile[(p + 1) * S + x];
             tile[p * S + x] = add(a, b);
-            tile[(p + h) * S + x] = sub(a, b);
+            tile[(p + 1) * S + x] = sub(a, b);
+        }
+        __syncthreads();
+        s = 1;
+    }
+    for (; s + 1 < k; s += 2) {                     // stages s (half-span h) and s+1 (half-span 2h)
+        const u32 h = 1u << s, quarter = 1u << (k - 2);
+        const bool firstTrivial = (s == 0);
+        for (u32 j = y; j < quarter; j += by) {
+            const u32 off = j & (h - 1);
+            const u32 p = ((j >> s) << (s + 2)) + off;
+            u64 a0 = tile[p * S + x], a1 = tile[(p + h) * S + x], a2 = tile[(p + 2 * h) * S + x], a3 = tile[(p + 3 * h) * S + x];
+            if (!firstTrivial) { const u64 wA = TW[off << (k - 1 - s)]; a1 = mul(a1, wA); a3 = mul(a3, wA); }
+            u64 b0 = add(a0, a1), b1 = sub(a0, a1), b2 = add(a2, a3), b3 = sub(a2, a3);
+            const u64 wB = TW[off << (k - 2 - s)], wC = TW[(off + h) << (k - 2 - s)];
+            b2 = mul(b2, wB); b3 = mul(b3, wC);
+            tile[p * S + x] = add(b0, b2); tile[(p + 2 * h) * S + x] = sub(b0, b2);
+            tile[(p + h) * S + x] = add(b1, b3); tile[(p + 3 * h) * S + x] = sub(b1, b3);
         }
         __syncthreads();
     }

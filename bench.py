@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- trace-cells/s of the STARK commit step (extend + merkelize) on MI355X.
+"""bench.py -- STARK prove time and trace-cells/s on MI355X.
 
-One "step" = one pass of the hot path over one synthetic trace that is already resident in HBM:
-  interpolate (LDE, blow-up 8, fft_p.js:187)  ->  merkelize (Poseidon leaves + tree, merklehash_p.js:44)
-i.e. extendAndMerkelize of src/stark/stark_gen_helpers.js:388-412, called through the C ABI
-(libpil2gl.so) by the Python mirror of the reference operators.  Synthetic uniformly random
-Goldilocks trace; inputs, outputs and the tree stay on the device (no PCIe in the timed region).
+One "step" (default --mode prove) = one full proof of a synthetic AIR whose witness is already resident in HBM:
+the stage loop of src/prover/prover.js:7-127 -- extendAndMerkelize (LDE blow-up 8 + Poseidon Merkle tree),
+constraint polynomial Q (expression evaluation on the extended domain, iNTT/split/NTT, tree), evaluations,
+FRI polynomial, FRI folding with trees, query openings -- driven by pil2gl.stark.stark_gen through the C ABI
+(libpil2gl.so).  The AIR is K = cols/2 copies of the reference's Fibonacci machine
+(test/state_machines/sm_fibonacci/fibonacci.pil), so the trace satisfies its constraints and the proof is a
+valid one (tests/test_stark_prove.py verifies such proofs and their bit-identity with the CPU oracle's).
+--mode commit times only extendAndMerkelize (stark_gen_helpers.js:388-412) on a uniformly random trace.
+Inputs, intermediates, trees and outputs stay on the device (no PCIe in the timed region).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|NBITSxCOLS]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|NBITSxCOLS] [--mode prove|commit]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same step on its
 own trace (weak scaling, no data-path collective); value = all ranks' cells / max-over-ranks time.
@@ -36,6 +40,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("PIL2GL_BENCH_WORKLOAD", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", default=os.environ.get("PIL2GL_BENCH_MODE", "prove"), choices=["prove", "commit"])
     ap.add_argument("--split", action="store_true", help="splitLinearHash leaves (linearhash_gpu.js)")
     return ap.parse_args()
 
@@ -52,6 +57,24 @@ def make_trace(n_rows, n_cols, seed, device):
         lo = torch.randint(0, 1 << 32, (m,), dtype=torch.int64, device=device, generator=g)
         out[o:o + m] = (hi << 32) | lo
     return out
+
+
+def fibonacci_trace_gpu(torch, dev, n_bits, n_pairs, rank):
+    """witness of K Fibonacci machines (sm_fibonacci.js:12-23), generated on the device (one lane per machine,
+    the recurrence is sequential in the row index), plus the constant columns L1/LLAST and the publics"""
+    import ctypes as C
+    import pil2gl
+    N = 1 << n_bits
+    rng = np.random.default_rng(0x5EED0000 + rank)
+    init = rng.integers(0, 0xFFFFFFFF00000001, size=2 * n_pairs, dtype=np.uint64)      # (l1_k(0), l2_k(0)) pairs
+    cm = torch.empty(N * 2 * n_pairs, dtype=torch.int64, device=dev)
+    pil2gl.call("pil2gl_synth_fibonacci_dev", n_bits, n_pairs, C.c_void_p(init.ctypes.data), C.c_void_p(cm.data_ptr()),
+                C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    consts = np.zeros((N, 2), dtype=np.uint64); consts[0, 0] = 1; consts[N - 1, 1] = 1
+    first = cm[:2].cpu().numpy().view(np.uint64); last = cm[(N - 1) * 2 * n_pairs:(N - 1) * 2 * n_pairs + 1].cpu().numpy().view(np.uint64)
+    publics = [int(first[1]), int(first[0]), int(last[0])]
+    return cm, consts, publics
 
 
 def ev_time(fn, iters):
@@ -132,16 +155,41 @@ def main():
         n_bits, n_cols = (int(v) for v in wl.lower().split("x"))
     N, E = 1 << n_bits, 1 << (n_bits + EXT_BITS)
 
-    src = make_trace(N, n_cols, 0x5EED0000 + rank, dev)
+    prove_ctx = None
+    if args.mode == "prove":
+        from pil2gl import stark
+        n_cols -= n_cols & 1                                   # pairs of columns
+        fri_steps = [n_bits + EXT_BITS]
+        while fri_steps[-1] > 10:                              # decreasing by <= 5 bits, as zkevm.starkstruct.json does
+            fri_steps.append(max(fri_steps[-1] - 5, 6))
+        ss = {"nBits": n_bits, "nBitsExt": n_bits + EXT_BITS, "nQueries": 64, "verificationHashType": "GL",
+              "splitLinearHash": bool(args.split), "steps": [{"nBits": b} for b in fri_steps]}
+        info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
+        be = stark.GpuBackend(local_rank, args.split)
+        src, consts, publics = fibonacci_trace_gpu(torch, dev, n_bits, n_cols // 2, rank)
+        setup = stark.build_const_tree(be, consts, info)
+        prove_ctx = (stark, be, setup, info, exprs, publics)
+    else:
+        src = make_trace(N, n_cols, 0x5EED0000 + rank, dev)
     dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
     MH = pil2gl.buildMerkleHash(args.split)
     nodes = torch.empty(MH._getNNodes(E * 4), dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     import ctypes as C
 
+    stage_times = {}
+
     def step():
+        if prove_ctx is not None:
+            stark_, be_, setup_, info_, exprs_, publics_ = prove_ctx
+            stark_.stark_gen(be_, src, setup_, info_, exprs_, publics_, timings=stage_times if collect[0] else None)
+            return
         pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
         pil2gl.call("pil2gl_merkelize_dev", pil2gl._ptr(dst), n_cols, E, int(args.split), pil2gl._ptr(nodes), C.c_void_p(stream))
+    collect = [False]
+    if prove_ctx is not None:
+        del dst, nodes                                         # the prove loop allocates its own buffers
+        dst = nodes = None
 
     def barrier():
         torch.cuda.synchronize()
@@ -163,6 +211,11 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = world * N * n_cols / (dt / args.steps)
+    if prove_ctx is not None and rank == 0:                    # one more, untimed-for-value, proof with a per-stage breakdown
+        collect[0] = True
+        step(); torch.cuda.synchronize()
+        collect[0] = False
+        dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
 
     out = None
     if rank == 0:
@@ -192,16 +245,25 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom["hbm_frac"], "traffic": load_pmc_traffic(dom["kernel"].split(" ")[0]),
                     "note": "Poseidon hashing is integer-ALU bound (no 64-bit multiplier on gfx950); its HBM fraction is small by nature, see kernels[]"}
+        if prove_ctx is not None:
+            metric = "STARK prove time (ms_per_step) and trace-cells/s, synthetic Fibonacci AIR, GL Poseidon Merkle + FRI, blow-up 8"
+            workload = "full proof (commit, Q, evals, FRI %s, %d queries) of 2^%d rows x %d cols -> 2^%d rows, %s linear hash, per GPU" % (
+                "/".join(str(x["nBits"]) for x in prove_ctx[3]["starkStruct"]["steps"]), prove_ctx[3]["starkStruct"]["nQueries"], n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain")
+        else:
+            metric = "trace-cells/s, STARK commit step (extend+merkelize), GL Poseidon Merkle, blow-up 8"
+            workload = "extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, %s linear hash, per GPU" % (n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain")
         out = {
-            "metric": "trace-cells/s, STARK commit step (extend+merkelize), GL Poseidon Merkle, blow-up 8",
+            "metric": metric,
             "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, %s linear hash, per GPU" % (n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain"),
+            "config": {"workload": workload, "mode": args.mode,
                        "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "GL-Poseidon-12",
                        "parallelism": "replicas x%d" % world if world > 1 else "single GPU"},
             "roofline": roofline, "kernels": kernels,
         }
+        if prove_ctx is not None:
+            out["prove"] = {"seconds": ms_per_step / 1e3, "stages_s": {k: round(v, 4) for k, v in stage_times.items()}}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(n_cols, args.split)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]

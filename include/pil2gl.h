@@ -133,6 +133,11 @@ int pil2gl_compute_evals_dev(const pil2gl_eval_desc *descs, uint32_t nEvals, uin
  * ctx are DEVICE pointers; prog/ctx structs themselves are host memory (copied at launch). */
 int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *ctx, void *stream);
 
+/* ---- synthetic workload for bench.py / tests (not a reference operator) ----
+ * witness of nPairs independent Fibonacci machines (test/state_machines/sm_fibonacci/sm_fibonacci.js:12-23):
+ * cm is 2^nBits x (2*nPairs) row-major (l1_k, l2_k), hostInit = 2*nPairs canonical start values (host pointer). */
+int pil2gl_synth_fibonacci_dev(uint32_t nBits, uint32_t nPairs, const uint64_t *hostInit, uint64_t *cm, void *stream);
+
 /* ---- diagnostics used by the parity tests ---------------------------------- */
 /* element-wise a*b, a+b, a-b on the device (n elements, host pointers) */
 int pil2gl_selftest_field(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *add, uint64_t *sub);

@@ -144,6 +144,20 @@ __global__ void evals_final_kernel(const u64 *__restrict__ partial, u32 nBlocks,
     out[e] = acc;
 }
 
+// Witness of K independent Fibonacci machines (test/state_machines/sm_fibonacci/sm_fibonacci.js:12-23):
+// l2' = l1, l1' = l1^2 + l2^2.  Sequential in the row index, so one lane per machine; bench/test support only.
+__global__ void synth_fibonacci_kernel(u32 nBits, u32 nPairs, const u64 *__restrict__ init, u64 *__restrict__ cm) {
+    const u32 k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nPairs) return;
+    u64 l1 = canon(init[2 * k]), l2 = canon(init[2 * k + 1]);
+    const u64 N = 1ull << nBits, W = 2ull * nPairs;
+    for (u64 i = 0; i < N; i++) {
+        cm[i * W + 2 * k] = l1; cm[i * W + 2 * k + 1] = l2;
+        const u64 n1 = add(mul(l1, l1), mul(l2, l2));
+        l2 = l1; l1 = n1;
+    }
+}
+
 inline unsigned nblk(u64 n, u32 t = 256) { return (unsigned)((n + t - 1) / t); }
 
 }  // namespace
@@ -316,6 +330,17 @@ int pil2gl_compute_evals_dev(const pil2gl_eval_desc *descs, uint32_t nEvals, uin
     KERNEL_CHECK();
     HIP_TRY(hipMemcpyAsync(hostEvals, res, (u64)nEvals * 24, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    return PIL2GL_OK;
+}
+
+int pil2gl_synth_fibonacci_dev(uint32_t nBits, uint32_t nPairs, const uint64_t *hostInit, uint64_t *cm, void *stream) {
+    P2_TRY(ensure_init());
+    if (!hostInit || !cm || nBits > 31 || nPairs == 0) return fail(PIL2GL_EINVAL, "bad synthetic trace arguments");
+    std::vector<u64> h(hostInit, hostInit + 2ull * nPairs);
+    u64 *d; P2_TRY(upload_small(h, 2, &d, as_stream(stream)));
+    synth_fibonacci_kernel<<<nblk(nPairs, 64), 64, 0, as_stream(stream)>>>(nBits, nPairs, d, cm);
+    KERNEL_CHECK();
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     return PIL2GL_OK;
 }
 

@@ -88,6 +88,7 @@ SIGNATURES = {
     "pil2gl_build_lev_dev": (_I, [_U32, vp, vp, vp]),
     "pil2gl_compute_evals_dev": (_I, [C.POINTER(EvalDesc), _U32, _U32, _U32, C.POINTER(vp), _U32, vp, vp]),
     "pil2gl_eval_program_dev": (_I, [C.POINTER(GlxProgram), C.POINTER(GlxCtx), vp]),
+    "pil2gl_synth_fibonacci_dev": (_I, [_U32, _U32, vp, vp, vp]),
     "pil2gl_debug_compact_program": (_I, [C.POINTER(GlxProgram), C.POINTER(GlxOp), C.POINTER(_U32)]),
     "pil2gl_selftest_field": (_I, [vp, vp, _U64, vp, vp, vp]),
     "pil2gl_selftest_ext": (_I, [vp, vp, _U64, vp, vp]),

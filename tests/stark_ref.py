@@ -1,0 +1,234 @@
+"""Test infrastructure for the prove loop: a CPU backend on the oracle (to produce the expected proof) and a
+verifier restating src/stark/stark_verify.js:8-218 + src/stark/fri.js:107-174 on python ints / oracle calls."""
+import numpy as np
+
+import gl_oracle as orc
+
+P = 0xFFFFFFFF00000001
+
+
+class OracleBackend:
+    """same interface as pil2gl.stark.GpuBackend, numpy arrays + oracle functions"""
+    name = "oracle"
+
+    def __init__(self, split=False):
+        self.split = split
+
+    def empty(self, n): return np.zeros(int(n), np.uint64)
+    def zeros(self, n): return np.zeros(int(n), np.uint64)
+    def from_host(self, a): return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1).copy()
+    def to_host(self, t): return t.reshape(-1)
+    def sync(self): pass
+
+    def interpolate(self, src, C, nb, dst, nbe): dst[:] = orc.interpolate(src.reshape(-1, C), nb, nbe).reshape(-1)
+    def fft(self, src, C, nb, dst): dst[:] = orc.fft_cols(src.reshape(-1, C), nb).reshape(-1)
+    def ifft(self, src, C, nb, dst): dst[:] = orc.ifft_cols(src.reshape(-1, C), nb).reshape(-1)
+
+    def merkelize(self, buf, w, h):
+        return {"elements": buf, "nodes": orc.merkelize(buf.reshape(h, w), self.split), "width": w, "height": h}
+
+    def root(self, tree): return [int(v) for v in tree["nodes"][-4:]]
+
+    def group_proof(self, tree, idx):
+        w = tree["width"]
+        return [int(v) for v in tree["elements"][idx * w:(idx + 1) * w]], [[int(x) for x in s] for s in orc.group_proof(tree["nodes"], tree["height"], idx)]
+
+    def poseidon(self, inp, cap, n): return [int(v) for v in orc.poseidon([int(v) % P for v in inp], [int(v) % P for v in cap], n)]
+    def build_x(self, nb, shift): return orc.build_x(nb, shift)
+    def build_zhinv(self, nb, nbe): return orc.build_zhinv(nb, nbe)
+    def q_split(self, qq1, nb, nbe, qDim, qDeg): return orc.compute_q_split(qq1, nb, nbe, qDim, qDeg).reshape(-1)
+    def x_div_x_sub_xi(self, nbe, xis): return orc.x_div_x_sub_xi(nbe, np.array(xis, dtype=np.uint64)).reshape(-1)
+    def build_lev(self, nb, xi): return orc.lev(nb, np.array(xi, dtype=np.uint64)).reshape(-1)
+
+    def compute_evals(self, descs, nb, eb, levs):
+        return [[int(v) for v in orc.eval_pol_at(buf.reshape(-1, width), off, dim, nb, eb, levs[li].reshape(-1, 3))]
+                for (buf, width, off, dim, li) in descs]
+
+    def eval_program(self, ops, n_tmp, sections, scalars, nb, prime_shift):
+        secs = [t.reshape(-1, w) for (t, w) in sections]          # views: destinations are written in place
+        orc.eval_program(ops, n_tmp, secs, scalars, nb, prime_shift)
+
+    def fri_fold(self, pol, pol_bits, out_bits, shift_inv, challenge):
+        return orc.fri_fold(pol.reshape(-1, 3), out_bits, shift_inv, np.array([int(c) % P for c in challenge], dtype=np.uint64)).reshape(-1)
+
+    def fri_transpose(self, pol, pol_bits, t_bits): return orc.fri_transpose(pol.reshape(-1, 3), t_bits).reshape(-1)
+
+
+# ---------------------------------------------------------------------------------------------- scalar op-list evaluation
+def _e3(v):
+    return list(v) if isinstance(v, (list, tuple)) else [v, 0, 0]
+
+
+def _mul(a, b):
+    if isinstance(a, list) and isinstance(b, list):
+        return [int(x) for x in orc.mul3([x % P for x in a], [x % P for x in b])]
+    if isinstance(a, list):
+        return [x * b % P for x in a]
+    if isinstance(b, list):
+        return [x * a % P for x in b]
+    return a * b % P
+
+
+def _add(a, b):
+    if isinstance(a, list) and isinstance(b, list):
+        return [(x + y) % P for x, y in zip(a, b)]
+    if isinstance(a, list):
+        return [(a[0] + b) % P, a[1], a[2]]
+    if isinstance(b, list):
+        return [(a + b[0]) % P, b[1], b[2]]
+    return (a + b) % P
+
+
+def _sub(a, b):                                  # f3g.js:60-71 incl. scalar - triple
+    if isinstance(a, list) and isinstance(b, list):
+        return [(x - y) % P for x, y in zip(a, b)]
+    if isinstance(a, list):
+        return [(a[0] - b) % P, a[1], a[2]]
+    if isinstance(b, list):
+        return [(a - b[0]) % P, (-b[1]) % P, (-b[2]) % P]
+    return (a - b) % P
+
+
+def exec_code(code, resolve):
+    """stark_verify.js:222-298 executeCode: returns the value of the last op"""
+    tmp = {}
+    res = None
+    for c in code:
+        src = [tmp[r["id"]] if r["type"] == "tmp" else resolve(r) for r in c["src"]]
+        res = {"add": _add, "sub": _sub, "mul": _mul}[c["op"]](src[0], src[1]) if c["op"] != "copy" else src[0]
+        tmp[c["dest"]["id"]] = res
+    return res
+
+
+def eval_expr(e, resolve):
+    if e.op == "leaf":
+        return resolve(e.leaf)
+    a, b = eval_expr(e.a, resolve), eval_expr(e.b, resolve)
+    return {"add": _add, "sub": _sub, "mul": _mul}[e.op](a, b)
+
+
+def _pow3(x, e):
+    r = [1, 0, 0]; b = list(x)
+    while e:
+        if e & 1:
+            r = _mul(r, b)
+        b = _mul(b, b); e >>= 1
+    return r
+
+
+def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcript=True):
+    from pil2gl.stark import Transcript, root_of_unity, SHIFT
+    proof, publics = res["proof"], res["publics"]
+    ss = info["starkStruct"]; nb, nbe = ss["nBits"], ss["nBitsExt"]; N = 1 << nb; steps = ss["steps"]
+    be = OracleBackend(split)
+    # transcript replay, calculateTranscriptVerify.js:7-103 (nStages = 1)
+    t = Transcript(be)
+    t.put(constRoot); t.put(publics)
+    t.put(proof["root1"])
+    vc = t.getField(); t.put(proof["root2"])
+    xi = t.getField()
+    for ev in proof["evals"]:
+        t.put(ev)
+    vf1 = t.getField(); vf2 = t.getField()
+    chF = []
+    for step in range(len(steps)):
+        chF.append(t.getField())
+        if step < len(steps) - 1:
+            t.put(proof["fri"][step + 1]["root"])
+        else:
+            for e in proof["fri"][-1]:
+                t.put(e)
+    chF.append(t.getField())
+    if check_transcript and not ([vc] == res["challenges"][1] and [xi] == res["challenges"][2] and [vf1, vf2] == res["challenges"][3] and chF == res["challengesFRISteps"]):
+        return False, "transcript does not reproduce the challenges"
+    tq = Transcript(be); tq.put(chF[-1])
+    queries = tq.getPermutations(ss["nQueries"], steps[0]["nBits"])
+    if check_transcript and queries != res["queries"]:
+        return False, "query positions differ"
+    challenges = {(2, 0): vc, (3, 0): xi, (4, 0): vf1, (4, 1): vf2}
+
+    # evaluations, stark_verify.js:95-152
+    xN = _pow3(xi, N)
+    Z = [int(v) for v in orc.inv3([(xN[0] - 1) % P, xN[1], xN[2]])]
+
+    def resolve(r):
+        ty = r["type"]
+        if ty == "eval": return list(proof["evals"][r["id"]])
+        if ty == "challenge": return list(challenges[(r["stage"], r["stageId"])])
+        if ty == "public": return publics[r["id"]]
+        if ty == "number": return int(r["value"]) % P
+        if ty == "Zi": return list(Z)
+        raise ValueError(ty)
+    lhs = exec_code(verifierInfo["qVerifier"]["code"], resolve)
+    nCm1 = info["mapSectionsN"]["cm1"]
+    q = [0, 0, 0]; xAcc = [1, 0, 0]
+    for i in range(info["qDeg"]):
+        evId = next(k for k, e in enumerate(info["evMap"]) if e["type"] == "cm" and e["id"] == nCm1 + i)
+        q = _add(q, _mul(xAcc, list(proof["evals"][evId]))); xAcc = _mul(xAcc, xN)
+    if _e3(lhs) != q:
+        return False, "Invalid evaluations"
+
+    # queries, stark_verify.js:158-218 + fri.js:107-174
+    wN, wE = root_of_unity(nb), root_of_unity(nbe)
+    for qi, idx in enumerate(queries):
+        pq = proof["fri"][0]["polQueries"][qi]
+        for (vals, sib), root in zip(pq, (proof["root1"], proof["root2"], constRoot)):
+            if [int(v) for v in orc.root_from_proof(np.array(vals, dtype=np.uint64), idx, np.array(sib, dtype=np.uint64), split)] != list(root):
+                return False, "Invalid root (query %d)" % qi
+        x = SHIFT * pow(wE, idx, P) % P
+        xdiv = []
+        for opening in info["openingPoints"]:
+            w = pow(wN, abs(opening), P)
+            den = _sub(x, [c * w % P for c in xi])
+            xdiv.append(_mul([int(v) for v in orc.inv3(den)], x))
+
+        def rq(r):
+            ty = r["type"]
+            if ty == "cm":
+                p = info["cmPolsMap"][r["id"]]; vals = pq[p["stage"] - 1][0]
+                return vals[p["stagePos"]] if p["dim"] == 1 else vals[p["stagePos"]:p["stagePos"] + 3]
+            if ty == "const": return pq[2][0][r["id"]]
+            if ty == "xDivXSubXi": return list(xdiv[r["id"]])
+            return resolve(r)
+
+        def pol_leaf(ev):
+            from pil2gl.stark import Expr
+            dim = 1 if ev["type"] == "const" else info["cmPolsMap"][ev["id"]]["dim"]
+            return Expr.leafOf({"type": ev["type"], "id": ev["id"], "prime": 0, "dim": dim})
+        val = _e3(eval_expr(verifierInfo["friexp"](pol_leaf), rq))
+        # walk the FRI layers for this query (fri.js:118-150)
+        pol_bits = nbe; cur_idx = idx; group = None
+        shift = SHIFT
+        for si in range(len(steps)):
+            if si == 0:
+                ev = val
+            else:
+                vals, sib = proof["fri"][si]["polQueries"][qi]
+                if [int(v) for v in orc.root_from_proof(np.array(vals, dtype=np.uint64), cur_idx, np.array(sib, dtype=np.uint64), split)] != list(proof["fri"][si]["root"]):
+                    return False, "Invalid FRI root step %d" % si
+                g = np.array(vals, dtype=np.uint64).reshape(-1, 3)
+                sinv = pow(shift * pow(root_of_unity(pol_bits), cur_idx, P) % P, P - 2, P)
+                ev = [int(v) for v in orc.fri_fold(g, 0, sinv, np.array(chF[si], dtype=np.uint64))[0]]
+            if si < len(steps) - 1:
+                nxt_groups = 1 << steps[si + 1]["nBits"]
+                group_idx = cur_idx // nxt_groups
+                nv = proof["fri"][si + 1]["polQueries"][qi][0]
+                if nv[3 * group_idx:3 * group_idx + 3] != ev:
+                    return False, "FRI layer %d mismatch (query %d)" % (si, qi)
+                red = pol_bits - steps[si]["nBits"]
+                for _ in range(red):
+                    shift = shift * shift % P
+                pol_bits = steps[si]["nBits"]
+                cur_idx = cur_idx % nxt_groups
+            else:
+                if list(proof["fri"][-1][cur_idx]) != ev:
+                    return False, "FRI last layer mismatch (query %d)" % qi
+    # low degree of the last polynomial (fri.js:154-171)
+    last = np.array(proof["fri"][-1], dtype=np.uint64)
+    lb = steps[-1]["nBits"]
+    coef = orc.fft3(last, inverse=True)
+    max_deg = 0 if lb - (nbe - nb) < 0 else 1 << (lb - (nbe - nb))
+    for i in range(max_deg + 1, coef.shape[0]):
+        if coef[i].any():
+            return False, "last polynomial is not low degree"
+    return True, "ok"

@@ -1,0 +1,97 @@
+"""End-to-end prove loop (commit -> Q -> evals -> FRI -> queries) on the synthetic Fibonacci AIR:
+the orchestration is exercised on the CPU oracle backend here (no GPU), and GPU-vs-oracle proof identity
+is asserted in the gpu-marked test."""
+import numpy as np
+import pytest
+
+from conftest import P
+
+
+def _setup(n_bits, n_pairs, steps, n_queries=8):
+    from pil2gl import stark
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": n_queries, "verificationHashType": "GL",
+          "steps": [{"nBits": b} for b in steps]}
+    info, exprs, vinfo = stark.fibonacci_air(n_pairs, ss)
+    cm, consts, publics = stark.fibonacci_trace(n_bits, n_pairs)
+    return stark, info, exprs, vinfo, cm, consts, publics
+
+
+def test_trace_satisfies_air():
+    stark, info, exprs, vinfo, cm, consts, publics = _setup(6, 2, [9, 5, 2])
+    N = cm.shape[0]
+    for i in range(N - 1):
+        for k in range(2):
+            l1, l2 = int(cm[i, 2 * k]), int(cm[i, 2 * k + 1])
+            assert int(cm[i + 1, 2 * k + 1]) == l1 and int(cm[i + 1, 2 * k]) == (l1 * l1 + l2 * l2) % P
+    assert publics == [int(cm[0, 1]), int(cm[0, 0]), int(cm[N - 1, 0])]
+
+
+@pytest.mark.parametrize("n_bits,n_pairs,steps", [(6, 1, [9, 5, 2]), (8, 3, [11, 7, 3])])
+def test_prove_and_verify_on_oracle_backend(oracle, n_bits, n_pairs, steps):
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _setup(n_bits, n_pairs, steps)
+    be = stark_ref.OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    # soundness smoke: a corrupted evaluation / witness must be rejected
+    bad = {**res, "proof": {**res["proof"], "evals": [list(e) for e in res["proof"]["evals"]]}}
+    bad["proof"]["evals"][0][0] ^= 1
+    assert not stark_ref.stark_verify(bad, setup["constRoot"], info, vinfo)[0]
+    # same corruption with the prover's own challenges re-derived: the evaluation identity itself must fail
+    bad2 = {**bad}
+    ok_b, why_b = stark_ref.stark_verify({**bad2, "challenges": None, "challengesFRISteps": None, "queries": None}, setup["constRoot"], info, vinfo, check_transcript=False)
+    assert not ok_b and why_b == "Invalid evaluations"
+    cm2 = cm.copy(); cm2[5, 0] ^= 1
+    res2 = stark.stark_gen(be, be.from_host(cm2), setup, info, exprs, publics)
+    ok2, why2 = stark_ref.stark_verify(res2, setup["constRoot"], info, vinfo)
+    assert not ok2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bits,n_pairs,steps,split", [(8, 2, [11, 7, 3], False), (12, 5, [15, 11, 7, 3], False), (10, 4, [13, 9, 4], True)])
+def test_gpu_proof_is_bit_identical_to_oracle_proof(oracle, n_bits, n_pairs, steps, split):
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _setup(n_bits, n_pairs, steps)
+    gpu = stark.GpuBackend(0, split)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    cpu = stark_ref.OracleBackend(split)
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, publics)
+    assert s_gpu["constRoot"] == s_cpu["constRoot"]
+    assert r_gpu["challenges"] == r_cpu["challenges"] and r_gpu["queries"] == r_cpu["queries"]
+    assert r_gpu["proof"] == r_cpu["proof"]
+    ok, why = stark_ref.stark_verify(r_gpu, s_gpu["constRoot"], info, vinfo, split)
+    assert ok, why
+
+
+@pytest.mark.gpu
+def test_synthetic_trace_kernel_matches_reference_recurrence():
+    import ctypes as C
+    import torch
+    import pil2gl
+    pil2gl.init(0)
+    n_bits, K = 7, 3
+    init = np.array([5, 9, 1 << 40, P - 1, 123456789, 987654321], dtype=np.uint64)
+    cm = torch.empty((1 << n_bits) * 2 * K, dtype=torch.int64, device="cuda")
+    pil2gl.call("pil2gl_synth_fibonacci_dev", n_bits, K, C.c_void_p(init.ctypes.data), C.c_void_p(cm.data_ptr()), None)
+    got = cm.cpu().numpy().view(np.uint64).reshape(1 << n_bits, 2 * K)
+    for k in range(K):
+        l1, l2 = int(init[2 * k]), int(init[2 * k + 1])
+        for i in range(1 << n_bits):
+            assert (int(got[i, 2 * k]), int(got[i, 2 * k + 1])) == (l1, l2)
+            l1, l2 = (l1 * l1 + l2 * l2) % P, l1
+
+
+@pytest.mark.gpu
+def test_config2_size_proof_verifies(oracle):
+    """BASELINE config 2 shape (2^20 rows x 8 cols, blow-up 8): the GPU proof passes the restated verifier"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _setup(20, 4, [23, 18, 13, 8], n_queries=16)
+    gpu = stark.GpuBackend(0, False)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    res = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    ok, why = stark_ref.stark_verify(res, s_gpu["constRoot"], info, vinfo)
+    assert ok, why

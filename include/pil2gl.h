@@ -97,6 +97,11 @@ int pil2gl_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t height,
 int pil2gl_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height,
                            uint64_t idx, uint64_t *hostVals, uint64_t *hostSiblings, uint32_t *nLevels);
 
+/* the same for nIdx rows at once (fri.js:83-105 opens every tree at every query): hostOut receives, per index,
+ * `width` row words followed by nLevels x 4 sibling words; one gather kernel, one device-to-host copy. */
+int pil2gl_group_proofs_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height,
+                            const uint64_t *hostIdxs, uint32_t nIdx, uint64_t *hostOut, uint32_t *nLevels);
+
 /* ---- FRI: src/stark/fri.js ------------------------------------------------ */
 /* FRI.fold(step>0, pol, challenge)  fri.js:22-61: pol has 2^polBits extension elements, out 2^outBits;
  * shiftInv = (1/7)^(2^(steps[0].nBits - polBits)) (fri.js:31-36, computed by the caller). */

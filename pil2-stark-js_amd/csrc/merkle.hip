@@ -84,6 +84,24 @@ __global__ void __launch_bounds__(256) poseidon_batch_kernel(const u64 *__restri
     for (u32 j = 0; j < nOut; j++) out[(u64)nOut * i + j] = st[j];
 }
 
+// gather of query openings (merklehash_p.js:142-168) for many indices at once: one block per query copies the row
+// and the sibling digest of every level into a packed staging area
+__global__ void group_proofs_kernel(const u64 *__restrict__ elems, const u64 *__restrict__ nodes, u64 width, u64 height,
+                                    const u64 *__restrict__ idxs, u32 nLevels, u64 *__restrict__ out) {
+    const u64 stride = width + 4ull * nLevels;
+    u64 *o = out + (u64)blockIdx.x * stride;
+    u64 idx = idxs[blockIdx.x];
+    for (u64 c = threadIdx.x; c < width; c += blockDim.x) o[c] = elems[idx * width + c];
+    if (threadIdx.x < 4) {
+        u64 offset = 0, n = height * 4;
+        for (u32 l = 0; l < nLevels; l++) {
+            o[width + 4 * l + threadIdx.x] = nodes[offset + (idx ^ 1) * 4 + threadIdx.x];
+            const u64 nextN = ((n - 1) / 8 + 1) * 4;
+            offset += nextN * 2; n = nextN; idx >>= 1;
+        }
+    }
+}
+
 }  // namespace
 
 using namespace pil2gl;
@@ -170,6 +188,26 @@ int pil2gl_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_
         offset += nextN * 2; n = nextN; idx >>= 1; lvl++;
     }
     if (nLevels) *nLevels = lvl;
+    return PIL2GL_OK;
+}
+
+int pil2gl_group_proofs_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height,
+                            const uint64_t *hostIdxs, uint32_t nIdx, uint64_t *hostOut, uint32_t *nLevels) {
+    P2_TRY(ensure_init());
+    if (!nIdx) return PIL2GL_OK;
+    if (!nodes || !hostIdxs || !hostOut || (!elems && width)) return fail(PIL2GL_EINVAL, "null buffer");
+    u32 lv = 0;
+    for (u64 n = height * 4; n > 4; n = ((n - 1) / 8 + 1) * 4) lv++;
+    for (u32 i = 0; i < nIdx; i++) if (hostIdxs[i] >= height) return fail(PIL2GL_EINVAL, "Out of range");     // merklehash_p.js:143
+    const u64 stride = width + 4ull * lv;
+    u64 *d;
+    P2_TRY(scratch(6, (u64)nIdx * (stride + 1), &d));
+    u64 *dIdx = d + (u64)nIdx * stride;
+    HIP_TRY(hipMemcpy(dIdx, hostIdxs, (u64)nIdx * 8, hipMemcpyHostToDevice));
+    group_proofs_kernel<<<nIdx, 64>>>(elems, nodes, width, height, dIdx, lv, d);
+    KERNEL_CHECK();
+    HIP_TRY(hipMemcpy(hostOut, d, (u64)nIdx * stride * 8, hipMemcpyDeviceToHost));
+    if (nLevels) *nLevels = lv;
     return PIL2GL_OK;
 }
 

@@ -225,6 +225,21 @@ class MerkleHash:
             offset += nextN * 2; n = nextN; idx >>= 1
         return v, mp
 
+    def getGroupProofs(self, tree, idxs):
+        """getGroupProof for a list of indices (fri.js:83-105 opens each tree at every query): one gather on the device"""
+        if not _is_dev(tree["nodes"]):
+            return [self.getGroupProof(tree, i) for i in idxs]
+        width, height = tree["width"], tree["height"]
+        for i in idxs:
+            if i < 0 or i >= height:
+                raise Pil2glError("Out of range")
+        nl = 0; n = height * 4
+        while n > 4:
+            n = ((n - 1) // 8 + 1) * 4; nl += 1
+        ii = np.array(idxs, dtype=np.uint64); out = np.zeros((len(idxs), width + 4 * nl), np.uint64); lv = C.c_uint32()
+        call("pil2gl_group_proofs_dev", _ptr(tree["elements"]), _ptr(tree["nodes"]), width, height, _ptr(ii), len(idxs), _ptr(out), C.byref(lv))
+        return [([int(v) for v in r[:width]], [[int(x) for x in r[width + 4 * l:width + 4 * l + 4]] for l in range(nl)]) for r in out]
+
     def calculateRootFromGroupProof(self, mp, idx, vals):
         value = self.lh.hash(vals)                      # merklehash_p.js:170-210
         for sib in mp:

@@ -7,51 +7,7 @@ import gl_oracle as orc
 P = 0xFFFFFFFF00000001
 
 
-class OracleBackend:
-    """same interface as pil2gl.stark.GpuBackend, numpy arrays + oracle functions"""
-    name = "oracle"
-
-    def __init__(self, split=False):
-        self.split = split
-
-    def empty(self, n): return np.zeros(int(n), np.uint64)
-    def zeros(self, n): return np.zeros(int(n), np.uint64)
-    def from_host(self, a): return np.ascontiguousarray(a, dtype=np.uint64).reshape(-1).copy()
-    def to_host(self, t): return t.reshape(-1)
-    def sync(self): pass
-
-    def interpolate(self, src, C, nb, dst, nbe): dst[:] = orc.interpolate(src.reshape(-1, C), nb, nbe).reshape(-1)
-    def fft(self, src, C, nb, dst): dst[:] = orc.fft_cols(src.reshape(-1, C), nb).reshape(-1)
-    def ifft(self, src, C, nb, dst): dst[:] = orc.ifft_cols(src.reshape(-1, C), nb).reshape(-1)
-
-    def merkelize(self, buf, w, h):
-        return {"elements": buf, "nodes": orc.merkelize(buf.reshape(h, w), self.split), "width": w, "height": h}
-
-    def root(self, tree): return [int(v) for v in tree["nodes"][-4:]]
-
-    def group_proof(self, tree, idx):
-        w = tree["width"]
-        return [int(v) for v in tree["elements"][idx * w:(idx + 1) * w]], [[int(x) for x in s] for s in orc.group_proof(tree["nodes"], tree["height"], idx)]
-
-    def poseidon(self, inp, cap, n): return [int(v) for v in orc.poseidon([int(v) % P for v in inp], [int(v) % P for v in cap], n)]
-    def build_x(self, nb, shift): return orc.build_x(nb, shift)
-    def build_zhinv(self, nb, nbe): return orc.build_zhinv(nb, nbe)
-    def q_split(self, qq1, nb, nbe, qDim, qDeg): return orc.compute_q_split(qq1, nb, nbe, qDim, qDeg).reshape(-1)
-    def x_div_x_sub_xi(self, nbe, xis): return orc.x_div_x_sub_xi(nbe, np.array(xis, dtype=np.uint64)).reshape(-1)
-    def build_lev(self, nb, xi): return orc.lev(nb, np.array(xi, dtype=np.uint64)).reshape(-1)
-
-    def compute_evals(self, descs, nb, eb, levs):
-        return [[int(v) for v in orc.eval_pol_at(buf.reshape(-1, width), off, dim, nb, eb, levs[li].reshape(-1, 3))]
-                for (buf, width, off, dim, li) in descs]
-
-    def eval_program(self, ops, n_tmp, sections, scalars, nb, prime_shift):
-        secs = [t.reshape(-1, w) for (t, w) in sections]          # views: destinations are written in place
-        orc.eval_program(ops, n_tmp, secs, scalars, nb, prime_shift)
-
-    def fri_fold(self, pol, pol_bits, out_bits, shift_inv, challenge):
-        return orc.fri_fold(pol.reshape(-1, 3), out_bits, shift_inv, np.array([int(c) % P for c in challenge], dtype=np.uint64)).reshape(-1)
-
-    def fri_transpose(self, pol, pol_bits, t_bits): return orc.fri_transpose(pol.reshape(-1, 3), t_bits).reshape(-1)
+from stark_backend import OracleBackend  # noqa: E402,F401
 
 
 # ---------------------------------------------------------------------------------------------- scalar op-list evaluation

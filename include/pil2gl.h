@@ -133,6 +133,21 @@ typedef struct { const uint64_t *buf; uint64_t width; uint64_t offset; uint32_t 
 int pil2gl_compute_evals_dev(const pil2gl_eval_desc *descs, uint32_t nEvals, uint32_t nBits, uint32_t extendBits,
                              const uint64_t *const *levs, uint32_t nLevs, uint64_t *hostEvals /* nEvals x 3 */, void *stream);
 
+/* ---- extension-weighted sums: the two steps that are matrix-vector products (csrc/dot.hip) ----
+ * acc[r][o] (+)= sum_c buf[r][c] * coef[o][c]   (coef: host array nOut x width x 3, one extension constant per base
+ * column; acc: device nRows x nOut x 3).  With coef = powers of vf2 this is the inner sum of the FRI polynomial
+ * (friPolinomial.js:26-36) for every opening at once. */
+int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, const uint64_t *hostCoef, uint32_t nOut,
+                            uint64_t *acc, int accumulate, void *stream);
+/* f[r] = Horner in vf1 over the openings of (acc[r][o] - K_o) * xDivXSubXi[r][o]   (friPolinomial.js:38-50);
+ * hostK: nOpen x 3 (K_o = sum_j ev_j vf2^(n_o - j)). */
+int pil2gl_fri_combine_dev(const uint64_t *acc, const uint64_t *hostK, const uint64_t vf1[3], const uint64_t *xDivXSubXi,
+                           uint32_t nOpen, uint64_t nRows, uint64_t *f, void *stream);
+/* hostOut[l][c] = sum_k buf[k*rowStep][c] * levs[l][k]   (stark_gen_helpers.js:250-264 for every column of a buffer
+ * and every opening at once; hostOut: nLev x width x 3, levs[l]: device nRows x 3). */
+int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, uint64_t rowStep, const uint64_t *const *levs,
+                            uint32_t nLev, uint64_t *hostOut, void *stream);
+
 /* ---- expression evaluator: src/prover/prover_helpers.js:23-259 ------------- */
 /* callCalculateExps / calculateExps: run the op-list on every row of the domain.  Section pointers in
  * ctx are DEVICE pointers; prog/ctx structs themselves are host memory (copied at launch). */
@@ -146,8 +161,10 @@ int pil2gl_synth_fibonacci_dev(uint32_t nBits, uint32_t nPairs, const uint64_t *
 /* ---- diagnostics used by the parity tests ---------------------------------- */
 /* element-wise a*b, a+b, a-b on the device (n elements, host pointers) */
 int pil2gl_selftest_field(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *add, uint64_t *sub);
-/* host-only: the op-list after validation and live-range renumbering of temporaries, as the kernel runs it */
-int pil2gl_debug_compact_program(const glx_program *prog, glx_op *outOps, uint32_t *nSlots);
+/* host-only: the op-list after validation, value numbering (each distinct cell loaded once, common sub-expressions
+ * merged) and live-range renumbering of temporaries, as the kernel runs it (without Horner-chain fusion).
+ * outOps must hold 2*nOps+16 entries; outInfo[0] = temporaries needed, outInfo[1] = ops written. */
+int pil2gl_debug_compact_program(const glx_program *prog, glx_op *outOps, uint32_t *outInfo);
 /* extension a*b and 1/a on the device (n triples) */
 int pil2gl_selftest_ext(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *inv);
 

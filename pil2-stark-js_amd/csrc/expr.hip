@@ -11,6 +11,9 @@
 #include <vector>
 #include <string.h>
 #include <algorithm>
+#include <array>
+#include <map>
+#include <stdlib.h>
 
 using namespace gl;
 
@@ -21,13 +24,20 @@ struct DevRef { u32 kind_dim;    // kind | dim << 8
                 u32 section;
                 int32_t rowOff;  // prime << primeShift, already scaled
                 u32 index; };
-struct DevOp { u32 op; u32 pad_; DevRef dest, src[2]; };     // 56 bytes
+struct DevOp { u32 op; u32 aux; DevRef dest, src[2]; };      // 56 bytes; aux: limb-pool offset of a GLX_LZ_MAD weight
+
+// internal ops produced by the host-side optimiser (never part of the ABI):
+// a Horner chain  t = X*t + c_i  over an extension constant X is evaluated as sum_i c_i * X^(n-i) with the lazy
+// 22-bit-limb accumulation of csrc/dot.hip: LZ_BEGIN zeroes the 3x6 partial sums, LZ_MAD adds value * weight
+// (the weight's limbs come from the limb pool), LZ_END folds them into the destination.
+enum { GLX_LZ_BEGIN = 4, GLX_LZ_MAD = 5, GLX_LZ_END = 6 };
 
 #define GLX_MAX_SECTIONS 24
 struct DevCtx {
     const DevOp *__restrict__ ops; u32 nOps;
     u32 nBits;
     const u64 *__restrict__ scalars;
+    const u32 *__restrict__ limbs;
     u64 *secPtr[GLX_MAX_SECTIONS];
     u32 secWidth[GLX_MAX_SECTIONS];
 };
@@ -57,6 +67,25 @@ __device__ __forceinline__ void load_ref(const DevRef r, const DevCtx &c, u64 ro
     }
 }
 
+__device__ __forceinline__ u64 fold6(const u64 S[6]) {       // see csrc/dot.hip
+    u64 r = canon(S[0]);
+    r = add(r, mul(S[1], 1ull << 22));
+    r = add(r, mul(S[2], 1ull << 44));
+    r = add(r, mul(S[3], 1ull << 32));
+    r = add(r, mul(S[4], 1ull << 54));
+    r = add(r, mul(S[5], ((1ull << 32) - 1) << 12));
+    return r;
+}
+__device__ __forceinline__ void lz_mad(u64 S[3][6], u64 v, const u32 *__restrict__ L) {
+    const u32 p0 = (u32)v, p1 = (u32)(v >> 32);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const u32 w0 = L[3 * k], w1 = L[3 * k + 1], w2 = L[3 * k + 2];
+        S[k][0] += (u64)p0 * w0; S[k][1] += (u64)p0 * w1; S[k][2] += (u64)p0 * w2;
+        S[k][3] += (u64)p1 * w0; S[k][4] += (u64)p1 * w1; S[k][5] += (u64)p1 * w2;
+    }
+}
+
 template <bool LDS_TMP>
 __global__ void __launch_bounds__(256) eval_kernel(DevCtx c, u64 *gtmp) {
     extern __shared__ u64 lds_tmp[];
@@ -65,14 +94,30 @@ __global__ void __launch_bounds__(256) eval_kernel(DevCtx c, u64 *gtmp) {
     else { T = gtmp + (size_t)blockIdx.x * blockDim.x + threadIdx.x; stride = gridDim.x * blockDim.x; }
     const u64 nRows = 1ull << c.nBits;
     for (u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x; row < nRows; row += (u64)gridDim.x * blockDim.x) {
+        u64 LZ[3][6];
         for (u32 k = 0; k < c.nOps; k++) {
             const DevOp op = c.ops[k];
             u64 a0, a1, a2, b0 = 0, b1 = 0, b2 = 0, r0, r1, r2;
+            if (op.op == GLX_LZ_BEGIN) {
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+#pragma unroll
+                    for (int i = 0; i < 6; i++) LZ[q][i] = 0;
+                continue;
+            }
+            if (op.op == GLX_LZ_MAD) {
+                load_ref(op.src[0], c, row, T, stride, a0, a1, a2);
+                const u32 *L = c.limbs + op.aux;
+                lz_mad(LZ, a0, L);
+                if ((op.src[0].kind_dim >> 8) == 3) { lz_mad(LZ, a1, L + 9); lz_mad(LZ, a2, L + 18); }
+                continue;
+            }
             const u32 da = op.src[0].kind_dim >> 8;
             u32 db = 1;
-            load_ref(op.src[0], c, row, T, stride, a0, a1, a2);
-            if (op.op != GLX_OP_COPY) { load_ref(op.src[1], c, row, T, stride, b0, b1, b2); db = op.src[1].kind_dim >> 8; }
-            if (op.op == GLX_OP_ADD) {                                  // f3g.js:47-58
+            if (op.op != GLX_LZ_END) load_ref(op.src[0], c, row, T, stride, a0, a1, a2);
+            if (op.op < GLX_OP_COPY) { load_ref(op.src[1], c, row, T, stride, b0, b1, b2); db = op.src[1].kind_dim >> 8; }
+            if (op.op == GLX_LZ_END) { r0 = fold6(LZ[0]); r1 = fold6(LZ[1]); r2 = fold6(LZ[2]); }
+            else if (op.op == GLX_OP_ADD) {                             // f3g.js:47-58
                 r0 = add(a0, b0);
                 if (da == 3 && db == 3) { r1 = add(a1, b1); r2 = add(a2, b2); }
                 else if (da == 3) { r1 = a1; r2 = a2; } else { r1 = b1; r2 = b2; }
@@ -104,20 +149,20 @@ __global__ void __launch_bounds__(256) eval_kernel(DevCtx c, u64 *gtmp) {
 
 using namespace pil2gl;
 
-// Validates the op-list and renumbers its temporaries by live range (linear scan): code.tmpUsed counts one
-// slot per op of the largest expression (codegen.js:83), far more than are ever live at once.
-static int compact_program(const glx_program *prog, const glx_ctx *ctx, std::vector<glx_op> &ops, u32 &nSlots) {
-    ops.assign(prog->ops, prog->ops + prog->nOps);
-    const u32 NONE = 0xFFFFFFFFu;
-    std::vector<u32> lastUse(prog->nTmp, NONE);
+// ------------------------------------------------------------------------------------------------ host-side passes
+struct IOp { u32 op; u32 aux; glx_ref dest; glx_ref src[2]; };
+static inline int n_src(u32 op) { return op < GLX_OP_COPY ? 2 : (op == GLX_OP_COPY || op == GLX_LZ_MAD) ? 1 : 0; }
+static inline bool has_dest(u32 op) { return op <= GLX_OP_COPY || op == GLX_LZ_END; }
+
+static int validate_program(const glx_program *prog, const glx_ctx *ctx) {
     for (u32 k = 0; k < prog->nOps; k++) {
-        const glx_op &o = ops[k];
+        const glx_op &o = prog->ops[k];
         if (o.op > GLX_OP_COPY) return fail(PIL2GL_EINVAL, "Invalid op: %u", o.op);      // prover_helpers.js:96
         const int ns = o.op == GLX_OP_COPY ? 1 : 2;
         for (int s = 0; s < ns + 1; s++) {
             const glx_ref &r = s < ns ? o.src[s] : o.dest;
             if (r.dim != 1 && r.dim != 3) return fail(PIL2GL_EINVAL, "invalid dim %u in op %u", r.dim, k);
-            if (r.kind == GLX_TMP) { if (r.index >= prog->nTmp) return fail(PIL2GL_EINVAL, "tmp %u out of range in op %u", r.index, k); if (s < ns) lastUse[r.index] = k; }
+            if (r.kind == GLX_TMP) { if (r.index >= prog->nTmp) return fail(PIL2GL_EINVAL, "tmp %u out of range in op %u", r.index, k); }
             else if (r.kind == GLX_SEC) {
                 if (!ctx) continue;
                 if (r.section >= ctx->nSections) return fail(PIL2GL_EINVAL, "section %u out of range in op %u", r.section, k);
@@ -128,42 +173,217 @@ static int compact_program(const glx_program *prog, const glx_ctx *ctx, std::vec
             } else return fail(PIL2GL_EINVAL, "Invalid reference type get");
         }
     }
-    std::vector<u32> slotOf(prog->nTmp, NONE), freeSlots;
-    nSlots = 0;
+    return PIL2GL_OK;
+}
+
+// Pass 1: value numbering.  Every distinct (section, column, row offset) operand is loaded once into a temporary
+// (the reference's op-lists re-read the same cell for every use, and every use is a strided, uncoalesced access
+// for a lane-per-row evaluator), identical sub-expressions are computed once, copies between temporaries vanish.
+// The output is in single-assignment form: temporary ids are value numbers.
+static int value_number(const glx_program *prog, const glx_ctx *ctx, std::vector<IOp> &out, u32 &nVal) {
+    std::map<std::array<u64, 4>, u32> scalarIndex;  // (dim, words) -> first pool offset holding that constant
+    struct Key { u32 op; u64 a, b; bool operator<(const Key &o) const { return op != o.op ? op < o.op : a != o.a ? a < o.a : b < o.b; } };
+    std::map<Key, u32> table;                       // expression -> value number
+    std::map<std::pair<u64, u64>, u32> loads;       // (section|dim|prime, column) -> value number
+    std::vector<u32> valDim;                        // dim of each value
+    const u32 NONE = 0xFFFFFFFFu;
+    std::vector<u32> cur(prog->nTmp, NONE);         // value currently held by each original tmp id
+    auto tmp_ref = [&](u32 v) { glx_ref r; memset(&r, 0, sizeof r); r.kind = GLX_TMP; r.dim = (uint8_t)valDim[v]; r.index = v; return r; };
+    auto operand_key = [](const glx_ref &r) { return ((u64)r.kind << 60) | ((u64)r.dim << 56) | (u64)r.index; };
+    out.clear();
     for (u32 k = 0; k < prog->nOps; k++) {
-        glx_op &o = ops[k];
+        const glx_op &o = prog->ops[k];
         const int ns = o.op == GLX_OP_COPY ? 1 : 2;
-        u32 dying[2]; int nd = 0;
+        glx_ref src[2]; memset(src, 0, sizeof src);
         for (int s = 0; s < ns; s++) {
+            const glx_ref &r = o.src[s];
+            if (r.kind == GLX_TMP) {
+                if (cur[r.index] == NONE) return fail(PIL2GL_EINVAL, "tmp %u read before written in op %u", r.index, k);
+                src[s] = tmp_ref(cur[r.index]);
+                src[s].dim = r.dim < src[s].dim ? r.dim : src[s].dim;       // a dim-1 read of a triple sees component 0 only
+            } else if (r.kind == GLX_SEC) {
+                const std::pair<u64, u64> lk(((u64)r.section << 40) | ((u64)r.dim << 32) | (u32)r.prime, r.index);
+                auto it = loads.find(lk);
+                if (it == loads.end()) {
+                    const u32 v = (u32)valDim.size(); valDim.push_back(r.dim);
+                    IOp ld; memset(&ld, 0, sizeof ld); ld.op = GLX_OP_COPY; ld.dest = tmp_ref(v); ld.src[0] = r;
+                    out.push_back(ld);
+                    it = loads.emplace(lk, v).first;
+                }
+                src[s] = tmp_ref(it->second);
+            } else {                                                         // scalar pool: wave-uniform, read in place
+                src[s] = r;
+                if (ctx && ctx->scalars) {                                   // encoders append one pool entry per use: merge equal constants
+                    const u64 *w = ctx->scalars + r.index;
+                    const std::array<u64, 4> key = { r.dim, w[0], r.dim == 3 ? w[1] : 0, r.dim == 3 ? w[2] : 0 };
+                    src[s].index = scalarIndex.emplace(key, r.index).first->second;
+                }
+            }
+        }
+        if (o.dest.kind == GLX_SEC) {                                        // stores are never merged; they invalidate loads
+            IOp st; memset(&st, 0, sizeof st); st.op = o.op; st.dest = o.dest; st.src[0] = src[0]; st.src[1] = src[1];
+            out.push_back(st);
+            for (auto it = loads.begin(); it != loads.end();) { if ((it->first.first >> 40) == o.dest.section) it = loads.erase(it); else ++it; }
+            continue;
+        }
+        if (o.op == GLX_OP_COPY && src[0].kind == GLX_TMP && src[0].dim == o.dest.dim) { cur[o.dest.index] = src[0].index; continue; }
+        Key key = { o.op | ((u32)o.dest.dim << 8), operand_key(src[0]), ns == 2 ? operand_key(src[1]) : 0 };
+        if ((o.op == GLX_OP_ADD || o.op == GLX_OP_MUL) && key.b < key.a) std::swap(key.a, key.b);
+        auto it = table.find(key);
+        if (it == table.end()) {
+            const u32 v = (u32)valDim.size(); valDim.push_back(o.dest.dim);
+            IOp n; memset(&n, 0, sizeof n); n.op = o.op; n.dest = tmp_ref(v); n.src[0] = src[0]; n.src[1] = src[1];
+            out.push_back(n);
+            it = table.emplace(key, v).first;
+        }
+        cur[o.dest.index] = it->second;
+    }
+    nVal = (u32)valDim.size();
+    return PIL2GL_OK;
+}
+
+static void push_limbs(std::vector<u32> &pool, u64 v) {
+    pool.push_back((u32)v & 0x3FFFFF); pool.push_back((u32)(v >> 22) & 0x3FFFFF); pool.push_back((u32)(v >> 44));
+}
+
+// Pass 2: Horner chains  t_i = X * t_(i-1) + c_i  over a scalar-pool extension constant X  ->  lazy dot product
+// sum_i c_i X^(n-i)  (same field element, see the kernel comment).  Chains must not interleave (one accumulator set).
+static void fuse_horner(std::vector<IOp> &ops, u32 nVal, const glx_ctx *ctx, std::vector<u32> &limbPool) {
+    const u32 NONE = 0xFFFFFFFFu;
+    std::vector<u32> def(nVal, NONE), uses(nVal, 0);
+    for (u32 k = 0; k < ops.size(); k++) {
+        for (int s = 0; s < n_src(ops[k].op); s++) if (ops[k].src[s].kind == GLX_TMP) uses[ops[k].src[s].index]++;
+        if (has_dest(ops[k].op) && ops[k].dest.kind == GLX_TMP) def[ops[k].dest.index] = k;
+    }
+    struct Link { u32 mulIdx, addIdx; glx_ref X, A, C; };
+    // link ending at ADD k: one operand is a single-use MUL(scalar dim3, value)
+    auto link_at = [&](u32 k, Link &L) {
+        const IOp &a = ops[k];
+        if (a.op != GLX_OP_ADD || a.dest.dim != 3) return false;
+        for (int s = 0; s < 2; s++) {
+            const glx_ref &m = a.src[s];
+            if (m.kind != GLX_TMP || uses[m.index] != 1 || def[m.index] == NONE) continue;
+            const IOp &mu = ops[def[m.index]];
+            if (mu.op != GLX_OP_MUL) continue;
+            for (int t = 0; t < 2; t++) {
+                if (mu.src[t].kind == GLX_SCALAR && mu.src[t].dim == 3 && mu.src[1 - t].kind != GLX_SEC) {
+                    L.mulIdx = def[m.index]; L.addIdx = k; L.X = mu.src[t]; L.A = mu.src[1 - t]; L.C = a.src[1 - s];
+                    return L.C.kind != GLX_SEC;
+                }
+            }
+        }
+        return false;
+    };
+    std::vector<bool> removed(ops.size(), false);
+    std::vector<std::vector<IOp>> insertAt(ops.size());      // replacement ops for position k
+    u32 busyUntil = 0;                                       // chains may not overlap in program order
+    std::vector<bool> consumed(ops.size(), false);
+    for (u32 k = (u32)ops.size(); k-- > 0;) {               // find chain ends from the back
+        Link L;
+        if (consumed[k] || !link_at(k, L)) continue;
+        // is this ADD's result the A of a later link? then it is not an end (it will be reached from that end)
+        std::vector<Link> chain; chain.push_back(L);
+        for (;;) {                                           // walk towards the start
+            const glx_ref &A = chain.back().A;
+            if (A.kind != GLX_TMP || uses[A.index] != 1 || def[A.index] == NONE) break;
+            Link P2;
+            if (!link_at(def[A.index], P2) || P2.X.index != L.X.index) break;
+            chain.push_back(P2);
+        }
+        const u32 n = (u32)chain.size();
+        if (n < 4 || n > 300) continue;                     // <= 1024 terms of < 2^54 per partial sum (3 per triple)
+        const u32 first = chain.back().mulIdx, last = chain.front().addIdx;
+        if (busyUntil && last >= busyUntil) continue;        // overlaps a chain already taken (we scan backwards)
+        bool ordered = true;
+        for (u32 i = 0; i + 1 < n; i++) ordered &= chain[i + 1].addIdx < chain[i].mulIdx;
+        if (!ordered) continue;
+        busyUntil = first;
+        // weights X^0 .. X^n
+        const u64 *xp = ctx->scalars + L.X.index;
+        std::vector<std::array<u64, 3>> pw(n + 1);
+        pw[0] = { 1, 0, 0 };
+        for (u32 i = 1; i <= n; i++) { u64 t[3]; h_e3_mul(pw[i - 1].data(), xp, t); pw[i] = { t[0], t[1], t[2] }; }
+        auto weight = [&](const std::array<u64, 3> &W, u32 dim) {
+            const u32 off = (u32)limbPool.size();
+            std::array<u64, 3> w = W;
+            for (u32 t = 0; t < dim; t++) {
+                for (int q = 0; q < 3; q++) push_limbs(limbPool, w[q]);
+                w = { w[2], h_add(w[0], w[2]), w[1] };      // times x  (x^3 = x + 1)
+            }
+            return off;
+        };
+        auto mad = [&](const glx_ref &v, const std::array<u64, 3> &W) {
+            IOp m; memset(&m, 0, sizeof m); m.op = GLX_LZ_MAD; m.src[0] = v; m.aux = weight(W, v.dim); return m;
+        };
+        // chain[n-1] is the innermost link: its A is t_0 (weight X^n), its C is c_1 (weight X^(n-1)), ...
+        for (u32 i = 0; i < n; i++) { removed[chain[i].mulIdx] = true; removed[chain[i].addIdx] = true; consumed[chain[i].addIdx] = true; }
+        IOp bg; memset(&bg, 0, sizeof bg); bg.op = GLX_LZ_BEGIN;
+        insertAt[first].push_back(bg);
+        insertAt[first].push_back(mad(chain[n - 1].A, pw[n]));
+        for (u32 i = 0; i < n; i++) {
+            const Link &lk = chain[n - 1 - i];               // link i+1 in program order
+            insertAt[lk.addIdx].push_back(mad(lk.C, pw[n - 1 - i]));
+        }
+        IOp en; memset(&en, 0, sizeof en); en.op = GLX_LZ_END; en.dest = ops[last].dest;
+        insertAt[last].push_back(en);
+    }
+    std::vector<IOp> res;
+    for (u32 k = 0; k < ops.size(); k++) {
+        for (const IOp &i : insertAt[k]) res.push_back(i);
+        if (!removed[k]) res.push_back(ops[k]);
+    }
+    ops.swap(res);
+}
+
+// Pass 3: renumber temporaries by live range (linear scan); the input is single-assignment.
+static int allocate_slots(std::vector<IOp> &ops, u32 nVal, u32 &nSlots) {
+    const u32 NONE = 0xFFFFFFFFu;
+    std::vector<u32> lastUse(nVal, NONE);
+    for (u32 k = 0; k < ops.size(); k++)
+        for (int s = 0; s < n_src(ops[k].op); s++) if (ops[k].src[s].kind == GLX_TMP) lastUse[ops[k].src[s].index] = k;
+    std::vector<u32> slotOf(nVal, NONE), freeSlots;
+    nSlots = 0;
+    for (u32 k = 0; k < ops.size(); k++) {
+        IOp &o = ops[k];
+        u32 dying[2]; int nd = 0;
+        for (int s = 0; s < n_src(o.op); s++) {
             glx_ref &r = o.src[s];
             if (r.kind != GLX_TMP) continue;
             const u32 id = r.index;
-            if (slotOf[id] == NONE) return fail(PIL2GL_EINVAL, "tmp %u read before written in op %u", id, k);
+            if (slotOf[id] == NONE) return fail(PIL2GL_EINVAL, "internal: value %u used before definition", id);
             r.index = slotOf[id];
             if (lastUse[id] == k && !(nd == 1 && dying[0] == id)) dying[nd++] = id;
         }
         // a lane reads both sources before it writes the destination, so a dying source's slot may be reused at once
         for (int f = 0; f < nd; f++) { freeSlots.push_back(slotOf[dying[f]]); slotOf[dying[f]] = NONE; }
-        if (o.dest.kind == GLX_TMP) {
+        if (has_dest(o.op) && o.dest.kind == GLX_TMP) {
             const u32 id = o.dest.index;
-            if (slotOf[id] == NONE) {
-                if (!freeSlots.empty()) { slotOf[id] = freeSlots.back(); freeSlots.pop_back(); }
-                else slotOf[id] = nSlots++;
-            }
+            if (!freeSlots.empty()) { slotOf[id] = freeSlots.back(); freeSlots.pop_back(); }
+            else slotOf[id] = nSlots++;
             o.dest.index = slotOf[id];
-            if (lastUse[id] == NONE || lastUse[id] <= k) { freeSlots.push_back(slotOf[id]); slotOf[id] = NONE; }   // never read again
+            if (lastUse[id] == NONE) { freeSlots.push_back(slotOf[id]); slotOf[id] = NONE; }   // never read
         }
     }
     return PIL2GL_OK;
 }
 
-// test hook (host only, no GPU needed): the compacted op-list that the kernel would run
-extern "C" int pil2gl_debug_compact_program(const glx_program *prog, glx_op *outOps, uint32_t *nSlots) {
+static int compile_program(const glx_program *prog, const glx_ctx *ctx, std::vector<IOp> &ops, u32 &nSlots, std::vector<u32> &limbPool, bool fuse) {
+    P2_TRY(validate_program(prog, ctx));
+    u32 nVal = 0;
+    P2_TRY(value_number(prog, ctx, ops, nVal));
+    if (fuse && ctx && ctx->scalars) fuse_horner(ops, nVal, ctx, limbPool);
+    return allocate_slots(ops, nVal, nSlots);
+}
+
+// test hook (host only, no GPU needed): the program after value numbering and slot allocation (no Horner fusion),
+// in the public op encoding, as the kernel would run it
+extern "C" int pil2gl_debug_compact_program(const glx_program *prog, glx_op *outOps, uint32_t *nSlots /* [2]: slots, ops */) {
     if (!prog || !outOps || !nSlots) return fail(PIL2GL_EINVAL, "null argument");
-    std::vector<glx_op> ops; u32 n = 0;
-    P2_TRY(compact_program(prog, nullptr, ops, n));
-    memcpy(outOps, ops.data(), ops.size() * sizeof(glx_op));
-    *nSlots = n;
+    std::vector<IOp> ops; std::vector<u32> pool; u32 n = 0;
+    P2_TRY(compile_program(prog, nullptr, ops, n, pool, false));
+    if (ops.size() > 2ull * prog->nOps + 16) return fail(PIL2GL_EINVAL, "internal: program grew unexpectedly");
+    for (size_t k = 0; k < ops.size(); k++) { memset(&outOps[k], 0, sizeof(glx_op)); outOps[k].op = ops[k].op; outOps[k].dest = ops[k].dest; outOps[k].src[0] = ops[k].src[0]; outOps[k].src[1] = ops[k].src[1]; }
+    nSlots[0] = n; nSlots[1] = (uint32_t)ops.size();
     return PIL2GL_OK;
 }
 
@@ -173,25 +393,27 @@ extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *c
     if (ctx->nBits > 31) return fail(PIL2GL_EINVAL, "domain too large");
     if (prog->nOps == 0) return PIL2GL_OK;
     hipStream_t st = as_stream(stream);
-    std::vector<glx_op> ops; u32 nSlots = 0;
-    P2_TRY(compact_program(prog, ctx, ops, nSlots));
+    std::vector<IOp> ops; std::vector<u32> limbPool; u32 nSlots = 0;
+    P2_TRY(compile_program(prog, ctx, ops, nSlots, limbPool, getenv("PIL2GL_EXPR_NOFUSE") == nullptr));
 
     if (ctx->nSections > GLX_MAX_SECTIONS) return fail(PIL2GL_EINVAL, "too many sections (%u > %d)", ctx->nSections, GLX_MAX_SECTIONS);
     // device form of the program (scratch slot 4): ops, then the scalar pool
     std::vector<DevOp> dops(ops.size());
     for (size_t k = 0; k < ops.size(); k++) {
         auto cv = [&](const glx_ref &r) { DevRef d; d.kind_dim = (u32)r.kind | ((u32)r.dim << 8); d.section = r.section; d.rowOff = (int32_t)((int64_t)r.prime * ((int64_t)1 << ctx->primeShift)); d.index = r.index; return d; };
-        dops[k].op = ops[k].op; dops[k].pad_ = 0; dops[k].dest = cv(ops[k].dest); dops[k].src[0] = cv(ops[k].src[0]); dops[k].src[1] = cv(ops[k].src[1]);
+        dops[k].op = ops[k].op; dops[k].aux = ops[k].aux; dops[k].dest = cv(ops[k].dest); dops[k].src[0] = cv(ops[k].src[0]); dops[k].src[1] = cv(ops[k].src[1]);
         for (int s = 0; s < 3; s++) { const glx_ref &r = s < 2 ? ops[k].src[s] : ops[k].dest; if ((int64_t)r.prime * ((int64_t)1 << ctx->primeShift) != (int64_t)(int32_t)((int64_t)r.prime * ((int64_t)1 << ctx->primeShift))) return fail(PIL2GL_EINVAL, "row offset overflow in op %zu", k); }
     }
-    const u64 opsWords = ((u64)dops.size() * sizeof(DevOp) + 7) / 8;
+    const u64 opsWords = ((u64)dops.size() * sizeof(DevOp) + 7) / 8, limbWords = (limbPool.size() * 4 + 7) / 8;
     u64 *d;
-    P2_TRY(scratch(4, opsWords + ctx->nScalars + 1, &d));
+    P2_TRY(scratch(4, opsWords + ctx->nScalars + limbWords + 2, &d));
     HIP_TRY(hipMemcpyAsync(d, dops.data(), dops.size() * sizeof(DevOp), hipMemcpyHostToDevice, st));
     if (ctx->nScalars) HIP_TRY(hipMemcpyAsync(d + opsWords, ctx->scalars, (u64)ctx->nScalars * 8, hipMemcpyHostToDevice, st));
+    if (!limbPool.empty()) HIP_TRY(hipMemcpyAsync(d + opsWords + ctx->nScalars + 1, limbPool.data(), limbPool.size() * 4, hipMemcpyHostToDevice, st));
     DevCtx c;
     c.ops = (const DevOp *)d; c.nOps = (u32)dops.size();
     c.scalars = d + opsWords;
+    c.limbs = (const u32 *)(d + opsWords + ctx->nScalars + 1);
     c.nBits = ctx->nBits;
     for (u32 i = 0; i < GLX_MAX_SECTIONS; i++) { c.secPtr[i] = i < ctx->nSections ? ctx->sections[i].ptr : nullptr; c.secWidth[i] = i < ctx->nSections ? (u32)ctx->sections[i].width : 0; }
     for (u32 i = 0; i < ctx->nSections; i++) if (ctx->sections[i].width >> 32) return fail(PIL2GL_EINVAL, "section %u too wide", i);

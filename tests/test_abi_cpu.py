@@ -78,11 +78,12 @@ def test_tmp_compaction_preserves_program(oracle):
         ref = [s.copy() for s in secs]
         oracle.eval_program(ops, n_tmp, ref, scalars, n_bits, 0)
         prog = oracle.make_program(ops, n_tmp, struct_op=_lib.GlxOp, struct_prog=_lib.GlxProgram)
-        out = (_lib.GlxOp * len(ops))(); n_slots = C.c_uint32()
-        assert lib.pil2gl_debug_compact_program(C.byref(prog), out, C.byref(n_slots)) == 0
-        assert n_slots.value <= n_tmp and (n_ops < 100 or n_slots.value < n_tmp // 2)
+        out = (_lib.GlxOp * (2 * len(ops) + 16))(); info = (C.c_uint32 * 2)()
+        assert lib.pil2gl_debug_compact_program(C.byref(prog), out, info) == 0
+        n_slots = C.c_uint32(info[0])
+        assert n_slots.value <= n_tmp + 64 and (n_ops < 100 or n_slots.value < n_tmp // 2)
         ops2 = []
-        for o in out:
+        for o in list(out)[:info[1]]:
             def ref_(r):
                 return (r.kind, r.dim, r.section, r.prime, r.index)
             ops2.append((o.op, ref_(o.dest), ref_(o.src[0]), ref_(o.src[1]) if o.op != 3 else None))

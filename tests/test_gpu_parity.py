@@ -441,3 +441,32 @@ def test_device_resident_extend_and_merkelize(gl, oracle):
     assert MH.root(tree) == nodes[-4:].tolist()
     v, mp = MH.getGroupProof(tree, 4097)
     assert v == e[4097].tolist() and MH.verifyGroupProof(MH.root(tree), mp, 4097, v)
+
+
+# ------------------------------------------------------------------ extension-weighted sums (csrc/dot.hip)
+def test_rows_and_cols_dot_ext(gl, oracle):
+    import ctypes as C
+    import torch
+    from pil2gl import _lib
+    rng = np.random.default_rng(31)
+    for n_rows, width, n_out in [(1000, 37, 2), (64, 1, 1), (4097, 100, 3), (300, 16, 4)]:
+        m = rand_field(rng, (n_rows, width)); m[0, 0] = P - 1; m[-1, -1] = 0
+        coef = rand_field(rng, (n_out, width, 3)); coef[0, 0] = [P - 1, P - 1, P - 1]
+        dm = torch.from_numpy(m.view(np.int64)).cuda(); acc = torch.zeros(n_rows * n_out * 3, dtype=torch.int64, device="cuda")
+        _lib.call("pil2gl_rows_dot_ext_dev", gl._ptr(dm), width, n_rows, gl._ptr(coef), n_out, gl._ptr(acc), 0, None)
+        _lib.call("pil2gl_rows_dot_ext_dev", gl._ptr(dm), width, n_rows, gl._ptr(coef), n_out, gl._ptr(acc), 1, None)   # accumulate: 2x
+        got = acc.cpu().numpy().view(np.uint64).reshape(n_rows, n_out, 3)
+        for r in (0, 1, n_rows // 2, n_rows - 1):
+            for o in range(n_out):
+                exp = [2 * sum(int(m[r, c]) * int(coef[o, c, k]) for c in range(width)) % P for k in range(3)]
+                assert got[r, o].tolist() == exp
+    # column sums against the oracle's per-column evaluation (stark_gen_helpers.js:250-264)
+    nb, eb, width = 11, 3, 9
+    buf = rand_field(rng, (1 << (nb + eb), width)); dbuf = torch.from_numpy(buf.view(np.int64)).cuda()
+    levs = [rand_field(rng, (1 << nb, 3)) for _ in range(2)]
+    dlevs = [torch.from_numpy(l.view(np.int64)).cuda() for l in levs]
+    lv = (C.c_void_p * 2)(*[t.data_ptr() for t in dlevs]); out = np.zeros((2, width, 3), np.uint64)
+    _lib.call("pil2gl_cols_dot_ext_dev", gl._ptr(dbuf), width, 1 << nb, 1 << eb, lv, 2, gl._ptr(out), None)
+    for l in range(2):
+        for c in range(width):
+            assert out[l, c].tolist() == oracle.eval_pol_at(buf, c, 1, nb, eb, levs[l]).tolist()

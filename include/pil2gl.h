@@ -165,6 +165,9 @@ int pil2gl_selftest_field(const uint64_t *a, const uint64_t *b, uint64_t n, uint
  * merged) and live-range renumbering of temporaries, as the kernel runs it (without Horner-chain fusion).
  * outOps must hold 2*nOps+16 entries; outInfo[0] = temporaries needed, outInfo[1] = ops written. */
 int pil2gl_debug_compact_program(const glx_program *prog, glx_op *outOps, uint32_t *outInfo);
+/* host-only: run the optimiser, generate the straight-line kernel source of the program and compile it with hiprtc
+ * (the path long programs take at run time); reports the code object size and the number of fused Horner terms. */
+int pil2gl_debug_jit_compile(const glx_program *prog, const glx_ctx *ctx, uint64_t *codeBytes, uint32_t *fusedOps);
 /* extension a*b and 1/a on the device (n triples) */
 int pil2gl_selftest_ext(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *inv);
 

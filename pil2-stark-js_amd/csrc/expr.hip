@@ -387,6 +387,141 @@ extern "C" int pil2gl_debug_compact_program(const glx_program *prog, glx_op *out
     return PIL2GL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ run-time compilation
+// The reference turns the op-list into JavaScript source and calls `new Function` on it (prover_helpers.js:31-45,
+// :83-107).  The same is done here with HIP source and hiprtc: the optimised op-list becomes one straight-line
+// kernel (temporaries in registers, dims and column offsets resolved statically), compiled once per distinct
+// program and cached.  Long programs on large domains take this path; short ones use the interpreter above.
+#include <hip/hiprtc.h>
+#include <sstream>
+#include <string>
+
+static const char *kFieldSrc =
+#include "gl_field_src.inc"
+    ;
+
+struct JitArgs {            // kernel argument block (by value)
+    const u64 *scalars; const u32 *limbs; u64 *sec[GLX_MAX_SECTIONS]; u32 nBits; u32 pad_;
+};
+struct JitEntry { hipModule_t mod; hipFunction_t fn; };
+static std::map<std::string, JitEntry> g_jit_cache;
+
+static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx_ctx *ctx) {
+    std::ostringstream o;
+    o << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n" << kFieldSrc << "\nusing namespace gl;\n";
+    o << "struct JitArgs { const u64 *scalars; const u32 *limbs; u64 *sec[" << GLX_MAX_SECTIONS << "]; u32 nBits; u32 pad_; };\n";
+    o << "__device__ __forceinline__ u64 fold6(const u64 S[6]) { u64 r = canon(S[0]); r = add(r, mul(S[1], 1ull << 22)); r = add(r, mul(S[2], 1ull << 44));"
+         " r = add(r, mul(S[3], 1ull << 32)); r = add(r, mul(S[4], 1ull << 54)); r = add(r, mul(S[5], ((1ull << 32) - 1) << 12)); return r; }\n";
+    o << "__device__ __forceinline__ void lz_mad(u64 S[3][6], u64 v, const u32 *__restrict__ L) { const u32 p0 = (u32)v, p1 = (u32)(v >> 32);\n"
+         " _Pragma(\"unroll\") for (int k = 0; k < 3; k++) { const u32 w0 = L[3*k], w1 = L[3*k+1], w2 = L[3*k+2];\n"
+         "  S[k][0] += (u64)p0 * w0; S[k][1] += (u64)p0 * w1; S[k][2] += (u64)p0 * w2; S[k][3] += (u64)p1 * w0; S[k][4] += (u64)p1 * w1; S[k][5] += (u64)p1 * w2; } }\n";
+    o << "__device__ __noinline__ E3 e3_mul_call(E3 a, E3 b) { return e3_mul(a, b); }\n";
+    o << "extern \"C\" __global__ void __launch_bounds__(256) jit_eval(JitArgs A) {\n";
+    o << " const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (row >= (1ull << A.nBits)) return;\n";
+    o << " const u64 mask = (1ull << A.nBits) - 1; const u64 *__restrict__ SC = A.scalars; const u32 *__restrict__ LM = A.limbs;\n";
+    o << " u64 LZ[3][6];\n";
+    for (u32 s = 0; s < nSlots; s++) o << " u64 t" << s << "_0 = 0, t" << s << "_1 = 0, t" << s << "_2 = 0;\n";
+    auto addr = [&](const glx_ref &r) {
+        std::ostringstream a;
+        const int64_t off = (int64_t)r.prime * ((int64_t)1 << ctx->primeShift);
+        a << "A.sec[" << r.section << "] + ((row + (u64)(" << off << "ll)) & mask) * " << ctx->sections[r.section].width << "ull + " << r.index;
+        return a.str();
+    };
+    auto rd = [&](const glx_ref &r, int c) {        // component c of an operand (0 beyond its dim)
+        std::ostringstream a;
+        if (c >= (int)r.dim) { a << "0ull"; return a.str(); }
+        if (r.kind == GLX_TMP) a << "t" << r.index << "_" << c;
+        else if (r.kind == GLX_SCALAR) a << "SC[" << (r.index + c) << "]";
+        else a << "(" << addr(r) << ")[" << c << "]";
+        return a.str();
+    };
+    for (size_t k = 0; k < ops.size(); k++) {
+        const IOp &p = ops[k];
+        if (p.op == GLX_LZ_BEGIN) { o << " for (int q = 0; q < 3; q++) for (int i = 0; i < 6; i++) LZ[q][i] = 0;\n"; continue; }
+        if (p.op == GLX_LZ_MAD) {
+            o << " lz_mad(LZ, " << rd(p.src[0], 0) << ", LM + " << p.aux << ");";
+            if (p.src[0].dim == 3) o << " lz_mad(LZ, " << rd(p.src[0], 1) << ", LM + " << p.aux + 9 << "); lz_mad(LZ, " << rd(p.src[0], 2) << ", LM + " << p.aux + 18 << ");";
+            o << "\n"; continue;
+        }
+        const glx_ref &a = p.src[0], &b = p.src[1];
+        std::string r[3];
+        const u32 da = a.dim, db = b.dim;
+        switch (p.op) {
+        case GLX_LZ_END: r[0] = "fold6(LZ[0])"; r[1] = "fold6(LZ[1])"; r[2] = "fold6(LZ[2])"; break;
+        case GLX_OP_ADD:
+            r[0] = "add(" + rd(a, 0) + ", " + rd(b, 0) + ")";
+            for (int c = 1; c < 3; c++) r[c] = (da == 3 && db == 3) ? "add(" + rd(a, c) + ", " + rd(b, c) + ")" : da == 3 ? rd(a, c) : rd(b, c);
+            break;
+        case GLX_OP_SUB:
+            r[0] = "sub(" + rd(a, 0) + ", " + rd(b, 0) + ")";
+            for (int c = 1; c < 3; c++) r[c] = (da == 3 && db == 3) ? "sub(" + rd(a, c) + ", " + rd(b, c) + ")" : da == 3 ? rd(a, c) : "neg(" + rd(b, c) + ")";
+            break;
+        case GLX_OP_MUL:
+            if (da == 3 && db == 3) {
+                o << " { E3 x_ = { { " << rd(a, 0) << ", " << rd(a, 1) << ", " << rd(a, 2) << " } }, y_ = { { " << rd(b, 0) << ", " << rd(b, 1) << ", " << rd(b, 2) << " } }; E3 z_ = e3_mul_call(x_, y_);";
+                r[0] = "z_.v[0]"; r[1] = "z_.v[1]"; r[2] = "z_.v[2]";
+            } else if (da == 3) { for (int c = 0; c < 3; c++) r[c] = "mul(" + rd(a, c) + ", " + rd(b, 0) + ")"; }
+            else { for (int c = 0; c < 3; c++) r[c] = c < (int)db || c == 0 ? "mul(" + rd(a, 0) + ", " + rd(b, c) + ")" : "0ull"; }
+            break;
+        default: for (int c = 0; c < 3; c++) r[c] = rd(a, c); break;     // copy
+        }
+        const glx_ref &d = p.dest;
+        const bool braced = (p.op == GLX_OP_MUL && da == 3 && db == 3);
+        if (!braced) o << " {";
+        if (d.kind == GLX_TMP) {
+            o << " const u64 n0_ = " << r[0] << ", n1_ = " << (d.dim == 3 ? r[1] : "0ull") << ", n2_ = " << (d.dim == 3 ? r[2] : "0ull") << ";";
+            o << " t" << d.index << "_0 = n0_; t" << d.index << "_1 = n1_; t" << d.index << "_2 = n2_; }\n";
+        } else {
+            o << " u64 *q_ = " << addr(d) << "; q_[0] = " << r[0] << ";";
+            if (d.dim == 3) o << " q_[1] = " << r[1] << "; q_[2] = " << r[2] << ";";
+            o << " }\n";
+        }
+    }
+    o << "}\n";
+    return o.str();
+}
+
+static int jit_build(const std::string &src, std::vector<char> &code) {
+    hiprtcProgram prog;
+    if (hiprtcCreateProgram(&prog, src.c_str(), "pil2gl_expr.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail(PIL2GL_EHIP, "hiprtcCreateProgram failed");
+    const char *opts[] = { "--offload-arch=gfx950", "-O3", "-ffp-contract=off" };
+    hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
+    if (rc != HIPRTC_SUCCESS) {
+        size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
+        std::string log(n, 0); if (n) hiprtcGetProgramLog(prog, &log[0]);
+        hiprtcDestroyProgram(&prog);
+        return fail(PIL2GL_EHIP, "hiprtc compile failed: %.300s", log.c_str());
+    }
+    size_t sz = 0; hiprtcGetCodeSize(prog, &sz);
+    code.resize(sz); hiprtcGetCode(prog, code.data());
+    hiprtcDestroyProgram(&prog);
+    return PIL2GL_OK;
+}
+static int jit_get(const std::string &src, hipFunction_t *fn) {
+    auto it = g_jit_cache.find(src);
+    if (it != g_jit_cache.end()) { *fn = it->second.fn; return PIL2GL_OK; }
+    std::vector<char> code;
+    P2_TRY(jit_build(src, code));
+    JitEntry e;
+    HIP_TRY(hipModuleLoadData(&e.mod, code.data()));
+    HIP_TRY(hipModuleGetFunction(&e.fn, e.mod, "jit_eval"));
+    g_jit_cache.emplace(src, e);
+    *fn = e.fn;
+    return PIL2GL_OK;
+}
+
+// test hook (host only): optimise the program, generate its kernel source and compile it with hiprtc (no GPU needed)
+extern "C" int pil2gl_debug_jit_compile(const glx_program *prog, const glx_ctx *ctx, uint64_t *codeBytes, uint32_t *fusedOps) {
+    if (!prog || !ctx || !codeBytes) return fail(PIL2GL_EINVAL, "null argument");
+    std::vector<IOp> ops; std::vector<u32> pool; u32 n = 0;
+    P2_TRY(compile_program(prog, ctx, ops, n, pool, true));
+    std::vector<char> code;
+    P2_TRY(jit_build(jit_source(ops, n, ctx), code));
+    *codeBytes = code.size();
+    if (fusedOps) { u32 f = 0; for (const IOp &o : ops) f += o.op == GLX_LZ_MAD; *fusedOps = f; }
+    return PIL2GL_OK;
+}
+
 extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *ctx, void *stream) {
     P2_TRY(ensure_init());
     if (!prog || !ctx || (prog->nOps && !prog->ops)) return fail(PIL2GL_EINVAL, "null program");
@@ -418,6 +553,22 @@ extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *c
     for (u32 i = 0; i < GLX_MAX_SECTIONS; i++) { c.secPtr[i] = i < ctx->nSections ? ctx->sections[i].ptr : nullptr; c.secWidth[i] = i < ctx->nSections ? (u32)ctx->sections[i].width : 0; }
     for (u32 i = 0; i < ctx->nSections; i++) if (ctx->sections[i].width >> 32) return fail(PIL2GL_EINVAL, "section %u too wide", i);
     const u64 nRows = 1ull << ctx->nBits;
+    {   // run-time compiled path for long programs on large domains (PIL2GL_EXPR_JIT=1 forces it, =0 disables it)
+        const char *e = getenv("PIL2GL_EXPR_JIT");
+        const bool want = e ? atoi(e) != 0 : (ops.size() >= 64 && ctx->nBits >= 16);
+        if (want && nSlots <= 200) {
+            hipFunction_t fn;
+            P2_TRY(jit_get(jit_source(ops, nSlots, ctx), &fn));
+            JitArgs A; memset(&A, 0, sizeof A);
+            A.scalars = c.scalars; A.limbs = c.limbs; A.nBits = ctx->nBits;
+            for (u32 i = 0; i < ctx->nSections; i++) A.sec[i] = ctx->sections[i].ptr;
+            size_t asz = sizeof A;
+            void *cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END };
+            HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)((nRows + 255) / 256), 1, 1, 256, 1, 1, 0, st, nullptr, cfg));
+            HIP_TRY(hipStreamSynchronize(st));
+            return PIL2GL_OK;
+        }
+    }
     const u32 slots = nSlots ? nSlots : 1;
     if ((size_t)slots * 3 * 64 * 8 <= 60 * 1024) {               // temporaries fit LDS at some block size
         u32 threads = 256;

@@ -91,3 +91,27 @@ def test_tmp_compaction_preserves_program(oracle):
         oracle.eval_program(ops2, max(1, n_slots.value), got, scalars, n_bits, 0)
         for a, b in zip(got, ref):
             assert (a == b).all(), n_ops
+
+
+def test_constraint_program_compiles_with_hiprtc_and_fuses_horner():
+    """the run-time compiled evaluator path: optimiser + source generator + hiprtc, on the synthetic AIR's cExp (no GPU)"""
+    import time
+    from pil2gl import stark
+    lib = _lib.load()
+    ss = {"nBits": 16, "nBitsExt": 19, "nQueries": 8, "steps": [{"nBits": 19}, {"nBits": 14}, {"nBits": 9}]}
+    info, exprs, _ = stark.fibonacci_air(10, ss)
+    ctx = {"pilInfo": info, "publics": [1, 2, 3], "challenges": [[], [[5, 6, 7]], [[1, 1, 1]], [[2, 2, 2], [3, 3, 3]]], "evals": [[i, i + 1, i + 2] for i in range(len(info["evMap"]))]}
+    ops, n_tmp, secs, scalars = stark.encode_code(exprs["expressionsCode"][0]["code"]["code"], "ext", ctx)
+    prog = stark.make_c_program(ops, n_tmp)
+    widths = {"const_ext": 2, "cm1_ext": 20, "q_ext": 3, "Zi_ext#0": 1}
+    cs = (_lib.GlxSection * len(secs))()
+    for i, name in enumerate(secs):
+        cs[i].ptr = 0; cs[i].width = widths[name]
+    c = _lib.GlxCtx(19, 3, len(secs), scalars.size, cs, scalars.ctypes.data_as(_lib.u64p))
+    nbytes = C.c_uint64(); fused = C.c_uint32()
+    t0 = time.time()
+    rc = lib.pil2gl_debug_jit_compile(C.byref(prog), C.byref(c), C.byref(nbytes), C.byref(fused))
+    assert rc == 0, lib.pil2gl_last_error()
+    assert nbytes.value > 1000
+    assert fused.value == 2 * 10 + 3          # every constraint became one lazy multiply-accumulate term
+    assert time.time() - t0 < 120

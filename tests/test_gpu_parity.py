@@ -470,3 +470,30 @@ def test_rows_and_cols_dot_ext(gl, oracle):
     for l in range(2):
         for c in range(width):
             assert out[l, c].tolist() == oracle.eval_pol_at(buf, c, 1, nb, eb, levs[l]).tolist()
+
+
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_expression_evaluator_interpreter_and_jit_agree(gl, oracle, jit, monkeypatch):
+    """the same random programs through the interpreter (PIL2GL_EXPR_JIT=0) and the hiprtc-compiled kernel (=1)"""
+    import torch
+    import ctypes as C
+    from pil2gl import _lib
+    monkeypatch.setenv("PIL2GL_EXPR_JIT", jit)
+    for n_ops, prime_shift in [(40, 0), (300, 2)]:
+        rng = np.random.default_rng(1000 + n_ops)
+        n_bits = 10
+        widths = [5, 9, 1, 3]
+        secs = [rand_field(rng, (1 << n_bits, w)) for w in widths]; secs[-1][:] = 0
+        scalars = rand_field(rng, 40)
+        ops, n_tmp = _random_program(rng, n_ops, widths, scalars.size, len(widths) - 1)
+        ref_secs = [s.copy() for s in secs]
+        oracle.eval_program(ops, n_tmp, ref_secs, scalars, n_bits, prime_shift)
+        dsecs = [torch.from_numpy(s.view(np.int64)).cuda() for s in secs]
+        prog = oracle.make_program(ops, n_tmp, struct_op=_lib.GlxOp, struct_prog=_lib.GlxProgram)
+        csecs = (_lib.GlxSection * len(dsecs))()
+        for i, s in enumerate(dsecs):
+            csecs[i].ptr = s.data_ptr(); csecs[i].width = widths[i]
+        ctx = _lib.GlxCtx(n_bits, prime_shift, len(dsecs), scalars.size, csecs, scalars.ctypes.data_as(_lib.u64p))
+        _lib.call("pil2gl_eval_program_dev", C.byref(prog), C.byref(ctx), None)
+        torch.cuda.synchronize()
+        assert (dsecs[-1].cpu().numpy().view(np.uint64).reshape(ref_secs[-1].shape) == ref_secs[-1]).all()

@@ -50,8 +50,9 @@ def test_prove_and_verify_on_oracle_backend(oracle, n_bits, n_pairs, steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_bits,n_pairs,steps,split", [(8, 2, [11, 7, 3], False), (12, 5, [15, 11, 7, 3], False), (10, 4, [13, 9, 4], True)])
-def test_gpu_proof_is_bit_identical_to_oracle_proof(oracle, n_bits, n_pairs, steps, split):
+@pytest.mark.parametrize("n_bits,n_pairs,steps,split,jit", [(8, 2, [11, 7, 3], False, "0"), (12, 5, [15, 11, 7, 3], False, "1"), (10, 4, [13, 9, 4], True, "1"), (13, 40, [16, 11, 6], False, "0")])
+def test_gpu_proof_is_bit_identical_to_oracle_proof(oracle, n_bits, n_pairs, steps, split, jit, monkeypatch):
+    monkeypatch.setenv("PIL2GL_EXPR_JIT", jit)
     import stark_ref
     stark, info, exprs, vinfo, cm, consts, publics = _setup(n_bits, n_pairs, steps)
     gpu = stark.GpuBackend(0, split)

@@ -408,7 +408,8 @@ static std::map<std::string, JitEntry> g_jit_cache;
 
 static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx_ctx *ctx) {
     std::ostringstream o;
-    o << "#include <hip/hip_runtime.h>\n#include <stdint.h>\n" << kFieldSrc << "\nusing namespace gl;\n";
+    // no #include: hiprtc pre-includes its built-in device runtime header; only the fixed-width typedefs are needed
+    o << "typedef unsigned long uint64_t; typedef unsigned int uint32_t; typedef long int64_t; typedef int int32_t;\n" << kFieldSrc << "\nusing namespace gl;\n";
     o << "struct JitArgs { const u64 *scalars; const u32 *limbs; u64 *sec[" << GLX_MAX_SECTIONS << "]; u32 nBits; u32 pad_; };\n";
     o << "__device__ __forceinline__ u64 fold6(const u64 S[6]) { u64 r = canon(S[0]); r = add(r, mul(S[1], 1ull << 22)); r = add(r, mul(S[2], 1ull << 44));"
          " r = add(r, mul(S[3], 1ull << 32)); r = add(r, mul(S[4], 1ull << 54)); r = add(r, mul(S[5], ((1ull << 32) - 1) << 12)); return r; }\n";
@@ -558,7 +559,11 @@ extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *c
         const bool want = e ? atoi(e) != 0 : (ops.size() >= 64 && ctx->nBits >= 16);
         if (want && nSlots <= 200) {
             hipFunction_t fn;
-            P2_TRY(jit_get(jit_source(ops, nSlots, ctx), &fn));
+            if (jit_get(jit_source(ops, nSlots, ctx), &fn) != PIL2GL_OK) {
+                static bool warned = false;
+                if (!warned) { fprintf(stderr, "pil2gl: run-time compilation unavailable (%s); using the interpreter kernel\n", pil2gl_last_error()); warned = true; }
+                goto interpreter;
+            }
             JitArgs A; memset(&A, 0, sizeof A);
             A.scalars = c.scalars; A.limbs = c.limbs; A.nBits = ctx->nBits;
             for (u32 i = 0; i < ctx->nSections; i++) A.sec[i] = ctx->sections[i].ptr;
@@ -569,6 +574,7 @@ extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *c
             return PIL2GL_OK;
         }
     }
+interpreter:
     const u32 slots = nSlots ? nSlots : 1;
     if ((size_t)slots * 3 * 64 * 8 <= 60 * 1024) {               // temporaries fit LDS at some block size
         u32 threads = 256;

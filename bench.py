@@ -15,6 +15,8 @@ Inputs, intermediates, trees and outputs stay on the device (no PCIe in the time
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same step on its
 own trace (weak scaling, no data-path collective); value = all ranks' cells / max-over-ranks time.
+--mode commit-sharded instead splits ONE trace's extendAndMerkelize by cosets over the ranks (pil2gl.parallel:
+all-gather of leaf digests over RCCL; strong scaling, value = that trace's cells / time).
 """
 import argparse
 import json
@@ -40,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("PIL2GL_BENCH_WORKLOAD", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default=os.environ.get("PIL2GL_BENCH_MODE", "prove"), choices=["prove", "commit"])
+    ap.add_argument("--mode", default=os.environ.get("PIL2GL_BENCH_MODE", "prove"), choices=["prove", "commit", "commit-sharded"])
     ap.add_argument("--split", action="store_true", help="splitLinearHash leaves (linearhash_gpu.js)")
     return ap.parse_args()
 
@@ -174,9 +176,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.mode == "commit-sharded":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     import pil2gl
     pil2gl.init(local_rank)
@@ -206,8 +209,15 @@ def main():
         src, consts, publics = fibonacci_trace_gpu(torch, dev, n_bits, n_cols // 2, rank)
         setup = stark.build_const_tree(be, consts, info)
         prove_ctx = (stark, be, setup, info, exprs, publics)
+    elif args.mode == "commit-sharded":                        # ONE trace, replicated; the cosets of its extension are split
+        from pil2gl import stark, parallel
+        if (1 << EXT_BITS) % world:
+            raise SystemExit("commit-sharded needs a world size dividing %d" % (1 << EXT_BITS))
+        shard_be = stark.GpuBackend(local_rank, args.split)
+        src = make_trace(N, n_cols, 0x5EED0000, dev)
     else:
         src = make_trace(N, n_cols, 0x5EED0000 + rank, dev)
+    sharded = args.mode == "commit-sharded"
     dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
     MH = pil2gl.buildMerkleHash(args.split)
     nodes = torch.empty(MH._getNNodes(E * 4), dtype=torch.int64, device=dev)
@@ -221,10 +231,13 @@ def main():
             stark_, be_, setup_, info_, exprs_, publics_ = prove_ctx
             stark_.stark_gen(be_, src, setup_, info_, exprs_, publics_, timings=stage_times if collect[0] else None)
             return
+        if sharded:
+            parallel.extend_and_merkelize_sharded(shard_be, src, n_cols, n_bits, n_bits + EXT_BITS)
+            return
         pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
         pil2gl.call("pil2gl_merkelize_dev", pil2gl._ptr(dst), n_cols, E, int(args.split), pil2gl._ptr(nodes), C.c_void_p(stream))
     collect = [False]
-    if prove_ctx is not None:
+    if prove_ctx is not None or sharded:
         del dst, nodes                                         # the prove loop allocates its own buffers
         dst = nodes = None
 
@@ -247,7 +260,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * N * n_cols / (dt / args.steps)
+    value = (1 if sharded else world) * N * n_cols / (dt / args.steps)
+    if sharded and rank == 0:
+        dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
     if prove_ctx is not None and rank == 0:                    # one more, untimed-for-value, proof with a per-stage breakdown
         collect[0] = True
         step(); torch.cuda.synchronize()
@@ -286,17 +301,21 @@ def main():
             metric = "STARK prove time (ms_per_step) and trace-cells/s, synthetic Fibonacci AIR, GL Poseidon Merkle + FRI, blow-up 8"
             workload = "full proof (commit, Q, evals, FRI %s, %d queries) of 2^%d rows x %d cols -> 2^%d rows, %s linear hash, per GPU" % (
                 "/".join(str(x["nBits"]) for x in prove_ctx[3]["starkStruct"]["steps"]), prove_ctx[3]["starkStruct"]["nQueries"], n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain")
+        elif sharded:
+            metric = "trace-cells/s, STARK commit step (extend+merkelize) of ONE trace split by cosets over the GPUs, GL Poseidon Merkle, blow-up 8"
+            workload = "extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, %s linear hash, %d of 8 cosets per GPU + all-gather of leaf digests" % (
+                n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain", (1 << EXT_BITS) // world)
         else:
             metric = "trace-cells/s, STARK commit step (extend+merkelize), GL Poseidon Merkle, blow-up 8"
             workload = "extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, %s linear hash, per GPU" % (n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain")
         out = {
             "metric": metric,
             "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "mode": args.mode,
                        "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "GL-Poseidon-12",
-                       "parallelism": "replicas x%d" % world if world > 1 else "single GPU"},
+                       "parallelism": ("coset-sharded x%d" % world) if sharded else ("replicas x%d" % world if world > 1 else "single GPU")},
             "roofline": roofline, "kernels": kernels,
         }
         if prove_ctx is not None:

@@ -64,6 +64,11 @@ int pil2gl_sync(void *stream);
  * evaluations on the coset 7*<w_E> in natural order (== extendPol, polutils.js:18-30). */
 int pil2gl_interpolate(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt);
 int pil2gl_interpolate_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt, void *stream);
+/* The same extension restricted to cosets j in [cosetBegin, cosetBegin+cosetCount) of the 2^(nBitsExt-nBits): dst is
+ * 2^nBits x (cosetCount*nPols), element (pos, j - cosetBegin, c) = interpolate()'s row (pos << b) + j, column c.
+ * One slice per GPU is the multi-GPU partition of extendAndMerkelize; the full range equals interpolate. */
+int pil2gl_interpolate_cosets_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
+                                  uint32_t cosetBegin, uint32_t cosetCount, void *stream);
 /* fft / ifft (buffSrc,nPols,nBits,buffDst)  fft_p.js:178-184: in-order multi-column NTT / iNTT,
  * root F.w[nBits]; ifft = fft, index j -> (n-j) mod n, times 1/n (fft/fft.js:165-174). src may equal dst. */
 int pil2gl_fft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst);
@@ -91,6 +96,9 @@ uint64_t pil2gl_merkle_num_nodes(uint64_t height);
  * then each level padded to an even node count with zero digests; root = last 4 words (:224-226). */
 int pil2gl_merkelize(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes);
 int pil2gl_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes, void *stream);
+/* The upper part of merkelize (merklehash_p.js:87-103) alone: nodes[0..4*height) already holds the leaf digests (e.g.
+ * gathered from the GPUs that hashed their own cosets); fills every higher level up to the root, zero padding included. */
+int pil2gl_merkelize_digests_dev(uint64_t *nodes, uint64_t height, void *stream);
 /* MerkleHash.getGroupProof(tree,idx)  merklehash_p.js:142-168: copies row idx (width words) to hostVals
  * and the sibling digest of every level (nLevels x 4 words) to hostSiblings; returns nLevels in *nLevels.
  * elems/nodes are DEVICE pointers (the tree stays in HBM); synchronises. */

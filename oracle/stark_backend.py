@@ -26,6 +26,33 @@ class OracleBackend:
     def fft(self, src, C, nb, dst): dst[:] = orc.fft_cols(src.reshape(-1, C), nb).reshape(-1)
     def ifft(self, src, C, nb, dst): dst[:] = orc.ifft_cols(src.reshape(-1, C), nb).reshape(-1)
 
+    # multi-process partition (pil2gl.parallel) restated on the full-domain oracle functions: the slice of the full
+    # extension, one linear hash per row, and the level loop of merklehash_p.js:87-103 with one poseidon per node pair
+    def interpolate_cosets(self, src, C, nb, dst, nbe, cb, cc):
+        full = orc.interpolate(src.reshape(-1, C), nb, nbe).reshape(1 << nb, 1 << (nbe - nb), C)
+        dst[:] = full[:, cb:cb + cc, :].reshape(-1)
+
+    def linear_hash_rows(self, buf, w, h):
+        return np.concatenate([orc.linear_hash(buf[i * w:(i + 1) * w], self.split) for i in range(h)])
+
+    def merkelize_digests(self, leaves, h):
+        nodes = np.zeros(orc.merkle_num_nodes(h), np.uint64)
+        nodes[:4 * h] = leaves[:4 * h]
+        p_in, n = 0, 4 * h
+        nxt = ((n - 1) // 8 + 1) * 4
+        p_out = p_in + nxt * 2
+        while n > 4:
+            for i in range(nxt // 4):
+                nodes[p_out + 4 * i:p_out + 4 * i + 4] = orc.poseidon(nodes[p_in + 8 * i:p_in + 8 * i + 8], None, 4)
+            n = nxt; nxt = ((n - 1) // 8 + 1) * 4; p_in = p_out; p_out = p_in + nxt * 2
+        return nodes
+
+    def as_torch(self, t):
+        import torch
+        return torch.from_numpy(np.ascontiguousarray(t).view(np.int64))
+
+    def from_torch(self, t): return t.cpu().numpy().view(np.uint64)
+
     def merkelize(self, buf, w, h):
         return {"elements": buf, "nodes": orc.merkelize(buf.reshape(h, w), self.split), "width": w, "height": h}
 

@@ -152,14 +152,14 @@ int pil2gl_poseidon_dev(const uint64_t *in, const uint64_t *cap, uint64_t count,
     return PIL2GL_OK;
 }
 
-int pil2gl_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes, void *stream) {
+int pil2gl_merkelize_digests_dev(uint64_t *nodes, uint64_t height, void *stream) {
     P2_TRY(ensure_init());
     if (height == 0) return fail(PIL2GL_EINVAL, "height must be > 0");
-    if (!nodes || (!elems && width)) return fail(PIL2GL_EINVAL, "null buffer");
+    if (!nodes) return fail(PIL2GL_EINVAL, "null buffer");
     hipStream_t st = as_stream(stream);
     // merklehash_p.js:49: nodes is a fresh (zeroed) BigUint64Array; the zero padding of odd levels relies on it
-    HIP_TRY(hipMemsetAsync(nodes, 0, pil2gl_merkle_num_nodes(height) * 8, st));
-    P2_TRY(pil2gl_linear_hash_rows_dev(elems, width, height, split, nodes, stream));
+    u64 total = pil2gl_merkle_num_nodes(height);
+    if (total > height * 4) HIP_TRY(hipMemsetAsync(nodes + height * 4, 0, (total - height * 4) * 8, st));
     // merklehash_p.js:87-103 (offsets in u64 words instead of bytes)
     u64 pIn = 0, n64 = height * 4;
     u64 nextN64 = ((n64 - 1) / 8 + 1) * 4;
@@ -172,6 +172,14 @@ int pil2gl_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t height,
         pOut = pIn + nextN64 * 2;
     }
     return PIL2GL_OK;
+}
+
+int pil2gl_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes, void *stream) {
+    P2_TRY(ensure_init());
+    if (height == 0) return fail(PIL2GL_EINVAL, "height must be > 0");
+    if (!nodes || (!elems && width)) return fail(PIL2GL_EINVAL, "null buffer");
+    P2_TRY(pil2gl_linear_hash_rows_dev(elems, width, height, split, nodes, stream));
+    return pil2gl_merkelize_digests_dev(nodes, height, stream);
 }
 
 int pil2gl_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height,

@@ -160,6 +160,7 @@ struct LdeParams {
     const u64 *twi, *twf, *pow7;    // pow256 tables: inverse root, forward root, coset shift 7
     u64 C, ninv;
     u32 n, k, extBits;
+    u32 cosetBegin, cosetCount;     // this call produces cosets [cosetBegin, cosetBegin+cosetCount) of the 2^extBits (multi-GPU: one slice per rank)
     u32 Wc, G, nColChunks;
 };
 
@@ -184,8 +185,10 @@ __global__ void lde_mid_kernel(LdeParams P) {
     for (u32 idx = tid; idx < P.G * K; idx += nth) {
         u32 pos = (gt * P.G + (idx >> k)) * K + (idx & (K - 1));
         u32 m = bitrev32(pos, P.n);                 // this row holds coefficient m of the column polynomial
-        Sc[idx] = mul(P.ninv, pow256(P.pow7, m));   // 7^m / N              (coset j = 0)
         Uc[idx] = root_pow(P.twf, P.n + P.extBits, m);   // w_E^m : step from coset j to j+1
+        u64 s0 = mul(P.ninv, pow256(P.pow7, m));    // 7^m / N              (coset j = 0)
+        if (P.cosetBegin) s0 = mul(s0, root_pow(P.twf, P.n + P.extBits, m * P.cosetBegin));   // (w_E^m)^cosetBegin, m*cb < 2^(n+b)
+        Sc[idx] = s0;
     }
     for (u32 t = y; t < K; t += by) tile[t * S + x] = valid ? P.src[base + (u64)t * P.C] : 0;
     __syncthreads();
@@ -194,7 +197,7 @@ __global__ void lde_mid_kernel(LdeParams P) {
 #pragma unroll
     for (int i = 0; i < EPT; i++) { u32 t = y + i * by; coef[i] = t < K ? tile[t * S + x] : 0; }
     __syncthreads();
-    const u32 nCosets = 1u << P.extBits;
+    const u32 nCosets = P.cosetCount;
     for (u32 j = 0; j < nCosets; j++) {
 #pragma unroll
         for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[t * S + x] = mul(coef[i], Sc[gi * K + t]); }
@@ -204,7 +207,7 @@ __global__ void lde_mid_kernel(LdeParams P) {
 #pragma unroll
             for (int i = 0; i < EPT; i++) {
                 u32 t = y + i * by;
-                if (t < K) P.dst[(((g * K + t) << P.extBits) + j) * P.C + c] = tile[t * S + x];
+                if (t < K) P.dst[((g * K + t) * P.cosetCount + j) * P.C + c] = tile[t * S + x];
             }
         }
         for (u32 idx = tid; idx < P.G * K; idx += nth) Sc[idx] = mul(Sc[idx], Uc[idx]);
@@ -312,12 +315,14 @@ int ntt_launch(const u64 *src, u64 C, u32 n, u64 *dst, bool inverse, hipStream_t
     return PIL2GL_OK;
 }
 
-int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st) {
+int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st, u32 cosetBegin, u32 cosetCount) {
     if (C == 0) return PIL2GL_OK;
     u32 eb = nExt - n;
+    if (cosetCount == 0) { cosetBegin = 0; cosetCount = 1u << eb; }
     u64 N = 1ull << n, E = 1ull << nExt;
     if (n == 0) {                       // constant polynomial: every coset point evaluates to it
-        broadcast_row_kernel<<<(unsigned)((E * C + 255) / 256), 256, 0, st>>>(src, dst, C, E);
+        (void)E;
+        broadcast_row_kernel<<<(unsigned)(((u64)cosetCount * C + 255) / 256), 256, 0, st>>>(src, dst, C, cosetCount);
         KERNEL_CHECK();
         return PIL2GL_OK;
     }
@@ -343,6 +348,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st)
         LdeParams P;
         P.src = coef; P.dst = dst; P.twi = tables().powWi; P.twf = tables().powW; P.pow7 = tables().pow7;
         P.C = C; P.ninv = h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb;
+        P.cosetBegin = cosetBegin; P.cosetCount = cosetCount;
         u64 totalGroups = 1ull << (n - kf);
         u32 nThreads = env_u32("PIL2GL_LDE_THREADS", 512);
         // LDS = tile (S*K) + two local twiddle tables (K) + coset scale tables (2*G*K); narrow matrices
@@ -378,7 +384,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st)
         int np = split_bits(n - kf, kmax, ks);
         u32 lo = kf;
         for (int i = 0; i < np; i++) {
-            P2_TRY(launch_pass(dst, dst, C << eb, n, lo, ks[i], true, false, 0, false, st));
+            P2_TRY(launch_pass(dst, dst, C * cosetCount, n, lo, ks[i], true, false, 0, false, st));
             lo += ks[i];
         }
     }
@@ -401,7 +407,14 @@ extern "C" {
 int pil2gl_interpolate_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt, void *stream) {
     P2_TRY(ensure_init());
     P2_TRY(check_ntt_args(src, dst, nBits, nBitsExt));
-    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream));
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), 0, 0);
+}
+int pil2gl_interpolate_cosets_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
+                                  uint32_t cosetBegin, uint32_t cosetCount, void *stream) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_ntt_args(src, dst, nBits, nBitsExt));
+    if (cosetCount == 0 || (uint64_t)cosetBegin + cosetCount > (1ull << (nBitsExt - nBits))) return fail(PIL2GL_EINVAL, "coset range [%u,%u) outside 2^%u", cosetBegin, cosetBegin + cosetCount, nBitsExt - nBits);
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount);
 }
 int pil2gl_fft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, void *stream) {
     P2_TRY(ensure_init());
@@ -426,7 +439,7 @@ static int host_wrap(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64
     int rc = PIL2GL_OK;
     e = hipMemcpy(dIn, src, nIn * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
-    if (rc == PIL2GL_OK) rc = mode == 0 ? lde_launch(dIn, nPols, nBits, dOut, nBitsOut, 0) : ntt_launch(dIn, nPols, nBits, dOut, mode == 2, 0);
+    if (rc == PIL2GL_OK) rc = mode == 0 ? lde_launch(dIn, nPols, nBits, dOut, nBitsOut, 0, 0, 0) : ntt_launch(dIn, nPols, nBits, dOut, mode == 2, 0);
     if (rc == PIL2GL_OK) { e = hipMemcpy(dst, dOut, nOut * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
     (void)hipFree(dIn); (void)hipFree(dOut);
     return rc;

@@ -80,6 +80,15 @@ def interpolate(buffSrc, nPols, nBits, buffDst, nBitsExt):
         call("pil2gl_interpolate", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), nBitsExt)
 
 
+def interpolateCosets(buffSrc, nPols, nBits, buffDst, nBitsExt, cosetBegin, cosetCount):
+    """interpolate restricted to cosets [cosetBegin, cosetBegin+cosetCount): dst is N x (cosetCount*nPols), device only
+    (the per-GPU slice of extendAndMerkelize, see pil2gl.parallel)"""
+    _check_len(buffSrc, nPols << nBits, "buffSrc"); _check_len(buffDst, (nPols * cosetCount) << nBits, "buffDst")
+    if not _same_side(buffSrc, buffDst):
+        raise Pil2glError("interpolateCosets works on device buffers")
+    call("pil2gl_interpolate_cosets_dev", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), nBitsExt, cosetBegin, cosetCount, _stream())
+
+
 def fft(buffSrc, nPols, nBits, buffDst):
     """fft_p.js:178"""
     _check_len(buffSrc, nPols << nBits, "buffSrc"); _check_len(buffDst, nPols << nBits, "buffDst")
@@ -195,6 +204,15 @@ class MerkleHash:
             nodes = np.zeros(n_nodes, np.uint64)
             call("pil2gl_merkelize", _ptr(buff), width, height, int(self.splitLinearHash), _ptr(nodes))
         return {"elements": buff, "nodes": nodes, "width": width, "height": height}
+
+    def merkelizeDigests(self, leaves, height):
+        """upper levels only (merklehash_p.js:87-103) from `height` leaf digests already computed (device buffer)"""
+        n_nodes = self._getNNodes(height * 4)
+        _check_len(leaves, height * 4, "leaves")
+        nodes = torch.empty(n_nodes, dtype=torch.int64, device=leaves.device)
+        nodes[:height * 4] = leaves.reshape(-1)[:height * 4]
+        call("pil2gl_merkelize_digests_dev", _ptr(nodes), height, _stream())
+        return nodes
 
     def getElement(self, tree, idx, subIdx):
         return _word(tree["elements"], tree["width"] * idx + subIdx)

@@ -61,6 +61,7 @@ SIGNATURES = {
     "pil2gl_sync": (_I, [vp]),
     "pil2gl_interpolate": (_I, [vp, _U64, _U32, vp, _U32]),
     "pil2gl_interpolate_dev": (_I, [vp, _U64, _U32, vp, _U32, vp]),
+    "pil2gl_interpolate_cosets_dev": (_I, [vp, _U64, _U32, vp, _U32, _U32, _U32, vp]),
     "pil2gl_fft": (_I, [vp, _U64, _U32, vp]),
     "pil2gl_ifft": (_I, [vp, _U64, _U32, vp]),
     "pil2gl_fft_dev": (_I, [vp, _U64, _U32, vp, vp]),
@@ -74,6 +75,7 @@ SIGNATURES = {
     "pil2gl_merkle_num_nodes": (_U64, [_U64]),
     "pil2gl_merkelize": (_I, [vp, _U64, _U64, _I, vp]),
     "pil2gl_merkelize_dev": (_I, [vp, _U64, _U64, _I, vp, vp]),
+    "pil2gl_merkelize_digests_dev": (_I, [vp, _U64, vp]),
     "pil2gl_group_proof_dev": (_I, [vp, vp, _U64, _U64, _U64, vp, vp, C.POINTER(_U32)]),
     "pil2gl_group_proofs_dev": (_I, [vp, vp, _U64, _U64, vp, _U32, vp, C.POINTER(_U32)]),
     "pil2gl_fri_fold": (_I, [vp, _U32, _U32, _U64, vp, vp]),

@@ -443,6 +443,34 @@ def test_device_resident_extend_and_merkelize(gl, oracle):
     assert v == e[4097].tolist() and MH.verifyGroupProof(MH.root(tree), mp, 4097, v)
 
 
+@pytest.mark.parametrize("nBits,nPols,ext,cb,cc", [(12, 8, 3, 0, 8), (12, 8, 3, 2, 2), (10, 1, 3, 7, 1), (14, 33, 3, 4, 4),
+                                                   (0, 3, 2, 1, 2), (3, 2, 1, 1, 1), (16, 100, 3, 5, 1), (21, 2, 2, 3, 1)])
+def test_interpolate_coset_slice(gl, oracle, nBits, nPols, ext, cb, cc):
+    """pil2gl_interpolate_cosets_dev = rows (pos << ext) + j, j in [cb, cb+cc), of the full interpolate"""
+    import torch
+    rng = np.random.default_rng(nBits * 31 + cb)
+    a = rand_field(rng, (1 << nBits, nPols))
+    src = torch.from_numpy(a.view(np.int64)).cuda()
+    dst = torch.empty((nPols * cc) << nBits, dtype=torch.int64, device="cuda")
+    gl.interpolateCosets(src, nPols, nBits, dst, nBits + ext, cb, cc)
+    e = oracle.interpolate(a, nBits, nBits + ext).reshape(1 << nBits, 1 << ext, nPols)
+    assert np.array_equal(dst.cpu().numpy().view(np.uint64), e[:, cb:cb + cc, :].reshape(-1))
+    with pytest.raises(gl.Pil2glError):
+        gl.interpolateCosets(src, nPols, nBits, dst, nBits + ext, (1 << ext) - cc + 1, cc)
+
+
+def test_merkelize_from_digests(gl, oracle):
+    import torch
+    rng = np.random.default_rng(23)
+    for h in (1, 2, 33, 1000, 1 << 14):
+        e = rand_field(rng, (h, 7))
+        nodes = oracle.merkelize(e, False)
+        MH = gl.buildMerkleHash(False)
+        leaves = torch.from_numpy(nodes[:4 * h].copy().view(np.int64)).cuda()
+        got = MH.merkelizeDigests(leaves, h).cpu().numpy().view(np.uint64)
+        assert np.array_equal(got, nodes)
+
+
 # ------------------------------------------------------------------ extension-weighted sums (csrc/dot.hip)
 def test_rows_and_cols_dot_ext(gl, oracle):
     import ctypes as C

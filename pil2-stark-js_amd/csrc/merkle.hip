@@ -8,6 +8,8 @@
 // One permutation per lane: the work is integer-ALU bound (about 600 64-bit modular
 // multiplication equivalents per permutation against 96 bytes of traffic), so the kernels only
 // need "not stupid" memory access: a row's 8-element chunk is 64 contiguous bytes per lane.
+// The MDS layers run on the matrix cores (poseidon_mds_mfma.cuh), which takes the operands of all 64 lanes
+// in one instruction: no lane leaves early -- out-of-range lanes hash a clamped (valid) index and skip the store.
 #include "common.h"
 #include "poseidon_gl.cuh"
 #include <algorithm>
@@ -17,71 +19,99 @@ using namespace gl;
 namespace {
 
 // sponge over `width` consecutive words (linearhash.js:29-40); width > 4
-__device__ __forceinline__ void sponge(const u64 *__restrict__ v, u32 width, u64 digest[4]) {
+__device__ __forceinline__ void sponge(const u64 *__restrict__ v, u32 width, u64 digest[4], const MdsMfma &m) {
     u64 st[12];
     st[8] = st[9] = st[10] = st[11] = 0;
     for (u32 i = 0; i < width; i += 8) {
         const u32 n = min(8u, width - i);
 #pragma unroll
         for (u32 j = 0; j < 8; j++) st[j] = j < n ? v[i + j] : 0;
-        poseidon_perm(st);
+        poseidon_perm(st, m);
         st[8] = st[0]; st[9] = st[1]; st[10] = st[2]; st[11] = st[3];
     }
     digest[0] = st[8]; digest[1] = st[9]; digest[2] = st[10]; digest[3] = st[11];
 }
-__device__ __forceinline__ void linear_hash_plain(const u64 *__restrict__ v, u32 width, u64 digest[4]) {
+__device__ __forceinline__ void linear_hash_plain(const u64 *__restrict__ v, u32 width, u64 digest[4], const MdsMfma &m) {
     if (width <= 4) {                               // linearhash.js:22-28, merklehash_worker.js:42-49
 #pragma unroll
         for (u32 j = 0; j < 4; j++) digest[j] = j < width ? v[j] : 0;
         return;
     }
-    sponge(v, width, digest);
+    sponge(v, width, digest, m);
 }
 
-__global__ void __launch_bounds__(256) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int split, u64 *__restrict__ out) {
-    const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= height) return;
+__global__ void __launch_bounds__(256, 2) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int split, u64 *__restrict__ out) {
+    const u64 row0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = row0 < height;
+    const u64 row = live ? row0 : height - 1;       // width, split are uniform: every lane takes the same path
     const u64 *v = in + row * width;
+    MdsMfma m;
+    mds_mfma_init(m);
     u64 d[4];
     if (!split || width <= 4) {
-        linear_hash_plain(v, (u32)width, d);
+        linear_hash_plain(v, (u32)width, d, m);
     } else {                                        // linearhash_gpu.js:30-66, glwasm.js:879-1087
         u32 w = (u32)width;
         u32 batch = max(8u, (w + 3) / 4);
         u64 hs[16];
         u32 nh = 0;
-        for (u32 b = 0; b < w; b += batch) { linear_hash_plain(v + b, min(batch, w - b), hs + nh); nh += 4; }
+        for (u32 b = 0; b < w; b += batch) { linear_hash_plain(v + b, min(batch, w - b), hs + nh, m); nh += 4; }
         if (nh <= 4) { d[0] = hs[0]; d[1] = hs[1]; d[2] = hs[2]; d[3] = hs[3]; }
-        else sponge(hs, nh, d);
+        else sponge(hs, nh, d, m);
     }
+    if (!live) return;
     u64 *o = out + 4 * row;
     o[0] = d[0]; o[1] = d[1]; o[2] = d[2]; o[3] = d[3];
 }
 
 // glwasm.js:1220-1254: out[i] = Poseidon(in[8i..8i+7], capacity 0)[0..3]
-__global__ void __launch_bounds__(256) merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, u64 *__restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nOps) return;
+__global__ void __launch_bounds__(256, 2) merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, u64 *__restrict__ out) {
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < nOps;
+    const u64 i = live ? i0 : nOps - 1;
+    MdsMfma m;
+    mds_mfma_init(m);
     u64 st[12];
 #pragma unroll
     for (int j = 0; j < 8; j++) st[j] = in[8 * i + j];
     st[8] = st[9] = st[10] = st[11] = 0;
-    poseidon_perm(st);
+    poseidon_perm(st, m);
+    if (!live) return;
     u64 *o = out + 4 * i;
     o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];
 }
 
 // batch of independent permutations (glwasm.js:216 `poseidon`, hash/poseidon/poseidon.js:57)
-__global__ void __launch_bounds__(256) poseidon_batch_kernel(const u64 *__restrict__ in, const u64 *__restrict__ cap, u64 count, u32 nOut, u64 *__restrict__ out) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
+__global__ void __launch_bounds__(256, 2) poseidon_batch_kernel(const u64 *__restrict__ in, const u64 *__restrict__ cap, u64 count, u32 nOut, u64 *__restrict__ out) {
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < count;
+    const u64 i = live ? i0 : count - 1;
+    MdsMfma m;
+    mds_mfma_init(m);
     u64 st[12];
 #pragma unroll
     for (int j = 0; j < 8; j++) st[j] = canon(in[8 * i + j]);          // F.e(): poseidon.js:65-67
 #pragma unroll
     for (int j = 0; j < 4; j++) st[8 + j] = cap ? canon(cap[4 * i + j]) : 0;
-    poseidon_perm(st);
+    poseidon_perm(st, m);
+    if (!live) return;
     for (u32 j = 0; j < nOut; j++) out[(u64)nOut * i + j] = st[j];
+}
+
+// diagnostics: MDS layers alone (both implementations), whole waves (n is padded by clamping)
+__global__ void __launch_bounds__(256, 2) mds_selftest_kernel(const u64 *__restrict__ in, u64 n, u32 layers, int mfma, u64 *__restrict__ out) {
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < n;
+    const u64 i = live ? i0 : n - 1;
+    MdsMfma m;
+    mds_mfma_init(m);
+    u64 st[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) st[j] = in[12 * i + j];
+    for (u32 l = 0; l < layers; l++) { if (mfma) mds_layer_mfma(st, m); else mds_layer(st); }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < 12; j++) out[12 * i + j] = canon(st[j]);
 }
 
 // gather of query openings (merklehash_p.js:142-168) for many indices at once: one block per query copies the row
@@ -252,6 +282,18 @@ int pil2gl_poseidon(const uint64_t *in, const uint64_t *cap, uint64_t count, uin
     PsArgs a = { count, nOut };
     return with_dev(in, count * 8, cap, cap ? count * 4 : 0, out, count * nOut,
                     [](const u64 *i, const u64 *c, u64 *o, void *p) { PsArgs *a = (PsArgs *)p; return pil2gl_poseidon_dev(i, c, a->count, a->nOut, o, nullptr); }, &a);
+}
+struct MdsArgs { u64 n; u32 layers; int mfma; };
+int pil2gl_selftest_mds(const uint64_t *states, uint64_t n, uint32_t layers, int mfma, uint64_t *out) {
+    if (n == 0) return PIL2GL_OK;
+    MdsArgs a = { n, layers, mfma };
+    return with_dev(states, n * 12, nullptr, 0, out, n * 12,
+                    [](const u64 *i, const u64 *, u64 *o, void *p) {
+                        MdsArgs *a = (MdsArgs *)p;
+                        mds_selftest_kernel<<<(unsigned)((a->n + 255) / 256), 256>>>(i, a->n, a->layers, a->mfma, o);
+                        KERNEL_CHECK();
+                        return (int)PIL2GL_OK;
+                    }, &a);
 }
 int pil2gl_merkelize(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes) {
     if (height == 0) return fail(PIL2GL_EINVAL, "height must be > 0");

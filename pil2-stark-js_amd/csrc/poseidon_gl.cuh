@@ -10,6 +10,7 @@
 // Values stay "lazy" (any u64 representative) between rounds; outputs are canonicalised.
 #pragma once
 #include "gl_field.cuh"
+#include "poseidon_mds_mfma.cuh"
 
 namespace gl {
 
@@ -51,6 +52,31 @@ __device__ __forceinline__ void mds_layer(u64 st[12]) {
 }
 
 // in-place permutation; st[] canonical or lazy in, canonical out.
+// Matrix-core form (poseidon_mds_mfma.cuh): the whole wave must reach every call (no lane may have left the kernel or
+// sit in another branch, because the MDS operands of all 64 lanes feed one MFMA); `m` comes from mds_mfma_init().
+__device__ inline void poseidon_perm(u64 st[12], const MdsMfma &m) {
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = pow7_lazy(add_lazy_canon(st[i], POSEIDON_GL_RC[r * 12 + i]));
+        mds_layer_mfma(st, m);
+    }
+#pragma unroll 1
+    for (int r = 0; r < 22; r++) {
+        st[0] = pow7_lazy(add_lazy_canon(st[0], POSEIDON_GL_PARTIAL_C0[r]));
+        mds_layer_mfma(st, m);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = pow7_lazy(add_lazy_canon(st[i], r == 26 ? POSEIDON_GL_RC26F[i] : POSEIDON_GL_RC[r * 12 + i]));
+        mds_layer_mfma(st, m);
+    }
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = canon(st[i]);
+}
+
+// vector-ALU form (any subset of lanes): in-place permutation; st[] canonical or lazy in, canonical out.
 // Rounds 4..25 use the folded constants (one addition per round, see poseidon_gl_constants.inc).
 __device__ inline void poseidon_perm(u64 st[12]) {
 #pragma unroll 1

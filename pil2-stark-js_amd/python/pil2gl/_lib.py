@@ -99,6 +99,7 @@ SIGNATURES = {
     "pil2gl_debug_jit_compile": (_I, [C.POINTER(GlxProgram), C.POINTER(GlxCtx), C.POINTER(_U64), C.POINTER(_U32)]),
     "pil2gl_selftest_field": (_I, [vp, vp, _U64, vp, vp, vp]),
     "pil2gl_selftest_ext": (_I, [vp, vp, _U64, vp, vp]),
+    "pil2gl_selftest_mds": (_I, [vp, _U64, _U32, _I, vp]),
 }
 
 _lib = None

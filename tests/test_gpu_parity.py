@@ -110,6 +110,37 @@ def test_poseidon_kats(gl):
         gl.poseidon([1, 2, 3])
 
 
+@pytest.mark.parametrize("mfma", [1, 0])
+def test_mds_layer_structured_inputs(gl, mfma):
+    """the MDS layer alone (matrix-core and vector-ALU forms) on inputs the hash never produces by chance: zero and
+    tiny bytes (row 0's signed accumulators go negative), all-ones bytes (largest sums), values >= p, one-hot states"""
+    from pil2gl import _lib
+    MC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+    M = [[MC[(j - i) % 12] + (8 if i == 0 and j == 0 else 0) for j in range(12)] for i in range(12)]
+    rng = np.random.default_rng(99)
+    states = [[0] * 12, [(1 << 64) - 1] * 12, [P - 1] * 12, [P] * 12, [1] * 12, list(range(12)), [0xFF00FF00FF00FF00] * 12,
+              [0x0101010101010101 * k for k in range(12)], [0x8080808080808080] * 12, [0x7F7F7F7F7F7F7F7F] * 12]
+    for j in range(12):
+        for v in (1, 0xFF, 1 << 63, (1 << 64) - 1, 0x80, 0x100):
+            s = [0] * 12; s[j] = v; states.append(s)
+    for _ in range(300):                     # random sparse bytes
+        s = []
+        for j in range(12):
+            b = rng.integers(0, 256, 8) * (rng.random(8) < 0.4)
+            s.append(int(sum(int(x) << (8 * k) for k, x in enumerate(b))))
+        states.append(s)
+    states += [[int(x) for x in rng.integers(0, 1 << 64, 12, dtype=np.uint64)] for _ in range(300)]
+    a = np.array(states, dtype=np.uint64)
+    for layers in (1, 2, 5):
+        out = np.zeros_like(a)
+        _lib.call("pil2gl_selftest_mds", gl._ptr(a), a.shape[0], layers, mfma, gl._ptr(out))
+        for k, s in enumerate(states):
+            cur = list(s)
+            for _ in range(layers):
+                cur = [sum(M[i][j] * cur[j] for j in range(12)) % P for i in range(12)]
+            assert [int(x) for x in out[k]] == cur, (layers, k, s)
+
+
 def test_linear_hash_golden(gl):
     g = golden("linearhash.json")
     for w, plain, split in H(g["index"]):

@@ -161,6 +161,32 @@ int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
  * ctx are DEVICE pointers; prog/ctx structs themselves are host memory (copied at launch). */
 int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *ctx, void *stream);
 
+/* ---- BN128 (BN254 scalar field) Merkle commitment: merklehash_bn128_p.js, merklehash_bn128_worker.js -------------
+ * Field elements are 4 little-endian u64 words.  tree.nodes and leaf digests are in MONTGOMERY form (R = 2^256), exactly
+ * what the reference's WASM leaves in memory (frm_toMontgomery, merklehash_bn128_worker.js:49,67,82), so files written
+ * by writeToFile are interchangeable; poseidon / group proofs / roots cross the boundary in normal form like the JS
+ * objects do (F.toObject, merklehash_bn128_p.js:167,241).  arity in {2,4,8,16}; Poseidon parameters for every
+ * t = 2..17 are generated on first use (csrc/bn128.hip). */
+/* circomlibjs poseidon(inputs[nIn], initState, nOut) -> out[nOut] for `count` independent calls (init may be NULL = 0) */
+int pil2gl_bn128_poseidon(const uint64_t *in, const uint64_t *init, uint64_t count, uint32_t nIn, uint32_t nOut, uint64_t *out);
+int pil2gl_bn128_poseidon_dev(const uint64_t *in, const uint64_t *init, uint64_t count, uint32_t nIn, uint32_t nOut, uint64_t *out, void *stream);
+/* worker linearHash(buffIn,width,st_i,st_n,arity,custom)  merklehash_bn128_worker.js:13-100 -> height x 4 words */
+int pil2gl_bn128_linear_hash_rows(const uint64_t *in, uint64_t width, uint64_t height, uint32_t arity, int custom, uint64_t *out);
+int pil2gl_bn128_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64_t height, uint32_t arity, int custom, uint64_t *out, void *stream);
+/* worker merkelizeLevel(buffIn,st_i,st_n,arity)  merklehash_bn128_worker.js:104-144: arity*4 words in -> 4 words out per op */
+int pil2gl_bn128_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint32_t arity, uint64_t *out, void *stream);
+/* MerkleHash._getNNodes(height)  merklehash_bn128_p.js:31-45 (in nodes; tree.nodes has 4x as many u64 words) */
+uint64_t pil2gl_bn128_merkle_num_nodes(uint64_t height, uint32_t arity);
+/* MerkleHash.merkelize(buff,width,height)  merklehash_bn128_p.js:47-129 */
+int pil2gl_bn128_merkelize(const uint64_t *elems, uint64_t width, uint64_t height, uint32_t arity, int custom, uint64_t *nodes);
+int pil2gl_bn128_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t height, uint32_t arity, int custom, uint64_t *nodes, void *stream);
+/* MerkleHash.getGroupProof(tree,idx)  merklehash_bn128_p.js:142-182: hostVals[width], hostSiblings[nLevels][arity][4] (normal form) */
+int pil2gl_bn128_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height, uint32_t arity,
+                                 uint64_t idx, uint64_t *hostVals, uint64_t *hostSiblings, uint32_t *nLevels);
+/* n elements between normal and Montgomery form (F.e / F.toObject); the host form is plain host arithmetic */
+int pil2gl_bn128_convert(const uint64_t *in, uint64_t n, int toMontgomery, uint64_t *out);
+int pil2gl_bn128_convert_dev(const uint64_t *in, uint64_t n, int toMontgomery, uint64_t *out, void *stream);
+
 /* ---- synthetic workload for bench.py / tests (not a reference operator) ----
  * witness of nPairs independent Fibonacci machines (test/state_machines/sm_fibonacci/sm_fibonacci.js:12-23):
  * cm is 2^nBits x (2*nPairs) row-major (l1_k, l2_k), hostInit = 2*nPairs canonical start values (host pointer). */

@@ -1,0 +1,468 @@
+// BN128 (BN254 scalar field) Poseidon linear hash and arity-ary Merkle tree, gfx950.
+//
+// Replaces src/helpers/hash/merklehash/merklehash_bn128_p.js:28-182 (merkelize, _getNNodes, getGroupProof), its worker
+// merklehash_bn128_worker.js:13-144 (linearHash, merkelizeLevel) and the third-party kernels those call
+// (circomlibjs@0.1.7 buildPoseidonWasm `poseidon`, wasmcurves@0.1.5 F1m `frm_toMontgomery`; neither is under the
+// reference tree).  The permutation follows the in-tree statement circuits.bn128/custom/poseidon.circom:6-45
+// (t = nInputs+1, RF = 8, RP = N_ROUNDS_P[t-2], x^5, dense round constants and MDS); its parameters are produced on the
+// host by the published Poseidon parameter generation (Grain LFSR) and agree with every constant set the reference holds
+// (tests/test_bn128_oracle.py pins the same generator; tests/test_gpu_bn128.py compares this one with it).
+//
+// Layout: one permutation per lane; the t state elements (8 limbs each, Montgomery form) live in LDS as
+// [buffer][element][limb][lane] (conflict-free, element index may be a run-time value), double-buffered because every
+// MDS row reads the whole previous state.  A row is accumulated unreduced in 17 limbs (t products) and reduced once.
+// Nodes are stored as the reference stores them: 4 little-endian u64 words of the Montgomery form.
+#include "common.h"
+#include "bn_field.cuh"
+#include <mutex>
+#include <vector>
+#include <string.h>
+
+using namespace pil2gl;
+using bn::u32;
+
+namespace {
+
+constexpr int BN_BLOCK = 64;
+constexpr int N_ROUNDS_F = 8;
+const int N_ROUNDS_P[16] = { 56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68 };   // poseidon.circom:8
+
+// ------------------------------------------------------------------------------------------ host 256-bit arithmetic
+struct U256 { u64 w[4]; };
+const U256 HR = { { 0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull } };
+const U256 HR2 = { { 0x1bb8e645ae216da7ull, 0x53fe3ab1e35c59e3ull, 0x8c49833d53bb8085ull, 0x0216d0b17f4e44a5ull } };
+const u64 HN0 = 0xc2e1f593efffffffull;
+typedef unsigned __int128 u128;
+
+bool h_ge(const U256 &a, const U256 &b) { for (int i = 3; i >= 0; i--) if (a.w[i] != b.w[i]) return a.w[i] > b.w[i]; return true; }
+U256 h_sub(const U256 &a, const U256 &b) { U256 r; u64 br = 0; for (int i = 0; i < 4; i++) { u128 d = (u128)a.w[i] - b.w[i] - br; r.w[i] = (u64)d; br = (u64)(d >> 64) & 1; } return r; }
+U256 h_addmod(const U256 &a, const U256 &b) {
+    U256 r; u64 c = 0;
+    for (int i = 0; i < 4; i++) { u128 s = (u128)a.w[i] + b.w[i] + c; r.w[i] = (u64)s; c = (u64)(s >> 64); }
+    if (c || h_ge(r, HR)) r = h_sub(r, HR);
+    return r;
+}
+U256 h_mont(const U256 &a, const U256 &b) {           // a*b/2^256 mod r
+    u64 t[6] = { 0, 0, 0, 0, 0, 0 };
+    for (int i = 0; i < 4; i++) {
+        u64 c = 0;
+        for (int j = 0; j < 4; j++) { u128 x = (u128)a.w[j] * b.w[i] + t[j] + c; t[j] = (u64)x; c = (u64)(x >> 64); }
+        u128 x = (u128)t[4] + c; t[4] = (u64)x; t[5] = (u64)(x >> 64);
+        u64 m = t[0] * HN0;
+        c = (u64)(((u128)m * HR.w[0] + t[0]) >> 64);
+        for (int j = 1; j < 4; j++) { u128 y = (u128)m * HR.w[j] + t[j] + c; t[j - 1] = (u64)y; c = (u64)(y >> 64); }
+        x = (u128)t[4] + c; t[3] = (u64)x; t[4] = t[5] + (u64)(x >> 64);
+    }
+    U256 r = { { t[0], t[1], t[2], t[3] } };
+    if (t[4] || h_ge(r, HR)) r = h_sub(r, HR);
+    return r;
+}
+U256 h_to_mont(const U256 &a) { return h_mont(a, HR2); }
+U256 h_from_mont(const U256 &a) { U256 one = { { 1, 0, 0, 0 } }; return h_mont(a, one); }
+U256 h_inv_mont(const U256 &a) {                      // a^(r-2), Montgomery in and out
+    U256 e = HR; e.w[0] -= 2;
+    U256 acc = h_to_mont(U256{ { 1, 0, 0, 0 } });
+    for (int i = 255; i >= 0; i--) {
+        acc = h_mont(acc, acc);
+        if ((e.w[i / 64] >> (i % 64)) & 1) acc = h_mont(acc, a);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------ Poseidon parameters
+// Grain LFSR parameter stream of the Poseidon paper's reference generator: 80-bit register initialised with
+// field=1 (2 bits), sbox=0 (4), n=254 (12), t (12), RF (10), RP (10), thirty ones; 160 warm-up steps; output bits are
+// self-shrunk (a 1 passes the next bit, a 0 drops it); field elements = 254 bits MSB first, rejected when >= r (round
+// constants) or reduced mod r (the 2t Cauchy points); M[i][j] = 1/(x_i + y_j).
+struct Grain {
+    uint8_t b[80]; int p = 0;
+    int step() { int nb = b[(p + 62) % 80] ^ b[(p + 51) % 80] ^ b[(p + 38) % 80] ^ b[(p + 23) % 80] ^ b[(p + 13) % 80] ^ b[p]; b[p] = (uint8_t)nb; p = (p + 1) % 80; return nb; }
+    int next() { int nb = step(); while (!nb) { step(); nb = step(); } return step(); }
+    U256 rnd() { U256 v = { { 0, 0, 0, 0 } }; for (int i = 0; i < 254; i++) { for (int k = 3; k > 0; k--) v.w[k] = (v.w[k] << 1) | (v.w[k - 1] >> 63); v.w[0] = (v.w[0] << 1) | (u64)next(); } return v; }
+    Grain(int t, int rp) {
+        int n = 0;
+        auto put = [&](unsigned v, int w) { for (int i = w - 1; i >= 0; i--) b[n++] = (v >> i) & 1; };
+        put(1, 2); put(0, 4); put(254, 12); put((unsigned)t, 12); put(N_ROUNDS_F, 10); put((unsigned)rp, 10);
+        while (n < 80) b[n++] = 1;
+        for (int i = 0; i < 160; i++) step();
+    }
+};
+
+struct Params { int t = 0, rp = 0; u32 *dC = nullptr, *dM = nullptr; };   // device tables, Montgomery, 8 limbs per element
+Params g_params[18];
+std::mutex g_mu;
+
+int get_params(int t, const Params **out) {
+    if (t < 2 || t > 17) return fail(PIL2GL_EINVAL, "BN128 Poseidon takes 1..16 inputs (t=%d)", t);
+    std::lock_guard<std::mutex> lk(g_mu);
+    Params &P = g_params[t];
+    if (!P.t) {
+        const int rp = N_ROUNDS_P[t - 2], nC = (N_ROUNDS_F + rp) * t;
+        Grain g(t, rp);
+        std::vector<U256> C((size_t)nC), M((size_t)t * t), xy((size_t)2 * t);
+        for (int i = 0; i < nC; i++) { U256 v = g.rnd(); while (h_ge(v, HR)) v = g.rnd(); C[i] = h_to_mont(v); }
+        for (int i = 0; i < 2 * t; i++) { U256 v = g.rnd(); while (h_ge(v, HR)) v = h_sub(v, HR); xy[i] = h_to_mont(v); }
+        for (int i = 0; i < t; i++) for (int j = 0; j < t; j++) M[(size_t)i * t + j] = h_inv_mont(h_addmod(xy[i], xy[t + j]));
+        u32 *dC = nullptr, *dM = nullptr;
+        HIP_TRY(hipMalloc((void **)&dC, (size_t)nC * 32)); HIP_TRY(hipMalloc((void **)&dM, (size_t)t * t * 32));
+        HIP_TRY(hipMemcpy(dC, C.data(), (size_t)nC * 32, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(dM, M.data(), (size_t)t * t * 32, hipMemcpyHostToDevice));
+        P.rp = rp; P.dC = dC; P.dM = dM; P.t = t;
+    }
+    *out = &P;
+    return PIL2GL_OK;
+}
+
+// ------------------------------------------------------------------------------------------ device side
+struct PermArgs { const u32 *C, *M; int t, rp; };
+
+#define S_AT(buf, j, l) S[((((buf) * tmax + (j)) * 8 + (l)) * BN_BLOCK) + lane]
+
+__device__ __forceinline__ void lds_load(const u32 *S, int tmax, int lane, int buf, int j, u32 x[8]) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) x[l] = S_AT(buf, j, l);
+}
+__device__ __forceinline__ void lds_store(u32 *S, int tmax, int lane, int buf, int j, const u32 x[8]) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) S_AT(buf, j, l) = x[l];
+}
+
+// permutation of the t elements in buffer `cur`; returns the buffer holding the result (poseidon.circom:22-44)
+__device__ int bn_perm(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
+    const int t = A.t, rounds = N_ROUNDS_F + A.rp;
+    for (int r = 0; r < rounds; r++) {
+        const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
+        for (int j = 0; j < t; j++) {
+            u32 x[8], c[8];
+            lds_load(S, tmax, lane, cur, j, x);
+#pragma unroll
+            for (int l = 0; l < 8; l++) c[l] = A.C[((size_t)r * t + j) * 8 + l];
+            bn::fr_add(x, c);
+            if (full || j == 0) {
+                u32 x2[8], x4[8];
+                bn::fr_mul(x2, x, x); bn::fr_mul(x4, x2, x2); bn::fr_mul(x, x4, x);
+            }
+            lds_store(S, tmax, lane, cur, j, x);
+        }
+        for (int i = 0; i < t; i++) {
+            u32 acc[17];
+#pragma unroll
+            for (int l = 0; l < 17; l++) acc[l] = 0;
+            for (int j = 0; j < t; j++) {
+                u32 y[8], m[8];
+                lds_load(S, tmax, lane, cur, j, y);
+#pragma unroll
+                for (int l = 0; l < 8; l++) m[l] = A.M[((size_t)i * t + j) * 8 + l];
+                bn::mac17(acc, y, m);
+            }
+            u32 o[8];
+            bn::redc17(o, acc);
+            lds_store(S, tmax, lane, cur ^ 1, i, o);
+        }
+        cur ^= 1;
+    }
+    return cur;
+}
+
+__device__ __forceinline__ void to_mont_store(u32 *S, int tmax, int lane, int buf, int j, const u64 w[4]) {
+    u32 x[8], r2[8], o[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x[2 * k] = (u32)w[k]; x[2 * k + 1] = (u32)(w[k] >> 32); }
+#pragma unroll
+    for (int l = 0; l < 8; l++) r2[l] = bn::r2_limb(l);
+    bn::fr_mul(o, x, r2);                            // frm_toMontgomery: x * 2^256 mod r (x < 2^256)
+    lds_store(S, tmax, lane, buf, j, o);
+}
+__device__ __forceinline__ void zero_store(u32 *S, int tmax, int lane, int buf, int j) {
+#pragma unroll
+    for (int l = 0; l < 8; l++) S_AT(buf, j, l) = 0;
+}
+__device__ __forceinline__ void digest_out(const u32 *S, int tmax, int lane, int buf, int j, u64 *o) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) o[k] = (u64)S_AT(buf, j, 2 * k) | ((u64)S_AT(buf, j, 2 * k + 1) << 32);
+}
+
+// leaf digests (merklehash_bn128_worker.js:42-98): one row per lane
+__global__ void __launch_bounds__(BN_BLOCK) bn_linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int arity, int custom,
+                                                                    PermArgs full, PermArgs last, u64 *__restrict__ out) {
+    extern __shared__ u32 S[];
+    const int lane = threadIdx.x, tmax = arity + 1;
+    const u64 row0 = (u64)blockIdx.x * BN_BLOCK + lane;
+    const bool live = row0 < height;
+    const u64 *v = in + (live ? row0 : height - 1) * width;
+    int cur = 0;
+    if (width <= 4) {                                // :45-50: up to four words taken as one 256-bit integer
+        u64 w[4] = { 0, 0, 0, 0 };
+        for (u64 k = 0; k < width; k++) w[k] = v[k];
+        to_mont_store(S, tmax, lane, 0, 0, w);
+    } else {
+        zero_store(S, tmax, lane, 0, 0);             // st = 0
+        const u64 nEl = (width + 2) / 3;             // 3 Goldilocks words per field element (:54-67)
+        u64 e = 0;
+        while (e < nEl) {
+            const u64 n = nEl - e < (u64)arity ? nEl - e : (u64)arity;
+            for (u64 k = 0; k < n; k++) {
+                u64 w[4] = { 0, 0, 0, 0 };
+                for (int q = 0; q < 3; q++) { const u64 idx = 3 * (e + k) + q; if (idx < width) w[q] = v[idx]; }
+                to_mont_store(S, tmax, lane, cur, 1 + (int)k, w);
+            }
+            if (n == (u64)arity) cur = bn_perm(S, tmax, lane, cur, full);
+            else if (custom) {                       // :87-93: zero-pad the last chunk to `arity` inputs
+                for (u64 k = n; k < (u64)arity; k++) zero_store(S, tmax, lane, cur, 1 + (int)k);
+                cur = bn_perm(S, tmax, lane, cur, full);
+            } else cur = bn_perm(S, tmax, lane, cur, last);      // :85-86: t = nLast + 1
+            e += n;
+        }
+    }
+    if (live) digest_out(S, tmax, lane, cur, 0, out + 4 * row0);
+}
+
+// parents (merklehash_bn128_worker.js:104-144): out[i] = Poseidon(0; in[arity*i .. arity*i+arity-1])[0]
+__global__ void __launch_bounds__(BN_BLOCK) bn_merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, int arity, PermArgs full, u64 *__restrict__ out) {
+    extern __shared__ u32 S[];
+    const int lane = threadIdx.x, tmax = arity + 1;
+    const u64 i0 = (u64)blockIdx.x * BN_BLOCK + lane;
+    const bool live = i0 < nOps;
+    const u64 *v = in + (live ? i0 : nOps - 1) * (u64)arity * 4;
+    zero_store(S, tmax, lane, 0, 0);
+    for (int k = 0; k < arity; k++) {                // children are already in Montgomery form
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const u64 w = v[4 * k + q]; S_AT(0, 1 + k, 2 * q) = (u32)w; S_AT(0, 1 + k, 2 * q + 1) = (u32)(w >> 32); }
+    }
+    const int cur = bn_perm(S, tmax, lane, 0, full);
+    if (live) digest_out(S, tmax, lane, cur, 0, out + 4 * i0);
+}
+
+// circomlibjs poseidon(inputs, initState, nOut): normal-form words in and out (transcript, verification, tests)
+__global__ void __launch_bounds__(BN_BLOCK) bn_poseidon_kernel(const u64 *__restrict__ in, const u64 *__restrict__ init, u64 count, int nIn, int nOut,
+                                                                 PermArgs full, u64 *__restrict__ out) {
+    extern __shared__ u32 S[];
+    const int lane = threadIdx.x, tmax = nIn + 1;
+    const u64 i0 = (u64)blockIdx.x * BN_BLOCK + lane;
+    const bool live = i0 < count;
+    const u64 i = live ? i0 : count - 1;
+    u64 w[4] = { 0, 0, 0, 0 };
+    if (init) for (int q = 0; q < 4; q++) w[q] = init[4 * i + q];
+    to_mont_store(S, tmax, lane, 0, 0, w);
+    for (int k = 0; k < nIn; k++) {
+        for (int q = 0; q < 4; q++) w[q] = in[(i * nIn + k) * 4 + q];
+        to_mont_store(S, tmax, lane, 0, 1 + k, w);
+    }
+    const int cur = bn_perm(S, tmax, lane, 0, full);
+    if (!live) return;
+    for (int k = 0; k < nOut; k++) {                 // out of Montgomery form: multiply by 1
+        u32 x[8], one[8] = { 1, 0, 0, 0, 0, 0, 0, 0 }, o[8];
+        lds_load(S, tmax, lane, cur, k, x);
+        bn::fr_mul(o, x, one);
+        for (int q = 0; q < 4; q++) out[(i * nOut + k) * 4 + q] = (u64)o[2 * q] | ((u64)o[2 * q + 1] << 32);
+    }
+}
+
+// Montgomery <-> normal form of n elements (frm_toMontgomery / F.toObject)
+__global__ void bn_convert_kernel(const u64 *__restrict__ in, u64 n, int toMont, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u32 x[8], k[8], o[8];
+    for (int q = 0; q < 4; q++) { x[2 * q] = (u32)in[4 * i + q]; x[2 * q + 1] = (u32)(in[4 * i + q] >> 32); }
+    for (int l = 0; l < 8; l++) k[l] = toMont ? bn::r2_limb(l) : (l == 0 ? 1u : 0u);
+    bn::fr_mul(o, x, k);
+    for (int q = 0; q < 4; q++) out[4 * i + q] = (u64)o[2 * q] | ((u64)o[2 * q + 1] << 32);
+}
+
+size_t lds_bytes(int tmax) { return (size_t)2 * tmax * 8 * BN_BLOCK * 4; }
+
+PermArgs perm_args(const Params *P) { PermArgs a; a.C = P->dC; a.M = P->dM; a.t = P->t; a.rp = P->rp; return a; }
+
+template <typename K>
+int set_lds_attr(K kernel, size_t bytes) {
+    HIP_TRY(hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return PIL2GL_OK;
+}
+
+int check_arity(uint32_t arity) {
+    if (arity < 2 || arity > 16 || (arity & (arity - 1))) return fail(PIL2GL_EINVAL, "arity must be 2, 4, 8 or 16 (got %u)", arity);
+    return PIL2GL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint64_t pil2gl_bn128_merkle_num_nodes(uint64_t height, uint32_t arity) {      // merklehash_bn128_p.js:31-45, in nodes
+    if (height == 0 || arity < 2) return 0;
+    uint64_t n = height, nextN = (n - 1) / arity + 1, acc = nextN * arity;
+    while (n > 1) {
+        n = nextN;
+        nextN = (n - 1) / arity + 1;
+        acc += n > 1 ? nextN * arity : 1;
+    }
+    return acc;
+}
+
+int pil2gl_bn128_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64_t height, uint32_t arity, int custom, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (height == 0) return PIL2GL_OK;
+    P2_TRY(check_arity(arity));
+    if (!out || (!in && width)) return fail(PIL2GL_EINVAL, "null buffer");
+    const Params *pf, *pl;
+    P2_TRY(get_params((int)arity + 1, &pf));
+    pl = pf;
+    const uint64_t nEl = (width + 2) / 3, nLast = nEl % arity;
+    if (width > 4 && !custom && nLast) P2_TRY(get_params((int)nLast + 1, &pl));
+    const size_t lds = lds_bytes((int)arity + 1);
+    P2_TRY(set_lds_attr(bn_linear_hash_kernel, lds));
+    const uint64_t blocks = (height + BN_BLOCK - 1) / BN_BLOCK;
+    if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
+    bn_linear_hash_kernel<<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+int pil2gl_bn128_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint32_t arity, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (nOps == 0) return PIL2GL_OK;
+    P2_TRY(check_arity(arity));
+    if (!in || !out) return fail(PIL2GL_EINVAL, "null buffer");
+    const Params *pf;
+    P2_TRY(get_params((int)arity + 1, &pf));
+    const size_t lds = lds_bytes((int)arity + 1);
+    P2_TRY(set_lds_attr(bn_merkle_level_kernel, lds));
+    const uint64_t blocks = (nOps + BN_BLOCK - 1) / BN_BLOCK;
+    if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
+    bn_merkle_level_kernel<<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+int pil2gl_bn128_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t height, uint32_t arity, int custom, uint64_t *nodes, void *stream) {
+    P2_TRY(ensure_init());
+    if (height == 0) return fail(PIL2GL_EINVAL, "height must be > 0");
+    P2_TRY(check_arity(arity));
+    if (!nodes || (!elems && width)) return fail(PIL2GL_EINVAL, "null buffer");
+    hipStream_t st = as_stream(stream);
+    // merklehash_bn128_p.js:51: nodes is a fresh (zeroed) array; the zero padding of short levels relies on it
+    HIP_TRY(hipMemsetAsync(nodes, 0, pil2gl_bn128_merkle_num_nodes(height, arity) * 32, st));
+    P2_TRY(pil2gl_bn128_linear_hash_rows_dev(elems, width, height, arity, custom, nodes, stream));
+    uint64_t pIn = 0, n = height, nextN = (n - 1) / arity + 1, pOut = pIn + nextN * arity * 4;   // :89-101, in u64 words
+    while (n > 1) {
+        P2_TRY(pil2gl_bn128_merkelize_level_dev(nodes + pIn, nextN, arity, nodes + pOut, stream));
+        n = nextN;
+        nextN = (n - 1) / arity + 1;
+        pIn = pOut;
+        pOut = pIn + nextN * arity * 4;
+    }
+    return PIL2GL_OK;
+}
+
+int pil2gl_bn128_poseidon_dev(const uint64_t *in, const uint64_t *init, uint64_t count, uint32_t nIn, uint32_t nOut, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (count == 0) return PIL2GL_OK;
+    if (nIn < 1 || nIn > 16) return fail(PIL2GL_EINVAL, "BN128 Poseidon takes 1..16 inputs (got %u)", nIn);
+    if (nOut < 1 || nOut > nIn + 1) return fail(PIL2GL_EINVAL, "nOut must be 1..nInputs+1");
+    if (!in || !out) return fail(PIL2GL_EINVAL, "null buffer");
+    const Params *pf;
+    P2_TRY(get_params((int)nIn + 1, &pf));
+    const size_t lds = lds_bytes((int)nIn + 1);
+    P2_TRY(set_lds_attr(bn_poseidon_kernel, lds));
+    bn_poseidon_kernel<<<(unsigned)((count + BN_BLOCK - 1) / BN_BLOCK), BN_BLOCK, lds, as_stream(stream)>>>(in, init, count, (int)nIn, (int)nOut, perm_args(pf), out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+int pil2gl_bn128_convert_dev(const uint64_t *in, uint64_t n, int toMontgomery, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (n == 0) return PIL2GL_OK;
+    if (!in || !out) return fail(PIL2GL_EINVAL, "null buffer");
+    bn_convert_kernel<<<(unsigned)((n + 255) / 256), 256, 0, as_stream(stream)>>>(in, n, toMontgomery, out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+// getGroupProof (merklehash_bn128_p.js:142-182): row values + all `arity` nodes of idx's group at every level, normal form
+int pil2gl_bn128_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height, uint32_t arity,
+                                 uint64_t idx, uint64_t *hostVals, uint64_t *hostSiblings, uint32_t *nLevels) {
+    P2_TRY(ensure_init());
+    if (idx >= height) return fail(PIL2GL_EINVAL, "Out of range");               // :145
+    P2_TRY(check_arity(arity));
+    if (!nodes || !hostSiblings || !nLevels || (width && (!elems || !hostVals))) return fail(PIL2GL_EINVAL, "null buffer");
+    if (width) HIP_TRY(hipMemcpy(hostVals, elems + idx * width, width * 8, hipMemcpyDeviceToHost));
+    uint32_t nbits = 0; while ((1u << nbits) < arity) nbits++;
+    uint64_t offset = 0, n = height, id = idx; uint32_t lv = 0;
+    std::vector<uint64_t> mont;
+    while (n > 1) {
+        const uint64_t si = id ^ (id & (arity - 1));
+        mont.resize((size_t)(lv + 1) * arity * 4);
+        HIP_TRY(hipMemcpy(mont.data() + (size_t)lv * arity * 4, nodes + (offset + si) * 4, (size_t)arity * 32, hipMemcpyDeviceToHost));
+        for (uint32_t i = 0; i < arity; i++) if (i >= n) memset(mont.data() + ((size_t)lv * arity + i) * 4, 0, 32);   // :165-170
+        const uint64_t nextN = (n - 1) / arity + 1;
+        offset += nextN * arity; n = nextN; id >>= nbits; lv++;
+    }
+    for (size_t k = 0; k < mont.size() / 4; k++) {
+        U256 v = { { mont[4 * k], mont[4 * k + 1], mont[4 * k + 2], mont[4 * k + 3] } };
+        v = h_from_mont(v);
+        memcpy(hostSiblings + 4 * k, v.w, 32);
+    }
+    *nLevels = lv;
+    return PIL2GL_OK;
+}
+
+// ---- host-pointer forms ----
+int pil2gl_bn128_poseidon(const uint64_t *in, const uint64_t *init, uint64_t count, uint32_t nIn, uint32_t nOut, uint64_t *out) {
+    P2_TRY(ensure_init());
+    if (count == 0) return PIL2GL_OK;
+    if (!in || !out) return fail(PIL2GL_EINVAL, "null buffer");
+    u64 *d = nullptr;
+    const u64 nI = count * nIn * 4, nS = init ? count * 4 : 0, nO = count * nOut * 4;
+    HIP_TRY(hipMalloc((void **)&d, (nI + nS + nO + 1) * 8));
+    int rc = PIL2GL_OK;
+    hipError_t e = hipMemcpy(d, in, nI * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nS) e = hipMemcpy(d + nI, init, nS * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
+    if (rc == PIL2GL_OK) rc = pil2gl_bn128_poseidon_dev(d, nS ? d + nI : nullptr, count, nIn, nOut, d + nI + nS, nullptr);
+    if (rc == PIL2GL_OK) { e = hipMemcpy(out, d + nI + nS, nO * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
+    (void)hipFree(d);
+    return rc;
+}
+
+int pil2gl_bn128_merkelize(const uint64_t *elems, uint64_t width, uint64_t height, uint32_t arity, int custom, uint64_t *nodes) {
+    P2_TRY(ensure_init());
+    if (height == 0) return fail(PIL2GL_EINVAL, "height must be > 0");
+    P2_TRY(check_arity(arity));
+    const u64 nE = width * height, nN = pil2gl_bn128_merkle_num_nodes(height, arity) * 4;
+    u64 *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (nE + nN + 1) * 8));
+    int rc = PIL2GL_OK;
+    hipError_t e = nE ? hipMemcpy(d, elems, nE * 8, hipMemcpyHostToDevice) : hipSuccess;
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
+    if (rc == PIL2GL_OK) rc = pil2gl_bn128_merkelize_dev(d, width, height, arity, custom, d + nE, nullptr);
+    if (rc == PIL2GL_OK) { e = hipMemcpy(nodes, d + nE, nN * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
+    (void)hipFree(d);
+    return rc;
+}
+
+int pil2gl_bn128_linear_hash_rows(const uint64_t *in, uint64_t width, uint64_t height, uint32_t arity, int custom, uint64_t *out) {
+    P2_TRY(ensure_init());
+    if (height == 0) return PIL2GL_OK;
+    const u64 nE = width * height, nO = height * 4;
+    u64 *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (nE + nO + 1) * 8));
+    int rc = PIL2GL_OK;
+    hipError_t e = nE ? hipMemcpy(d, in, nE * 8, hipMemcpyHostToDevice) : hipSuccess;
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
+    if (rc == PIL2GL_OK) rc = pil2gl_bn128_linear_hash_rows_dev(d, width, height, arity, custom, d + nE, nullptr);
+    if (rc == PIL2GL_OK) { e = hipMemcpy(out, d + nE, nO * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
+    (void)hipFree(d);
+    return rc;
+}
+
+int pil2gl_bn128_convert(const uint64_t *in, uint64_t n, int toMontgomery, uint64_t *out) {     // host-only arithmetic (a few values: roots, proofs)
+    if (n && (!in || !out)) return fail(PIL2GL_EINVAL, "null buffer");
+    for (uint64_t k = 0; k < n; k++) {
+        U256 v = { { in[4 * k], in[4 * k + 1], in[4 * k + 2], in[4 * k + 3] } };
+        v = toMontgomery ? h_to_mont(v) : h_from_mont(v);
+        memcpy(out + 4 * k, v.w, 32);
+    }
+    return PIL2GL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// BN254 scalar field Fr for gfx950: eight 32-bit limbs, Montgomery form with R = 2^256 (the form wasmcurves' F1m keeps
+// in memory, so tree.nodes is byte-compatible with merklehash_bn128_p.js).  gfx950 has no 64-bit multiplier; every
+// step below is one v_mad_u64_u32 whose 64-bit result cannot overflow:  (2^32-1)^2 + 2*(2^32-1) = 2^64 - 1.
+#pragma once
+#include <stdint.h>
+
+namespace bn {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+// r = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+#define BN_R_LIMBS { 0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u, 0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u }
+#define BN_R2_LIMBS { 0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u, 0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u }
+constexpr u32 N0INV = 0xefffffffu;                   // -r^-1 mod 2^32
+
+__device__ __forceinline__ u32 r_limb(int i) { constexpr u32 R[8] = BN_R_LIMBS; return R[i]; }
+__device__ __forceinline__ u32 r2_limb(int i) { constexpr u32 R2[8] = BN_R2_LIMBS; return R2[i]; }
+
+// a >= r ?   (n limbs of a against r extended with zeros)
+template <int N>
+__device__ __forceinline__ bool ge_r(const u32 *a) {
+    bool ge = true;                                  // equal so far => ge
+#pragma unroll
+    for (int i = 0; i < N; i++) {                    // from the least significant limb up: the last difference decides
+        const u32 ri = i < 8 ? r_limb(i) : 0u;
+        if (a[i] != ri) ge = a[i] > ri;
+    }
+    return ge;
+}
+template <int N>
+__device__ __forceinline__ void sub_r(u32 *a) {
+    u32 borrow = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const u32 ri = i < 8 ? r_limb(i) : 0u;
+        const u64 d = (u64)a[i] - ri - borrow;
+        a[i] = (u32)d;
+        borrow = (u32)(d >> 63);
+    }
+}
+
+// a = a + b mod r   (a, b < r)
+__device__ __forceinline__ void fr_add(u32 a[8], const u32 b[8]) {
+    u32 t[9];
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { c += (u64)a[i] + b[i]; t[i] = (u32)c; c >>= 32; }
+    t[8] = (u32)c;
+    if (ge_r<9>(t)) sub_r<9>(t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = t[i];
+}
+
+// out = a * b / 2^256 mod r   (CIOS; a < 2^256, b < r  =>  out < r after one conditional subtraction)
+__device__ __forceinline__ void fr_mul(u32 out[8], const u32 a[8], const u32 b[8]) {
+    u32 t[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const u64 x = (u64)a[j] * b[i] + t[j] + c; t[j] = (u32)x; c = x >> 32; }
+        u64 x = (u64)t[8] + c; t[8] = (u32)x; t[9] = (u32)(x >> 32);
+        const u32 m = t[0] * N0INV;
+        c = ((u64)m * r_limb(0) + t[0]) >> 32;
+#pragma unroll
+        for (int j = 1; j < 8; j++) { const u64 y = (u64)m * r_limb(j) + t[j] + c; t[j - 1] = (u32)y; c = y >> 32; }
+        x = (u64)t[8] + c; t[7] = (u32)x; t[8] = t[9] + (u32)(x >> 32);
+    }
+    if (ge_r<9>(t)) sub_r<9>(t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = t[i];
+}
+
+// acc (17 limbs) += a * b   (the 512-bit product is formed in fresh limbs, then added with one carry chain)
+__device__ __forceinline__ void mac17(u32 acc[17], const u32 a[8], const u32 b[8]) {
+    u32 p[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) p[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const u64 x = (u64)a[j] * b[i] + p[i + j] + c; p[i + j] = (u32)x; c = x >> 32; }
+        p[i + 8] = (u32)c;
+    }
+    u64 c = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { c += (u64)acc[i] + p[i]; acc[i] = (u32)c; c >>= 32; }
+    acc[16] += (u32)c;
+}
+
+// Montgomery reduction of a 17-limb accumulator T < 32 * r^2:  out = T / 2^256 mod r
+__device__ __forceinline__ void redc17(u32 out[8], u32 acc[17]) {
+    u32 top = 0;                                     // carry out of limb 16 (T + m*r*2^(32i) < 2^544 + ..., one bit)
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const u32 m = acc[i] * N0INV;
+        u64 c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const u64 x = (u64)m * r_limb(j) + acc[i + j] + c; acc[i + j] = (u32)x; c = x >> 32; }
+#pragma unroll
+        for (int k = i + 8; k < 17; k++) { c += acc[k]; acc[k] = (u32)c; c >>= 32; }
+        top += (u32)c;
+    }
+    (void)top;                                       // T/2^256 + r < 2^261 fits limbs 8..16
+    u32 t[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = acc[8 + i];
+    for (int k = 0; k < 34 && ge_r<9>(t); k++) sub_r<9>(t);      // < 32*r*(r/2^256) + r < 8r in practice (t <= 17: < 5r)
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = t[i];
+}
+
+}  // namespace bn

@@ -1,0 +1,120 @@
+"""GPU parity of the BN128 Merkle path through the C ABI against the CPU oracle, bit-exact, and the
+reference-written final proof replayed through the device permutation."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, P, rand_field
+
+pytestmark = pytest.mark.gpu
+
+ROOT_C = 4996530440829051953383356903338638570209318620783152464040752714611525657817   # test/final/verifier.circom:3299
+
+
+@pytest.fixture(scope="module")
+def bn():
+    import pil2gl
+    pil2gl.init(0)
+    from pil2gl import bn128
+    return bn128
+
+
+@pytest.fixture(scope="module")
+def orc():
+    import bn128_oracle
+    return bn128_oracle
+
+
+def test_poseidon_every_width(bn, orc):
+    rng = np.random.default_rng(5)
+    for n_in in range(1, 17):
+        ins = [[int.from_bytes(rng.bytes(32), "little") % orc.R for _ in range(n_in)] for _ in range(3)]
+        ins.append([0] * n_in); ins.append([orc.R - 1] * n_in)
+        init = [int.from_bytes(rng.bytes(32), "little") % orc.R for _ in ins]
+        init[-2] = 0
+        n_out = 1 if n_in % 3 else n_in + 1
+        got = bn.poseidon_batch(ins, init, n_out)
+        for a, s, g in zip(ins, init, got):
+            assert g == orc.poseidon(a, s, n_out), n_in
+    # inputs above the modulus are reduced like F.e()
+    assert bn.poseidon([orc.R + 5, 7], orc.R + 1, 2) == orc.poseidon([5, 7], 1, 2)
+
+
+def test_montgomery_conversion(bn, orc):
+    vals = [0, 1, orc.R - 1, 1 << 200, 0x123456789ABCDEF << 100]
+    m = bn.to_montgomery(vals)
+    for v, w in zip(vals, m):
+        assert [int(x) for x in w] == orc.to_montgomery_words(v)
+    assert bn.from_montgomery(m) == vals
+
+
+@pytest.mark.parametrize("arity,custom", [(16, False), (4, True), (8, False), (4, False), (16, True), (2, False)])
+def test_linear_hash_rows(bn, orc, arity, custom):
+    from pil2gl import _lib
+    import pil2gl
+    rng = np.random.default_rng(arity * 2 + custom)
+    for width in [1, 2, 3, 4, 5, 6, 7, 9, 12, 13, 21, 36, 47, 48, 49, 50, 97, 100]:
+        if arity == 2 and width > 30:
+            continue
+        h = 5
+        a = rand_field(rng, (h, width))
+        a[0, :] = 0; a[1, :] = P - 1
+        out = np.zeros((h, 4), np.uint64)
+        _lib.call("pil2gl_bn128_linear_hash_rows", pil2gl._ptr(a), width, h, arity, int(custom), pil2gl._ptr(out))
+        for i in range(h):
+            want = orc.to_montgomery_words(orc.linear_hash_worker(a[i].tolist(), arity, custom))
+            assert [int(x) for x in out[i]] == want, (width, i)
+
+
+@pytest.mark.parametrize("arity,custom,N,nPols,idx", [(16, False, 256, 3, 3), (4, True, 256, 3, 3), (16, False, 256, 9, 3), (8, False, 33, 9, 32),
+                                                      (4, True, 70, 21, 69), (16, False, 1, 5, 0), (16, False, 300, 100, 299), (2, False, 9, 7, 4)])
+def test_merkle_tree_and_proofs(bn, orc, arity, custom, N, nPols, idx, tmp_path):
+    """test/merklehash_bn128_p.test.js shapes (pols[i][j] = i + 1000 j) plus ragged heights"""
+    import torch
+    a = np.array([[i + j * 1000 for j in range(nPols)] for i in range(N)], dtype=np.uint64)
+    MH = bn.buildMerkleHash(arity, custom)
+    want = orc.merkelize(a.tolist(), arity, custom)
+    for dev in (False, True):
+        buf = torch.from_numpy(a.view(np.int64)).cuda().reshape(-1) if dev else a.reshape(-1).copy()
+        tree = MH.merkelize(buf, nPols, N)
+        nodes = tree["nodes"].cpu().numpy().view(np.uint64) if dev else tree["nodes"]
+        assert len(nodes) == 4 * orc.merkle_num_nodes(N, arity)
+        assert bn.from_montgomery(nodes) == want
+        assert MH.root(tree) == want[-1]
+        v, mp = MH.getGroupProof(tree, idx)
+        assert v == a[idx].tolist() and mp == orc.group_proof(want, N, arity, idx)
+        if N > 1 and nPols != 4:
+            assert MH.verifyGroupProof(MH.root(tree), mp, idx, v)
+            bad = list(v); bad[0] ^= 1
+            assert not MH.verifyGroupProof(MH.root(tree), mp, idx, bad)
+    f = str(tmp_path / "t.bin")
+    MH.writeToFile(tree, f)
+    t2 = MH.readFromFile(f)
+    assert (t2["nodes"] == nodes).all() and (t2["elements"] == a.reshape(-1)).all()
+    with pytest.raises(bn.Pil2glError):
+        MH.getGroupProof(tree, N)
+
+
+def test_reference_final_proof_through_gpu(bn):
+    """every Merkle opening of test/final/verifier.proof.zkin.json (arity 4, t = 5 and 4) and its transcript, on the device"""
+    p = json.load(open(os.path.join(GOLDEN, "ref_final_verifier.proof.zkin.json")))
+    MH = bn.buildMerkleHash(4, False)
+    T = bn.Transcript(16)
+    T.put([int(x) for x in p["publics"]]); T.put(int(p["root1"])); T.getField(); T.getField()
+    T.put(int(p["root2"])); T.getField(); T.getField()
+    T.put(int(p["root3"])); T.getField()
+    T.put(int(p["rootQ"])); T.getField()
+    T.put([[int(x) for x in e] for e in p["evals"]]); T.getField(); T.getField(); T.getField()
+    for s in range(1, 5):
+        T.put(int(p["s%d_root" % s])); T.getField()
+    T.put([[int(x) for x in e] for e in p["finalPol"]])
+    ys = T.getPermutations(32, 17)
+    for q in range(32):
+        for vk, sk, rt in (("s0_vals1", "s0_siblings1", int(p["root1"])), ("s0_vals3", "s0_siblings3", int(p["root3"])),
+                           ("s0_valsQ", "s0_siblingsQ", int(p["rootQ"])), ("s0_valsC", "s0_siblingsC", ROOT_C)):
+            assert MH.verifyGroupProof(rt, p[sk][q], ys[q], [int(x) for x in p[vk][q]]), (vk, q)
+        for s, bits in ((1, 14), (2, 11), (3, 7), (4, 4)):
+            assert MH.verifyGroupProof(int(p["s%d_root" % s]), p["s%d_siblings" % s][q], ys[q] % (1 << bits),
+                                       [int(x) for x in p["s%d_vals" % s][q]]), (s, q)

@@ -146,6 +146,33 @@ FN(GroupProofDev) {  // (devElems, devNodes, width, height, idx, vals BigUint64A
     napi_value v; napi_create_uint32(env, nl, &v); return v;
 }
 
+// ---- BN128 Merkle commitment (merklehash_bn128_p.js / merklehash_bn128_worker.js) ----
+FN(Bn128Poseidon) {  // (in BigUint64Array(4*nIn*count) normal form, init BigUint64Array(4*count)|null, count, nIn, nOut, out(4*nOut*count))
+    Args a(env, info); uint64_t count = a.u64(2), nIn = a.u64(3), nOut = a.u64(4);
+    uint64_t *in = a.arr(0, 4 * nIn * count), *init = a.is_nullish(1) ? nullptr : a.arr(1, 4 * count), *out = a.arr(5, 4 * nOut * count); if (!a.ok) return nullptr;
+    P2(env, pil2gl_bn128_poseidon(in, init, count, (uint32_t)nIn, (uint32_t)nOut, out)); return mk_undefined(env);
+}
+FN(Bn128LinearHashRows) { // (in, width, height, arity, custom, out(4*height) Montgomery)  merklehash_bn128_worker.js:13
+    Args a(env, info); uint64_t w = a.u64(1), h = a.u64(2), arity = a.u64(3); int custom = (int)a.u64(4);
+    uint64_t *in = a.arr(0, w * h), *out = a.arr(5, 4 * h); if (!a.ok) return nullptr;
+    P2(env, pil2gl_bn128_linear_hash_rows(in, w, h, (uint32_t)arity, custom, out)); return mk_undefined(env);
+}
+FN(Bn128MerkleNumNodes) { Args a(env, info); uint64_t h = a.u64(0), arity = a.u64(1); if (!a.ok) return nullptr; napi_value v; napi_create_double(env, (double)pil2gl_bn128_merkle_num_nodes(h, (uint32_t)arity), &v); return v; }
+FN(Bn128Merkelize) { // (elems, width, height, arity, custom, nodes(4*nNodes))  merklehash_bn128_p.js:47
+    Args a(env, info); uint64_t w = a.u64(1), h = a.u64(2), arity = a.u64(3); int custom = (int)a.u64(4);
+    uint64_t *el = a.arr(0, w * h), *nodes = a.arr(5, 4 * pil2gl_bn128_merkle_num_nodes(h, (uint32_t)arity)); if (!a.ok) return nullptr;
+    P2(env, pil2gl_bn128_merkelize(el, w, h, (uint32_t)arity, custom, nodes)); return mk_undefined(env);
+}
+FN(Bn128MerkelizeDev) { // (devElems, width, height, arity, custom, devNodes)
+    Args a(env, info); uint64_t el = a.u64(0), w = a.u64(1), h = a.u64(2), arity = a.u64(3); int custom = (int)a.u64(4); uint64_t nodes = a.u64(5); if (!a.ok) return nullptr;
+    P2(env, pil2gl_bn128_merkelize_dev((const uint64_t *)(uintptr_t)el, w, h, (uint32_t)arity, custom, (uint64_t *)(uintptr_t)nodes, a.stream(6))); return mk_undefined(env);
+}
+FN(Bn128Convert) {   // (in BigUint64Array(4n), n, toMontgomery, out)
+    Args a(env, info); uint64_t n = a.u64(1); int toM = (int)a.u64(2);
+    uint64_t *in = a.arr(0, 4 * n), *out = a.arr(3, 4 * n); if (!a.ok) return nullptr;
+    P2(env, pil2gl_bn128_convert(in, n, toM, out)); return mk_undefined(env);
+}
+
 // ---- FRI ----
 FN(FriFold) {        // (pol, polBits, outBits, shiftInv, challenge[3], out)  fri.js:22
     Args a(env, info); uint32_t pb = (uint32_t)a.u64(1), ob = (uint32_t)a.u64(2); uint64_t sinv = a.u64(3);
@@ -183,6 +210,8 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "interpolateDev", InterpolateDev }, { "fftDev", FftDev }, { "ifftDev", IfftDev },
         { "poseidon", Poseidon }, { "linearHashRows", LinearHashRows }, { "merkelizeLevel", MerkelizeLevel },
         { "merkleNumNodes", MerkleNumNodes }, { "merkelize", Merkelize }, { "merkelizeDev", MerkelizeDev }, { "groupProofDev", GroupProofDev },
+        { "bn128Poseidon", Bn128Poseidon }, { "bn128LinearHashRows", Bn128LinearHashRows }, { "bn128MerkleNumNodes", Bn128MerkleNumNodes },
+        { "bn128Merkelize", Bn128Merkelize }, { "bn128MerkelizeDev", Bn128MerkelizeDev }, { "bn128Convert", Bn128Convert },
         { "friFold", FriFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
     };
     for (auto &f : fns) {

@@ -5,6 +5,8 @@ module.exports = {
     fft_p: require("./fft_p.js"),
     buildMerkleHash: require("./merklehash_p.js"),
     buildPoseidon: require("./poseidon.js"),
+    buildMerkleHashBN128: require("./merklehash_bn128_p.js"),
+    TranscriptBN128: require("./transcript_bn128.js"),
     FRI: require("./fri.js"),
     prover_helpers: require("./prover_helpers.js"),
 };

@@ -121,5 +121,53 @@ class ChunkedBuffer {
             assert.deepStrictEqual([ctx.q_ext[3 * i], ctx.q_ext[3 * i + 1], ctx.q_ext[3 * i + 2]], [mod(t * 3n), mod(t * 1n), mod(t * 4n)], "callCalculateExps row " + i);
         }
     }
+    // --- BN128 Merkle commitment (merklehash_bn128_p.js, linearhash.bn128.js, transcript.bn128.js)
+    {
+        const buildMHBN = require(path.join(root, "pil2-stark-js_amd/js/merklehash_bn128_p.js"));
+        const TranscriptBN = require(path.join(root, "pil2-stark-js_amd/js/transcript_bn128.js"));
+        const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden/bn128_merkle.json")));
+        assert.strictEqual(buildMHBN.poseidon([1n, 2n], 0n).toString(), g.poseidon.out_t3);
+        assert.deepStrictEqual(buildMHBN.poseidon(g.poseidon.in.map(BigInt), BigInt(g.poseidon.init), 17).map(String), g.poseidon.out17);
+        for (const t of g.trees) {          // test/merklehash_bn128_p.test.js shapes
+            const MH = await buildMHBN(t.arity, t.custom);
+            const pols = new BigUint64Array(t.N * t.nPols);
+            for (let i = 0; i < t.N; i++) for (let j = 0; j < t.nPols; j++) pols[i * t.nPols + j] = BigInt(i + j * 1000);
+            const cbn = new ChunkedBuffer(pols.length, 1000); cbn.set(pols, 0);
+            for (const buf of [pols, cbn]) {
+                const tree = await MH.merkelize(buf, t.nPols, t.N);
+                assert.strictEqual(MH.root(tree).toString(), t.root, `bn128 root arity ${t.arity}`);
+                const [v, mp] = MH.getGroupProof(tree, t.idx);
+                assert.deepStrictEqual(mp.map((l) => l.map(String)), t.proof);
+                assert(MH.verifyGroupProof(MH.root(tree), mp, t.idx, v));
+                v[0] = v[0] + 1n;
+                assert(!MH.verifyGroupProof(MH.root(tree), mp, t.idx, v));
+                if (buf === pols) {
+                    const f = path.join(require("os").tmpdir(), `pil2gl_bn_${process.pid}.bin`);
+                    await MH.writeToFile(tree, f);
+                    const t2 = await MH.readFromFile(f);
+                    fs.unlinkSync(f);
+                    assert.deepStrictEqual(t2.nodes, tree.nodes);
+                    assert.deepStrictEqual(t2.elements, pols);
+                }
+            }
+        }
+        // a proof the reference prover wrote (test/final/verifier.proof.zkin.json): transcript -> query positions -> openings
+        const p = JSON.parse(fs.readFileSync(path.join(root, "tests/golden/ref_final_verifier.proof.zkin.json")));
+        const T = new TranscriptBN(16);
+        T.put(p.publics.map(BigInt)); T.put(BigInt(p.root1)); T.getField(); T.getField();
+        T.put(BigInt(p.root2)); T.getField(); T.getField();
+        T.put(BigInt(p.root3)); T.getField();
+        T.put(BigInt(p.rootQ)); T.getField();
+        T.put(p.evals.map((e) => e.map(BigInt))); T.getField(); T.getField(); T.getField();
+        for (let s = 1; s <= 4; s++) { T.put(BigInt(p[`s${s}_root`])); T.getField(); }
+        T.put(p.finalPol.map((e) => e.map(BigInt)));
+        const ys = T.getPermutations(32, 17);
+        const MH4 = await buildMHBN(4, false);
+        for (const q of [0, 13, 31]) {
+            assert(MH4.verifyGroupProof(BigInt(p.root1), p.s0_siblings1[q], ys[q], p.s0_vals1[q].map(BigInt)), "final proof root1 q" + q);
+            assert(MH4.verifyGroupProof(BigInt(p.rootQ), p.s0_siblingsQ[q], ys[q], p.s0_valsQ[q].map(BigInt)), "final proof rootQ q" + q);
+            assert(MH4.verifyGroupProof(BigInt(p.s2_root), p.s2_siblings[q], ys[q] % (1 << 11), p.s2_vals[q].map(BigInt)), "final proof s2 q" + q);
+        }
+    }
     console.log("addon parity OK");
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -16,9 +16,10 @@ def test_addon_loads_and_exports():
     assert os.path.exists(ADDON), "addon not built (make -C pil2-stark-js_amd)"
     js = ("const m=require(%r);const a=m.native;"
           "for (const k of ['interpolate','fft','ifft','merkelize','merkelizeLevel','linearHashRows','poseidon','friFold',"
-          "'friTranspose','devAlloc','devFree','devUpload','devDownload','interpolateDev','merkelizeDev','groupProofDev','evalProgramDev'])"
+          "'friTranspose','bn128Poseidon','bn128Merkelize','bn128MerkelizeDev','bn128LinearHashRows','bn128Convert','devAlloc','devFree','devUpload','devDownload','interpolateDev','merkelizeDev','groupProofDev','evalProgramDev'])"
           " if (typeof a[k] !== 'function') throw new Error('missing '+k);"
           "if (a.merkleNumNodes(256) !== 2044) throw new Error('merkleNumNodes');"
+          "if (a.bn128MerkleNumNodes(256, 16) !== 273) throw new Error('bn128MerkleNumNodes');"
           "for (const k of ['fft','ifft','interpolate']) if (typeof m.fft_p[k] !== 'function') throw new Error(k);"
           "console.log('ok')") % os.path.join(ROOT, "pil2-stark-js_amd", "js", "index.js")
     out = subprocess.run([NODE, "-e", js], capture_output=True, text=True, timeout=60)

@@ -8,6 +8,9 @@
 // host by the published Poseidon parameter generation (Grain LFSR) and agree with every constant set the reference holds
 // (tests/test_bn128_oracle.py pins the same generator; tests/test_gpu_bn128.py compares this one with it).
 //
+// The partial rounds run in the sparse form (derivation below, next to derive_sparse()): 2t-1 products per round instead
+// of t^2; outputs are the same field elements as the dense statement (the dense form is kept for tests).
+//
 // Layout: one permutation per lane; the t state elements (8 limbs each, Montgomery form) live in LDS as
 // [buffer][element][limb][lane] (conflict-free, element index may be a run-time value), double-buffered because every
 // MDS row reads the whole previous state.  A row is accumulated unreduced in 17 limbs (t products) and reduced once.
@@ -17,6 +20,8 @@
 #include <mutex>
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
+#include <algorithm>
 
 using namespace pil2gl;
 using bn::u32;
@@ -42,6 +47,7 @@ U256 h_addmod(const U256 &a, const U256 &b) {
     if (c || h_ge(r, HR)) r = h_sub(r, HR);
     return r;
 }
+U256 h_addraw(const U256 &a, const U256 &b) { U256 r; u64 c = 0; for (int i = 0; i < 4; i++) { u128 s = (u128)a.w[i] + b.w[i] + c; r.w[i] = (u64)s; c = (u64)(s >> 64); } return r; }
 U256 h_mont(const U256 &a, const U256 &b) {           // a*b/2^256 mod r
     u64 t[6] = { 0, 0, 0, 0, 0, 0 };
     for (int i = 0; i < 4; i++) {
@@ -57,6 +63,8 @@ U256 h_mont(const U256 &a, const U256 &b) {           // a*b/2^256 mod r
     if (t[4] || h_ge(r, HR)) r = h_sub(r, HR);
     return r;
 }
+U256 h_submod(const U256 &a, const U256 &b) { return h_ge(a, b) ? h_sub(a, b) : h_sub(h_addraw(a, HR), b); }   // a, b < r < 2^254
+bool h_is_zero(const U256 &a) { return !(a.w[0] | a.w[1] | a.w[2] | a.w[3]); }
 U256 h_to_mont(const U256 &a) { return h_mont(a, HR2); }
 U256 h_from_mont(const U256 &a) { U256 one = { { 1, 0, 0, 0 } }; return h_mont(a, one); }
 U256 h_inv_mont(const U256 &a) {                      // a^(r-2), Montgomery in and out
@@ -88,33 +96,119 @@ struct Grain {
     }
 };
 
-struct Params { int t = 0, rp = 0; u32 *dC = nullptr, *dM = nullptr; };   // device tables, Montgomery, 8 limbs per element
+// device tables of one state width t, Montgomery form, 8 limbs per element, one allocation:
+//   C8[8][t]  constants of the 4+4 full rounds (the first of the second half also carries what the partial rounds pushed out)
+//   M[t][t]   dense MDS;  D[t-1][t-1] = Mhat^RP;  S[RP] scalar constants;  V[RP][t-1], W[RP][t-1] sparse rows / columns
+//   Cd[(8+RP)][t] the original constants, for the dense (test) form
+struct Params { int t = 0, rp = 0; u32 *base = nullptr, *C8, *M, *D, *S, *V, *W, *Cd; u32 m00[8]; };
 Params g_params[18];
 std::mutex g_mu;
+
+typedef std::vector<U256> Vec;
+Vec mat_vec(const Vec &A, const Vec &x, int n) {        // A (n x n) * x
+    Vec y((size_t)n);
+    for (int i = 0; i < n; i++) { U256 a = { { 0, 0, 0, 0 } }; for (int j = 0; j < n; j++) a = h_addmod(a, h_mont(A[(size_t)i * n + j], x[j])); y[i] = a; }
+    return y;
+}
+int mat_inv(Vec &A, int n) {                             // Gauss-Jordan in place (Montgomery form)
+    const U256 one = h_to_mont(U256{ { 1, 0, 0, 0 } });
+    Vec I((size_t)n * n, U256{ { 0, 0, 0, 0 } });
+    for (int i = 0; i < n; i++) I[(size_t)i * n + i] = one;
+    for (int c = 0; c < n; c++) {
+        int p = c;
+        while (p < n && h_is_zero(A[(size_t)p * n + c])) p++;
+        if (p == n) return fail(PIL2GL_EINVAL, "singular MDS sub-matrix");
+        if (p != c) for (int j = 0; j < n; j++) { std::swap(A[(size_t)p * n + j], A[(size_t)c * n + j]); std::swap(I[(size_t)p * n + j], I[(size_t)c * n + j]); }
+        const U256 iv = h_inv_mont(A[(size_t)c * n + c]);
+        for (int j = 0; j < n; j++) { A[(size_t)c * n + j] = h_mont(A[(size_t)c * n + j], iv); I[(size_t)c * n + j] = h_mont(I[(size_t)c * n + j], iv); }
+        for (int r = 0; r < n; r++) {
+            if (r == c || h_is_zero(A[(size_t)r * n + c])) continue;
+            const U256 f = A[(size_t)r * n + c];
+            for (int j = 0; j < n; j++) {
+                A[(size_t)r * n + j] = h_submod(A[(size_t)r * n + j], h_mont(f, A[(size_t)c * n + j]));
+                I[(size_t)r * n + j] = h_submod(I[(size_t)r * n + j], h_mont(f, I[(size_t)c * n + j]));
+            }
+        }
+    }
+    A = I;
+    return PIL2GL_OK;
+}
+
+// Sparse form of the RP partial rounds.  Dense statement: x_{k+1} = M * sigma(x_k + c_k), sigma = x^5 on element 0 only.
+//  (1) constants: with e_0 = c_0, s_k = e_k[0], e_{k+1} = c_{k+1} + M*(0, e_k[1:]), the sequence y_{k+1} = M*sigma'(y_k + s_k e0)
+//      satisfies x_k + c_k = y_k + e_k; what is left, f = M*(0, e_{RP-1}[1:]), joins the next full round's constants.
+//  (2) matrices: M = [[m00, v],[w, Mh]].  With D_k = diag(1, Mh^k), M*D_k = D_{k+1} * [[m00, v*Mh^k],[Mh^-(k+1) w, I]], and
+//      D_k commutes with sigma', so y_k = D_k u_k with u_{k+1} = [[m00, V_k],[W_k, I]] * sigma'(u_k): 2t-1 products;
+//      one dense multiplication by D_RP = diag(1, Mh^RP) closes the sequence.
+int derive_sparse(int t, int rp, const Vec &C, const Vec &M, Vec &C8, Vec &D, Vec &S, Vec &V, Vec &W) {
+    const int n = t - 1;
+    const U256 zero = { { 0, 0, 0, 0 } };
+    Vec Mh((size_t)n * n), v((size_t)n), w((size_t)n);
+    for (int i = 0; i < n; i++) { v[i] = M[(size_t)1 + i]; w[i] = M[(size_t)(i + 1) * t]; for (int j = 0; j < n; j++) Mh[(size_t)i * n + j] = M[(size_t)(i + 1) * t + 1 + j]; }
+    Vec Mhi = Mh;
+    P2_TRY(mat_inv(Mhi, n));
+    S.resize((size_t)rp); V.resize((size_t)rp * n); W.resize((size_t)rp * n); C8.resize((size_t)8 * t);
+    Vec e(C.begin() + (size_t)4 * t, C.begin() + (size_t)5 * t), f;
+    for (int k = 0; k < rp; k++) {
+        S[k] = e[0];
+        Vec et = e; et[0] = zero;
+        Vec Me = mat_vec(M, et, t);
+        if (k + 1 < rp) for (int j = 0; j < t; j++) e[j] = h_addmod(C[(size_t)(5 + k) * t + j], Me[j]);
+        else f = Me;
+    }
+    Vec vk = v, wk = mat_vec(Mhi, w, n);
+    for (int k = 0; k < rp; k++) {
+        for (int j = 0; j < n; j++) { V[(size_t)k * n + j] = vk[j]; W[(size_t)k * n + j] = wk[j]; }
+        Vec nv((size_t)n);
+        for (int j = 0; j < n; j++) { U256 a = zero; for (int i = 0; i < n; i++) a = h_addmod(a, h_mont(vk[i], Mh[(size_t)i * n + j])); nv[j] = a; }
+        vk = nv;
+        wk = mat_vec(Mhi, wk, n);
+    }
+    D.assign((size_t)n * n, zero);
+    const U256 one = h_to_mont(U256{ { 1, 0, 0, 0 } });
+    for (int i = 0; i < n; i++) D[(size_t)i * n + i] = one;
+    for (int k = 0; k < rp; k++) {
+        Vec nd((size_t)n * n);
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) { U256 a = zero; for (int q = 0; q < n; q++) a = h_addmod(a, h_mont(Mh[(size_t)i * n + q], D[(size_t)q * n + j])); nd[(size_t)i * n + j] = a; }
+        D = nd;
+    }
+    for (int r = 0; r < 4; r++) for (int j = 0; j < t; j++) {
+        C8[(size_t)r * t + j] = C[(size_t)r * t + j];
+        C8[(size_t)(4 + r) * t + j] = r == 0 ? h_addmod(C[(size_t)(4 + rp) * t + j], f[j]) : C[(size_t)(4 + rp + r) * t + j];
+    }
+    return PIL2GL_OK;
+}
 
 int get_params(int t, const Params **out) {
     if (t < 2 || t > 17) return fail(PIL2GL_EINVAL, "BN128 Poseidon takes 1..16 inputs (t=%d)", t);
     std::lock_guard<std::mutex> lk(g_mu);
     Params &P = g_params[t];
     if (!P.t) {
-        const int rp = N_ROUNDS_P[t - 2], nC = (N_ROUNDS_F + rp) * t;
+        const int rp = N_ROUNDS_P[t - 2], nC = (N_ROUNDS_F + rp) * t, n = t - 1;
         Grain g(t, rp);
-        std::vector<U256> C((size_t)nC), M((size_t)t * t), xy((size_t)2 * t);
+        Vec C((size_t)nC), M((size_t)t * t), xy((size_t)2 * t);
         for (int i = 0; i < nC; i++) { U256 v = g.rnd(); while (h_ge(v, HR)) v = g.rnd(); C[i] = h_to_mont(v); }
         for (int i = 0; i < 2 * t; i++) { U256 v = g.rnd(); while (h_ge(v, HR)) v = h_sub(v, HR); xy[i] = h_to_mont(v); }
         for (int i = 0; i < t; i++) for (int j = 0; j < t; j++) M[(size_t)i * t + j] = h_inv_mont(h_addmod(xy[i], xy[t + j]));
-        u32 *dC = nullptr, *dM = nullptr;
-        HIP_TRY(hipMalloc((void **)&dC, (size_t)nC * 32)); HIP_TRY(hipMalloc((void **)&dM, (size_t)t * t * 32));
-        HIP_TRY(hipMemcpy(dC, C.data(), (size_t)nC * 32, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(dM, M.data(), (size_t)t * t * 32, hipMemcpyHostToDevice));
-        P.rp = rp; P.dC = dC; P.dM = dM; P.t = t;
+        Vec C8, D, S, V, W;
+        P2_TRY(derive_sparse(t, rp, C, M, C8, D, S, V, W));
+        Vec all;
+        auto put = [&](const Vec &x) { size_t o = all.size(); all.insert(all.end(), x.begin(), x.end()); return o; };
+        const size_t oC8 = put(C8), oM = put(M), oD = put(D), oS = put(S), oV = put(V), oW = put(W), oCd = put(C);
+        (void)n;
+        u32 *d = nullptr;
+        HIP_TRY(hipMalloc((void **)&d, all.size() * 32));
+        HIP_TRY(hipMemcpy(d, all.data(), all.size() * 32, hipMemcpyHostToDevice));
+        P.base = d; P.C8 = d + oC8 * 8; P.M = d + oM * 8; P.D = d + oD * 8; P.S = d + oS * 8; P.V = d + oV * 8; P.W = d + oW * 8; P.Cd = d + oCd * 8;
+        memcpy(P.m00, M[0].w, 32);
+        P.rp = rp; P.t = t;
     }
     *out = &P;
     return PIL2GL_OK;
 }
 
 // ------------------------------------------------------------------------------------------ device side
-struct PermArgs { const u32 *C, *M; int t, rp; };
+struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8]; };
 
 #define S_AT(buf, j, l) S[((((buf) * tmax + (j)) * 8 + (l)) * BN_BLOCK) + lane]
 
@@ -126,39 +220,96 @@ __device__ __forceinline__ void lds_store(u32 *S, int tmax, int lane, int buf, i
 #pragma unroll
     for (int l = 0; l < 8; l++) S_AT(buf, j, l) = x[l];
 }
-
-// permutation of the t elements in buffer `cur`; returns the buffer holding the result (poseidon.circom:22-44)
-__device__ int bn_perm(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
-    const int t = A.t, rounds = N_ROUNDS_F + A.rp;
-    for (int r = 0; r < rounds; r++) {
-        const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
-        for (int j = 0; j < t; j++) {
-            u32 x[8], c[8];
-            lds_load(S, tmax, lane, cur, j, x);
+__device__ __forceinline__ void load_const(const u32 *p, size_t idx, u32 c[8]) {       // wave-uniform address
 #pragma unroll
-            for (int l = 0; l < 8; l++) c[l] = A.C[((size_t)r * t + j) * 8 + l];
-            bn::fr_add(x, c);
-            if (full || j == 0) {
-                u32 x2[8], x4[8];
-                bn::fr_mul(x2, x, x); bn::fr_mul(x4, x2, x2); bn::fr_mul(x, x4, x);
-            }
-            lds_store(S, tmax, lane, cur, j, x);
+    for (int l = 0; l < 8; l++) c[l] = p[idx * 8 + l];
+}
+__device__ __forceinline__ void pow5(u32 x[8]) {
+    u32 x2[8], x4[8];
+    bn::fr_mul(x2, x, x); bn::fr_mul(x4, x2, x2); bn::fr_mul(x, x4, x);
+}
+
+// x^5 on elements [0, nSbox) after adding constants C[0..t), then the dense n x n matrix A applied to elements
+// [first, first+n) of buffer cur into buffer cur^1 (elements below `first` are copied)
+__device__ __forceinline__ void add_sbox(u32 *S, int tmax, int lane, int cur, int t, const u32 *C, size_t cOff, int nSbox) {
+    for (int j = 0; j < t; j++) {
+        u32 x[8], c[8];
+        lds_load(S, tmax, lane, cur, j, x);
+        load_const(C, cOff + j, c);
+        bn::fr_add(x, c);
+        if (j < nSbox) pow5(x);
+        lds_store(S, tmax, lane, cur, j, x);
+    }
+}
+__device__ __forceinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, const u32 *A, int n, int first) {
+    for (int j = 0; j < first; j++) { u32 x[8]; lds_load(S, tmax, lane, cur, j, x); lds_store(S, tmax, lane, cur ^ 1, j, x); }
+    for (int i = 0; i < n; i++) {
+        u32 acc[17];
+#pragma unroll
+        for (int l = 0; l < 17; l++) acc[l] = 0;
+        for (int j = 0; j < n; j++) {
+            u32 y[8], m[8];
+            lds_load(S, tmax, lane, cur, first + j, y);
+            load_const(A, (size_t)i * n + j, m);
+            bn::mac17(acc, y, m);
         }
-        for (int i = 0; i < t; i++) {
+        u32 o[8];
+        bn::redc17(o, acc);
+        lds_store(S, tmax, lane, cur ^ 1, first + i, o);
+    }
+}
+
+// permutation of the t elements in buffer `cur`; returns the buffer holding the result
+__device__ int bn_perm(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
+    const int t = A.t;
+    if (A.dense) {                                   // poseidon.circom:22-44 as written (tests)
+        for (int r = 0; r < N_ROUNDS_F + A.rp; r++) {
+            const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
+            add_sbox(S, tmax, lane, cur, t, A.Cd, (size_t)r * t, full ? t : 1);
+            dense_mul(S, tmax, lane, cur, A.M, t, 0);
+            cur ^= 1;
+        }
+        return cur;
+    }
+    for (int r = 0; r < 4; r++) {
+        add_sbox(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
+        dense_mul(S, tmax, lane, cur, A.M, t, 0);
+        cur ^= 1;
+    }
+    {   // partial rounds, sparse form, in place: element 0 stays in registers
+        u32 x0[8], m00[8];
+        lds_load(S, tmax, lane, cur, 0, x0);
+#pragma unroll
+        for (int l = 0; l < 8; l++) m00[l] = A.m00[l];
+        const int n = t - 1;
+        for (int k = 0; k < A.rp; k++) {
+            u32 c[8];
+            load_const(A.S, (size_t)k, c);
+            bn::fr_add(x0, c);
+            pow5(x0);
             u32 acc[17];
 #pragma unroll
             for (int l = 0; l < 17; l++) acc[l] = 0;
-            for (int j = 0; j < t; j++) {
-                u32 y[8], m[8];
-                lds_load(S, tmax, lane, cur, j, y);
-#pragma unroll
-                for (int l = 0; l < 8; l++) m[l] = A.M[((size_t)i * t + j) * 8 + l];
-                bn::mac17(acc, y, m);
+            bn::mac17(acc, x0, m00);
+            for (int j = 0; j < n; j++) {
+                u32 y[8], vv[8], ww[8], p[8];
+                lds_load(S, tmax, lane, cur, 1 + j, y);
+                load_const(A.V, (size_t)k * n + j, vv);
+                bn::mac17(acc, y, vv);               // row 0:   m00*x0 + sum V_kj * y_j
+                load_const(A.W, (size_t)k * n + j, ww);
+                bn::fr_mul(p, x0, ww);               // column:  y_j + W_kj * x0
+                bn::fr_add(y, p);
+                lds_store(S, tmax, lane, cur, 1 + j, y);
             }
-            u32 o[8];
-            bn::redc17(o, acc);
-            lds_store(S, tmax, lane, cur ^ 1, i, o);
+            bn::redc17(x0, acc);
         }
+        lds_store(S, tmax, lane, cur, 0, x0);
+        dense_mul(S, tmax, lane, cur, A.D, n, 1);    // diag(1, Mh^RP)
+        cur ^= 1;
+    }
+    for (int r = 4; r < 8; r++) {
+        add_sbox(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
+        dense_mul(S, tmax, lane, cur, A.M, t, 0);
         cur ^= 1;
     }
     return cur;
@@ -271,7 +422,14 @@ __global__ void bn_convert_kernel(const u64 *__restrict__ in, u64 n, int toMont,
 
 size_t lds_bytes(int tmax) { return (size_t)2 * tmax * 8 * BN_BLOCK * 4; }
 
-PermArgs perm_args(const Params *P) { PermArgs a; a.C = P->dC; a.M = P->dM; a.t = P->t; a.rp = P->rp; return a; }
+PermArgs perm_args(const Params *P) {
+    PermArgs a;
+    a.C8 = P->C8; a.M = P->M; a.D = P->D; a.S = P->S; a.V = P->V; a.W = P->W; a.Cd = P->Cd; a.t = P->t; a.rp = P->rp;
+    static const bool dense = getenv("PIL2GL_BN128_DENSE") && atoi(getenv("PIL2GL_BN128_DENSE"));
+    a.dense = dense ? 1 : 0;
+    memcpy(a.m00, P->m00, 32);
+    return a;
+}
 
 template <typename K>
 int set_lds_attr(K kernel, size_t bytes) {

@@ -42,6 +42,19 @@ def test_poseidon_every_width(bn, orc):
     assert bn.poseidon([orc.R + 5, 7], orc.R + 1, 2) == orc.poseidon([5, 7], 1, 2)
 
 
+def test_dense_statement_of_the_permutation_agrees():
+    """the library's default runs the partial rounds in sparse form; PIL2GL_BN128_DENSE=1 runs poseidon.circom:22-44 as written"""
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path[:0] = [%r, %r]; import numpy as np; import pil2gl; pil2gl.init(0); from pil2gl import bn128; import bn128_oracle as o\n"
+            "for n in (1, 2, 4, 5, 8, 16):\n"
+            "    a = [(7 ** (k + 3)) %% o.R for k in range(n)]\n"
+            "    assert bn128.poseidon(a, 11, n + 1) == o.poseidon(a, 11, n + 1), n\n"
+            "print('dense ok')\n") % (os.path.join(os.path.dirname(GOLDEN), "..", "pil2-stark-js_amd", "python"), os.path.join(os.path.dirname(GOLDEN), "..", "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, PIL2GL_BN128_DENSE="1"))
+    assert r.returncode == 0 and "dense ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_montgomery_conversion(bn, orc):
     vals = [0, 1, orc.R - 1, 1 << 200, 0x123456789ABCDEF << 100]
     m = bn.to_montgomery(vals)

@@ -12,8 +12,8 @@
 // of t^2; outputs are the same field elements as the dense statement (the dense form is kept for tests).
 //
 // Layout: one permutation per lane; the t state elements (8 limbs each, Montgomery form) live in LDS as
-// [buffer][element][limb][lane] (conflict-free, element index may be a run-time value), double-buffered because every
-// MDS row reads the whole previous state.  A row is accumulated unreduced in 17 limbs (t products) and reduced once.
+// [element][limb][lane] (conflict-free, element index may be a run-time value); a dense layer keeps its new rows in
+// registers until all are done (dense_mul).  A row is accumulated unreduced in 17 limbs (t products) and reduced once.
 // Nodes are stored as the reference stores them: 4 little-endian u64 words of the Montgomery form.
 #include "common.h"
 #include "bn_field.cuh"
@@ -231,7 +231,7 @@ __device__ __forceinline__ void pow5(u32 x[8]) {
 
 // x^5 on elements [0, nSbox) after adding constants C[0..t), then the dense n x n matrix A applied to elements
 // [first, first+n) of buffer cur into buffer cur^1 (elements below `first` are copied)
-__device__ __forceinline__ void add_sbox(u32 *S, int tmax, int lane, int cur, int t, const u32 *C, size_t cOff, int nSbox) {
+__device__ __noinline__ void add_sbox(u32 *S, int tmax, int lane, int cur, int t, const u32 *C, size_t cOff, int nSbox) {
     for (int j = 0; j < t; j++) {
         u32 x[8], c[8];
         lds_load(S, tmax, lane, cur, j, x);
@@ -241,8 +241,11 @@ __device__ __forceinline__ void add_sbox(u32 *S, int tmax, int lane, int cur, in
         lds_store(S, tmax, lane, cur, j, x);
     }
 }
-__device__ __forceinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, const u32 *A, int n, int first) {
-    for (int j = 0; j < first; j++) { u32 x[8]; lds_load(S, tmax, lane, cur, j, x); lds_store(S, tmax, lane, cur ^ 1, j, x); }
+// In place: every row reads the whole old state, so the n new elements wait in a per-lane private array (scratch memory,
+// 17 x 32 B, a few KB of traffic per permutation against ~10^5 multiply steps) until all rows are done; one LDS buffer per
+// wave then suffices (4 waves per CU at t = 17 instead of 2).
+__device__ __noinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, const u32 *A, int n, int first) {
+    u32 nw[17 * 8];
     for (int i = 0; i < n; i++) {
         u32 acc[17];
 #pragma unroll
@@ -255,26 +258,29 @@ __device__ __forceinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, c
         }
         u32 o[8];
         bn::redc17(o, acc);
-        lds_store(S, tmax, lane, cur ^ 1, first + i, o);
+#pragma unroll
+        for (int l = 0; l < 8; l++) nw[i * 8 + l] = o[l];
+    }
+    for (int i = 0; i < n; i++) {
+#pragma unroll
+        for (int l = 0; l < 8; l++) S_AT(cur, first + i, l) = nw[i * 8 + l];
     }
 }
 
 // permutation of the t elements in buffer `cur`; returns the buffer holding the result
-__device__ int bn_perm(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
+__device__ __noinline__ int bn_perm(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
     const int t = A.t;
     if (A.dense) {                                   // poseidon.circom:22-44 as written (tests)
         for (int r = 0; r < N_ROUNDS_F + A.rp; r++) {
             const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
             add_sbox(S, tmax, lane, cur, t, A.Cd, (size_t)r * t, full ? t : 1);
             dense_mul(S, tmax, lane, cur, A.M, t, 0);
-            cur ^= 1;
         }
         return cur;
     }
     for (int r = 0; r < 4; r++) {
         add_sbox(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
         dense_mul(S, tmax, lane, cur, A.M, t, 0);
-        cur ^= 1;
     }
     {   // partial rounds, sparse form, in place: element 0 stays in registers
         u32 x0[8], m00[8];
@@ -305,12 +311,10 @@ __device__ int bn_perm(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
         }
         lds_store(S, tmax, lane, cur, 0, x0);
         dense_mul(S, tmax, lane, cur, A.D, n, 1);    // diag(1, Mh^RP)
-        cur ^= 1;
     }
     for (int r = 4; r < 8; r++) {
         add_sbox(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
         dense_mul(S, tmax, lane, cur, A.M, t, 0);
-        cur ^= 1;
     }
     return cur;
 }
@@ -420,7 +424,7 @@ __global__ void bn_convert_kernel(const u64 *__restrict__ in, u64 n, int toMont,
     for (int q = 0; q < 4; q++) out[4 * i + q] = (u64)o[2 * q] | ((u64)o[2 * q + 1] << 32);
 }
 
-size_t lds_bytes(int tmax) { return (size_t)2 * tmax * 8 * BN_BLOCK * 4; }
+size_t lds_bytes(int tmax) { return (size_t)tmax * 8 * BN_BLOCK * 4; }
 
 PermArgs perm_args(const Params *P) {
     PermArgs a;

@@ -9,7 +9,7 @@ from conftest import P
 
 def _setup(n_bits, n_pairs, steps, n_queries=8):
     from pil2gl import stark
-    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": n_queries, "verificationHashType": "GL",
+    ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": n_queries, "verificationHashType": "GL",
           "steps": [{"nBits": b} for b in steps]}
     info, exprs, vinfo = stark.fibonacci_air(n_pairs, ss)
     cm, consts, publics = stark.fibonacci_trace(n_bits, n_pairs)
@@ -26,7 +26,9 @@ def test_trace_satisfies_air():
     assert publics == [int(cm[0, 1]), int(cm[0, 0]), int(cm[N - 1, 0])]
 
 
-@pytest.mark.parametrize("n_bits,n_pairs,steps", [(6, 1, [9, 5, 2]), (8, 3, [11, 7, 3])])
+# (10, 1, [11, 7, 3]) is BASELINE config 1: the reference's Fibonacci starkStruct (fibonacci.starkstruct.gpu.json: nBits 10,
+# nBitsExt 11, 8 queries, steps 11/7/3)
+@pytest.mark.parametrize("n_bits,n_pairs,steps", [(6, 1, [9, 5, 2]), (8, 3, [11, 7, 3]), (10, 1, [11, 7, 3])])
 def test_prove_and_verify_on_oracle_backend(oracle, n_bits, n_pairs, steps):
     import stark_ref
     stark, info, exprs, vinfo, cm, consts, publics = _setup(n_bits, n_pairs, steps)
@@ -50,7 +52,7 @@ def test_prove_and_verify_on_oracle_backend(oracle, n_bits, n_pairs, steps):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_bits,n_pairs,steps,split,jit", [(8, 2, [11, 7, 3], False, "0"), (12, 5, [15, 11, 7, 3], False, "1"), (10, 4, [13, 9, 4], True, "1"), (13, 40, [16, 11, 6], False, "0")])
+@pytest.mark.parametrize("n_bits,n_pairs,steps,split,jit", [(8, 2, [11, 7, 3], False, "0"), (10, 1, [11, 7, 3], False, "0"), (12, 5, [15, 11, 7, 3], False, "1"), (10, 4, [13, 9, 4], True, "1"), (13, 40, [16, 11, 6], False, "0")])
 def test_gpu_proof_is_bit_identical_to_oracle_proof(oracle, n_bits, n_pairs, steps, split, jit, monkeypatch):
     monkeypatch.setenv("PIL2GL_EXPR_JIT", jit)
     import stark_ref

@@ -161,6 +161,14 @@ int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
  * ctx are DEVICE pointers; prog/ctx structs themselves are host memory (copied at launch). */
 int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *ctx, void *stream);
 
+/* ---- stage-2 witness hints (hints_helpers.js:91-114) ------------------------------------------------------------
+ * calculateZ(F,num,den)  polutils.js:128-143: out[0] = 1, out[i] = out[i-1]*num[i-1]/den[i-1]   (num, den: n rows)
+ * calculateS(F,num,den)  polutils.js:145-164: out[i] = out[i-1] + num/den[i]                    (num: ONE element)
+ * dimNum/dimDen in {1,3} (base or cubic-extension columns, row-major); out has dimension 3 if either has, else 1.
+ * A zero denominator yields 0 for that ratio (the reference's batchInverse would poison the whole column). */
+int pil2gl_gprod_dev(const uint64_t *num, uint32_t dimNum, const uint64_t *den, uint32_t dimDen, uint64_t n, uint64_t *out, void *stream);
+int pil2gl_gsum_dev(const uint64_t *num, uint32_t dimNum, const uint64_t *den, uint32_t dimDen, uint64_t n, uint64_t *out, void *stream);
+
 /* ---- BN128 (BN254 scalar field) Merkle commitment: merklehash_bn128_p.js, merklehash_bn128_worker.js -------------
  * Field elements are 4 little-endian u64 words.  tree.nodes and leaf digests are in MONTGOMERY form (R = 2^256), exactly
  * what the reference's WASM leaves in memory (frm_toMontgomery, merklehash_bn128_worker.js:49,67,82), so files written

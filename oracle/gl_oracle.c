@@ -615,3 +615,39 @@ int or_eval_program(const glx_program *prog, const glx_ctx *ctx, uint64_t rowBeg
     }
     return bad ? -1 : 0;
 }
+
+/* ---- stage-2 witness hints: polutils.js:128-164 ------------------------------------------------
+ * Elements of dimension 1 are embedded as (v,0,0); the result has dimension 3 when either input has, else 1. */
+static void load_dim(const uint64_t *p, uint64_t i, int dim, uint64_t r[3]) {
+    if (dim == 3) { r[0] = p[3 * i]; r[1] = p[3 * i + 1]; r[2] = p[3 * i + 2]; } else { r[0] = p[i]; r[1] = 0; r[2] = 0; }
+}
+static void store_dim(uint64_t *p, uint64_t i, int dim, const uint64_t r[3]) {
+    if (dim == 3) { p[3 * i] = r[0]; p[3 * i + 1] = r[1]; p[3 * i + 2] = r[2]; } else p[i] = r[0];
+}
+/* calculateZ (polutils.js:128-143): z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1] */
+void or_gprod(const uint64_t *num, int dimNum, const uint64_t *den, int dimDen, uint64_t n, uint64_t *out) {
+    int dimOut = (dimNum == 3 || dimDen == 3) ? 3 : 1;
+    uint64_t z[3] = { 1, 0, 0 };
+    for (uint64_t i = 0; i < n; i++) {
+        store_dim(out, i, dimOut, z);
+        uint64_t a[3], d[3], di[3], r[3];
+        load_dim(num, i, dimNum, a); load_dim(den, i, dimDen, d);
+        or3_inv(d, di);
+        or3_mul(a, di, r);
+        or3_mul(z, r, z);
+    }
+}
+/* calculateS (polutils.js:145-164): s[i] = sum_{j<=i} num / den[j], num a single element */
+void or_gsum(const uint64_t *num, int dimNum, const uint64_t *den, int dimDen, uint64_t n, uint64_t *out) {
+    int dimOut = (dimNum == 3 || dimDen == 3) ? 3 : 1;
+    uint64_t s[3] = { 0, 0, 0 }, a[3];
+    load_dim(num, 0, dimNum, a);
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t d[3], di[3], r[3];
+        load_dim(den, i, dimDen, d);
+        or3_inv(d, di);
+        or3_mul(a, di, r);
+        add3(s, r, s);
+        store_dim(out, i, dimOut, s);
+    }
+}

@@ -115,6 +115,18 @@ def batch_inverse3(a):
     lib().or3_batch_inverse(_ptr(a), C.c_uint64(a.shape[0]), _ptr(r)); return r
 
 
+# ---- stage-2 hints (polutils.js:128-164) ----
+def _hint(fn, num, den, dim_num, dim_den):
+    num, den = _u(num).reshape(-1), _u(den).reshape(-1)
+    n = den.size // dim_den
+    out = np.zeros(n * (3 if 3 in (dim_num, dim_den) else 1), np.uint64)
+    getattr(lib(), fn)(_ptr(num), C.c_int(dim_num), _ptr(den), C.c_int(dim_den), C.c_uint64(n), _ptr(out)); return out
+
+
+def gprod(num, den, dim_num, dim_den): return _hint("or_gprod", num, den, dim_num, dim_den)
+def gsum(num, den, dim_num, dim_den): return _hint("or_gsum", num, den, dim_num, dim_den)
+
+
 # ---- NTT ----
 def fft(p):
     p = _u(p).copy(); lib().or_fft(_ptr(p), C.c_int(int(p.size).bit_length() - 1), C.c_uint64(1)); return p

@@ -1,0 +1,128 @@
+// Stage-2 witness hints on the device: the grand product / grand sum columns
+//   calculateZ(F,num,den)  src/helpers/polutils.js:128-143   z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1]
+//   calculateS(F,num,den)  src/helpers/polutils.js:145-164   s[i] = s[i-1] + num / den[i]        (num: one element)
+// called from resolveHint (src/prover/hints_helpers.js:91-114).  The reference walks the column serially with BigInt
+// arithmetic after one batch inversion; here every ratio gets its own extension-field inversion (ALU is free at this
+// size) and the running product / sum is a three-kernel scan: per-block inclusive scan + block totals, scan of the
+// totals, then the fix-up (for the product: shifted by one row, z[0] = 1).  Operands may be base (dim 1) or cubic
+// extension (dim 3) columns, row-major; the result is dim 3 if either operand is, else dim 1.
+#include "common.h"
+#include "gl_field.cuh"
+
+using namespace gl;
+using namespace pil2gl;
+
+namespace {
+
+constexpr int SCAN_THREADS = 256, SCAN_ITEMS = 8, SCAN_CHUNK = SCAN_THREADS * SCAN_ITEMS;
+
+__device__ __forceinline__ E3 ld_dim(const u64 *p, u64 i, u32 dim) { return dim == 3 ? E3{ { p[3 * i], p[3 * i + 1], p[3 * i + 2] } } : E3{ { p[i], 0, 0 } }; }
+__device__ __forceinline__ void st3(u64 *p, u64 i, const E3 &v) { p[3 * i] = v.v[0]; p[3 * i + 1] = v.v[1]; p[3 * i + 2] = v.v[2]; }
+template <bool PROD> __device__ __forceinline__ E3 comb(const E3 &a, const E3 &b) { return PROD ? e3_mul(a, b) : e3_add(a, b); }
+template <bool PROD> __device__ __forceinline__ E3 ident() { return PROD ? E3{ { 1, 0, 0 } } : E3{ { 0, 0, 0 } }; }
+
+// inclusive scan of the 256 per-thread totals in LDS (Hillis-Steele); returns this thread's exclusive prefix
+template <bool PROD>
+__device__ E3 block_exclusive(E3 total, E3 *sh, E3 *blockTotal) {
+    const u32 t = threadIdx.x;
+    sh[t] = total;
+    __syncthreads();
+    for (u32 d = 1; d < SCAN_THREADS; d <<= 1) {
+        E3 v = sh[t];
+        if (t >= d) v = comb<PROD>(sh[t - d], v);
+        __syncthreads();
+        sh[t] = v;
+        __syncthreads();
+    }
+    const E3 ex = t ? sh[t - 1] : ident<PROD>();
+    *blockTotal = sh[SCAN_THREADS - 1];
+    __syncthreads();
+    return ex;
+}
+
+// pass 1: ratios, block-local inclusive scan into tmp (n x 3), block totals
+template <bool PROD>
+__global__ void __launch_bounds__(SCAN_THREADS) hint_scan1(const u64 *__restrict__ num, u32 dimNum, const u64 *__restrict__ den, u32 dimDen, u64 n,
+                                                          u64 *__restrict__ tmp, u64 *__restrict__ totals) {
+    __shared__ E3 sh[SCAN_THREADS];
+    const u64 base = (u64)blockIdx.x * SCAN_CHUNK + (u64)threadIdx.x * SCAN_ITEMS;
+    E3 loc[SCAN_ITEMS];
+    E3 run = ident<PROD>();
+    const E3 numS = PROD ? ident<true>() : ld_dim(num, 0, dimNum);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const u64 i = base + k;
+        if (i < n) {
+            const E3 d = ld_dim(den, i, dimDen);
+            const E3 di = (d.v[1] | d.v[2]) ? e3_inv(d) : E3{ { inv(d.v[0]), 0, 0 } };
+            const E3 r = e3_mul(PROD ? ld_dim(num, i, dimNum) : numS, di);
+            run = comb<PROD>(run, r);
+        }
+        loc[k] = run;
+    }
+    E3 bt;
+    const E3 ex = block_exclusive<PROD>(run, sh, &bt);
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { const u64 i = base + k; if (i < n) st3(tmp, i, comb<PROD>(ex, loc[k])); }
+    if (threadIdx.x == 0) st3(totals, blockIdx.x, bt);
+}
+// pass 2: exclusive scan of the block totals, one block (each thread walks a contiguous run)
+template <bool PROD>
+__global__ void __launch_bounds__(SCAN_THREADS) hint_scan2(u64 *__restrict__ totals, u64 nb) {
+    __shared__ E3 sh[SCAN_THREADS];
+    const u64 per = (nb + SCAN_THREADS - 1) / SCAN_THREADS, b0 = (u64)threadIdx.x * per;
+    E3 run = ident<PROD>();
+    for (u64 k = 0; k < per; k++) { const u64 i = b0 + k; if (i < nb) run = comb<PROD>(run, ld_dim(totals, i, 3)); }
+    E3 bt;
+    E3 ex = block_exclusive<PROD>(run, sh, &bt);
+    for (u64 k = 0; k < per; k++) {
+        const u64 i = b0 + k;
+        if (i < nb) { const E3 v = ld_dim(totals, i, 3); st3(totals, i, ex); ex = comb<PROD>(ex, v); }
+    }
+}
+// pass 3: add the block prefix; the product column is the EXCLUSIVE scan (z[0] = 1), the sum column the inclusive one
+template <bool PROD>
+__global__ void hint_scan3(const u64 *__restrict__ tmp, const u64 *__restrict__ totals, u64 n, u32 dimOut, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    E3 v;
+    if (PROD) {
+        if (i == 0) v = ident<true>();
+        else { const u64 j = i - 1; v = comb<true>(ld_dim(totals, j / SCAN_CHUNK, 3), ld_dim(tmp, j, 3)); }
+    } else v = comb<false>(ld_dim(totals, i / SCAN_CHUNK, 3), ld_dim(tmp, i, 3));
+    if (dimOut == 3) st3(out, i, v); else out[i] = v.v[0];
+}
+
+template <bool PROD>
+int run_hint(const u64 *num, u32 dimNum, const u64 *den, u32 dimDen, u64 n, u64 *out, hipStream_t st) {
+    if (n == 0) return PIL2GL_OK;
+    if (!num || !den || !out) return fail(PIL2GL_EINVAL, "null buffer");
+    if ((dimNum != 1 && dimNum != 3) || (dimDen != 1 && dimDen != 3)) return fail(PIL2GL_EINVAL, "dimensions must be 1 or 3");
+    const u64 nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (nb > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
+    u64 *tmp, *totals;
+    P2_TRY(scratch(8, n * 3, &tmp));
+    P2_TRY(scratch(9, nb * 3, &totals));
+    hint_scan1<PROD><<<(unsigned)nb, SCAN_THREADS, 0, st>>>(num, dimNum, den, dimDen, n, tmp, totals);
+    KERNEL_CHECK();
+    hint_scan2<PROD><<<1, SCAN_THREADS, 0, st>>>(totals, nb);
+    KERNEL_CHECK();
+    hint_scan3<PROD><<<(unsigned)((n + 255) / 256), 256, 0, st>>>(tmp, totals, n, (dimNum == 3 || dimDen == 3) ? 3u : 1u, out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pil2gl_gprod_dev(const uint64_t *num, uint32_t dimNum, const uint64_t *den, uint32_t dimDen, uint64_t n, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    return run_hint<true>(num, dimNum, den, dimDen, n, out, as_stream(stream));
+}
+int pil2gl_gsum_dev(const uint64_t *num, uint32_t dimNum, const uint64_t *den, uint32_t dimDen, uint64_t n, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    return run_hint<false>(num, dimNum, den, dimDen, n, out, as_stream(stream));
+}
+
+}  // extern "C"

@@ -107,6 +107,27 @@ def ifft(buffSrc, nPols, nBits, buffDst):
         call("pil2gl_ifft", _ptr(buffSrc), nPols, nBits, _ptr(buffDst))
 
 
+# ----------------------------------------------------------------------------- stage-2 hints (polutils.js:128-164)
+def _hint(fn, num, den, dimNum, dimDen, out):
+    n = int(np.prod(den.shape)) // dimDen
+    if not _same_side(num, den, out) :
+        raise Pil2glError("hint columns must be device buffers")
+    if out is None:
+        out = torch.empty(n * (3 if 3 in (dimNum, dimDen) else 1), dtype=torch.int64, device=den.device)
+    call(fn, _ptr(num), dimNum, _ptr(den), dimDen, n, _ptr(out), _stream())
+    return out
+
+
+def calculateZ(num, den, dimNum=3, dimDen=3, out=None):
+    """polutils.js:128 calculateZ: z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1] (device columns)"""
+    return _hint("pil2gl_gprod_dev", num, den, dimNum, dimDen, out)
+
+
+def calculateS(num, den, dimNum=3, dimDen=3, out=None):
+    """polutils.js:145 calculateS: s[i] = s[i-1] + num / den[i], num one element (device buffers)"""
+    return _hint("pil2gl_gsum_dev", num, den, dimNum, dimDen, out)
+
+
 # ----------------------------------------------------------------------------- poseidon / linear hash
 def poseidon(inputs, capacity=None, nOuts=4):
     """hash/poseidon/poseidon.js:57 poseidon(inputs[8], capacity[4]?, nOuts=4) -> list of ints"""

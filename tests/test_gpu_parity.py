@@ -502,6 +502,31 @@ def test_merkelize_from_digests(gl, oracle):
         assert np.array_equal(got, nodes)
 
 
+# ------------------------------------------------------------------ stage-2 hints (csrc/hints.hip)
+@pytest.mark.parametrize("n,dimNum,dimDen", [(1, 3, 3), (5, 1, 1), (2048, 3, 3), (2049, 1, 3), (70000, 3, 1), (1 << 18, 3, 3), (300001, 1, 1)])
+def test_gprod_gsum_columns(gl, oracle, n, dimNum, dimDen):
+    """calculateZ / calculateS (polutils.js:128-164) against the serial oracle; the product telescopes to 1 when the
+    numerators are a rotation of the denominators (how a permutation argument uses it)"""
+    import torch
+    rng = np.random.default_rng(n + dimNum)
+    num = rand_field(rng, n * dimNum); den = rand_field(rng, n * dimDen)
+    den[den == 0] = 1
+    dn, dd = torch.from_numpy(num.view(np.int64)).cuda(), torch.from_numpy(den.view(np.int64)).cuda()
+    z = gl.calculateZ(dn, dd, dimNum, dimDen).cpu().numpy().view(np.uint64)
+    assert np.array_equal(z, oracle.gprod(num, den, dimNum, dimDen))
+    s = gl.calculateS(dn[:dimNum].contiguous(), dd, dimNum, dimDen).cpu().numpy().view(np.uint64)
+    assert np.array_equal(s, oracle.gsum(num[:dimNum], den, dimNum, dimDen))
+    if dimNum == dimDen and n > 1:
+        rot = np.roll(den.reshape(n, dimDen), 1, axis=0).reshape(-1).copy()
+        z2 = gl.calculateZ(torch.from_numpy(rot.view(np.int64)).cuda(), dd, dimNum, dimDen).cpu().numpy().view(np.uint64).reshape(n, -1)
+        last = oracle.gprod(rot, den, dimNum, dimDen).reshape(n, -1)[-1]
+        assert np.array_equal(z2[-1], last)
+        # z[n-1] * num[n-1]/den[n-1] closes the cycle: equals 1
+        d = den.reshape(n, dimDen)
+        if dimDen == 1:
+            assert int(z2[-1][0]) * int(rot.reshape(n, 1)[-1][0]) % P == int(d[-1][0]) % P
+
+
 # ------------------------------------------------------------------ extension-weighted sums (csrc/dot.hip)
 def test_rows_and_cols_dot_ext(gl, oracle):
     import ctypes as C

@@ -1,7 +1,7 @@
 """The CPU oracle against vectors produced by the reference's own modules
 (tests/golden/*.json, generator: oracle/gen_golden.js) and the reference's KATs."""
 import numpy as np
-from conftest import golden, H, U, P
+from conftest import golden, H, U, P, rand_field
 
 
 def test_field_ops(oracle):
@@ -146,3 +146,24 @@ def test_zerofiers(oracle):
         assert oracle.build_one_row_zerofier_inv(nb, nbe, 0).tolist() == first
         assert oracle.build_one_row_zerofier_inv(nb, nbe, (1 << nb) - 1).tolist() == last
         assert oracle.build_frame_zerofier(nb, nbe, 2, 1).tolist() == frame
+
+
+def test_hint_columns_against_python_integers(oracle):
+    """calculateZ / calculateS (polutils.js:128-164) restated with Python integers on base-field columns"""
+    rng = np.random.default_rng(3)
+    n = 50
+    num = [int(x) for x in rand_field(rng, n)]; den = [int(x) or 1 for x in rand_field(rng, n)]
+    z = [1]
+    for i in range(1, n):
+        z.append(z[-1] * num[i - 1] * pow(den[i - 1], P - 2, P) % P)
+    assert [int(x) for x in oracle.gprod(np.array(num, dtype=np.uint64), np.array(den, dtype=np.uint64), 1, 1)] == z
+    s, acc = [], 0
+    for i in range(n):
+        acc = (acc + num[0] * pow(den[i], P - 2, P)) % P
+        s.append(acc)
+    assert [int(x) for x in oracle.gsum(np.array(num[:1], dtype=np.uint64), np.array(den, dtype=np.uint64), 1, 1)] == s
+    # extension columns: dim-1 operands embed as (v, 0, 0)
+    num3 = np.zeros((n, 3), np.uint64); num3[:, 0] = num
+    den3 = np.zeros((n, 3), np.uint64); den3[:, 0] = den
+    z3 = oracle.gprod(num3, den3, 3, 3).reshape(n, 3)
+    assert [int(x) for x in z3[:, 0]] == z and not z3[:, 1:].any()

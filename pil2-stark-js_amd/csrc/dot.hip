@@ -60,15 +60,25 @@ __global__ void __launch_bounds__(256) rows_dot_kernel(RowsDotParams P) {
 #pragma unroll
             for (int i = 0; i < 6; i++) S[o][k][i] = 0;
     const u64 myRow = row0 + lane;
-    for (u64 c0 = 0; c0 < P.width; c0 += CW) {
+    // element e = lane + 64 i of a tile -> (row e >> 4, col e & 15): coalesced 128-byte row segments.  The next tile is
+    // fetched into registers while the current one is consumed from LDS (the mads of a tile take far less time than
+    // its loads are in flight, so without the overlap a wave mostly waits).
+    u64 nxt[CW];
+    auto fetch = [&](u64 c0) {
         const u32 cw = (u32)min((u64)CW, P.width - c0);
-        // coalesced load: element e = lane + 64 i -> (row e >> 4, col e & 15): 128-byte row segments
-#pragma unroll 4
+#pragma unroll
         for (u32 i = 0; i < CW; i++) {
             const u32 e = lane + 64 * i, r = e >> 4, c = e & 15;
             const u64 gr = row0 + r;
-            T[r * LD + c] = (c < cw && gr < P.nRows) ? P.buf[gr * P.width + c0 + c] : 0;
+            nxt[i] = (c < cw && gr < P.nRows) ? P.buf[gr * P.width + c0 + c] : 0;
         }
+    };
+    fetch(0);
+    for (u64 c0 = 0; c0 < P.width; c0 += CW) {
+        const u32 cw = (u32)min((u64)CW, P.width - c0);
+#pragma unroll
+        for (u32 i = 0; i < CW; i++) { const u32 e = lane + 64 * i; T[(e >> 4) * LD + (e & 15)] = nxt[i]; }
+        if (c0 + CW < P.width) fetch(c0 + CW);
         // wave-local hand-off through LDS: every lane of this wave wrote, every lane reads; no other wave involved
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)
         __builtin_amdgcn_wave_barrier();

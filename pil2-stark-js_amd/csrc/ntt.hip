@@ -44,16 +44,18 @@ __device__ __forceinline__ void dif_stages(u64 *tile, const u64 *TW, u32 k, u32 
     for (; s >= 1; s -= 2) {                        // stages s (half-span h) and s-1 (half-span h/2)
         const u32 h = 1u << s, q = h >> 1, quarter = 1u << (k - 2);
         const bool lastTrivial = (s == 1);
+        const u32 qS = q * S, hS = h * S;           // one multiplication per butterfly instead of four
         for (u32 j = y; j < quarter; j += by) {
             const u32 off = j & (q - 1);
             const u32 p = ((j >> (s - 1)) << (s + 1)) + off;
-            u64 a0 = tile[p * S + x], a1 = tile[(p + q) * S + x], a2 = tile[(p + h) * S + x], a3 = tile[(p + h + q) * S + x];
+            const u32 i0 = p * S + x, i1 = i0 + qS, i2 = i0 + hS, i3 = i2 + qS;
+            u64 a0 = tile[i0], a1 = tile[i1], a2 = tile[i2], a3 = tile[i3];
             const u64 wA = TW[off << (k - 1 - s)], wB = TW[(off + q) << (k - 1 - s)];
             u64 b0 = add(a0, a2), b2 = mul(sub(a0, a2), wA);
             u64 b1 = add(a1, a3), b3 = mul(sub(a1, a3), wB);
             u64 c0 = add(b0, b1), c1 = sub(b0, b1), c2 = add(b2, b3), c3 = sub(b2, b3);
             if (!lastTrivial) { const u64 wC = TW[off << (k - s)]; c1 = mul(c1, wC); c3 = mul(c3, wC); }
-            tile[p * S + x] = c0; tile[(p + q) * S + x] = c1; tile[(p + h) * S + x] = c2; tile[(p + h + q) * S + x] = c3;
+            tile[i0] = c0; tile[i1] = c1; tile[i2] = c2; tile[i3] = c3;
         }
         __syncthreads();
     }
@@ -85,16 +87,18 @@ __device__ __forceinline__ void dit_stages(u64 *tile, const u64 *TW, u32 k, u32 
     for (; s + 1 < k; s += 2) {                     // stages s (half-span h) and s+1 (half-span 2h)
         const u32 h = 1u << s, quarter = 1u << (k - 2);
         const bool firstTrivial = (s == 0);
+        const u32 hS = h * S;
         for (u32 j = y; j < quarter; j += by) {
             const u32 off = j & (h - 1);
             const u32 p = ((j >> s) << (s + 2)) + off;
-            u64 a0 = tile[p * S + x], a1 = tile[(p + h) * S + x], a2 = tile[(p + 2 * h) * S + x], a3 = tile[(p + 3 * h) * S + x];
+            const u32 i0 = p * S + x, i1 = i0 + hS, i2 = i1 + hS, i3 = i2 + hS;
+            u64 a0 = tile[i0], a1 = tile[i1], a2 = tile[i2], a3 = tile[i3];
             if (!firstTrivial) { const u64 wA = TW[off << (k - 1 - s)]; a1 = mul(a1, wA); a3 = mul(a3, wA); }
             u64 b0 = add(a0, a1), b1 = sub(a0, a1), b2 = add(a2, a3), b3 = sub(a2, a3);
             const u64 wB = TW[off << (k - 2 - s)], wC = TW[(off + h) << (k - 2 - s)];
             b2 = mul(b2, wB); b3 = mul(b3, wC);
-            tile[p * S + x] = add(b0, b2); tile[(p + 2 * h) * S + x] = sub(b0, b2);
-            tile[(p + h) * S + x] = add(b1, b3); tile[(p + 3 * h) * S + x] = sub(b1, b3);
+            tile[i0] = add(b0, b2); tile[i2] = sub(b0, b2);
+            tile[i1] = add(b1, b3); tile[i3] = sub(b1, b3);
         }
         __syncthreads();
     }

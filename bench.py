@@ -31,7 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-WORKLOADS = {"c2": (20, 8), "c3": (24, 100)}      # BASELINE.json configs[1], configs[2]
+WORKLOADS = {"c2": (20, 8), "c3": (24, 100), "c5": (26, 200)}      # BASELINE.json configs[1], configs[2], configs[4] (c5: sharded only)
 EXT_BITS = 3
 
 
@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default=os.environ.get("PIL2GL_BENCH_MODE", "prove"), choices=["prove", "commit", "commit-sharded"])
     ap.add_argument("--split", action="store_true", help="splitLinearHash leaves (linearhash_gpu.js)")
+    ap.add_argument("--shard-of", type=int, default=0, help="commit-sharded on ONE GPU: run rank 0's share of a K-GPU job (per-GPU time/memory rehearsal, e.g. --workload c5 --shard-of 8)")
     return ap.parse_args()
 
 
@@ -167,8 +168,41 @@ def load_pmc_traffic(kernel):
         return None
 
 
+def rehearse_shard(args):
+    """--mode commit-sharded --shard-of K on one GPU: rank 0's share of a K-GPU sharded commit (its cosets of the LDE in the
+    trace's own memory, its leaves, a tree over stand-in digests), to show the per-GPU time and memory of e.g. config 5."""
+    import pil2gl
+    from pil2gl import stark, parallel
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    n_bits, n_cols = WORKLOADS[args.workload] if args.workload in WORKLOADS else (int(v) for v in args.workload.lower().split("x"))
+    K = args.shard_of
+    be = stark.GpuBackend(0, args.split)
+    N = 1 << n_bits
+    src = make_trace(N, n_cols, 0x5EED0000, dev)
+    times = []
+    for i in range(args.warmup + args.steps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        st = parallel.extend_and_merkelize_sharded(be, src, n_cols, n_bits, n_bits + EXT_BITS, overwrite_src=True, rehearse_world=K)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if i >= args.warmup:
+            times.append(dt)
+        del st
+    dt = sum(times) / len(times)
+    free, total = torch.cuda.mem_get_info()
+    print(json.dumps({"metric": "per-GPU time of a %d-GPU coset-sharded commit (rank 0's share run alone; digests of the other ranks stood in)" % K,
+                      "value": N * n_cols / dt, "unit": "trace-cells/s (whole trace / per-GPU time: the job rate if the %d ranks run in parallel)" % K,
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+                      "dtype": "u64", "data": "synthetic",
+                      "config": {"workload": "extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, %d of %d cosets on this GPU" % (n_bits, n_cols, n_bits + EXT_BITS, (1 << EXT_BITS) // K, 1 << EXT_BITS),
+                                 "mode": "commit-sharded rehearsal", "shard_of": K},
+                      "peak_torch_GB": torch.cuda.max_memory_allocated() / 1e9, "device_GB_in_use_at_end": (total - free) / 1e9}), flush=True)
+
+
 def main():
     args = parse()
+    if args.mode == "commit-sharded" and args.shard_of:
+        return rehearse_shard(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -176,7 +210,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or args.mode == "commit-sharded":
+    if world > 1 or (args.mode == "commit-sharded" and not args.shard_of):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -211,7 +245,7 @@ def main():
         prove_ctx = (stark, be, setup, info, exprs, publics)
     elif args.mode == "commit-sharded":                        # ONE trace, replicated; the cosets of its extension are split
         from pil2gl import stark, parallel
-        if (1 << EXT_BITS) % world:
+        if (1 << EXT_BITS) % (args.shard_of or world):
             raise SystemExit("commit-sharded needs a world size dividing %d" % (1 << EXT_BITS))
         shard_be = stark.GpuBackend(local_rank, args.split)
         src = make_trace(N, n_cols, 0x5EED0000, dev)
@@ -232,7 +266,8 @@ def main():
             stark_.stark_gen(be_, src, setup_, info_, exprs_, publics_, timings=stage_times if collect[0] else None)
             return
         if sharded:
-            parallel.extend_and_merkelize_sharded(shard_be, src, n_cols, n_bits, n_bits + EXT_BITS)
+            parallel.extend_and_merkelize_sharded(shard_be, src, n_cols, n_bits, n_bits + EXT_BITS,
+                                                  overwrite_src=bool(args.shard_of), rehearse_world=args.shard_of or None)
             return
         pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
         pil2gl.call("pil2gl_merkelize_dev", pil2gl._ptr(dst), n_cols, E, int(args.split), pil2gl._ptr(nodes), C.c_void_p(stream))

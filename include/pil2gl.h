@@ -69,6 +69,11 @@ int pil2gl_interpolate_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, 
  * One slice per GPU is the multi-GPU partition of extendAndMerkelize; the full range equals interpolate. */
 int pil2gl_interpolate_cosets_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
                                   uint32_t cosetBegin, uint32_t cosetCount, void *stream);
+/* Same with a caller-provided workspace of 2^nBits x nPols words for the coefficient matrix instead of the library's own
+ * scratch; workspace == src is allowed (src is then overwritten): at config 5 a rank holds the 107 GB trace and its
+ * 107 GB coset slice and nothing else. */
+int pil2gl_interpolate_cosets_ws_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
+                                     uint32_t cosetBegin, uint32_t cosetCount, uint64_t *workspace, void *stream);
 /* fft / ifft (buffSrc,nPols,nBits,buffDst)  fft_p.js:178-184: in-order multi-column NTT / iNTT,
  * root F.w[nBits]; ifft = fft, index j -> (n-j) mod n, times 1/n (fft/fft.js:165-174). src may equal dst. */
 int pil2gl_fft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst);

@@ -28,7 +28,7 @@ class OracleBackend:
 
     # multi-process partition (pil2gl.parallel) restated on the full-domain oracle functions: the slice of the full
     # extension, one linear hash per row, and the level loop of merklehash_p.js:87-103 with one poseidon per node pair
-    def interpolate_cosets(self, src, C, nb, dst, nbe, cb, cc):
+    def interpolate_cosets(self, src, C, nb, dst, nbe, cb, cc, ws=None):
         full = orc.interpolate(src.reshape(-1, C), nb, nbe).reshape(1 << nb, 1 << (nbe - nb), C)
         dst[:] = full[:, cb:cb + cc, :].reshape(-1)
 
@@ -46,6 +46,11 @@ class OracleBackend:
                 nodes[p_out + 4 * i:p_out + 4 * i + 4] = orc.poseidon(nodes[p_in + 8 * i:p_in + 8 * i + 8], None, 4)
             n = nxt; nxt = ((n - 1) // 8 + 1) * 4; p_in = p_out; p_out = p_in + nxt * 2
         return nodes
+
+    def merkelize_digest_parts(self, parts, N, cc):
+        world = len(parts)
+        leaves = np.stack([p.cpu().numpy().view(np.uint64).reshape(N, cc * 4) for p in parts], axis=1).reshape(-1)
+        return self.merkelize_digests(leaves, N * cc * world)
 
     def as_torch(self, t):
         import torch

@@ -319,7 +319,7 @@ int ntt_launch(const u64 *src, u64 C, u32 n, u64 *dst, bool inverse, hipStream_t
     return PIL2GL_OK;
 }
 
-int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st, u32 cosetBegin, u32 cosetCount) {
+int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st, u32 cosetBegin, u32 cosetCount, u64 *work) {
     if (C == 0) return PIL2GL_OK;
     u32 eb = nExt - n;
     if (cosetCount == 0) { cosetBegin = 0; cosetCount = 1u << eb; }
@@ -338,8 +338,8 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
     if (n > kf) {
         u32 ks[32];
         int np = split_bits(n - kf, kmax, ks);
-        u64 *tmp;
-        P2_TRY(scratch(0, N * C, &tmp));
+        u64 *tmp = work;                            // caller's workspace (may be src itself: every pass is in place)
+        if (!tmp) P2_TRY(scratch(0, N * C, &tmp));
         u32 lo = n;
         for (int i = 0; i < np; i++) {
             lo -= ks[i];
@@ -406,19 +406,35 @@ static int check_ntt_args(const void *src, const void *dst, uint32_t nBits, uint
     return PIL2GL_OK;
 }
 
+// a coset slice only ever indexes 2^nBits * cosetCount local rows: the full extension may be larger than one device holds
+static int check_coset_args(const void *src, const void *dst, uint32_t nBits, uint32_t nBitsExt, uint32_t cosetBegin, uint32_t cosetCount) {
+    if (!src || !dst) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nBitsExt < nBits) return fail(PIL2GL_EINVAL, "nBitsExt (%u) < nBits (%u)", nBitsExt, nBits);
+    if (nBits > 27 || nBitsExt > 31) return fail(PIL2GL_EINVAL, "domain of 2^%u rows (extended 2^%u) is not supported", nBits, nBitsExt);
+    if (cosetCount == 0 || (uint64_t)cosetBegin + cosetCount > (1ull << (nBitsExt - nBits))) return fail(PIL2GL_EINVAL, "coset range [%u,%u) outside 2^%u", cosetBegin, cosetBegin + cosetCount, nBitsExt - nBits);
+    if (((uint64_t)cosetCount << nBits) > (1ull << 27)) return fail(PIL2GL_EINVAL, "slice of %u cosets x 2^%u rows exceeds 2^27 local rows", cosetCount, nBits);
+    return PIL2GL_OK;
+}
+
 extern "C" {
 
 int pil2gl_interpolate_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt, void *stream) {
     P2_TRY(ensure_init());
     P2_TRY(check_ntt_args(src, dst, nBits, nBitsExt));
-    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), 0, 0);
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), 0, 0, nullptr);
 }
 int pil2gl_interpolate_cosets_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
                                   uint32_t cosetBegin, uint32_t cosetCount, void *stream) {
     P2_TRY(ensure_init());
-    P2_TRY(check_ntt_args(src, dst, nBits, nBitsExt));
-    if (cosetCount == 0 || (uint64_t)cosetBegin + cosetCount > (1ull << (nBitsExt - nBits))) return fail(PIL2GL_EINVAL, "coset range [%u,%u) outside 2^%u", cosetBegin, cosetBegin + cosetCount, nBitsExt - nBits);
-    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount);
+    P2_TRY(check_coset_args(src, dst, nBits, nBitsExt, cosetBegin, cosetCount));
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount, nullptr);
+}
+int pil2gl_interpolate_cosets_ws_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
+                                     uint32_t cosetBegin, uint32_t cosetCount, uint64_t *workspace, void *stream) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_coset_args(src, dst, nBits, nBitsExt, cosetBegin, cosetCount));
+    if (!workspace) return fail(PIL2GL_EINVAL, "null workspace");
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount, workspace);
 }
 int pil2gl_fft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, void *stream) {
     P2_TRY(ensure_init());
@@ -443,7 +459,7 @@ static int host_wrap(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64
     int rc = PIL2GL_OK;
     e = hipMemcpy(dIn, src, nIn * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
-    if (rc == PIL2GL_OK) rc = mode == 0 ? lde_launch(dIn, nPols, nBits, dOut, nBitsOut, 0, 0, 0) : ntt_launch(dIn, nPols, nBits, dOut, mode == 2, 0);
+    if (rc == PIL2GL_OK) rc = mode == 0 ? lde_launch(dIn, nPols, nBits, dOut, nBitsOut, 0, 0, 0, nullptr) : ntt_launch(dIn, nPols, nBits, dOut, mode == 2, 0);
     if (rc == PIL2GL_OK) { e = hipMemcpy(dst, dOut, nOut * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
     (void)hipFree(dIn); (void)hipFree(dOut);
     return rc;

@@ -80,13 +80,18 @@ def interpolate(buffSrc, nPols, nBits, buffDst, nBitsExt):
         call("pil2gl_interpolate", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), nBitsExt)
 
 
-def interpolateCosets(buffSrc, nPols, nBits, buffDst, nBitsExt, cosetBegin, cosetCount):
+def interpolateCosets(buffSrc, nPols, nBits, buffDst, nBitsExt, cosetBegin, cosetCount, workspace=None):
     """interpolate restricted to cosets [cosetBegin, cosetBegin+cosetCount): dst is N x (cosetCount*nPols), device only
-    (the per-GPU slice of extendAndMerkelize, see pil2gl.parallel)"""
+    (the per-GPU slice of extendAndMerkelize, see pil2gl.parallel).  workspace: N*nPols words for the coefficients
+    (default: library scratch); passing buffSrc itself overwrites the trace and saves that much memory."""
     _check_len(buffSrc, nPols << nBits, "buffSrc"); _check_len(buffDst, (nPols * cosetCount) << nBits, "buffDst")
     if not _same_side(buffSrc, buffDst):
         raise Pil2glError("interpolateCosets works on device buffers")
-    call("pil2gl_interpolate_cosets_dev", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), nBitsExt, cosetBegin, cosetCount, _stream())
+    if workspace is None:
+        call("pil2gl_interpolate_cosets_dev", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), nBitsExt, cosetBegin, cosetCount, _stream())
+    else:
+        _check_len(workspace, nPols << nBits, "workspace")
+        call("pil2gl_interpolate_cosets_ws_dev", _ptr(buffSrc), nPols, nBits, _ptr(buffDst), nBitsExt, cosetBegin, cosetCount, _ptr(workspace), _stream())
 
 
 def fft(buffSrc, nPols, nBits, buffDst):

@@ -10,7 +10,7 @@ tree redundantly, so each holds the full node array and can open any Merkle path
 the rank that owns its coset (open_rows).
 
 `be` is a backend object (pil2gl.stark.GpuBackend in production; the tests pass their CPU checker) providing
-interpolate_cosets / linear_hash_rows / merkelize_digests / as_torch / from_torch.
+interpolate_cosets / linear_hash_rows / merkelize_digest_parts / as_torch.
 """
 import numpy as np
 
@@ -39,25 +39,35 @@ def _comm_tensor(be, t, group):
     return x
 
 
-def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None):
+def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None, overwrite_src=False, rehearse_world=None):
     """Sharded extendAndMerkelize.  `src` = the full N x n_pols trace on every rank.
     Returns {"local": N x (cc*n_pols) slice (row pos, coset jl, col c), "nodes": full tree.nodes, "width", "height",
     "cosetBegin", "cosetCount", "extBits"}; tree root = last 4 words of nodes, identical on all ranks and to the
-    single-GPU merkelize of the full extension."""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    single-GPU merkelize of the full extension.
+    overwrite_src: let the LDE use the trace buffer for its coefficient matrix (config 5: 107 GB trace + 107 GB slice per
+    GPU, no third buffer).  rehearse_world=K: run rank 0's share of a K-rank job alone, standing in copies of the own
+    digests for the gathered ones (a one-GPU rehearsal of the per-GPU time and memory; the tree is not a real root)."""
+    if rehearse_world:
+        rank, world = 0, int(rehearse_world)
+    else:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
     eb = n_bits_ext - n_bits
     cb, cc = coset_range(rank, world, eb)
     N = 1 << n_bits
     local = be.empty(N * cc * n_pols)
-    be.interpolate_cosets(src, n_pols, n_bits, local, n_bits_ext, cb, cc)
+    be.interpolate_cosets(src, n_pols, n_bits, local, n_bits_ext, cb, cc, src if overwrite_src else None)
     digests = be.linear_hash_rows(local, n_pols, N * cc)             # [N*cc][4], local row = pos*cc + jl
-    mine = _comm_tensor(be, digests, group).reshape(-1)
-    gathered = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(gathered, mine, group=group)
-    # [world][N][cc*4] -> [N][world][cc*4]: leaf index = pos*2^eb + r*cc + jl (natural row order of the extension)
-    leaves = torch.stack(gathered).reshape(world, N, cc * 4).permute(1, 0, 2).contiguous().reshape(-1)
+    if rehearse_world:
+        mine = be.as_torch(digests).reshape(-1)
+        gathered = [mine] * world
+    else:
+        mine = _comm_tensor(be, digests, group).reshape(-1)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)
+    # part r is [N][cc*4]; leaf index = pos*2^eb + r*cc + jl (natural row order of the extension), written straight into
+    # the node array (no stacked / permuted copies: at config 5 the leaf level alone is 17 GB)
     height = N << eb
-    nodes = be.merkelize_digests(be.from_torch(leaves), height)
+    nodes = be.merkelize_digest_parts(gathered, N, cc)
     return {"local": local, "nodes": nodes, "width": n_pols, "height": height,
             "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
 

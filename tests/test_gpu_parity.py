@@ -488,6 +488,13 @@ def test_interpolate_coset_slice(gl, oracle, nBits, nPols, ext, cb, cc):
     assert np.array_equal(dst.cpu().numpy().view(np.uint64), e[:, cb:cb + cc, :].reshape(-1))
     with pytest.raises(gl.Pil2glError):
         gl.interpolateCosets(src, nPols, nBits, dst, nBits + ext, (1 << ext) - cc + 1, cc)
+    # caller-provided workspace, and the trace itself as workspace (overwritten, no library scratch)
+    want = dst.clone()
+    ws = torch.empty_like(src)
+    dst.zero_(); gl.interpolateCosets(src, nPols, nBits, dst, nBits + ext, cb, cc, workspace=ws)
+    assert torch.equal(dst, want) and np.array_equal(src.cpu().numpy().view(np.uint64).reshape(a.shape), a)
+    dst.zero_(); gl.interpolateCosets(src, nPols, nBits, dst, nBits + ext, cb, cc, workspace=src)
+    assert torch.equal(dst, want)
 
 
 def test_merkelize_from_digests(gl, oracle):

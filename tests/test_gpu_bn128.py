@@ -131,3 +131,22 @@ def test_reference_final_proof_through_gpu(bn):
         for s, bits in ((1, 14), (2, 11), (3, 7), (4, 4)):
             assert MH.verifyGroupProof(int(p["s%d_root" % s]), p["s%d_siblings" % s][q], ys[q] % (1 << bits),
                                        [int(x) for x in p["s%d_vals" % s][q]]), (s, q)
+
+
+def test_config4_shape_tree_opens(bn):
+    """BASELINE config 4's shape (100 columns, BN128 linear hash, arity 16; 2^24 extended rows here, 2^27 in the config):
+    every opened path of the device-built tree recomputes the root through the host-side verification rule"""
+    import torch
+    h, w = 1 << 24, 100
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    buf = torch.randint(0, 0x7FFFFFFFFFFFFFFF, (h * w,), dtype=torch.int64, device="cuda", generator=g) % 0xFFFFFFFF00000001
+    MH = bn.buildMerkleHash(16, False)
+    tree = MH.merkelize(buf, w, h)
+    root = MH.root(tree)
+    for idx in (0, 1, h - 1, 12345678, (h // 3) | 15):
+        v, mp = MH.getGroupProof(tree, idx)
+        assert len(mp) == 6 and all(len(l) == 16 for l in mp)
+        assert v == [int(x) for x in buf[idx * w:(idx + 1) * w].cpu().numpy().view(np.uint64)]
+        assert MH.verifyGroupProof(root, mp, idx, v)
+    v[3] ^= 1
+    assert not MH.verifyGroupProof(root, mp, idx, v)

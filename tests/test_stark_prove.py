@@ -98,3 +98,29 @@ def test_config2_size_proof_verifies(oracle):
     res = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
     ok, why = stark_ref.stark_verify(res, s_gpu["constRoot"], info, vinfo)
     assert ok, why
+
+
+@pytest.mark.gpu
+def test_config3_size_proof_verifies(oracle):
+    """BASELINE config 3, the bench's default workload (2^24 rows x 100 cols, blow-up 8, FRI 27/22/17/12/7, 64 queries): the
+    proof the GPU writes at full size passes the restated verifier (openings, evaluation identity, FRI folds)"""
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.mem_get_info()[0] < 200e9:
+        pytest.skip("needs ~190 GB of free device memory")
+    import stark_ref
+    import bench
+    from pil2gl import stark
+    n_bits, n_cols = 24, 100
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 64, "verificationHashType": "GL", "splitLinearHash": False,
+          "steps": [{"nBits": b} for b in (27, 22, 17, 12, 7)]}
+    info, exprs, vinfo = stark.fibonacci_air(n_cols // 2, ss)
+    gpu = stark.GpuBackend(0, False)
+    cm, consts, publics = bench.fibonacci_trace_gpu(torch, torch.device("cuda", 0), n_bits, n_cols // 2, 0)
+    setup = stark.build_const_tree(gpu, consts, info)
+    res = stark.stark_gen(gpu, cm, setup, info, exprs, publics)
+    del cm
+    torch.cuda.empty_cache()
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    # and the witness it proves really is K Fibonacci machines ending in the public output
+    assert len(res["proof"]["evals"]) > 0 and res["publics"] == publics

@@ -208,13 +208,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local_rank %= max(1, torch.cuda.device_count())            # rehearsing N ranks on fewer GPUs: ranks share devices
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or (args.mode == "commit-sharded" and not args.shard_of):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("PIL2GL_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path with ranks sharing a GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     import pil2gl
     pil2gl.init(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -291,7 +296,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3

@@ -173,6 +173,10 @@ int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *ctx, void *s
  * A zero denominator yields 0 for that ratio (the reference's batchInverse would poison the whole column). */
 int pil2gl_gprod_dev(const uint64_t *num, uint32_t dimNum, const uint64_t *den, uint32_t dimDen, uint64_t n, uint64_t *out, void *stream);
 int pil2gl_gsum_dev(const uint64_t *num, uint32_t dimNum, const uint64_t *den, uint32_t dimDen, uint64_t n, uint64_t *out, void *stream);
+/* calculateH1H2(F,f,t)  polutils.js:105-126: the multiset f (every value must occur in t) merged into t; h1[i], h2[i] =
+ * entries 2i, 2i+1 of the merged sequence.  f, t, h1, h2: n rows of dimension dim (1 or 3).  Returns PIL2GL_EINVAL with
+ * the reference's "Number not included" message when some f[j] is missing from t (synchronises the stream). */
+int pil2gl_h1h2_dev(const uint64_t *f, const uint64_t *t, uint64_t n, uint32_t dim, uint64_t *h1, uint64_t *h2, void *stream);
 
 /* ---- BN128 (BN254 scalar field) Merkle commitment: merklehash_bn128_p.js, merklehash_bn128_worker.js -------------
  * Field elements are 4 little-endian u64 words.  tree.nodes and leaf digests are in MONTGOMERY form (R = 2^256), exactly

@@ -127,6 +127,20 @@ def gprod(num, den, dim_num, dim_den): return _hint("or_gprod", num, den, dim_nu
 def gsum(num, den, dim_num, dim_den): return _hint("or_gsum", num, den, dim_num, dim_den)
 
 
+def h1h2(f, t):
+    """calculateH1H2 (polutils.js:105-126), literally: f, t lists of ints or of 3-tuples (small cases; pure Python)"""
+    idx_t, s = {}, []
+    for i, v in enumerate(t):
+        idx_t[v] = i
+        s.append((v, i))
+    for i, v in enumerate(f):
+        if v not in idx_t:
+            raise ValueError("Number not included: w:%d" % i)
+        s.append((v, idx_t[v]))
+    s.sort(key=lambda e: e[1])                       # stable, like Array.prototype.sort in Node >= 11
+    return [s[2 * i][0] for i in range(len(f))], [s[2 * i + 1][0] for i in range(len(f))]
+
+
 # ---- NTT ----
 def fft(p):
     p = _u(p).copy(); lib().or_fft(_ptr(p), C.c_int(int(p.size).bit_length() - 1), C.c_uint64(1)); return p

@@ -126,3 +126,128 @@ int pil2gl_gsum_dev(const uint64_t *num, uint32_t dimNum, const uint64_t *den, u
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// calculateH1H2(F, f, t)  src/helpers/polutils.js:105-126 (hint "h1h2", hints_helpers.js:115-121).
+// The reference builds s = [(t[i], i)] ++ [(f[j], idx_t[f[j]])] with idx_t[v] = LAST i with t[i] = v, sorts it stably by
+// the index and reads h1[i] = s[2i], h2[i] = s[2i+1].  All entries with the same index carry the same VALUE, so the
+// sorted sequence is "t[i] repeated 1 + cnt[i] times, for i = 0..n-1", with cnt[i] = #{j : f[j] = t[i]} when i is the last
+// occurrence of its value and 0 otherwise.  No sort is needed: a hash table value -> last index, the counts, an
+// exclusive scan of (1 + cnt) for the group starts, and one binary search per output position.
+namespace {
+
+constexpr u64 H_EMPTY = ~0ull;
+
+__device__ __forceinline__ u64 key_hash(const u64 *p, u64 i, u32 dim) {
+    u64 h = 0x9E3779B97F4A7C15ull;
+    for (u32 k = 0; k < dim; k++) { h ^= p[i * dim + k] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 31; }
+    return h;
+}
+__device__ __forceinline__ bool key_eq(const u64 *a, u64 i, const u64 *b, u64 j, u32 dim) {
+    for (u32 k = 0; k < dim; k++) if (a[i * dim + k] != b[j * dim + k]) return false;
+    return true;
+}
+__global__ void h1h2_insert(const u64 *__restrict__ t, u64 n, u32 dim, unsigned long long *__restrict__ table, u64 mask) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 s = key_hash(t, i, dim) & mask;
+    for (;;) {
+        unsigned long long cur = table[s];
+        if (cur == H_EMPTY) {
+            cur = atomicCAS(&table[s], (unsigned long long)H_EMPTY, (unsigned long long)i);
+            if (cur == H_EMPTY) return;                          // claimed the slot
+        }
+        if (key_eq(t, i, t, cur, dim)) { atomicMax(&table[s], (unsigned long long)i); return; }   // same value: keep the last index
+        s = (s + 1) & mask;
+    }
+}
+__global__ void h1h2_count(const u64 *__restrict__ f, const u64 *__restrict__ t, u64 n, u32 dim, const unsigned long long *__restrict__ table, u64 mask,
+                           unsigned long long *__restrict__ cnt, unsigned long long *__restrict__ missing) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    u64 s = key_hash(f, j, dim) & mask;
+    for (;;) {
+        const unsigned long long cur = table[s];
+        if (cur == H_EMPTY) { atomicMin(missing, (unsigned long long)j); return; }      // "Number not included" (polutils.js:115)
+        if (key_eq(f, j, t, cur, dim)) { atomicAdd(&cnt[cur], 1ull); return; }
+        s = (s + 1) & mask;
+    }
+}
+// in: cnt[i];  out: start[i] = sum_{k<i} (1 + cnt[k])  -- block-local exclusive scan + block totals (u64 adds)
+__global__ void __launch_bounds__(SCAN_THREADS) h1h2_scan1(const unsigned long long *__restrict__ cnt, u64 n, u64 *__restrict__ start, u64 *__restrict__ totals) {
+    __shared__ u64 sh[SCAN_THREADS];
+    const u64 base = (u64)blockIdx.x * SCAN_CHUNK + (u64)threadIdx.x * SCAN_ITEMS;
+    u64 loc[SCAN_ITEMS], run = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { const u64 i = base + k; loc[k] = run; if (i < n) run += 1 + cnt[i]; }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (u32 d = 1; d < SCAN_THREADS; d <<= 1) {
+        u64 v = sh[threadIdx.x];
+        if (threadIdx.x >= d) v += sh[threadIdx.x - d];
+        __syncthreads();
+        sh[threadIdx.x] = v;
+        __syncthreads();
+    }
+    const u64 ex = threadIdx.x ? sh[threadIdx.x - 1] : 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { const u64 i = base + k; if (i < n) start[i] = ex + loc[k]; }
+    if (threadIdx.x == SCAN_THREADS - 1) totals[blockIdx.x] = sh[SCAN_THREADS - 1];
+}
+__global__ void h1h2_scan2(u64 *__restrict__ totals, u64 nb) {           // tiny: one thread
+    if (blockIdx.x || threadIdx.x) return;
+    u64 run = 0;
+    for (u64 b = 0; b < nb; b++) { const u64 v = totals[b]; totals[b] = run; run += v; }
+}
+__global__ void h1h2_scan3(u64 *__restrict__ start, const u64 *__restrict__ totals, u64 n) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) start[i] += totals[i / SCAN_CHUNK];
+}
+// output position p in [0, 2n): its group is the last i with start[i] <= p
+__global__ void h1h2_expand(const u64 *__restrict__ t, const u64 *__restrict__ start, u64 n, u32 dim, u64 *__restrict__ h1, u64 *__restrict__ h2) {
+    const u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= 2 * n) return;
+    u64 lo = 0, hi = n - 1;
+    while (lo < hi) { const u64 mid = (lo + hi + 1) >> 1; if (start[mid] <= p) lo = mid; else hi = mid - 1; }
+    u64 *o = (p & 1) ? h2 : h1;
+    for (u32 k = 0; k < dim; k++) o[(p >> 1) * dim + k] = t[lo * dim + k];
+}
+
+}  // namespace
+
+extern "C" int pil2gl_h1h2_dev(const uint64_t *f, const uint64_t *t, uint64_t n, uint32_t dim, uint64_t *h1, uint64_t *h2, void *stream) {
+    P2_TRY(ensure_init());
+    if (n == 0) return PIL2GL_OK;
+    if (!f || !t || !h1 || !h2) return fail(PIL2GL_EINVAL, "null buffer");
+    if (dim != 1 && dim != 3) return fail(PIL2GL_EINVAL, "dimension must be 1 or 3");
+    if (n > (1ull << 30)) return fail(PIL2GL_EINVAL, "column too long");
+    hipStream_t st = as_stream(stream);
+    u64 cap = 2; while (cap < 2 * n) cap <<= 1;
+    const u64 nb = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    u64 *ws;                                             // table[cap] | cnt[n] | start[n] | totals[nb] | missing[1]
+    P2_TRY(scratch(10, cap + 2 * n + nb + 1, &ws));
+    unsigned long long *table = (unsigned long long *)ws, *cnt = table + cap;
+    u64 *start = ws + cap + n, *totals = start + n;
+    unsigned long long *missing = (unsigned long long *)(totals + nb);
+    HIP_TRY(hipMemsetAsync(table, 0xFF, cap * 8, st));
+    HIP_TRY(hipMemsetAsync(cnt, 0, n * 8, st));
+    HIP_TRY(hipMemsetAsync(missing, 0xFF, 8, st));
+    const unsigned g = (unsigned)((n + 255) / 256);
+    h1h2_insert<<<g, 256, 0, st>>>(t, n, dim, table, cap - 1);
+    KERNEL_CHECK();
+    h1h2_count<<<g, 256, 0, st>>>(f, t, n, dim, table, cap - 1, cnt, missing);
+    KERNEL_CHECK();
+    h1h2_scan1<<<(unsigned)nb, SCAN_THREADS, 0, st>>>(cnt, n, start, totals);
+    KERNEL_CHECK();
+    h1h2_scan2<<<1, 1, 0, st>>>(totals, nb);
+    KERNEL_CHECK();
+    h1h2_scan3<<<g, 256, 0, st>>>(start, totals, n);
+    KERNEL_CHECK();
+    h1h2_expand<<<(unsigned)((2 * n + 255) / 256), 256, 0, st>>>(t, start, n, dim, h1, h2);
+    KERNEL_CHECK();
+    unsigned long long miss = 0;
+    HIP_TRY(hipMemcpyAsync(&miss, missing, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (miss != H_EMPTY) return fail(PIL2GL_EINVAL, "Number not included: w:%llu", miss);     // polutils.js:115
+    return PIL2GL_OK;
+}

@@ -133,6 +133,16 @@ def calculateS(num, den, dimNum=3, dimDen=3, out=None):
     return _hint("pil2gl_gsum_dev", num, den, dimNum, dimDen, out)
 
 
+def calculateH1H2(f, t, dim=1):
+    """polutils.js:105 calculateH1H2(F, f, t) on device columns -> (h1, h2)"""
+    n = int(np.prod(t.shape)) // dim
+    if not _same_side(f, t):
+        raise Pil2glError("hint columns must be device buffers")
+    h1 = torch.empty(n * dim, dtype=torch.int64, device=t.device); h2 = torch.empty_like(h1)
+    call("pil2gl_h1h2_dev", _ptr(f), _ptr(t), n, dim, _ptr(h1), _ptr(h2), _stream())
+    return h1, h2
+
+
 # ----------------------------------------------------------------------------- poseidon / linear hash
 def poseidon(inputs, capacity=None, nOuts=4):
     """hash/poseidon/poseidon.js:57 poseidon(inputs[8], capacity[4]?, nOuts=4) -> list of ints"""

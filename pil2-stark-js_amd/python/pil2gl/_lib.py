@@ -100,6 +100,7 @@ SIGNATURES = {
     "pil2gl_debug_jit_compile": (_I, [C.POINTER(GlxProgram), C.POINTER(GlxCtx), C.POINTER(_U64), C.POINTER(_U32)]),
     "pil2gl_gprod_dev": (_I, [vp, _U32, vp, _U32, _U64, vp, vp]),
     "pil2gl_gsum_dev": (_I, [vp, _U32, vp, _U32, _U64, vp, vp]),
+    "pil2gl_h1h2_dev": (_I, [vp, vp, _U64, _U32, vp, vp, vp]),
     "pil2gl_bn128_poseidon": (_I, [vp, vp, _U64, _U32, _U32, vp]),
     "pil2gl_bn128_poseidon_dev": (_I, [vp, vp, _U64, _U32, _U32, vp, vp]),
     "pil2gl_bn128_linear_hash_rows": (_I, [vp, _U64, _U64, _U32, _I, vp]),

@@ -534,6 +534,30 @@ def test_gprod_gsum_columns(gl, oracle, n, dimNum, dimDen):
             assert int(z2[-1][0]) * int(rot.reshape(n, 1)[-1][0]) % P == int(d[-1][0]) % P
 
 
+@pytest.mark.parametrize("n,dim,distinct", [(1, 1, 1), (8, 1, 3), (1000, 1, 1000), (5000, 3, 70), (1 << 16, 1, 1 << 12), (70001, 3, 70001), (4096, 1, 1)])
+def test_h1h2_columns(gl, oracle, n, dim, distinct):
+    """calculateH1H2 (polutils.js:105-126) against the literal restatement: tables with repeated values (the last index
+    wins), lookups hitting few or many entries, base and extension columns; a value missing from t is the reference's error"""
+    import torch
+    rng = np.random.default_rng(n * 7 + dim)
+    vals = rand_field(rng, (distinct, dim))
+    t = vals[rng.integers(0, distinct, n)] if distinct < n else vals[rng.permutation(n)]
+    f = t[rng.integers(0, n, n)]
+    if n >= 8:
+        f[: n // 4] = t[0]                       # one heavily used entry
+    dt, df = torch.from_numpy(t.reshape(-1).copy().view(np.int64)).cuda(), torch.from_numpy(f.reshape(-1).copy().view(np.int64)).cuda()
+    h1, h2 = gl.calculateH1H2(df, dt, dim)
+    key = (lambda r: int(r[0])) if dim == 1 else (lambda r: tuple(int(x) for x in r))
+    w1, w2 = oracle.h1h2([key(r) for r in f], [key(r) for r in t])
+    g1 = h1.cpu().numpy().view(np.uint64).reshape(n, dim); g2 = h2.cpu().numpy().view(np.uint64).reshape(n, dim)
+    assert [key(r) for r in g1] == w1 and [key(r) for r in g2] == w2
+    if n > 1 and distinct > 1:
+        bad = f.copy(); bad[n // 2] = (bad[n // 2] + np.uint64(12345)) % np.uint64(P)
+        if key(bad[n // 2]) not in {key(r) for r in t}:
+            with pytest.raises(gl.Pil2glError, match="Number not included"):
+                gl.calculateH1H2(torch.from_numpy(bad.reshape(-1).copy().view(np.int64)).cuda(), dt, dim)
+
+
 # ------------------------------------------------------------------ extension-weighted sums (csrc/dot.hip)
 def test_rows_and_cols_dot_ext(gl, oracle):
     import ctypes as C

@@ -146,6 +146,58 @@ FN(GroupProofDev) {  // (devElems, devNodes, width, height, idx, vals BigUint64A
     napi_value v; napi_create_uint32(env, nl, &v); return v;
 }
 
+// ---- STARK step helpers and stage-2 hints (device pointers; js/stark_gen_helpers.js and js/polutils.js stage host buffers) ----
+#define DP(i) ((uint64_t *)(uintptr_t)a.u64(i))
+FN(BuildXDev) {        // (nBits, shift, dX)  stark_gen_helpers.js:111-116,139-144
+    Args a(env, info); uint32_t nBits = (uint32_t)a.u64(0); uint64_t shift = a.u64(1); uint64_t *x = DP(2); if (!a.ok) return nullptr;
+    P2(env, pil2gl_build_x_dev(nBits, shift, x, a.stream(3))); return mk_undefined(env);
+}
+FN(BuildZhInvDev) {    // (nBits, nBitsExt, dOut)  polutils.js:39-55
+    Args a(env, info); uint32_t nb = (uint32_t)a.u64(0), nbe = (uint32_t)a.u64(1); uint64_t *o = DP(2); if (!a.ok) return nullptr;
+    P2(env, pil2gl_build_zhinv_dev(nb, nbe, o, a.stream(3))); return mk_undefined(env);
+}
+FN(BuildOneRowZerofierInvDev) {   // (nBits, nBitsExt, rowIndex, dOut)  polutils.js:57-71
+    Args a(env, info); uint32_t nb = (uint32_t)a.u64(0), nbe = (uint32_t)a.u64(1); uint64_t row = a.u64(2); uint64_t *o = DP(3); if (!a.ok) return nullptr;
+    P2(env, pil2gl_build_one_row_zerofier_inv_dev(nb, nbe, row, o, a.stream(4))); return mk_undefined(env);
+}
+FN(BuildFrameZerofierDev) {       // (nBits, nBitsExt, offsetMin, offsetMax, dOut)  polutils.js:74-102
+    Args a(env, info); uint32_t nb = (uint32_t)a.u64(0), nbe = (uint32_t)a.u64(1); uint64_t mn = a.u64(2), mx = a.u64(3); uint64_t *o = DP(4); if (!a.ok) return nullptr;
+    P2(env, pil2gl_build_frame_zerofier_dev(nb, nbe, mn, mx, o, a.stream(5))); return mk_undefined(env);
+}
+FN(ComputeQSplitDev) { // (dQq1, nBits, nBitsExt, qDim, qDeg, dQq2)  stark_gen_helpers.js:179-190
+    Args a(env, info); uint64_t *q1 = DP(0); uint32_t nb = (uint32_t)a.u64(1), nbe = (uint32_t)a.u64(2), qDim = (uint32_t)a.u64(3), qDeg = (uint32_t)a.u64(4); uint64_t *q2 = DP(5); if (!a.ok) return nullptr;
+    P2(env, pil2gl_compute_q_split_dev(q1, nb, nbe, qDim, qDeg, q2, a.stream(6))); return mk_undefined(env);
+}
+FN(XDivXSubXiDev) {    // (nBitsExt, xi BigUint64Array(3), nOpen, iOpen, dOut)  stark_gen_helpers.js:293-322
+    Args a(env, info); uint32_t nbe = (uint32_t)a.u64(0); uint64_t *xi = a.arr(1, 3); uint64_t nOpen = a.u64(2), iOpen = a.u64(3); uint64_t *o = DP(4); if (!a.ok) return nullptr;
+    P2(env, pil2gl_x_div_x_sub_xi_dev(nbe, xi, nOpen, iOpen, o, a.stream(5))); return mk_undefined(env);
+}
+FN(BuildLevDev) {      // (nBits, xi BigUint64Array(3), dLev)  stark_gen_helpers.js:216-231
+    Args a(env, info); uint32_t nb = (uint32_t)a.u64(0); uint64_t *xi = a.arr(1, 3); uint64_t *lev = DP(2); if (!a.ok) return nullptr;
+    P2(env, pil2gl_build_lev_dev(nb, xi, lev, a.stream(3))); return mk_undefined(env);
+}
+FN(ComputeEvalsDev) {  // (descs BigUint64Array(5*nEvals) = [dBuf,width,offset,dim,levIndex]*, nEvals, nBits, extendBits, levs BigUint64Array(nLev) device ptrs, out BigUint64Array(3*nEvals))
+    Args a(env, info); uint64_t nEv = a.u64(1); uint64_t *d = a.arr(0, 5 * nEv); uint32_t nb = (uint32_t)a.u64(2), eb = (uint32_t)a.u64(3);
+    uint64_t nLev = 0; uint64_t *levs = a.arr(4, 1, &nLev); uint64_t *out = a.arr(5, 3 * nEv); if (!a.ok) return nullptr;
+    std::vector<pil2gl_eval_desc> descs(nEv);
+    for (uint64_t i = 0; i < nEv; i++) { descs[i].buf = (const uint64_t *)(uintptr_t)d[5 * i]; descs[i].width = d[5 * i + 1]; descs[i].offset = d[5 * i + 2]; descs[i].dim = (uint32_t)d[5 * i + 3]; descs[i].levIndex = (uint32_t)d[5 * i + 4]; }
+    std::vector<const uint64_t *> lp(nLev);
+    for (uint64_t i = 0; i < nLev; i++) lp[i] = (const uint64_t *)(uintptr_t)levs[i];
+    P2(env, pil2gl_compute_evals_dev(descs.data(), (uint32_t)nEv, nb, eb, lp.data(), (uint32_t)nLev, out, nullptr)); return mk_undefined(env);
+}
+FN(GprodDev) {         // (dNum, dimNum, dDen, dimDen, n, dOut)  polutils.js:128-143
+    Args a(env, info); uint64_t *num = DP(0); uint32_t dn = (uint32_t)a.u64(1); uint64_t *den = DP(2); uint32_t dd = (uint32_t)a.u64(3); uint64_t n = a.u64(4); uint64_t *o = DP(5); if (!a.ok) return nullptr;
+    P2(env, pil2gl_gprod_dev(num, dn, den, dd, n, o, a.stream(6))); return mk_undefined(env);
+}
+FN(GsumDev) {          // (dNum (one element), dimNum, dDen, dimDen, n, dOut)  polutils.js:145-164
+    Args a(env, info); uint64_t *num = DP(0); uint32_t dn = (uint32_t)a.u64(1); uint64_t *den = DP(2); uint32_t dd = (uint32_t)a.u64(3); uint64_t n = a.u64(4); uint64_t *o = DP(5); if (!a.ok) return nullptr;
+    P2(env, pil2gl_gsum_dev(num, dn, den, dd, n, o, a.stream(6))); return mk_undefined(env);
+}
+FN(H1H2Dev) {          // (dF, dT, n, dim, dH1, dH2)  polutils.js:105-126
+    Args a(env, info); uint64_t *f = DP(0), *t = DP(1); uint64_t n = a.u64(2); uint32_t dim = (uint32_t)a.u64(3); uint64_t *h1 = DP(4), *h2 = DP(5); if (!a.ok) return nullptr;
+    P2(env, pil2gl_h1h2_dev(f, t, n, dim, h1, h2, a.stream(6))); return mk_undefined(env);
+}
+
 // ---- BN128 Merkle commitment (merklehash_bn128_p.js / merklehash_bn128_worker.js) ----
 FN(Bn128Poseidon) {  // (in BigUint64Array(4*nIn*count) normal form, init BigUint64Array(4*count)|null, count, nIn, nOut, out(4*nOut*count))
     Args a(env, info); uint64_t count = a.u64(2), nIn = a.u64(3), nOut = a.u64(4);
@@ -212,6 +264,9 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "merkleNumNodes", MerkleNumNodes }, { "merkelize", Merkelize }, { "merkelizeDev", MerkelizeDev }, { "groupProofDev", GroupProofDev },
         { "bn128Poseidon", Bn128Poseidon }, { "bn128LinearHashRows", Bn128LinearHashRows }, { "bn128MerkleNumNodes", Bn128MerkleNumNodes },
         { "bn128Merkelize", Bn128Merkelize }, { "bn128MerkelizeDev", Bn128MerkelizeDev }, { "bn128Convert", Bn128Convert },
+        { "buildXDev", BuildXDev }, { "buildZhInvDev", BuildZhInvDev }, { "buildOneRowZerofierInvDev", BuildOneRowZerofierInvDev },
+        { "buildFrameZerofierDev", BuildFrameZerofierDev }, { "computeQSplitDev", ComputeQSplitDev }, { "xDivXSubXiDev", XDivXSubXiDev },
+        { "buildLevDev", BuildLevDev }, { "computeEvalsDev", ComputeEvalsDev }, { "gprodDev", GprodDev }, { "gsumDev", GsumDev }, { "h1h2Dev", H1H2Dev },
         { "friFold", FriFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
     };
     for (auto &f : fns) {

@@ -9,4 +9,6 @@ module.exports = {
     TranscriptBN128: require("./transcript_bn128.js"),
     FRI: require("./fri.js"),
     prover_helpers: require("./prover_helpers.js"),
+    stark_gen_helpers: require("./stark_gen_helpers.js"),
+    polutils: require("./polutils.js"),
 };

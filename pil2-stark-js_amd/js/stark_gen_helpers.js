@@ -1,0 +1,120 @@
+// Drop-ins for the data-parallel stages of src/stark/stark_gen_helpers.js, same names, `ctx` object and return values:
+//   buildXTables(ctx)            the x_n / x_ext loops of initProverStark             stark_gen_helpers.js:111-116,139-144
+//   computeQStark(ctx, options)                                                       stark_gen_helpers.js:168-208
+//   computeEvalsStark(ctx, options)                                                   stark_gen_helpers.js:210-273
+//   computeFRIStark(ctx, options)                                                     stark_gen_helpers.js:275-335
+// ctx is the reference's prover context (ctx.q_ext, ctx.cm<k>_ext, ctx.const_ext, ctx.x_ext, ctx.xDivXSubXi_ext, ctx.f_ext
+// are BigBuffers / BigUint64Arrays; ctx.MH, ctx.trees, ctx.challenges, ctx.pilInfo, ctx.expressionsInfo as the reference
+// builds them).  Each stage uploads what it reads, runs on the device and stores what the reference stores.
+"use strict";
+const { addon, upload, download } = require("./native.js");
+const { callCalculateExps } = require("./prover_helpers.js");
+
+const P = 0xFFFFFFFF00000001n;
+const SHIFT = 7n;
+const W32 = 7277203076849721926n;                  // F.w[32] (f3g.js:40)
+const mulm = (a, b) => (a * b) % P;
+function powm(a, e) { let r = 1n; a %= P; while (e > 0n) { if (e & 1n) r = mulm(r, a); a = mulm(a, a); e >>= 1n; } return r; }
+const invm = (a) => powm(a, P - 2n);
+const rootOfUnity = (bits) => powm(W32, 1n << BigInt(32 - bits));
+function e3mul(a, b) {      // f3g.js:94-102
+    const A = mulm(a[0] + a[1], b[0] + b[1]), B = mulm(a[0] + a[2], b[0] + b[2]), C = mulm(a[1] + a[2], b[1] + b[2]);
+    const D = mulm(a[0], b[0]), E = mulm(a[1], b[1]), F = mulm(a[2], b[2]), G = (D - E + P) % P;
+    return [(C + G - F + P) % P, (((A + C - E - E - D) % P) + 2n * P) % P, (B - G + P) % P];
+}
+const e3scale = (a, s) => [mulm(a[0], s), mulm(a[1], s), mulm(a[2], s)];
+const asE3 = (v) => (Array.isArray(v) ? v.map(BigInt) : [BigInt(v), 0n, 0n]);
+
+function devTmp(n) { return addon.devAlloc(n); }
+
+module.exports.buildXTables = function buildXTables(ctx) {
+    for (const [buf, bits, shift] of [[ctx.x_n, ctx.nBits, 1n], [ctx.x_ext, ctx.nBitsExt, SHIFT]]) {
+        if (!buf) continue;
+        const n = 1 << bits, d = devTmp(n);
+        try { addon.buildXDev(bits, shift, d); download(buf, d, n); } finally { addon.devFree(d); }
+    }
+};
+
+module.exports.computeQStark = async function computeQStark(ctx, options) {
+    const qStage = ctx.pilInfo.nStages + 1, qDim = ctx.pilInfo.qDim, qDeg = ctx.pilInfo.qDeg, extN = ctx.extN;
+    const dQ = devTmp(qDim * extN), dQ1 = devTmp(qDim * extN), dQ2 = devTmp(qDim * qDeg * extN);
+    try {
+        upload(dQ, ctx.q_ext, qDim * extN);
+        addon.ifftDev(dQ, qDim, ctx.nBitsExt, dQ1);                                        // :177
+        addon.computeQSplitDev(dQ1, ctx.nBits, ctx.nBitsExt, qDim, qDeg, dQ2);              // :179-190
+        addon.fftDev(dQ2, qDim * qDeg, ctx.nBitsExt, dQ2);                                  // :192
+        download(ctx["cm" + qStage + "_ext"], dQ2, qDim * qDeg * extN);
+    } finally { addon.devFree(dQ); addon.devFree(dQ1); addon.devFree(dQ2); }
+    const nPolsQ = ctx.pilInfo.mapSectionsN["cm" + qStage] || 0;
+    ctx.trees[qStage] = await ctx.MH.merkelize(ctx["cm" + qStage + "_ext"], nPolsQ, extN);   // :197
+    return [ctx.MH.root(ctx.trees[qStage])];
+};
+
+function openingXi(ctx, opening, divideByShift) {
+    let w = 1n;
+    const wN = rootOfUnity(ctx.nBits);
+    for (let j = 0; j < Math.abs(Number(opening)); ++j) w = mulm(w, wN);
+    if (Number(opening) < 0) w = invm(w);
+    const xiChallenge = asE3(ctx.challenges[ctx.pilInfo.nStages + 1][0]);
+    let xi = e3scale(xiChallenge, w);
+    if (divideByShift) xi = e3scale(xi, invm(SHIFT));
+    return xi;
+}
+
+module.exports.computeEvalsStark = async function computeEvalsStark(ctx, options) {
+    const N = ctx.N, nOpen = ctx.pilInfo.openingPoints.length;
+    const ptrs = [];
+    try {
+        const levs = new BigUint64Array(nOpen);
+        for (let i = 0; i < nOpen; i++) {                                                    // :216-231
+            const xi = openingXi(ctx, ctx.pilInfo.openingPoints[i], true);
+            const d = devTmp(3 * N); ptrs.push(d);
+            addon.buildLevDev(ctx.nBits, BigUint64Array.from(xi), d);
+            levs[i] = d;
+        }
+        const uploaded = new Map();                                                          // each section once
+        const devOf = (name, buf, words) => {
+            if (!uploaded.has(name)) { const d = devTmp(words); ptrs.push(d); upload(d, buf, words); uploaded.set(name, d); }
+            return uploaded.get(name);
+        };
+        const nEv = ctx.pilInfo.evMap.length, descs = new BigUint64Array(5 * nEv);
+        for (let i = 0; i < nEv; i++) {                                                      // :233-247
+            const ev = ctx.pilInfo.evMap[i];
+            let name, size, offset, dim;
+            if (ev.type == "const") { name = "const_ext"; size = ctx.pilInfo.nConstants; offset = ev.id; dim = 1; }
+            else if (ev.type == "cm") { const p = ctx.pilInfo.cmPolsMap[ev.id]; name = "cm" + p.stage + "_ext"; size = ctx.pilInfo.mapSectionsN["cm" + p.stage]; offset = p.stagePos; dim = p.dim; }
+            else throw new Error("Invalid ev type: " + ev.type);
+            const d = devOf(name, ctx[name], size * ctx.extN);
+            descs.set([d, BigInt(size), BigInt(offset), BigInt(dim), BigInt(ctx.pilInfo.openingPoints.findIndex((p) => p === ev.prime))], 5 * i);
+        }
+        const out = new BigUint64Array(3 * nEv);
+        addon.computeEvalsDev(descs, nEv, ctx.nBits, ctx.extendBits, levs, out);             // :248-264
+        ctx.evals = [];
+        for (let i = 0; i < nEv; i++) ctx.evals[i] = [out[3 * i], out[3 * i + 1], out[3 * i + 2]];
+    } finally { for (const d of ptrs) addon.devFree(d); }
+    if (ctx.pilInfo.starkStruct.hashCommits) throw new Error("hashCommits: hash ctx.evals with the reference's calculateHashStark");
+    return ctx.evals;
+};
+
+module.exports.computeFRIStark = async function computeFRIStark(ctx, options) {
+    const stage = ctx.pilInfo.nStages + 2, nOpen = ctx.pilInfo.openingPoints.length, extN = ctx.extN;
+    ctx.friPol = []; ctx.friProof = []; ctx.friTrees = [];
+    const s0_trees = [];
+    for (let i = 0; i < ctx.pilInfo.nStages + 1; ++i) s0_trees.push(ctx.trees[i + 1]);
+    s0_trees.push(ctx.constTree);
+    ctx.friTrees[0] = s0_trees;
+    ctx.friProof[0] = {};
+    const dX = devTmp(3 * extN * nOpen);
+    try {
+        for (let i = 0; i < nOpen; i++)                                                      // :293-322
+            addon.xDivXSubXiDev(ctx.nBitsExt, BigUint64Array.from(openingXi(ctx, ctx.pilInfo.openingPoints[i], false)), nOpen, i, dX);
+        download(ctx.xDivXSubXi_ext, dX, 3 * extN * nOpen);
+    } finally { addon.devFree(dX); }
+    await callCalculateExps(stage, ctx.expressionsInfo.expressionsCode.find((e) => e.expId === ctx.pilInfo.friExpId).code, "ext", ctx,
+                            options.parallelExec, options.useThreads, false);               // :324
+    ctx.friPol[0] = new Array(extN);
+    for (let i = 0; i < extN; i++) {
+        const g = (k) => (ctx.f_ext instanceof BigUint64Array ? ctx.f_ext[k] : ctx.f_ext.getElement(k));
+        ctx.friPol[0][i] = [g(i * 3), g(i * 3 + 1), g(i * 3 + 2)];
+    }
+};

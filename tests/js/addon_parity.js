@@ -121,6 +121,122 @@ class ChunkedBuffer {
             assert.deepStrictEqual([ctx.q_ext[3 * i], ctx.q_ext[3 * i + 1], ctx.q_ext[3 * i + 2]], [mod(t * 3n), mod(t * 1n), mod(t * 4n)], "callCalculateExps row " + i);
         }
     }
+    // --- stark_gen_helpers.js / polutils.js drop-ins against BigInt restatements of the reference loops (small sizes)
+    {
+        const SGH = require(path.join(root, "pil2-stark-js_amd/js/stark_gen_helpers.js"));
+        const PU = require(path.join(root, "pil2-stark-js_amd/js/polutils.js"));
+        const P = 0xFFFFFFFF00000001n, SH = 7n, W32 = 7277203076849721926n;
+        const mod = (a) => ((a % P) + P) % P, mul = (a, b) => mod(a * b);
+        const pow = (a, e) => { let r = 1n; a = mod(a); while (e > 0n) { if (e & 1n) r = mul(r, a); a = mul(a, a); e >>= 1n; } return r; };
+        const inv = (a) => pow(a, P - 2n), w = (bits) => pow(W32, 1n << BigInt(32 - bits));
+        const e3mul = (a, b) => {       // f3g.js:94-102
+            const A = mul(a[0] + a[1], b[0] + b[1]), B = mul(a[0] + a[2], b[0] + b[2]), C = mul(a[1] + a[2], b[1] + b[2]);
+            const D = mul(a[0], b[0]), E = mul(a[1], b[1]), F = mul(a[2], b[2]), G = mod(D - E);
+            return [mod(C + G - F), mod(A + C - E - E - D), mod(B - G)];
+        };
+        const e3add = (a, b) => [mod(a[0] + b[0]), mod(a[1] + b[1]), mod(a[2] + b[2])];
+        const nBits = 4, nBitsExt = 6, N = 16, extN = 64, eb = 2;
+        let seed = 12345n; const rnd = () => { seed = mod(seed * 6364136223846793005n + 1442695040888963407n); return seed; };
+        // zerofier tables (polutils.js:39-102), written at a non-zero offset of a larger buffer
+        const zh = new BigUint64Array(extN + 5); PU.buildZhInv(zh, 5, null, nBits, nBitsExt, true);
+        const sn = pow(SH, BigInt(N));
+        for (let i = 0; i < extN; i++) assert.strictEqual(zh[5 + i], inv(mod(mul(sn, pow(w(eb), BigInt(i % 4))) - 1n)), "buildZhInv " + i);
+        for (const row of [0, N - 1]) {
+            const z1 = new BigUint64Array(extN); PU.buildOneRowZerofierInv(z1, 0, null, null, nBits, nBitsExt, row, true);
+            const rootR = pow(w(nBits), BigInt(row));
+            for (let i = 0; i < extN; i++) { const x = mul(SH, pow(w(nBitsExt), BigInt(i))); assert.strictEqual(z1[i], inv(mul(mod(x - rootR), zh[5 + i])), "oneRow " + row + " " + i); }
+        }
+        const zf = new BigUint64Array(extN); PU.buildFrameZerofierInv(zf, 0, null, null, nBits, nBitsExt, { offsetMin: 1, offsetMax: 2 }, true);
+        for (let i = 0; i < extN; i++) {
+            const x = mul(SH, pow(w(nBitsExt), BigInt(i)));
+            let zi = mod(x - 1n); zi = mul(zi, mod(x - pow(w(nBits), BigInt(N - 1)))); zi = mul(zi, mod(x - pow(w(nBits), BigInt(N - 2))));
+            assert.strictEqual(zf[i], zi, "frame zerofier " + i);
+        }
+        // hints (polutils.js:105-164)
+        const num = [], den = [], num3 = [], den3 = [];
+        for (let i = 0; i < 40; i++) { num.push(rnd()); den.push(rnd() || 1n); num3.push([rnd(), rnd(), rnd()]); den3.push([rnd(), 0n, 0n]); }
+        const z = await PU.calculateZ(null, num, den);
+        let acc = 1n; for (let i = 0; i < 40; i++) { assert.strictEqual(z[i], acc, "calculateZ " + i); acc = mul(acc, mul(num[i], inv(den[i]))); }
+        const z3 = await PU.calculateZ(null, num3, den3);
+        let acc3 = [1n, 0n, 0n]; for (let i = 0; i < 40; i++) { assert.deepStrictEqual(z3[i], acc3, "calculateZ ext " + i); acc3 = e3mul(acc3, e3mul(num3[i], [inv(den3[i][0]), 0n, 0n])); }
+        const sS = await PU.calculateS(null, num[0], den);
+        let accS = 0n; for (let i = 0; i < 40; i++) { accS = mod(accS + mul(num[0], inv(den[i]))); assert.strictEqual(sS[i], accS, "calculateS " + i); }
+        const tt = [5n, 9n, 5n, 2n, 7n, 9n, 1n, 3n], ff = [9n, 9n, 5n, 3n, 3n, 3n, 1n, 2n];
+        const [h1, h2] = PU.calculateH1H2(null, ff, tt);
+        {   // literal reference algorithm (polutils.js:105-126)
+            const idx_t = {}, sArr = [];
+            for (let i = 0; i < tt.length; i++) { idx_t[tt[i]] = i; sArr.push([tt[i], i]); }
+            for (let i = 0; i < ff.length; i++) sArr.push([ff[i], idx_t[ff[i]]]);
+            sArr.sort((a, b) => a[1] - b[1]);
+            for (let i = 0; i < ff.length; i++) { assert.strictEqual(h1[i], sArr[2 * i][0]); assert.strictEqual(h2[i], sArr[2 * i + 1][0]); }
+        }
+        assert.throws(() => PU.calculateH1H2(null, [4n], [5n]), /Number not included/);
+        // the three stages on a small context
+        const MHs = await buildMH(false);
+        const ctx = {
+            nBits, nBitsExt, extendBits: eb, N, extN, MH: MHs, trees: [], challenges: [[], [], [[rnd(), rnd(), rnd()]]], publics: [], evals: [], subproofValues: [],
+            pilInfo: { nStages: 1, qDim: 3, qDeg: 2, nConstants: 2, openingPoints: [0, 1], mapSectionsN: { cm1: 3, cm2: 6 }, boundaries: [{ name: "everyRow" }],
+                starkStruct: {}, friExpId: 7,
+                cmPolsMap: [{ stage: 1, dim: 1, stagePos: 0 }, { stage: 1, dim: 1, stagePos: 2 }, { stage: 2, dim: 3, stagePos: 0 }, { stage: 2, dim: 3, stagePos: 3 }],
+                evMap: [{ type: "cm", id: 0, prime: 0 }, { type: "cm", id: 1, prime: 1 }, { type: "const", id: 1, prime: 0 }, { type: "cm", id: 3, prime: 1 }] },
+            q_ext: new BigUint64Array(3 * extN), cm1_ext: new BigUint64Array(3 * extN), cm2_ext: new BigUint64Array(6 * extN), const_ext: new BigUint64Array(2 * extN),
+            x_ext: new BigUint64Array(extN), x_n: new BigUint64Array(N), Zi_ext: new BigUint64Array(extN), xDivXSubXi_ext: new BigUint64Array(3 * extN * 2), f_ext: new BigUint64Array(3 * extN),
+        };
+        for (const k of ["q_ext", "cm1_ext", "const_ext"]) for (let i = 0; i < ctx[k].length; i++) ctx[k][i] = rnd();
+        SGH.buildXTables(ctx);
+        for (let i = 0; i < extN; i++) assert.strictEqual(ctx.x_ext[i], mul(SH, pow(w(nBitsExt), BigInt(i))));
+        for (let i = 0; i < N; i++) assert.strictEqual(ctx.x_n[i], pow(w(nBits), BigInt(i)));
+        // computeQStark (stark_gen_helpers.js:168-208)
+        const [rootQ] = await SGH.computeQStark(ctx, {});
+        {
+            const qq1 = new BigUint64Array(3 * extN), qq2 = new BigUint64Array(6 * extN), want = new BigUint64Array(6 * extN);
+            await ifft(ctx.q_ext, 3, nBitsExt, qq1);
+            let curS = 1n; const shiftIn = pow(inv(SH), BigInt(N));
+            for (let p = 0; p < 2; p++) { for (let i = 0; i < N; i++) for (let k = 0; k < 3; k++) qq2[i * 6 + 3 * p + k] = mul(qq1[p * N * 3 + i * 3 + k], curS); curS = mul(curS, shiftIn); }
+            await fft(qq2, 6, nBitsExt, want);
+            assert.deepStrictEqual(ctx.cm2_ext, want, "computeQStark cm2_ext");
+            assert.deepStrictEqual(rootQ, MHs.root(await MHs.merkelize(want, 6, extN)));
+        }
+        // computeEvalsStark (:210-273)
+        const evals = await SGH.computeEvalsStark(ctx, {});
+        {
+            const xiC = ctx.challenges[2][0];
+            for (let e = 0; e < ctx.pilInfo.evMap.length; e++) {
+                const ev = ctx.pilInfo.evMap[e];
+                const wv = ev.prime == 1 ? w(nBits) : 1n, xi = xiC.map((c) => mul(mul(c, wv), inv(SH)));
+                const lev = new BigUint64Array(3 * N), levI = new BigUint64Array(3 * N);
+                let cur = [1n, 0n, 0n];
+                for (let k = 0; k < N; k++) { lev.set(cur, 3 * k); cur = e3mul(cur, xi); }
+                await ifft(lev, 3, nBits, levI);
+                let accE = [0n, 0n, 0n];
+                for (let k = 0; k < N; k++) {
+                    let v;
+                    if (ev.type == "const") v = [ctx.const_ext[(k << eb) * 2 + ev.id], 0n, 0n];
+                    else { const pm = ctx.pilInfo.cmPolsMap[ev.id], buf = ctx["cm" + pm.stage + "_ext"], sz = ctx.pilInfo.mapSectionsN["cm" + pm.stage], o = (k << eb) * sz + pm.stagePos; v = pm.dim == 1 ? [buf[o], 0n, 0n] : [buf[o], buf[o + 1], buf[o + 2]]; }
+                    accE = e3add(accE, e3mul(v, [levI[3 * k], levI[3 * k + 1], levI[3 * k + 2]]));
+                }
+                assert.deepStrictEqual(evals[e], accE, "computeEvalsStark " + e);
+            }
+        }
+        // computeFRIStark (:275-335): xDivXSubXi by its defining identity, f_ext through the op-list
+        ctx.trees[1] = "t1"; ctx.trees[2] = "t2"; ctx.constTree = "tc";
+        ctx.expressionsInfo = { expressionsCode: [{ expId: 7, code: { tmpUsed: 1, code: [
+            { op: "mul", dest: { type: "tmp", id: 0, dim: 3 }, src: [{ type: "cm", id: 0, prime: 0, dim: 1 }, { type: "xDivXSubXi", id: 1, dim: 3 }] },
+            { op: "add", dest: { type: "f", dim: 3 }, src: [{ type: "tmp", id: 0, dim: 3 }, { type: "xDivXSubXi", id: 0, dim: 3 }] } ] } }] };
+        await SGH.computeFRIStark(ctx, {});
+        assert.deepStrictEqual(ctx.friTrees[0], ["t1", "t2", "tc"]);
+        for (let k = 0; k < extN; k++) {
+            const x = ctx.x_ext[k], X = [];
+            for (let i = 0; i < 2; i++) {
+                const xi = ctx.challenges[2][0].map((c) => mul(c, i == 1 ? w(nBits) : 1n));
+                const v = [0, 1, 2].map((c) => ctx.xDivXSubXi_ext[3 * (k * 2 + i) + c]);
+                assert.deepStrictEqual(e3mul(v, [mod(x - xi[0]), mod(-xi[1]), mod(-xi[2])]), [x, 0n, 0n], "xDivXSubXi " + k);
+                X.push(v);
+            }
+            const wantF = e3add(e3mul([ctx.cm1_ext[3 * k], 0n, 0n], X[1]), X[0]);
+            assert.deepStrictEqual(ctx.friPol[0][k], wantF, "computeFRIStark f " + k);
+        }
+    }
     // --- BN128 Merkle commitment (merklehash_bn128_p.js, linearhash.bn128.js, transcript.bn128.js)
     {
         const buildMHBN = require(path.join(root, "pil2-stark-js_amd/js/merklehash_bn128_p.js"));

@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/fib_flow.json: the synthetic Fibonacci AIR in the reference's pilInfo / expressionsInfo shape,
+its witness, and the proof the CPU checker backend produces for it -- the expected output of tests/js/prove_flow.js,
+which drives the same proof from Node through the JS drop-in modules."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "pil2-stark-js_amd", "python")]
+import gl_oracle
+gl_oracle.build()
+from pil2gl import stark
+from stark_backend import OracleBackend
+
+
+def s(v):
+    if isinstance(v, dict):
+        return {k: s(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [s(x) for x in v]
+    if isinstance(v, int) and not isinstance(v, bool) and (v > 2 ** 31 or v < 0):
+        return str(v)
+    return v
+
+
+n_bits, pairs = 6, 2
+ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 9}, {"nBits": 5}, {"nBits": 2}]}
+info, exprs, _ = stark.fibonacci_air(pairs, ss)
+cm, consts, publics = stark.fibonacci_trace(n_bits, pairs)
+be = OracleBackend()
+setup = stark.build_const_tree(be, consts, info)
+res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+out = {"pilInfo": info, "expressionsInfo": exprs, "cm1": [str(int(v)) for v in cm.reshape(-1)], "consts": [str(int(v)) for v in consts.reshape(-1)],
+       "publics": [str(v) for v in publics], "constRoot": [str(v) for v in setup["constRoot"]],
+       "proof": json.loads(json.dumps(res["proof"], default=int)), "challenges": res["challenges"], "queries": res["queries"]}
+
+
+def strs(v):
+    if isinstance(v, dict):
+        return {k: strs(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [strs(x) for x in v]
+    if isinstance(v, int) and not isinstance(v, bool):
+        return str(v)
+    return v
+
+
+for k in ("proof", "challenges"):
+    out[k] = strs(out[k])
+json.dump(out, open(os.path.join(ROOT, "tests/golden/fib_flow.json"), "w"))
+print("ok", os.path.getsize(os.path.join(ROOT, "tests/golden/fib_flow.json")))

@@ -1,0 +1,90 @@
+// A whole proof driven from Node in the order of src/prover/prover.js:7-127 (nStages = 1) with the reference's own
+// function boundaries, every data-parallel piece coming from the drop-in modules of pil2-stark-js_amd/js:
+//   extendAndMerkelize (fft_p.interpolate + MH.merkelize), callCalculateExps, computeQStark, computeEvalsStark,
+//   computeFRIStark, FRI.fold / proofQueries, Transcript over the device Poseidon.
+// The proof must equal, field by field, the proof the CPU checker wrote for the same AIR and witness
+// (tests/golden/fib_flow.json, oracle/gen_fib_flow_golden.py).
+"use strict";
+const fs = require("fs");
+const path = require("path");
+const assert = require("assert");
+const root = path.join(__dirname, "..", "..");
+const J = (p) => path.join(root, "pil2-stark-js_amd/js", p);
+const { interpolate } = require(J("fft_p.js"));
+const buildMH = require(J("merklehash_p.js"));
+const getPoseidon = require(J("poseidon.js"));
+const Transcript = require(J("transcript.js"));
+const FRI = require(J("fri.js"));
+const { callCalculateExps } = require(J("prover_helpers.js"));
+const SGH = require(J("stark_gen_helpers.js"));
+const { buildZhInv } = require(J("polutils.js"));
+
+const big = (v) => (Array.isArray(v) ? v.map(big) : (typeof v === "string" && /^[0-9]+$/.test(v) ? BigInt(v) : v));
+function bigProof(p) {      // golden proof: decimal strings -> BigInt, everything else untouched
+    if (Array.isArray(p)) return p.map(bigProof);
+    if (p && typeof p === "object") { const o = {}; for (const k of Object.keys(p)) o[k] = bigProof(p[k]); return o; }
+    return typeof p === "string" ? BigInt(p) : p;
+}
+
+(async () => {
+    const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden/fib_flow.json")));
+    const pilInfo = g.pilInfo, ss = pilInfo.starkStruct;
+    const poseidon = getPoseidon(), MH = await buildMH(false);
+    const nBits = ss.nBits, nBitsExt = ss.nBitsExt, N = 1 << nBits, extN = 1 << nBitsExt;
+    const ctx = { prover: "stark", pilInfo, expressionsInfo: g.expressionsInfo, nBits, nBitsExt, extendBits: nBitsExt - nBits, N, extN, MH,
+        publics: g.publics.map(BigInt), challenges: [[], [], [], []], evals: [], subproofValues: [], trees: [] };
+    // setup (stark_buildConstTree.js:6-43) and initProverStark (stark_gen_helpers.js:104-160)
+    ctx.const_n = BigUint64Array.from(g.consts, BigInt);
+    ctx.const_ext = new BigUint64Array(pilInfo.nConstants * extN);
+    await interpolate(ctx.const_n, pilInfo.nConstants, nBits, ctx.const_ext, nBitsExt);
+    ctx.constTree = await MH.merkelize(ctx.const_ext, pilInfo.nConstants, extN);
+    assert.deepStrictEqual(MH.root(ctx.constTree), g.constRoot.map(BigInt), "constant tree root");
+    ctx.cm1_n = BigUint64Array.from(g.cm1, BigInt);
+    ctx.cm1_ext = new BigUint64Array(pilInfo.mapSectionsN.cm1 * extN);
+    ctx.cm2_ext = new BigUint64Array(pilInfo.mapSectionsN.cm2 * extN);
+    ctx.q_ext = new BigUint64Array(pilInfo.qDim * extN);
+    ctx.f_ext = new BigUint64Array(3 * extN);
+    ctx.x_n = new BigUint64Array(N); ctx.x_ext = new BigUint64Array(extN);
+    ctx.Zi_ext = new BigUint64Array(pilInfo.boundaries.length * extN);
+    ctx.xDivXSubXi_ext = new BigUint64Array(3 * extN * pilInfo.openingPoints.length);
+    SGH.buildXTables(ctx);
+    buildZhInv(ctx.Zi_ext, 0, null, nBits, nBitsExt, true);
+    ctx.fri = new FRI(ss, MH);
+    const transcript = new Transcript(poseidon);
+    transcript.put(MH.root(ctx.constTree)); transcript.put(ctx.publics);                        // prover.js:148-189
+    // stage 1: extendAndMerkelize (stark_gen_helpers.js:388-412)
+    await interpolate(ctx.cm1_n, pilInfo.mapSectionsN.cm1, nBits, ctx.cm1_ext, nBitsExt);
+    ctx.trees[1] = await MH.merkelize(ctx.cm1_ext, pilInfo.mapSectionsN.cm1, extN);
+    const root1 = MH.root(ctx.trees[1]); transcript.put(root1);
+    // stage 2: quotient (challenges are stored at [stage - 1], setChallengesStark :414-431)
+    ctx.challenges[1] = [transcript.getField()];
+    await callCalculateExps(2, ctx.expressionsInfo.expressionsCode.find((e) => e.expId === pilInfo.cExpId).code, "ext", ctx, false, false, false);
+    const [root2] = await SGH.computeQStark(ctx, {}); transcript.put(root2);
+    // evaluations
+    ctx.challenges[2] = [transcript.getField()];
+    const evals = await SGH.computeEvalsStark(ctx, {});
+    for (const ev of evals) transcript.put(ev);
+    ctx.challenges[3] = [transcript.getField(), transcript.getField()];
+    await SGH.computeFRIStark(ctx, { parallelExec: false, useThreads: false });
+    // FRI folding (computeFRIFolding :337-356) and queries (:474-493, fri.js:83-105)
+    for (let step = 0; step < ss.steps.length; step++) {
+        const challenge = transcript.getField();
+        const sp = await ctx.fri.fold(step, ctx.friPol[step], challenge);
+        ctx.friPol[step + 1] = sp.pol; ctx.friProof[step + 1] = sp.proof;
+        if (step < ss.steps.length - 1) { ctx.friTrees[step + 1] = sp.tree; transcript.put(sp.proof.root); }
+        else for (const e of sp.proof) transcript.put(e);
+    }
+    const tq = new Transcript(poseidon); tq.put(transcript.getField());
+    const friQueries = tq.getPermutations(ss.nQueries, ss.steps[0].nBits);
+    assert.deepStrictEqual(friQueries, g.queries, "query positions");
+    ctx.fri.proofQueries(ctx.friProof, ctx.friTrees, friQueries.slice());
+    const proof = { root1, root2, evals: ctx.evals, fri: ctx.friProof };                         // genProofStark :362-386
+    const want = bigProof(g.proof);
+    assert.deepStrictEqual(ctx.challenges, bigProof(g.challenges), "challenges");
+    assert.deepStrictEqual(proof.root1, want.root1, "root1");
+    assert.deepStrictEqual(proof.root2, want.root2, "root2");
+    assert.deepStrictEqual(proof.evals, want.evals, "evals");
+    assert.deepStrictEqual(proof.fri.length, want.fri.length);
+    for (let s = 0; s < want.fri.length; s++) assert.deepStrictEqual(proof.fri[s], want.fri[s], "fri[" + s + "]");
+    console.log("prove flow OK");
+})().catch((e) => { console.error(e); process.exit(1); });

@@ -31,3 +31,11 @@ def test_addon_loads_and_exports():
 def test_js_modules_match_goldens_on_gpu():
     out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "addon_parity.js")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "addon parity OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_whole_proof_driven_from_node():
+    """prover.js's stage order over the JS drop-in modules: the proof equals the CPU checker's proof field by field"""
+    out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "prove_flow.js")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "prove flow OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

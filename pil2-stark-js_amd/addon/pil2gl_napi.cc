@@ -239,6 +239,16 @@ FN(FriTranspose) {   // (pol, polBits, transposeBits, out)  fri.js:187
     P2(env, pil2gl_fri_transpose(pol, pb, tb, out)); return mk_undefined(env);
 }
 
+FN(FriFoldDev) {     // (dPol, polBits, outBits, shiftInv, challenge BigUint64Array(3), dOut)
+    Args a(env, info); uint64_t pol = a.u64(0); uint32_t pb = (uint32_t)a.u64(1), ob = (uint32_t)a.u64(2); uint64_t sinv = a.u64(3);
+    uint64_t *ch = a.arr(4, 3); uint64_t out = a.u64(5); if (!a.ok) return nullptr;
+    P2(env, pil2gl_fri_fold_dev((const uint64_t *)(uintptr_t)pol, pb, ob, sinv, ch, (uint64_t *)(uintptr_t)out, a.stream(6))); return mk_undefined(env);
+}
+FN(FriTransposeDev) { // (dPol, polBits, transposeBits, dOut)
+    Args a(env, info); uint64_t pol = a.u64(0); uint32_t pb = (uint32_t)a.u64(1), tb = (uint32_t)a.u64(2); uint64_t out = a.u64(3); if (!a.ok) return nullptr;
+    P2(env, pil2gl_fri_transpose_dev((const uint64_t *)(uintptr_t)pol, pb, tb, (uint64_t *)(uintptr_t)out, a.stream(4))); return mk_undefined(env);
+}
+
 // ---- expression evaluator ----
 // (opsBuf BigUint64Array = packed glx_op[], nOps, nTmp, nBits, primeShift, sectionPtrs BigUint64Array, sectionWidths BigUint64Array, scalars BigUint64Array)
 FN(EvalProgramDev) {
@@ -267,6 +277,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "buildXDev", BuildXDev }, { "buildZhInvDev", BuildZhInvDev }, { "buildOneRowZerofierInvDev", BuildOneRowZerofierInvDev },
         { "buildFrameZerofierDev", BuildFrameZerofierDev }, { "computeQSplitDev", ComputeQSplitDev }, { "xDivXSubXiDev", XDivXSubXiDev },
         { "buildLevDev", BuildLevDev }, { "computeEvalsDev", ComputeEvalsDev }, { "gprodDev", GprodDev }, { "gsumDev", GsumDev }, { "h1h2Dev", H1H2Dev },
+        { "friFoldDev", FriFoldDev }, { "friTransposeDev", FriTransposeDev },
         { "friFold", FriFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
     };
     for (auto &f : fns) {

@@ -2,7 +2,7 @@
 // {pol, tree, proof}; proofQueries(proof, trees, friQueries) (fri.js:7-105).  `pol` is an array of [a,b,c] BigInt
 // triples as in the reference; the fold and the transposition run on the GPU.
 "use strict";
-const { addon } = require("./native.js");
+const { addon, isDev, DevBuffer } = require("./native.js");
 const P = 0xFFFFFFFF00000001n;
 
 function powmod(b, e) { let r = 1n; b %= P; while (e > 0n) { if (e & 1n) r = r * b % P; b = b * b % P; e >>= 1n; } return r; }
@@ -21,6 +21,7 @@ class FRI {
     }
 
     async fold(step, pol, challenge) {
+        if (isDev(pol)) return this.foldDev(step, pol, challenge);
         const polBits = log2(pol.length);
         if (step === 0) { if (polBits !== this.inNBits) throw new Error("Invalid polynomial size"); }
         else if ((1 << polBits) !== pol.length) throw new Error("Invalid polynomial size");
@@ -46,6 +47,30 @@ class FRI {
             proof = pol2_e.slice();
         }
         return { pol: pol2_e, tree, proof };
+    }
+
+    // the same step on a device-resident polynomial (3 * 2^bits words): folds, transposes and commits without leaving HBM;
+    // only the last step's polynomial is returned as the reference's array of triples
+    async foldDev(step, pol, challenge) {
+        const polBits = log2(pol.length / 3);
+        if (3 * 2 ** polBits !== pol.length || (step === 0 && polBits !== this.inNBits)) throw new Error("Invalid polynomial size");
+        let shiftInv = powmod(7n, P - 2n);
+        if (step > 0) for (let j = 0; j < this.steps[0].nBits - this.steps[step - 1].nBits; j++) shiftInv = shiftInv * shiftInv % P;
+        const outBits = this.steps[step].nBits;
+        let pol2 = pol;
+        if (step > 0) {
+            pol2 = new DevBuffer(3 * 2 ** outBits);
+            addon.friFoldDev(pol.ptr, polBits, outBits, shiftInv, BigUint64Array.from(challenge, BigInt), pol2.ptr);
+        }
+        if (step !== this.steps.length - 1) {
+            const nGroups = 1 << this.steps[step + 1].nBits, groupSize = (1 << outBits) / nGroups;
+            const tb = new DevBuffer(3 * 2 ** outBits);
+            addon.friTransposeDev(pol2.ptr, outBits, this.steps[step + 1].nBits, tb.ptr);
+            const tree = await this.MH.merkelize(tb, 3 * groupSize, nGroups);
+            return { pol: pol2, tree, proof: { root: this.MH.root(tree) } };
+        }
+        const last = unpack(pol2.toHost());
+        return { pol: last, tree: undefined, proof: last.slice() };
     }
 
     proofQueries(proof, trees, friQueries) {                                  // fri.js:83-105

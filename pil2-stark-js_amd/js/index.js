@@ -2,6 +2,7 @@
 "use strict";
 module.exports = {
     native: require("./native.js").addon,
+    DevBuffer: require("./native.js").DevBuffer,
     fft_p: require("./fft_p.js"),
     buildMerkleHash: require("./merklehash_p.js"),
     buildPoseidon: require("./poseidon.js"),

@@ -4,7 +4,7 @@
 // the caller's buffer (:47), nodes is a new BigUint64Array laid out exactly as the reference's (:28-42, :87-103).
 "use strict";
 const fs = require("fs");
-const { addon, isFlat, upload } = require("./native.js");
+const { addon, isFlat, isDev, DevBuffer, upload } = require("./native.js");
 const getPoseidon = require("./poseidon.js");
 
 module.exports = async function buildMerkleHash(splitLinearHash = false) {
@@ -35,6 +35,11 @@ class MerkleHash {
     _getNNodes(n) { return addon.merkleNumNodes(n / 4); }      // merklehash_p.js:28-42, n = 4*height
 
     async merkelize(buff, width, height) {
+        if (isDev(buff)) {          // resident: the tree is built next to its leaves and stays there
+            const nodes = new DevBuffer(this._getNNodes(height * 4));
+            addon.merkelizeDev(buff.ptr, width, height, this.splitLinearHash ? 1 : 0, nodes.ptr);
+            return { elements: buff, nodes, width, height };
+        }
         const tree = { elements: buff, nodes: new BigUint64Array(this._getNNodes(height * 4)), width, height };
         if (isFlat(buff)) {
             addon.merkelize(buff, width, height, this.splitLinearHash ? 1 : 0, tree.nodes);
@@ -56,18 +61,25 @@ class MerkleHash {
 
     getElement(tree, idx, subIdx) {
         const e = tree.elements;
-        return isFlat(e) ? e[tree.width * idx + subIdx] : e.getElement(tree.width * idx + subIdx);
+        return isFlat(e) ? e[tree.width * idx + subIdx] : e.getElement(tree.width * idx + subIdx);     // DevBuffer answers getElement too
     }
 
     getGroupProof(tree, idx) {          // merklehash_p.js:142-168
         if ((idx < 0) || (idx >= tree.height)) throw new Error("Out of range");
+        if (isDev(tree.elements) && isDev(tree.nodes)) {        // only the opened row and its siblings cross PCIe
+            const vals = new BigUint64Array(Math.max(1, tree.width)), sib = new BigUint64Array(4 * 64);
+            const nl = addon.groupProofDev(tree.elements.ptr, tree.nodes.ptr, tree.width, tree.height, idx, vals, sib);
+            const mpd = [];
+            for (let l = 0; l < nl; l++) mpd.push([sib[4 * l], sib[4 * l + 1], sib[4 * l + 2], sib[4 * l + 3]]);
+            return [Array.from(vals.subarray(0, tree.width)), mpd];
+        }
         const v = new Array(tree.width);
         for (let i = 0; i < tree.width; i++) v[i] = this.getElement(tree, idx, i);
         const mp = [];
         let offset = 0, n = tree.height * 4;
         while (n > 4) {
             const si = (idx ^ 1) * 4;
-            mp.push([tree.nodes[offset + si], tree.nodes[offset + si + 1], tree.nodes[offset + si + 2], tree.nodes[offset + si + 3]]);
+            mp.push(isFlat(tree.nodes) ? [tree.nodes[offset + si], tree.nodes[offset + si + 1], tree.nodes[offset + si + 2], tree.nodes[offset + si + 3]] : Array.from(tree.nodes.slice(offset + si, offset + si + 4)));
             const nextN = (Math.floor((n - 1) / 8) + 1) * 4;
             offset += nextN * 2; n = nextN; idx = idx >> 1;
         }

@@ -8,12 +8,13 @@
 // One deviation, on purpose: buildZhInv honours `offset` when it fills rows >= 2^extendBits; the reference's second loop
 // (polutils.js:51-53) ignores it and overwrites the table at offset 0 (harmless there because everyRow is boundary 0).
 "use strict";
-const { addon, isFlat, download } = require("./native.js");
+const { addon, isFlat, isDev, download } = require("./native.js");
 
 function setRange(buffTo, offset, tmp) {
     if (isFlat(buffTo)) buffTo.set(tmp, offset); else buffTo.set(tmp, offset);
 }
 function withOut(n, fn, buffTo, offset) {
+    if (isDev(buffTo)) { fn(buffTo.addr(offset)); return; }         // resident table: written in place
     const d = addon.devAlloc(n);
     try {
         fn(d);

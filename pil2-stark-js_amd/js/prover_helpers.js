@@ -5,7 +5,7 @@
 // ctx buffers (const_n, cm{s}_n/_ext, x_n/x_ext, Zi_ext, xDivXSubXi_ext, q_ext, f_ext) may be BigUint64Array or
 // BigBuffer-like; referenced sections are staged to the device, destinations copied back.
 "use strict";
-const { addon, upload, download } = require("./native.js");
+const { addon, isDev, upload, download } = require("./native.js");
 const P = 0xFFFFFFFF00000001n;
 const OP = { add: 0, sub: 1, mul: 2, copy: 3 };
 const TMP = 0, SEC = 1, SCALAR = 2;
@@ -88,6 +88,7 @@ module.exports.callCalculateExps = async function callCalculateExps(stage, code,
             const host = ctx[s.name];
             if (!host) throw new Error("ctx." + s.name + " is not allocated");
             const n = rows * s.width, base = s.zi === undefined ? 0 : s.zi * rows;
+            if (isDev(host)) { ptrs[i] = host.addr(base); widths[i] = BigInt(s.width); devs.push(null); return; }     // resident section
             const d = addon.devAlloc(n);
             devs.push(d);
             if (base === 0 && n === host.length) upload(d, host, n);
@@ -95,9 +96,9 @@ module.exports.callCalculateExps = async function callCalculateExps(stage, code,
             ptrs[i] = d; widths[i] = BigInt(s.width);
         });
         addon.evalProgramDev(enc.ops, enc.nOps, enc.nTmp, nBits, dom === "n" ? 0 : ctx.extendBits, ptrs, widths, enc.scalars);
-        enc.sections.forEach((s, i) => { if (s.written) download(ctx[s.name], devs[i], rows * s.width); });
+        enc.sections.forEach((s, i) => { if (s.written && devs[i] !== null) download(ctx[s.name], devs[i], rows * s.width); });
     } finally {
-        for (const d of devs) addon.devFree(d);
+        for (const d of devs) if (d !== null) addon.devFree(d);
     }
 };
 module.exports.encode = encode;

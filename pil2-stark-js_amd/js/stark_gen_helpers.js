@@ -7,7 +7,7 @@
 // are BigBuffers / BigUint64Arrays; ctx.MH, ctx.trees, ctx.challenges, ctx.pilInfo, ctx.expressionsInfo as the reference
 // builds them).  Each stage uploads what it reads, runs on the device and stores what the reference stores.
 "use strict";
-const { addon, upload, download } = require("./native.js");
+const { addon, isDev, upload, download } = require("./native.js");
 const { callCalculateExps } = require("./prover_helpers.js");
 
 const P = 0xFFFFFFFF00000001n;
@@ -30,21 +30,25 @@ function devTmp(n) { return addon.devAlloc(n); }
 module.exports.buildXTables = function buildXTables(ctx) {
     for (const [buf, bits, shift] of [[ctx.x_n, ctx.nBits, 1n], [ctx.x_ext, ctx.nBitsExt, SHIFT]]) {
         if (!buf) continue;
-        const n = 1 << bits, d = devTmp(n);
+        const n = 1 << bits;
+        if (isDev(buf)) { addon.buildXDev(bits, shift, buf.ptr); continue; }
+        const d = devTmp(n);
         try { addon.buildXDev(bits, shift, d); download(buf, d, n); } finally { addon.devFree(d); }
     }
 };
 
 module.exports.computeQStark = async function computeQStark(ctx, options) {
     const qStage = ctx.pilInfo.nStages + 1, qDim = ctx.pilInfo.qDim, qDeg = ctx.pilInfo.qDeg, extN = ctx.extN;
-    const dQ = devTmp(qDim * extN), dQ1 = devTmp(qDim * extN), dQ2 = devTmp(qDim * qDeg * extN);
+    const qIn = ctx.q_ext, qOut = ctx["cm" + qStage + "_ext"];
+    const dQ = isDev(qIn) ? null : devTmp(qDim * extN), dQ1 = devTmp(qDim * extN), dQ2 = isDev(qOut) ? null : devTmp(qDim * qDeg * extN);
     try {
-        upload(dQ, ctx.q_ext, qDim * extN);
-        addon.ifftDev(dQ, qDim, ctx.nBitsExt, dQ1);                                        // :177
-        addon.computeQSplitDev(dQ1, ctx.nBits, ctx.nBitsExt, qDim, qDeg, dQ2);              // :179-190
-        addon.fftDev(dQ2, qDim * qDeg, ctx.nBitsExt, dQ2);                                  // :192
-        download(ctx["cm" + qStage + "_ext"], dQ2, qDim * qDeg * extN);
-    } finally { addon.devFree(dQ); addon.devFree(dQ1); addon.devFree(dQ2); }
+        if (dQ !== null) upload(dQ, qIn, qDim * extN);
+        const pQ = dQ !== null ? dQ : qIn.ptr, pQ2 = dQ2 !== null ? dQ2 : qOut.ptr;
+        addon.ifftDev(pQ, qDim, ctx.nBitsExt, dQ1);                                         // :177
+        addon.computeQSplitDev(dQ1, ctx.nBits, ctx.nBitsExt, qDim, qDeg, pQ2);              // :179-190
+        addon.fftDev(pQ2, qDim * qDeg, ctx.nBitsExt, pQ2);                                  // :192
+        if (dQ2 !== null) download(qOut, dQ2, qDim * qDeg * extN);
+    } finally { if (dQ !== null) addon.devFree(dQ); addon.devFree(dQ1); if (dQ2 !== null) addon.devFree(dQ2); }
     const nPolsQ = ctx.pilInfo.mapSectionsN["cm" + qStage] || 0;
     ctx.trees[qStage] = await ctx.MH.merkelize(ctx["cm" + qStage + "_ext"], nPolsQ, extN);   // :197
     return [ctx.MH.root(ctx.trees[qStage])];
@@ -74,6 +78,7 @@ module.exports.computeEvalsStark = async function computeEvalsStark(ctx, options
         }
         const uploaded = new Map();                                                          // each section once
         const devOf = (name, buf, words) => {
+            if (isDev(buf)) return buf.ptr;                                                  // resident section
             if (!uploaded.has(name)) { const d = devTmp(words); ptrs.push(d); upload(d, buf, words); uploaded.set(name, d); }
             return uploaded.get(name);
         };
@@ -104,14 +109,16 @@ module.exports.computeFRIStark = async function computeFRIStark(ctx, options) {
     s0_trees.push(ctx.constTree);
     ctx.friTrees[0] = s0_trees;
     ctx.friProof[0] = {};
-    const dX = devTmp(3 * extN * nOpen);
+    const xRes = isDev(ctx.xDivXSubXi_ext);
+    const dX = xRes ? ctx.xDivXSubXi_ext.ptr : devTmp(3 * extN * nOpen);
     try {
         for (let i = 0; i < nOpen; i++)                                                      // :293-322
             addon.xDivXSubXiDev(ctx.nBitsExt, BigUint64Array.from(openingXi(ctx, ctx.pilInfo.openingPoints[i], false)), nOpen, i, dX);
-        download(ctx.xDivXSubXi_ext, dX, 3 * extN * nOpen);
-    } finally { addon.devFree(dX); }
+        if (!xRes) download(ctx.xDivXSubXi_ext, dX, 3 * extN * nOpen);
+    } finally { if (!xRes) addon.devFree(dX); }
     await callCalculateExps(stage, ctx.expressionsInfo.expressionsCode.find((e) => e.expId === ctx.pilInfo.friExpId).code, "ext", ctx,
                             options.parallelExec, options.useThreads, false);               // :324
+    if (isDev(ctx.f_ext)) { ctx.friPol[0] = ctx.f_ext; return; }     // resident: FRI.fold takes the device polynomial as it is
     ctx.friPol[0] = new Array(extN);
     for (let i = 0; i < extN; i++) {
         const g = (k) => (ctx.f_ext instanceof BigUint64Array ? ctx.f_ext[k] : ctx.f_ext.getElement(k));

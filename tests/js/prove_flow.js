@@ -18,6 +18,7 @@ const FRI = require(J("fri.js"));
 const { callCalculateExps } = require(J("prover_helpers.js"));
 const SGH = require(J("stark_gen_helpers.js"));
 const { buildZhInv } = require(J("polutils.js"));
+const { DevBuffer } = require(J("native.js"));
 
 const big = (v) => (Array.isArray(v) ? v.map(big) : (typeof v === "string" && /^[0-9]+$/.test(v) ? BigInt(v) : v));
 function bigProof(p) {      // golden proof: decimal strings -> BigInt, everything else untouched
@@ -26,30 +27,35 @@ function bigProof(p) {      // golden proof: decimal strings -> BigInt, everythi
     return typeof p === "string" ? BigInt(p) : p;
 }
 
-(async () => {
-    const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden/fib_flow.json")));
+async function prove(g, resident) {
+    // resident: every large buffer is a DevBuffer (HBM); the modules then work in place and only roots, evaluations,
+    // the last FRI polynomial and the opened rows ever reach the JS heap
+    const alloc = (n) => (resident ? new DevBuffer(n) : new BigUint64Array(n));
+    const fromHost = (a) => (resident ? DevBuffer.from(a) : a);
     const pilInfo = g.pilInfo, ss = pilInfo.starkStruct;
     const poseidon = getPoseidon(), MH = await buildMH(false);
     const nBits = ss.nBits, nBitsExt = ss.nBitsExt, N = 1 << nBits, extN = 1 << nBitsExt;
     const ctx = { prover: "stark", pilInfo, expressionsInfo: g.expressionsInfo, nBits, nBitsExt, extendBits: nBitsExt - nBits, N, extN, MH,
         publics: g.publics.map(BigInt), challenges: [[], [], [], []], evals: [], subproofValues: [], trees: [] };
     // setup (stark_buildConstTree.js:6-43) and initProverStark (stark_gen_helpers.js:104-160)
-    ctx.const_n = BigUint64Array.from(g.consts, BigInt);
-    ctx.const_ext = new BigUint64Array(pilInfo.nConstants * extN);
+    ctx.const_n = fromHost(g.consts instanceof BigUint64Array ? g.consts : BigUint64Array.from(g.consts, BigInt));
+    ctx.const_ext = alloc(pilInfo.nConstants * extN);
     await interpolate(ctx.const_n, pilInfo.nConstants, nBits, ctx.const_ext, nBitsExt);
     ctx.constTree = await MH.merkelize(ctx.const_ext, pilInfo.nConstants, extN);
     assert.deepStrictEqual(MH.root(ctx.constTree), g.constRoot.map(BigInt), "constant tree root");
-    ctx.cm1_n = BigUint64Array.from(g.cm1, BigInt);
-    ctx.cm1_ext = new BigUint64Array(pilInfo.mapSectionsN.cm1 * extN);
-    ctx.cm2_ext = new BigUint64Array(pilInfo.mapSectionsN.cm2 * extN);
-    ctx.q_ext = new BigUint64Array(pilInfo.qDim * extN);
-    ctx.f_ext = new BigUint64Array(3 * extN);
-    ctx.x_n = new BigUint64Array(N); ctx.x_ext = new BigUint64Array(extN);
-    ctx.Zi_ext = new BigUint64Array(pilInfo.boundaries.length * extN);
-    ctx.xDivXSubXi_ext = new BigUint64Array(3 * extN * pilInfo.openingPoints.length);
+    ctx.cm1_n = fromHost(g.cm1 instanceof BigUint64Array ? g.cm1 : BigUint64Array.from(g.cm1, BigInt));
+    ctx.cm1_ext = alloc(pilInfo.mapSectionsN.cm1 * extN);
+    ctx.cm2_ext = alloc(pilInfo.mapSectionsN.cm2 * extN);
+    ctx.q_ext = alloc(pilInfo.qDim * extN);
+    ctx.f_ext = alloc(3 * extN);
+    ctx.x_n = alloc(N); ctx.x_ext = alloc(extN);
+    ctx.Zi_ext = alloc(pilInfo.boundaries.length * extN);
+    ctx.xDivXSubXi_ext = alloc(3 * extN * pilInfo.openingPoints.length);
     SGH.buildXTables(ctx);
     buildZhInv(ctx.Zi_ext, 0, null, nBits, nBitsExt, true);
     ctx.fri = new FRI(ss, MH);
+    require(J("native.js")).addon.sync();
+    const tStart = process.hrtime.bigint();
     const transcript = new Transcript(poseidon);
     transcript.put(MH.root(ctx.constTree)); transcript.put(ctx.publics);                        // prover.js:148-189
     // stage 1: extendAndMerkelize (stark_gen_helpers.js:388-412)
@@ -79,6 +85,9 @@ function bigProof(p) {      // golden proof: decimal strings -> BigInt, everythi
     assert.deepStrictEqual(friQueries, g.queries, "query positions");
     ctx.fri.proofQueries(ctx.friProof, ctx.friTrees, friQueries.slice());
     const proof = { root1, root2, evals: ctx.evals, fri: ctx.friProof };                         // genProofStark :362-386
+    require(J("native.js")).addon.sync();
+    const seconds = Number(process.hrtime.bigint() - tStart) / 1e9;
+    if (!g.proof) return { proof, ctx, seconds };
     const want = bigProof(g.proof);
     assert.deepStrictEqual(ctx.challenges, bigProof(g.challenges), "challenges");
     assert.deepStrictEqual(proof.root1, want.root1, "root1");
@@ -86,5 +95,14 @@ function bigProof(p) {      // golden proof: decimal strings -> BigInt, everythi
     assert.deepStrictEqual(proof.evals, want.evals, "evals");
     assert.deepStrictEqual(proof.fri.length, want.fri.length);
     for (let s = 0; s < want.fri.length; s++) assert.deepStrictEqual(proof.fri[s], want.fri[s], "fri[" + s + "]");
+    if (resident) assert(ctx.trees[1].nodes instanceof DevBuffer && ctx.friTrees[1].nodes instanceof DevBuffer && ctx.friPol[1] instanceof DevBuffer);
+    return { proof, ctx, seconds };
+}
+module.exports = { prove };
+
+if (require.main === module) (async () => {
+    const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden/fib_flow.json")));
+    await prove(g, false);
+    await prove(g, true);
     console.log("prove flow OK");
 })().catch((e) => { console.error(e); process.exit(1); });

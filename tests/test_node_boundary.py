@@ -39,3 +39,11 @@ def test_whole_proof_driven_from_node():
     """prover.js's stage order over the JS drop-in modules: the proof equals the CPU checker's proof field by field"""
     out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "prove_flow.js")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "prove flow OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_config2_proof_from_node_device_resident():
+    """config 2's shape proved from Node with HBM-resident buffers: digest of the proof equals the CPU checker's"""
+    out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "prove_c2.js")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "prove c2 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]

@@ -158,6 +158,18 @@ def cpu_baseline(n_cols, split):
             "sample": "extend+merkelize of 2^%d x %d random trace, blow-up 8, OpenMP C oracle, %.1f s" % (n_bits, n_cols, t)}
 
 
+def load_pmc_lde_traffic():
+    """HBM bytes of ONE interpolate from the committed PMC summary: all ntt_pass_kernel + lde_mid_kernel launches of the
+    profiled run divided by the number of LDEs in it (one lde_mid launch each)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            sb = json.load(f)["_sum_bytes"]
+        n = sb["lde_mid_kernel"]["launches"]
+        return int((sb["lde_mid_kernel"]["bytes"] + sb["ntt_pass_kernel"]["bytes"]) / n)
+    except Exception:
+        return None
+
+
 def load_pmc_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/pmc_traffic.json), if any"""
     p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -328,6 +340,10 @@ def main():
             {"kernel": "interpolate (ntt_pass_kernel x / lde_mid_kernel)", "ms": t_lde, "alg_bytes": 8 * N * n_cols * (1 + (1 << EXT_BITS))},
             {"kernel": "merkle_level_kernel (first level)", "ms": t_lvl, "alg_bytes": 32 * E + 16 * E, "perms": E // 2},
         ]
+        if wl == "c3":                                          # the committed PMC passes were taken at config 3
+            kernels[0]["traffic"] = load_pmc_traffic("linear_hash_kernel")
+            kernels[1]["traffic"] = load_pmc_lde_traffic()
+            kernels[2]["traffic"] = load_pmc_traffic("merkle_level_kernel")
         for k in kernels:
             k["GBps"] = k["alg_bytes"] / k["ms"] / 1e6
             k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS

@@ -29,11 +29,12 @@ def main():
     fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
     res = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); bytes = "
                        "(2*FETCH_SIZE + WRITE_SIZE)*1024 of the largest launch of each kernel (gfx950 FETCH_SIZE correction, see tools/pmc_summary.py)",
-           "_raw_KB": {}}
+           "_raw_KB": {}, "_sum_bytes": {}}
     for k in sorted(set(fetch) | set(write)):
         f, w = fetch.get(k, [0.0]), write.get(k, [0.0])
         res["_raw_KB"][k] = {"FETCH_SIZE": [len(f), sum(f) / len(f), max(f)], "WRITE_SIZE": [len(w), sum(w) / len(w), max(w)]}
         res[k] = int((2 * max(f) + max(w)) * 1024)
+        res["_sum_bytes"][k] = {"launches": max(len(f), len(w)), "bytes": int((2 * sum(f) + sum(w)) * 1024)}
     out = sys.argv[3] if len(sys.argv) > 3 else "profiles/pmc_traffic.json"
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if not k.startswith("_")}, indent=1))

@@ -1,6 +1,11 @@
 // BN254 scalar field Fr for gfx950: eight 32-bit limbs, Montgomery form with R = 2^256 (the form wasmcurves' F1m keeps
-// in memory, so tree.nodes is byte-compatible with merklehash_bn128_p.js).  gfx950 has no 64-bit multiplier; every
-// step below is one v_mad_u64_u32 whose 64-bit result cannot overflow:  (2^32-1)^2 + 2*(2^32-1) = 2^64 - 1.
+// in memory, so tree.nodes is byte-compatible with merklehash_bn128_p.js).  gfx950 has no 64-bit multiplier: products are
+// accumulated COLUMN BY COLUMN (product scanning) into a 64-bit accumulator plus a carry word,
+//     v_mad_u64_u32  lo, vcc, x, y, lo        ; lo += x*y, carry-out in vcc
+//     v_addc_co_u32  hi, vcc, 0, hi, vcc      ; hi += carry
+// two instructions per 32x32 product.  The compiler never uses the multiply-add's carry-out (it re-derives carries with
+// 64-bit adds and compares: 4 instructions), hence the inline assembly; measured 10.2 against 12.8-15.3 issue cycles per
+// product (tools/bn_microbench.hip), results identical to the operand-scanning forms kept below as fr_mul_os / mac17_os.
 #pragma once
 #include <stdint.h>
 
@@ -52,8 +57,45 @@ __device__ __forceinline__ void fr_add(u32 a[8], const u32 b[8]) {
     for (int i = 0; i < 8; i++) a[i] = t[i];
 }
 
-// out = a * b / 2^256 mod r   (CIOS; a < 2^256, b < r  =>  out < r after one conditional subtraction)
+// (lo, hi) += x * y      /     (lo, hi) += x
+__device__ __forceinline__ void acc_mad(u64 &lo, u32 &hi, u32 x, u32 y) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ void acc_add(u64 &lo, u32 &hi, u32 x) {
+    asm("v_mad_u64_u32 %0, vcc, %2, 1, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x) : "vcc");
+}
+__device__ __forceinline__ void acc_shift(u64 &lo, u32 &hi) { lo = (lo >> 32) | ((u64)hi << 32); hi = 0; }
+
+// out = a * b / 2^256 mod r   (finely integrated product scanning; a < 2^256, b < r => out < r after one subtraction)
 __device__ __forceinline__ void fr_mul(u32 out[8], const u32 a[8], const u32 b[8]) {
+    u32 m[8], t[9], rl[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rl[i] = r_limb(i);
+    u64 lo = 0; u32 hi = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < i; j++) { acc_mad(lo, hi, a[j], b[i - j]); acc_mad(lo, hi, m[j], rl[i - j]); }
+        acc_mad(lo, hi, a[i], b[0]);
+        m[i] = (u32)lo * N0INV;
+        acc_mad(lo, hi, m[i], rl[0]);                // low word becomes 0
+        acc_shift(lo, hi);
+    }
+#pragma unroll
+    for (int i = 8; i < 16; i++) {
+#pragma unroll
+        for (int j = i - 7; j < 8; j++) { acc_mad(lo, hi, a[j], b[i - j]); acc_mad(lo, hi, m[j], rl[i - j]); }
+        t[i - 8] = (u32)lo;
+        acc_shift(lo, hi);
+    }
+    t[8] = (u32)lo;
+    if (ge_r<9>(t)) sub_r<9>(t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = t[i];
+}
+
+// operand-scanning (CIOS) form of the same product, compiler-generated carries (reference implementation for tests)
+__device__ __forceinline__ void fr_mul_os(u32 out[8], const u32 a[8], const u32 b[8]) {
     u32 t[10];
 #pragma unroll
     for (int i = 0; i < 10; i++) t[i] = 0;
@@ -74,8 +116,24 @@ __device__ __forceinline__ void fr_mul(u32 out[8], const u32 a[8], const u32 b[8
     for (int i = 0; i < 8; i++) out[i] = t[i];
 }
 
-// acc (17 limbs) += a * b   (the 512-bit product is formed in fresh limbs, then added with one carry chain)
+// acc (17 limbs) += a * b, column by column: column k takes the old limb k and the products a_j * b_(k-j)
 __device__ __forceinline__ void mac17(u32 acc[17], const u32 a[8], const u32 b[8]) {
+    u64 lo = 0; u32 hi = 0;
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        acc_add(lo, hi, acc[k]);
+#pragma unroll
+        for (int j = (k > 7 ? k - 7 : 0); j <= (k < 7 ? k : 7); j++) acc_mad(lo, hi, a[j], b[k - j]);
+        acc[k] = (u32)lo;
+        acc_shift(lo, hi);
+    }
+    acc_add(lo, hi, acc[15]);
+    acc[15] = (u32)lo;
+    acc_shift(lo, hi);
+    acc[16] += (u32)lo;
+}
+// operand-scanning form (reference implementation for tests)
+__device__ __forceinline__ void mac17_os(u32 acc[17], const u32 a[8], const u32 b[8]) {
     u32 p[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) p[i] = 0;
@@ -92,8 +150,36 @@ __device__ __forceinline__ void mac17(u32 acc[17], const u32 a[8], const u32 b[8
     acc[16] += (u32)c;
 }
 
-// Montgomery reduction of a 17-limb accumulator T < 32 * r^2:  out = T / 2^256 mod r
+// Montgomery reduction of a 17-limb accumulator T < 32 * r^2:  out = T / 2^256 mod r   (product scanning)
 __device__ __forceinline__ void redc17(u32 out[8], u32 acc[17]) {
+    u32 m[8], t[9], rl[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rl[i] = r_limb(i);
+    u64 lo = 0; u32 hi = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        acc_add(lo, hi, acc[k]);
+#pragma unroll
+        for (int j = 0; j < k; j++) acc_mad(lo, hi, m[j], rl[k - j]);
+        m[k] = (u32)lo * N0INV;
+        acc_mad(lo, hi, m[k], rl[0]);
+        acc_shift(lo, hi);
+    }
+#pragma unroll
+    for (int k = 8; k < 16; k++) {
+        acc_add(lo, hi, acc[k]);
+#pragma unroll
+        for (int j = k - 7; j < 8; j++) acc_mad(lo, hi, m[j], rl[k - j]);
+        t[k - 8] = (u32)lo;
+        acc_shift(lo, hi);
+    }
+    t[8] = (u32)lo + acc[16];                        // T/2^256 + r < 2^261: the ninth limb cannot overflow
+    for (int k = 0; k < 34 && ge_r<9>(t); k++) sub_r<9>(t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = t[i];
+}
+// operand-scanning form (reference implementation for tests)
+__device__ __forceinline__ void redc17_os(u32 out[8], u32 acc[17]) {
     u32 top = 0;                                     // carry out of limb 16 (T + m*r*2^(32i) < 2^544 + ..., one bit)
 #pragma unroll
     for (int i = 0; i < 8; i++) {

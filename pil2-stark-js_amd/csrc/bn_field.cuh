@@ -45,14 +45,51 @@ __device__ __forceinline__ void sub_r(u32 *a) {
     }
 }
 
+// t (9 limbs, t < 2^288) -> t - r if t >= r, else t; only limbs 0..7 of the result are kept (callers guarantee < 2^256 then).
+// One borrow chain through vcc and eight selects instead of the compare-then-subtract the compiler generates.
+__device__ __forceinline__ void cond_sub_r(u32 t[9]) {
+    u32 d0, d1, d2, d3, d4, d5, d6, d7, d8;
+    // the limbs of r travel in VGPRs: a literal and the vcc borrow-in would both need the single constant-bus slot
+    asm("v_sub_co_u32 %0, vcc, %9, %18\n\t"
+        "v_subb_co_u32 %1, vcc, %10, %19, vcc\n\t"
+        "v_subb_co_u32 %2, vcc, %11, %20, vcc\n\t"
+        "v_subb_co_u32 %3, vcc, %12, %21, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %13, %22, vcc\n\t"
+        "v_subb_co_u32 %5, vcc, %14, %23, vcc\n\t"
+        "v_subb_co_u32 %6, vcc, %15, %24, vcc\n\t"
+        "v_subb_co_u32 %7, vcc, %16, %25, vcc\n\t"
+        "v_subbrev_co_u32 %8, vcc, 0, %17, vcc\n\t"          // final borrow in vcc: t < r
+        "v_cndmask_b32 %0, %0, %9, vcc\n\t"
+        "v_cndmask_b32 %1, %1, %10, vcc\n\t"
+        "v_cndmask_b32 %2, %2, %11, vcc\n\t"
+        "v_cndmask_b32 %3, %3, %12, vcc\n\t"
+        "v_cndmask_b32 %4, %4, %13, vcc\n\t"
+        "v_cndmask_b32 %5, %5, %14, vcc\n\t"
+        "v_cndmask_b32 %6, %6, %15, vcc\n\t"
+        "v_cndmask_b32 %7, %7, %16, vcc\n\t"
+        "v_cndmask_b32 %8, %8, %17, vcc"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7), "=&v"(d8)
+        : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(t[8]),
+          "v"(r_limb(0)), "v"(r_limb(1)), "v"(r_limb(2)), "v"(r_limb(3)), "v"(r_limb(4)), "v"(r_limb(5)), "v"(r_limb(6)), "v"(r_limb(7)) : "vcc");
+    t[0] = d0; t[1] = d1; t[2] = d2; t[3] = d3; t[4] = d4; t[5] = d5; t[6] = d6; t[7] = d7; t[8] = d8;
+}
+
 // a = a + b mod r   (a, b < r)
 __device__ __forceinline__ void fr_add(u32 a[8], const u32 b[8]) {
     u32 t[9];
-    u64 c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { c += (u64)a[i] + b[i]; t[i] = (u32)c; c >>= 32; }
-    t[8] = (u32)c;
-    if (ge_r<9>(t)) sub_r<9>(t);
+    asm("v_add_co_u32 %0, vcc, %9, %17\n\t"
+        "v_addc_co_u32 %1, vcc, %10, %18, vcc\n\t"
+        "v_addc_co_u32 %2, vcc, %11, %19, vcc\n\t"
+        "v_addc_co_u32 %3, vcc, %12, %20, vcc\n\t"
+        "v_addc_co_u32 %4, vcc, %13, %21, vcc\n\t"
+        "v_addc_co_u32 %5, vcc, %14, %22, vcc\n\t"
+        "v_addc_co_u32 %6, vcc, %15, %23, vcc\n\t"
+        "v_addc_co_u32 %7, vcc, %16, %24, vcc\n\t"
+        "v_addc_co_u32 %8, vcc, 0, 0, vcc"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8])
+        : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]),
+          "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+    cond_sub_r(t);
 #pragma unroll
     for (int i = 0; i < 8; i++) a[i] = t[i];
 }
@@ -89,7 +126,7 @@ __device__ __forceinline__ void fr_mul(u32 out[8], const u32 a[8], const u32 b[8
         acc_shift(lo, hi);
     }
     t[8] = (u32)lo;
-    if (ge_r<9>(t)) sub_r<9>(t);
+    cond_sub_r(t);
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = t[i];
 }
@@ -174,7 +211,9 @@ __device__ __forceinline__ void redc17(u32 out[8], u32 acc[17]) {
         acc_shift(lo, hi);
     }
     t[8] = (u32)lo + acc[16];                        // T/2^256 + r < 2^261: the ninth limb cannot overflow
-    for (int k = 0; k < 34 && ge_r<9>(t); k++) sub_r<9>(t);
+    // T < 17 r^2 in every caller (at most 17 products): T/2^256 + r < 17*0.19 r + r < 5 r, so five subtractions at most
+#pragma unroll
+    for (int k = 0; k < 5; k++) cond_sub_r(t);
 #pragma unroll
     for (int i = 0; i < 8; i++) out[i] = t[i];
 }

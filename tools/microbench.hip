@@ -26,6 +26,35 @@ __device__ __forceinline__ u64 mul_v3(u64 a, u64 b) {
     u64 w = (u64)a1 * b1 + (u >> 32) + (v >> 32);
     return reduce128_v3((v << 32) | (u32)t, w);
 }
+// ---- carry-flag variant: product by columns with the multiply-add's carry-out, reduction on borrow/carry chains
+__device__ __forceinline__ void acc_mad64(u64 &lo, u32 &hi, u32 x, u32 y) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(lo), "+v"(hi) : "v"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ u64 mul_cf(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    u64 acc = t >> 32; u32 hi = 0;
+    acc_mad64(acc, hi, a0, b1);
+    acc_mad64(acc, hi, a1, b0);
+    const u32 w1 = (u32)acc;
+    acc = (acc >> 32) | ((u64)hi << 32);
+    acc = (u64)a1 * b1 + acc;                                   // cannot overflow: the full product is < 2^128
+    const u32 w2 = (u32)acc, w3 = (u32)(acc >> 32);
+    const u64 lo = ((u64)w1 << 32) | (u32)t;
+    // lo + w2*EPS - w3 with the wraps folded back: carry -> +EPS, borrow -> -EPS
+    u64 r; u32 c, br, rl, rh;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc" : "=&v"(r), "=&v"(c) : "v"(w2), "v"(lo) : "vcc");
+    rl = (u32)r; rh = (u32)(r >> 32);
+    asm("v_sub_co_u32 %0, vcc, %0, %3\n\tv_subbrev_co_u32 %1, vcc, 0, %1, vcc\n\tv_subb_co_u32 %2, vcc, %4, 0, vcc"
+        : "+v"(rl), "+v"(rh), "=&v"(br) : "v"(w3), "v"(c) : "vcc");
+    // br = c - 0 - borrow  in {-1, 0, 1} (two's complement): the net number of 2^64 wraps still to add back as EPS
+    // r += br * EPS:  br = +1 -> r + EPS = (lo - 1, hi + 1 - borrow);  br = -1 -> r - EPS = (lo - 0xFFFFFFFF, hi - borrow)
+    const u32 e = 0u - ((br + 1u) >> 1);                         // 0xFFFFFFFF when br = +1, else 0
+    asm("v_sub_co_u32 %0, vcc, %0, %2\n\tv_subb_co_u32 %1, vcc, %1, %3, vcc" : "+v"(rl), "+v"(rh) : "v"(br), "v"(e) : "vcc");
+    return ((u64)rh << 32) | rl;
+}
+__device__ __forceinline__ u64 pow7_cf(u64 x) { u64 x2 = mul_cf(x, x), x3 = mul_cf(x2, x), x4 = mul_cf(x2, x2); return mul_cf(x3, x4); }
+
 __device__ __forceinline__ u64 pow7_v3(u64 x) { u64 x2 = mul_v3(x, x), x3 = mul_v3(x2, x), x4 = mul_v3(x2, x2); return mul_v3(x3, x4); }
 
 // MDS via v_dot2_u32_u16 on 16-bit limb planes
@@ -111,6 +140,8 @@ __global__ void __launch_bounds__(256) k_ops(uint64_t *out, int iters, uint64_t 
             if (OP == 15) { a0 = __builtin_amdgcn_perm(a0, b0, 0x05040100); b0 = __builtin_amdgcn_perm(b0, c0, 0x07060302); c0 = __builtin_amdgcn_perm(c0, d0, 0x05040100); d0 = __builtin_amdgcn_perm(d0, a0, 0x07060302) + 1; }
             if (OP == 16) { a = pow7_v3(a); b = pow7_v3(b); c = pow7_v3(c); d = pow7_v3(d); }
             if (OP == 17) { a0 = __umul24(a0, b0) + c0; b0 = b0 * 3 + d0; c0 = (c0 << 3) + a0; d0 = d0 ^ b0; }
+            if (OP == 18) { a = mul_cf(a, b); b = mul_cf(b, c); c = mul_cf(c, d); d = mul_cf(d, a); }
+            if (OP == 19) { a = pow7_cf(a); b = pow7_cf(b); c = pow7_cf(c); d = pow7_cf(d); }
             if (OP == 9) { a0 = __mulhi((int)a0, (int)b0) + 1; b0 = (a0 << 3) + c0; c0 = (b0 >> 5) ^ d0; d0 = c0 + a0; }
         }
     }
@@ -143,10 +174,15 @@ float timeit(F f) {
 int main() {
     uint64_t *out; CHECK(hipMalloc((void **)&out, 8ull * 256 * 4096));
     const int blocks = 256 * 8, iters = 2000;
-    const char *names[] = { "mul_lazy (GL mul)", "mad_u64_u32", "mul_lo_u32+add", "mul_hi_u32+add", "mul_u24+add", "add_lazy", "add u64", "pow7_lazy", "canon add/sub", "misc32", "mul_v3", "add_c/sub_c", "add_lazy_c", "udot2", "udot4", "v_perm", "pow7_v3", "4 simple" };
-    const double per[] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32 };   // ops per thread per iter
+    const char *names[] = { "mul_lazy (GL mul)", "mad_u64_u32", "mul_lo_u32+add", "mul_hi_u32+add", "mul_u24+add", "add_lazy", "add u64", "pow7_lazy", "canon add/sub", "misc32", "mul_v3", "add_c/sub_c", "add_lazy_c", "udot2", "udot4", "v_perm", "pow7_v3", "4 simple", "mul_cf (carry flags)", "pow7_cf" };
+    const double per[] = { 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32, 32 };   // ops per thread per iter
 #define RUN(OP) { float ms = timeit([&] { hipLaunchKernelGGL(k_ops<OP>, dim3(blocks), dim3(256), 0, 0, out, iters, 12345ull); }); \
     double ops = (double)blocks * 256 * iters * per[OP]; printf("%-20s %8.3f ms  %8.2f Gop/s  (%.2f cyc/wave-op/SIMD @2.4GHz)\n", names[OP], ms, ops / ms / 1e6, 2.4e9 * 1024 * 64 / (ops / (ms * 1e-3))); }
+    RUN(18) RUN(19)
+    { uint64_t *hv = (uint64_t *)malloc(8 * 256), *hw = (uint64_t *)malloc(8 * 256);
+      hipLaunchKernelGGL(k_ops<0>, dim3(1), dim3(256), 0, 0, out, 3, 0xFFFFFFFF00000000ull); hipMemcpy(hv, out, 2048, hipMemcpyDeviceToHost);
+      hipLaunchKernelGGL(k_ops<18>, dim3(1), dim3(256), 0, 0, out, 3, 0xFFFFFFFF00000000ull); hipMemcpy(hw, out, 2048, hipMemcpyDeviceToHost);
+      int bad = 0; for (int i = 0; i < 256; i++) bad += (hv[i] % 0xFFFFFFFF00000001ull) != (hw[i] % 0xFFFFFFFF00000001ull); printf("mul_cf == mul_lazy (mod p): %s\n", bad ? "NO" : "yes"); }
     RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15) RUN(16) RUN(17)
     RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9)
     { uint64_t h[3][64]; int it = 3;

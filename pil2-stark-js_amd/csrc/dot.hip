@@ -169,12 +169,15 @@ __global__ void __launch_bounds__(256) cols_dot_kernel(ColsDotParams P) {
         for (int q = 0; q < 3; q++)
             P.partial[((chunk * P.nLev + l) * P.width + c) * 3 + q] = fold6(S[l][q]);
 }
-__global__ void cols_dot_final_kernel(const u64 *__restrict__ partial, u64 nChunks, u64 n /* nLev*width*3 */, u64 *__restrict__ out) {
+// sums chunks [blockIdx.y * per, ...) of partial[nChunks][n] into out[blockIdx.y][n]; run twice (nChunks -> <=64 groups -> 1)
+// so that the reduction over thousands of chunks is not left to n threads
+__global__ void cols_dot_final_kernel(const u64 *__restrict__ partial, u64 nChunks, u64 per, u64 n /* nLev*width*3 */, u64 *__restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const u64 c0 = (u64)blockIdx.y * per, c1 = min(nChunks, c0 + per);
     u64 acc = 0;
-    for (u64 ch = 0; ch < nChunks; ch++) acc = add(acc, partial[ch * n + i]);
-    out[i] = acc;
+    for (u64 ch = c0; ch < c1; ch++) acc = add(acc, partial[ch * n + i]);
+    out[(u64)blockIdx.y * n + i] = acc;
 }
 // canonical u64 -> three 22/22/20-bit limbs
 __global__ void limbs_kernel(const u64 *__restrict__ in, u64 n, u32 *__restrict__ out) {
@@ -247,9 +250,10 @@ int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
     const u32 rpc = 1024;
     const u64 nChunks = (nRows + rpc - 1) / rpc, n = (u64)nLev * width * 3;
     u64 *d;
-    P2_TRY(scratch(7, ((u64)nLev * nRows * 9 * 4 + 7) / 8 + nChunks * n + n + 1, &d));
+    const u64 nGroups = std::min<u64>(64, nChunks), per = (nChunks + nGroups - 1) / nGroups;
+    P2_TRY(scratch(7, ((u64)nLev * nRows * 9 * 4 + 7) / 8 + nChunks * n + nGroups * n + n + 1, &d));
     u32 *limbs = (u32 *)d;
-    u64 *partial = d + ((u64)nLev * nRows * 9 * 4 + 7) / 8, *res = partial + nChunks * n;
+    u64 *partial = d + ((u64)nLev * nRows * 9 * 4 + 7) / 8, *part2 = partial + nChunks * n, *res = part2 + nGroups * n;
     for (u32 l = 0; l < nLev; l++) limbs_kernel<<<nblk(nRows * 3), 256, 0, st>>>(levs[l], nRows * 3, limbs + (u64)l * nRows * 9);
     ColsDotParams P = { buf, width, nRows, rowStep, limbs, nLev, partial, rpc };
     const u32 threads = (u32)std::min<u64>(256, (width + 63) / 64 * 64);
@@ -260,7 +264,8 @@ int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
     case 3: cols_dot_kernel<3><<<grid, threads, 0, st>>>(P); break;
     default: cols_dot_kernel<4><<<grid, threads, 0, st>>>(P); break;
     }
-    cols_dot_final_kernel<<<nblk(n), 256, 0, st>>>(partial, nChunks, n, res);
+    cols_dot_final_kernel<<<dim3(nblk(n), (unsigned)nGroups), 256, 0, st>>>(partial, nChunks, per, n, part2);
+    cols_dot_final_kernel<<<dim3(nblk(n), 1), 256, 0, st>>>(part2, (nChunks + per - 1) / per, nGroups, n, res);
     KERNEL_CHECK();
     HIP_TRY(hipMemcpyAsync(hostOut, res, n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));

@@ -101,13 +101,38 @@ __global__ void q_split_kernel(const u64 *__restrict__ qq1, u32 nBits, u32 nBits
     const u64 p = r / qDim, k = r - p * qDim;
     qq2[o] = mul(qq1[(p * N + i) * qDim + k], sPow[p]);
 }
-// stark_gen_helpers.js:302-322: (x_k - xi)^-1 * x_k with F.sub(scalar, triple) (f3g.js:66)
-__global__ void x_div_x_sub_xi_kernel(u32 nBitsExt, E3 xi, u64 nOpen, u64 iOpen, const u64 *__restrict__ powW, u64 *__restrict__ out) {
-    const u64 k = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= (1ull << nBitsExt)) return;
-    const u64 x = mul(7, root_pow(powW, nBitsExt, (u32)k));
-    E3 den = { { sub(x, xi.v[0]), neg(xi.v[1]), neg(xi.v[2]) } };
-    st3(out + 3 * (k * nOpen + iOpen), e3_scale(e3_inv(den), x));
+// stark_gen_helpers.js:302-322: (x_k - xi)^-1 * x_k with F.sub(scalar, triple) (f3g.js:66).
+// A lane takes XD_BATCH rows k, k+T, k+2T, ... (T = threads in the grid: neighbouring lanes stay on neighbouring rows) and
+// inverts their denominators with ONE extension inversion (Montgomery's trick, the device form of the reference's
+// F.batchInverse :316); x advances by the constant w_E^T from row to row.
+constexpr int XD_BATCH = 8;
+__global__ void x_div_x_sub_xi_kernel(u32 nBitsExt, E3 xi, u64 nOpen, u64 iOpen, const u64 *__restrict__ powW, u64 wStep, u64 *__restrict__ out) {
+    const u64 E = 1ull << nBitsExt, T = (u64)gridDim.x * blockDim.x;
+    const u64 k0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k0 >= E) return;
+    u64 xs[XD_BATCH];
+    E3 den[XD_BATCH], pre[XD_BATCH];
+    u64 x = mul(7, root_pow(powW, nBitsExt, (u32)k0));
+    int n = 0;
+#pragma unroll
+    for (int i = 0; i < XD_BATCH; i++) {
+        if (k0 + (u64)i * T < E) {
+            xs[i] = x;
+            den[i] = E3{ { sub(x, xi.v[0]), neg(xi.v[1]), neg(xi.v[2]) } };
+            pre[i] = i ? e3_mul(pre[i - 1], den[i]) : den[i];
+            x = mul(x, wStep);
+            n = i + 1;
+        }
+    }
+    E3 inv = e3_inv(pre[n - 1]);
+#pragma unroll
+    for (int i = XD_BATCH - 1; i >= 0; i--) {
+        if (i < n) {
+            const E3 di = i ? e3_mul(inv, pre[i - 1]) : inv;
+            if (i) inv = e3_mul(inv, den[i]);
+            st3(out + 3 * ((k0 + (u64)i * T) * nOpen + iOpen), e3_scale(di, xs[i]));
+        }
+    }
 }
 // stark_gen_helpers.js:216-229: lev[k] = xi^k; xiPow[b] = xi^(2^b)
 __global__ void lev_pow_kernel(u32 nBits, const u64 *__restrict__ xiPow, u64 *__restrict__ lev) {
@@ -294,7 +319,11 @@ int pil2gl_x_div_x_sub_xi_dev(uint32_t nBitsExt, const uint64_t xi[3], uint64_t 
     P2_TRY(ensure_init());
     if (!xi || !out || iOpen >= nOpen || nBitsExt > 31) return fail(PIL2GL_EINVAL, "bad xDivXSubXi arguments");
     E3 x = { { xi[0], xi[1], xi[2] } };
-    x_div_x_sub_xi_kernel<<<nblk(1ull << nBitsExt), 256, 0, as_stream(stream)>>>(nBitsExt, x, nOpen, iOpen, tables().powW, out);
+    const u64 E = 1ull << nBitsExt;
+    const unsigned blocks = nblk((E + XD_BATCH - 1) / XD_BATCH);
+    const u64 T = (u64)blocks * 256;
+    const u64 wStep = h_pow(h_root(nBitsExt), T);                                   // w_E^T
+    x_div_x_sub_xi_kernel<<<blocks, 256, 0, as_stream(stream)>>>(nBitsExt, x, nOpen, iOpen, tables().powW, wStep, out);
     KERNEL_CHECK();
     return PIL2GL_OK;
 }

@@ -1,64 +1,32 @@
-// Drop-in for src/helpers/transcript/transcript.bn128.js (:1-106); `poseidon` is the BigInt form exported by
-// merklehash_bn128_p.js, so F.e / F.toObject are the identity here.
+// Drop-in for src/helpers/transcript/transcript.bn128.js (constructor (poseidon, nInputs); put, getField, getFields1,
+// getFields253, getState, getPermutations).  `poseidon` is the BigInt form exported by ./merklehash_bn128_p.js (no F.e /
+// F.toObject needed).  Rate nInputs, nInputs+1 outputs per permutation, output 0 is the new state; a challenge limb is
+// one of the three low 64-bit words of an output, and 253 bits of an output feed the query indices.
 "use strict";
-const { poseidon: defaultPoseidon } = require("./merklehash_bn128_p.js");
+const { Duplex, indicesFromFields, absorbAll } = require("./transcript_core.js");
+const { poseidon: devicePoseidon } = require("./merklehash_bn128_p.js");
+const W64 = 0xFFFFFFFFFFFFFFFFn;
 
-class Transcript {
+module.exports = class Transcript {
     constructor(poseidon, nInputs) {
         if (typeof poseidon === "number") { nInputs = poseidon; poseidon = undefined; }
-        this.poseidon = poseidon || defaultPoseidon;
+        this.poseidon = poseidon || devicePoseidon;
         this.nInputs = nInputs || 16;
-        this.state = 0n;
-        this.pending = []; this.out = []; this.out3 = [];
+        this.limbs = [];                        // 64-bit words of the output currently being cut up (the reference's out3)
+        // a permutation drops limbs still waiting (transcript.bn128.js:62); absorbing alone does not (:78-83)
+        this.core = new Duplex((block, st) => this.poseidon(block, st, this.nInputs + 1), this.nInputs, 0n, (out) => out[0], () => { this.limbs = []; });
     }
-    getState() { if (this.pending.length > 0) this.updateState(); return this.state; }
-    getField() { return [this.getFields1(), this.getFields1(), this.getFields1()]; }
+    get state() { return this.core.state; }
+    put(a) { absorbAll(this.core, a, BigInt); }
+    getFields253() { return this.core.next(); }
     getFields1() {
-        if (this.out3.length > 0) return this.out3.shift();
-        if (this.out.length > 0) {
-            const v = this.out.shift();
-            this.out3[0] = v & 0xFFFFFFFFFFFFFFFFn;
-            this.out3[1] = (v >> 64n) & 0xFFFFFFFFFFFFFFFFn;
-            this.out3[2] = (v >> 128n) & 0xFFFFFFFFFFFFFFFFn;
-            return this.getFields1();
+        if (this.limbs.length === 0) {
+            const v = this.core.next();         // may permute, which clears limbs: take the output first, cut it after
+            this.limbs = [v & W64, (v >> 64n) & W64, (v >> 128n) & W64];
         }
-        this.updateState();
-        return this.getFields1();
+        return this.limbs.shift();
     }
-    getFields253() {
-        if (this.out.length > 0) return this.out.shift();
-        this.updateState();
-        return this.getFields253();
-    }
-    updateState() {
-        while (this.pending.length < this.nInputs) this.pending.push(0n);
-        this.out = this.poseidon(this.pending, this.state, this.nInputs + 1);
-        this.out3 = []; this.pending = [];
-        this.state = this.out[0];
-    }
-    put(a) { if (Array.isArray(a)) { for (let i = 0; i < a.length; i++) this.put(a[i]); } else this._add1(a); }
-    _add1(a) {
-        this.out = [];
-        this.pending.push(BigInt(a));
-        if (this.pending.length == this.nInputs) this.updateState();
-    }
-    getPermutations(n, nBits) {
-        const res = [];
-        const totalBits = n * nBits;
-        const NFields = Math.floor((totalBits - 1) / 253) + 1;
-        const fields = [];
-        for (let i = 0; i < NFields; i++) fields[i] = this.getFields253();
-        let curField = 0, curBit = 0n;
-        for (let i = 0; i < n; i++) {
-            let a = 0;
-            for (let j = 0; j < nBits; j++) {
-                if ((fields[curField] >> curBit) & 1n) a = a + (1 << j);
-                curBit++;
-                if (curBit == 253n) { curBit = 0n; curField++; }
-            }
-            res.push(a);
-        }
-        return res;
-    }
-}
-module.exports = Transcript;
+    getField() { return [this.getFields1(), this.getFields1(), this.getFields1()]; }
+    getState() { return this.core.settle(); }
+    getPermutations(n, nBits) { return indicesFromFields(() => this.core.next(), n, nBits, 253); }
+};

@@ -13,8 +13,15 @@ class OracleBackend:
     """same interface as pil2gl.stark.GpuBackend, numpy arrays + oracle functions"""
     name = "oracle"
 
-    def __init__(self, split=False):
-        self.split = split
+    def __init__(self, split=False, hash_type="GL", arity=16, custom=False):
+        self.split, self.hash_type, self.arity, self.custom = split, hash_type, arity, custom
+
+    def new_transcript(self):
+        if self.hash_type == "BN128":
+            import bn128_oracle
+            return bn128_oracle.TranscriptBN128(self.arity if self.custom else 16)
+        from pil2gl.stark import Transcript
+        return Transcript(self)
 
     def empty(self, n): return np.zeros(int(n), np.uint64)
     def zeros(self, n): return np.zeros(int(n), np.uint64)
@@ -59,13 +66,24 @@ class OracleBackend:
     def from_torch(self, t): return t.cpu().numpy().view(np.uint64)
 
     def merkelize(self, buf, w, h):
+        if self.hash_type == "BN128":
+            import bn128_oracle
+            rows = [[int(v) for v in r] for r in buf.reshape(h, w)]
+            return {"elements": buf, "nodes": bn128_oracle.merkelize(rows, self.arity, self.custom), "width": w, "height": h}
         return {"elements": buf, "nodes": orc.merkelize(buf.reshape(h, w), self.split), "width": w, "height": h}
 
-    def root(self, tree): return [int(v) for v in tree["nodes"][-4:]]
+    def root(self, tree):
+        if self.hash_type == "BN128":
+            return int(tree["nodes"][-1])
+        return [int(v) for v in tree["nodes"][-4:]]
 
     def group_proof(self, tree, idx):
         w = tree["width"]
-        return [int(v) for v in tree["elements"][idx * w:(idx + 1) * w]], [[int(x) for x in s] for s in orc.group_proof(tree["nodes"], tree["height"], idx)]
+        vals = [int(v) for v in tree["elements"][idx * w:(idx + 1) * w]]
+        if self.hash_type == "BN128":
+            import bn128_oracle
+            return vals, bn128_oracle.group_proof(tree["nodes"], tree["height"], self.arity, idx)
+        return vals, [[int(x) for x in s] for s in orc.group_proof(tree["nodes"], tree["height"], idx)]
 
     def group_proofs(self, tree, idxs): return [self.group_proof(tree, i) for i in idxs]
 

@@ -72,13 +72,21 @@ def _pow3(x, e):
     return r
 
 
-def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcript=True):
-    from pil2gl.stark import Transcript, root_of_unity, SHIFT
+def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcript=True, hash_type="GL", arity=16, custom=False):
+    from pil2gl.stark import root_of_unity, SHIFT
     proof, publics = res["proof"], res["publics"]
     ss = info["starkStruct"]; nb, nbe = ss["nBits"], ss["nBitsExt"]; N = 1 << nb; steps = ss["steps"]
-    be = OracleBackend(split)
+    be = OracleBackend(split, hash_type, arity, custom)
+
+    def path_root(vals, idx, sib):
+        """calculateRootFromGroupProof of the tree kind in use (merklehash_p.js:170-210 / merklehash_bn128_p.js:184-232)"""
+        if hash_type == "BN128":
+            import bn128_oracle
+            return bn128_oracle.root_from_group_proof(sib, idx, [int(v) for v in vals], arity, custom)
+        return [int(v) for v in orc.root_from_proof(np.array(vals, dtype=np.uint64), idx, np.array(sib, dtype=np.uint64), split)]
+    same_root = (lambda a, b: int(a) == int(b)) if hash_type == "BN128" else (lambda a, b: list(a) == list(b))
     # transcript replay, calculateTranscriptVerify.js:7-103 (nStages = 1)
-    t = Transcript(be)
+    t = be.new_transcript()
     t.put(constRoot); t.put(publics)
     t.put(proof["root1"])
     vc = t.getField(); t.put(proof["root2"])
@@ -97,7 +105,7 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
     chF.append(t.getField())
     if check_transcript and not ([vc] == res["challenges"][1] and [xi] == res["challenges"][2] and [vf1, vf2] == res["challenges"][3] and chF == res["challengesFRISteps"]):
         return False, "transcript does not reproduce the challenges"
-    tq = Transcript(be); tq.put(chF[-1])
+    tq = be.new_transcript(); tq.put(chF[-1])
     queries = tq.getPermutations(ss["nQueries"], steps[0]["nBits"])
     if check_transcript and queries != res["queries"]:
         return False, "query positions differ"
@@ -129,7 +137,7 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
     for qi, idx in enumerate(queries):
         pq = proof["fri"][0]["polQueries"][qi]
         for (vals, sib), root in zip(pq, (proof["root1"], proof["root2"], constRoot)):
-            if [int(v) for v in orc.root_from_proof(np.array(vals, dtype=np.uint64), idx, np.array(sib, dtype=np.uint64), split)] != list(root):
+            if not same_root(path_root(vals, idx, sib), root):
                 return False, "Invalid root (query %d)" % qi
         x = SHIFT * pow(wE, idx, P) % P
         xdiv = []
@@ -160,7 +168,7 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
                 ev = val
             else:
                 vals, sib = proof["fri"][si]["polQueries"][qi]
-                if [int(v) for v in orc.root_from_proof(np.array(vals, dtype=np.uint64), cur_idx, np.array(sib, dtype=np.uint64), split)] != list(proof["fri"][si]["root"]):
+                if not same_root(path_root(vals, cur_idx, sib), proof["fri"][si]["root"]):
                     return False, "Invalid FRI root step %d" % si
                 g = np.array(vals, dtype=np.uint64).reshape(-1, 3)
                 sinv = pow(shift * pow(root_of_unity(pol_bits), cur_idx, P) % P, P - 2, P)

@@ -124,3 +124,44 @@ def test_config3_size_proof_verifies(oracle):
     assert ok, why
     # and the witness it proves really is K Fibonacci machines ending in the public output
     assert len(res["proof"]["evals"]) > 0 and res["publics"] == publics
+
+
+def _bn_case(n_bits=5, pairs=1):
+    from pil2gl import stark
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 4, "verificationHashType": "BN128", "steps": [{"nBits": n_bits + 3}, {"nBits": 4}]}
+    info, exprs, vinfo = stark.fibonacci_air(pairs, ss)
+    cm, consts, publics = stark.fibonacci_trace(n_bits, pairs)
+    return stark, info, exprs, vinfo, cm, consts, publics
+
+
+@pytest.mark.parametrize("arity,custom", [(16, False), (4, True)])
+def test_bn128_proof_on_oracle_backend_verifies(oracle, arity, custom):
+    """verificationHashType BN128 (stark_gen_helpers.js:95-99): BN128 trees and transcript in the same stage loop"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _bn_case()
+    be = stark_ref.OracleBackend(False, "BN128", arity, custom)
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    assert isinstance(res["proof"]["root1"], int) and len(res["proof"]["fri"][0]["polQueries"][0][0][1][0]) == arity
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo, hash_type="BN128", arity=arity, custom=custom)
+    assert ok, why
+    bad = {**res, "proof": {**res["proof"], "root2": res["proof"]["root2"] ^ 1}}
+    assert not stark_ref.stark_verify(bad, setup["constRoot"], info, vinfo, hash_type="BN128", arity=arity, custom=custom)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("arity,custom,n_bits,pairs", [(16, False, 5, 1), (4, True, 5, 1), (8, False, 6, 3)])
+def test_gpu_bn128_proof_is_identical_to_oracle_proof(oracle, arity, custom, n_bits, pairs):
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _bn_case(n_bits, pairs)
+    gpu = stark.GpuBackend(0, False, "BN128", arity, custom)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    cpu = stark_ref.OracleBackend(False, "BN128", arity, custom)
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, publics)
+    assert s_gpu["constRoot"] == s_cpu["constRoot"]
+    assert r_gpu["challenges"] == r_cpu["challenges"] and r_gpu["queries"] == r_cpu["queries"]
+    assert r_gpu["proof"] == r_cpu["proof"]
+    ok, why = stark_ref.stark_verify(r_gpu, s_gpu["constRoot"], info, vinfo, hash_type="BN128", arity=arity, custom=custom)
+    assert ok, why

@@ -59,6 +59,9 @@ class OracleBackend:
         leaves = np.stack([p.cpu().numpy().view(np.uint64).reshape(N, cc * 4) for p in parts], axis=1).reshape(-1)
         return self.merkelize_digests(leaves, N * cc * world)
 
+    def merkle_siblings(self, nodes, height, idxs):
+        return [[[int(x) for x in s] for s in orc.group_proof(nodes, height, i)] for i in idxs]
+
     def as_torch(self, t):
         import torch
         return torch.from_numpy(np.ascontiguousarray(t).view(np.int64))

@@ -95,3 +95,140 @@ def open_rows(be, stree, idxs, group=None):
     x = out if dist.get_backend(group) == "nccl" or not out.is_cuda else out.cpu()
     dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
     return x.cpu().numpy().view(np.uint64)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# One proof over several GPUs: every rank runs the same transcript (all absorbed values are
+# replicated), the big stage-1 objects stay split by cosets, and three small exchanges complete the proof:
+#   all-gather of leaf digests (commit), all-gather of q on the extended domain (3 words per row), all-gather of the FRI
+#   polynomial (3 words per row); the evaluations come from the rank that owns coset 0.
+# A local slice holds rows (pos, jl) = full row pos*2^b + cosetBegin + jl, pos-major; "next row" (prime 1 = +2^b rows) is
+# +cosetCount rows in a slice, so the evaluator runs on it with its prime shift set to log2(cosetCount).
+def _log2(n):
+    b = n.bit_length() - 1
+    if 1 << b != n:
+        raise ValueError("%d is not a power of two" % n)
+    return b
+
+
+def coset_slice(be, full, n_bits, ext_bits, cb, cc, width):
+    """rows of cosets [cb, cb+cc) of a full (2^(n+b) x width) buffer, in local-slice order"""
+    t = be.as_torch(full).reshape(1 << n_bits, 1 << ext_bits, width)
+    return be.from_torch(t[:, cb:cb + cc, :].contiguous().reshape(-1))
+
+
+def all_gather_rows(be, local, n_bits, cc, width, group=None):
+    """local slices (N*cc rows x width) of every rank -> the full buffer in natural row order, on every rank"""
+    world = dist.get_world_size(group)
+    mine = _comm_tensor(be, local, group).reshape(-1)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(parts, mine, group=group)
+    N = 1 << n_bits
+    full = torch.stack([p.reshape(N, cc * width) for p in parts], dim=1).reshape(-1)      # [N][world][cc*width]
+    return be.from_torch(full)
+
+
+def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None):
+    """pil2gl.stark.stark_gen with stage 1, the constraint evaluation and the FRI polynomial split by cosets over the
+    ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
+    single-process one.  Not sharded yet: the Q commitment and the FRI folding run replicated (small next to stage 1)."""
+    from . import stark as S
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ss = info["starkStruct"]
+    nb, nbe = ss["nBits"], ss["nBitsExt"]
+    eb, N, E = nbe - nb, 1 << ss["nBits"], 1 << ss["nBitsExt"]
+    cb, cc = coset_range(rank, world, eb)
+    lb = _log2(cc)
+    nloc = nb + lb                                              # local slices have 2^nloc rows
+    qDim, qDeg = info["qDim"], info["qDeg"]
+    nCm1, nQ, nC = info["mapSectionsN"]["cm1"], info["mapSectionsN"]["cm2"], info["nConstants"]
+    assert info["nStages"] == 1 and ss["steps"][0]["nBits"] == nbe
+    ctx = {"pilInfo": info, "publics": list(publics), "challenges": [[], [], [], []], "evals": []}
+    constTree = setup["constTree"]
+    transcript = be.new_transcript()
+    transcript.put(setup["constRoot"]); transcript.put(publics)
+
+    # stage 1, split by cosets; the tree (all nodes) is on every rank, the rows are not
+    st = extend_and_merkelize_sharded(be, cm1_n, nCm1, nb, nbe, group)
+    root1 = be.root({"nodes": st["nodes"]}); transcript.put(root1)
+
+    # quotient: the constraint expression on the local rows, then one all-gather of q
+    ctx["challenges"][1] = [transcript.getField()]
+    sl = lambda full, w: coset_slice(be, full, nb, eb, cb, cc, w)
+    loc = {"const_ext": sl(constTree["elements"], nC), "cm1_ext": st["local"], "x_ext": sl(be.build_x(nbe, S.SHIFT), 1),
+           "Zi_ext#0": sl(be.build_zhinv(nb, nbe), 1), "q_ext": be.empty(qDim << nloc)}
+    widths = {"const_ext": nC, "cm1_ext": nCm1, "cm2_ext": nQ, "q_ext": qDim, "f_ext": 3, "x_ext": 1, "Zi_ext#0": 1,
+              "xDivXSubXi_ext": 3 * len(info["openingPoints"])}
+
+    def run_local(code):
+        ops, n_tmp, secs, scalars = S.encode_code(code["code"], "ext", ctx)
+        be.eval_program(ops, n_tmp, [(loc[s], widths[s]) for s in secs], scalars, nloc, lb)
+    run_local(exprs["expressionsCode"][info["cExpId"]]["code"])
+    q_ext = all_gather_rows(be, loc["q_ext"], nb, cc, qDim, group)
+    del loc["q_ext"]
+    # computeQStark (stark_gen_helpers.js:168-208), replicated
+    qq1 = be.empty(qDim << nbe)
+    be.ifft(q_ext, qDim, nbe, qq1)
+    qq2 = be.q_split(qq1, nb, nbe, qDim, qDeg)
+    cm2_ext = be.empty(nQ << nbe)
+    be.fft(qq2, nQ, nbe, cm2_ext)
+    del qq1, qq2, q_ext
+    tree2 = be.merkelize(cm2_ext, nQ, E)
+    root2 = be.root(tree2); transcript.put(root2)
+    loc["cm2_ext"] = sl(cm2_ext, nQ)
+
+    # evaluations: only rows k << b are read, i.e. coset 0: its owner computes them and everybody receives them
+    xi = transcript.getField()
+    ctx["challenges"][2] = [xi]
+    wN = S.root_of_unity(nb)
+    xis, n_ev = [], len(info["evMap"])
+    for opening in info["openingPoints"]:
+        w = pow(wN, abs(opening), S.P)
+        if opening < 0:
+            w = S._inv(w)
+        xis.append(S.ext_scale(xi, w))
+    ev_t = torch.zeros(n_ev * 3, dtype=torch.int64)
+    if cb == 0:
+        levs = [be.build_lev(nb, S.ext_scale(x, S._inv(S.SHIFT))) for x in xis]
+        descs = []
+        for ev in info["evMap"]:
+            li = info["openingPoints"].index(ev["prime"])
+            if ev["type"] == "const":
+                descs.append((loc["const_ext"], nC, ev["id"], 1, li))
+            else:
+                p = info["cmPolsMap"][ev["id"]]
+                descs.append((loc["cm%d_ext" % p["stage"]], widths["cm%d_ext" % p["stage"]], p["stagePos"], p["dim"], li))
+        evals = be.compute_evals(descs, nb, lb, levs)          # row k of the domain is local row k << log2(cc)
+        ev_t = torch.from_numpy(np.array(evals, dtype=np.uint64).reshape(-1).view(np.int64).copy())
+        del levs
+    owner = 0                                                   # coset 0 always belongs to rank 0
+    if dist.get_backend(group) == "nccl":
+        ev_t = ev_t.to(be.as_torch(loc["cm1_ext"]).device)
+    dist.broadcast(ev_t, src=owner, group=group)
+    ctx["evals"] = [[int(v) for v in r] for r in ev_t.cpu().numpy().view(np.uint64).reshape(n_ev, 3)]
+    for ev in ctx["evals"]:
+        transcript.put(ev)
+
+    # FRI polynomial on the local rows, then one all-gather
+    ctx["challenges"][3] = [transcript.getField(), transcript.getField()]
+    loc["xDivXSubXi_ext"] = sl(be.x_div_x_sub_xi(nbe, xis), widths["xDivXSubXi_ext"])
+    loc["f_ext"] = be.empty(3 << nloc)
+    if not (hasattr(be, "fri_polynomial_fast") and be.fri_polynomial_fast(info, loc, widths, ctx["evals"], ctx["challenges"][3][0], ctx["challenges"][3][1], nloc, loc["f_ext"])):
+        run_local(exprs["expressionsCode"][info["friExpId"]]["code"])
+    f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, group)
+
+    # folding and its trees, replicated; openings: stage-1 rows from their owners, everything else is local
+    friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, f_ext, transcript)
+    chq = transcript.getField(); challengesFRI.append(chq)
+    tq = be.new_transcript(); tq.put(chq)
+    queries = tq.getPermutations(ss["nQueries"], ss["steps"][0]["nBits"])
+    rows1 = open_rows(be, st, queries, group)
+    sib1 = be.merkle_siblings(st["nodes"], E, queries)
+    p2, pc = be.group_proofs(tree2, queries), be.group_proofs(constTree, queries)
+    friProof[0]["polQueries"] = [[[[int(v) for v in rows1[i]], sib1[i]], list(p2[i]), list(pc[i])] for i in range(len(queries))]
+    q = list(queries)
+    for step in range(1, len(ss["steps"])):
+        q = [qi % (1 << ss["steps"][step]["nBits"]) for qi in q]
+        friProof[step]["polQueries"] = [list(p_) for p_ in be.group_proofs(friTrees[step], q)]
+    proof = {"root1": root1, "root2": root2, "evals": ctx["evals"], "fri": friProof}
+    return {"proof": proof, "publics": list(publics), "challenges": ctx["challenges"], "challengesFRISteps": challengesFRI, "queries": queries}

@@ -17,9 +17,12 @@ def _free_port():
     return p
 
 
-def _launch(world, *args, timeout=600):
+PROVE_WORKER = os.path.join(ROOT, "tests", "workers", "sharded_prove_worker.py")
+
+
+def _launch(world, *args, timeout=600, worker=None):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), WORKER, *args]
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), worker or WORKER, *args]
     env = dict(os.environ, OMP_NUM_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
@@ -54,3 +57,16 @@ def test_sharded_commit_gloo_cpu(oracle, world, split):
 @pytest.mark.parametrize("world,nbits,npols", [(2, 10, 9), (4, 13, 33)])
 def test_sharded_commit_gpu_ranks(oracle, world, nbits, npols):
     _launch(world, "--backend", "gpu", "--nbits", str(nbits), "--extbits", "3", "--npols", str(npols))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_proof_equals_single_process_proof_cpu(oracle, world):
+    """one proof over `world` ranks (commit, constraint evaluation and FRI polynomial split by cosets; q, evaluations and
+    the FRI polynomial exchanged): every rank ends with the proof of the ordinary prove loop, bit for bit"""
+    _launch(world, "--backend", "oracle", worker=PROVE_WORKER)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,nbits,pairs,steps", [(2, 8, 3, "11,7,3"), (4, 10, 20, "13,9,4")])
+def test_sharded_proof_gpu_ranks(oracle, world, nbits, pairs, steps):
+    _launch(world, "--backend", "gpu", "--nbits", str(nbits), "--pairs", str(pairs), "--steps", steps, worker=PROVE_WORKER)

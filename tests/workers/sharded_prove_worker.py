@@ -1,0 +1,53 @@
+"""One rank of the sharded-proof test (launched by tests/test_parallel.py under torch.distributed.run): every rank runs
+pil2gl.parallel.stark_gen_sharded and compares the proof it receives with the proof of the ordinary single-process prove
+loop on the same backend -- they must be identical, field by field.
+--backend oracle : CPU checker backend over gloo (host logic of the partition: slices, gathers, evaluation owner, openings)
+--backend gpu    : the HIP library on cuda:0 for every rank, exchange over gloo"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
+
+import torch.distributed as dist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--backend", default="oracle")
+    ap.add_argument("--nbits", type=int, default=6)
+    ap.add_argument("--pairs", type=int, default=2)
+    ap.add_argument("--steps", default="9,5,2")
+    a = ap.parse_args()
+    dist.init_process_group("gloo")
+    rank = dist.get_rank()
+    import gl_oracle as orc
+    orc.build(); orc.set_threads(2)
+    from pil2gl import stark, parallel
+    steps = [int(x) for x in a.steps.split(",")]
+    ss = {"nBits": a.nbits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
+    info, exprs, _ = stark.fibonacci_air(a.pairs, ss)
+    cm, consts, publics = stark.fibonacci_trace(a.nbits, a.pairs)
+    if a.backend == "gpu":
+        be = stark.GpuBackend(0)
+    else:
+        from stark_backend import OracleBackend
+        be = OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    got = parallel.stark_gen_sharded(be, be.from_host(cm), setup, info, exprs, publics)
+    want = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    for k in ("challenges", "challengesFRISteps", "queries", "publics"):
+        assert got[k] == want[k], "rank %d: %s differ" % (rank, k)
+    for k in ("root1", "root2", "evals"):
+        assert got["proof"][k] == want["proof"][k], "rank %d: proof.%s differs" % (rank, k)
+    assert got["proof"]["fri"] == want["proof"]["fri"], "rank %d: FRI part of the proof differs" % rank
+    dist.barrier()
+    dist.destroy_process_group()
+    print("rank %d ok" % rank)
+
+
+if __name__ == "__main__":
+    main()

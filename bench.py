@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("PIL2GL_BENCH_WORKLOAD", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default=os.environ.get("PIL2GL_BENCH_MODE", "prove"), choices=["prove", "commit", "commit-sharded"])
+    ap.add_argument("--mode", default=os.environ.get("PIL2GL_BENCH_MODE", "prove"), choices=["prove", "commit", "commit-sharded", "prove-sharded"])
     ap.add_argument("--split", action="store_true", help="splitLinearHash leaves (linearhash_gpu.js)")
     ap.add_argument("--shard-of", type=int, default=0, help="commit-sharded on ONE GPU: run rank 0's share of a K-GPU job (per-GPU time/memory rehearsal, e.g. --workload c5 --shard-of 8)")
     return ap.parse_args()
@@ -211,10 +211,47 @@ def rehearse_shard(args):
                       "peak_torch_GB": torch.cuda.max_memory_allocated() / 1e9, "device_GB_in_use_at_end": (total - free) / 1e9}), flush=True)
 
 
+def rehearse_prove(args):
+    """--mode prove-sharded --shard-of K on one GPU: rank 0's share of a K-GPU sharded proof (own slices standing in for the
+    gathered q / FRI polynomial / digests; the evaluations are computed here anyway because rank 0 owns coset 0)"""
+    import pil2gl
+    from pil2gl import stark, parallel
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    n_bits, n_cols = WORKLOADS[args.workload] if args.workload in WORKLOADS else (int(v) for v in args.workload.lower().split("x"))
+    n_cols -= n_cols & 1
+    K = args.shard_of
+    fri_steps = [n_bits + EXT_BITS]
+    while fri_steps[-1] > 10:
+        fri_steps.append(max(fri_steps[-1] - 5, 6))
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + EXT_BITS, "nQueries": 64, "verificationHashType": "GL", "splitLinearHash": bool(args.split),
+          "steps": [{"nBits": b} for b in fri_steps]}
+    info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
+    be = stark.GpuBackend(0, args.split)
+    src, consts, publics = fibonacci_trace_gpu(torch, dev, n_bits, n_cols // 2, 0)
+    setup = stark.build_const_tree(be, consts, info)
+    times = []
+    for i in range(args.warmup + args.steps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        parallel.stark_gen_sharded(be, src, setup, info, exprs, publics, rehearse_world=K)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        if i >= args.warmup:
+            times.append(dt)
+    dt = sum(times) / len(times)
+    print(json.dumps({"metric": "per-GPU time of ONE proof split over %d GPUs (rank 0's share run alone, exchanges stood in)" % K,
+                      "value": (1 << n_bits) * n_cols / dt, "unit": "trace-cells/s (the job rate if the %d ranks run in parallel and the exchanges are free)" % K,
+                      "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "u64", "data": "synthetic",
+                      "config": {"workload": "full proof of 2^%d rows x %d cols, blow-up 8, %d of %d cosets on this GPU" % (n_bits, n_cols, (1 << EXT_BITS) // K, 1 << EXT_BITS),
+                                 "mode": "prove-sharded rehearsal", "shard_of": K},
+                      "peak_torch_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+
+
 def main():
     args = parse()
     if args.mode == "commit-sharded" and args.shard_of:
         return rehearse_shard(args)
+    if args.mode == "prove-sharded" and args.shard_of:
+        return rehearse_prove(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -223,7 +260,7 @@ def main():
     local_rank %= max(1, torch.cuda.device_count())            # rehearsing N ranks on fewer GPUs: ranks share devices
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or (args.mode == "commit-sharded" and not args.shard_of):
+    if world > 1 or (args.mode in ("commit-sharded", "prove-sharded") and not args.shard_of):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -247,7 +284,8 @@ def main():
     N, E = 1 << n_bits, 1 << (n_bits + EXT_BITS)
 
     prove_ctx = None
-    if args.mode == "prove":
+    prove_sharded = args.mode == "prove-sharded"
+    if args.mode in ("prove", "prove-sharded"):
         from pil2gl import stark
         n_cols -= n_cols & 1                                   # pairs of columns
         fri_steps = [n_bits + EXT_BITS]
@@ -257,7 +295,7 @@ def main():
               "splitLinearHash": bool(args.split), "steps": [{"nBits": b} for b in fri_steps]}
         info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
         be = stark.GpuBackend(local_rank, args.split)
-        src, consts, publics = fibonacci_trace_gpu(torch, dev, n_bits, n_cols // 2, rank)
+        src, consts, publics = fibonacci_trace_gpu(torch, dev, n_bits, n_cols // 2, 0 if prove_sharded else rank)   # sharded: ONE trace
         setup = stark.build_const_tree(be, consts, info)
         prove_ctx = (stark, be, setup, info, exprs, publics)
     elif args.mode == "commit-sharded":                        # ONE trace, replicated; the cosets of its extension are split
@@ -280,6 +318,10 @@ def main():
     def step():
         if prove_ctx is not None:
             stark_, be_, setup_, info_, exprs_, publics_ = prove_ctx
+            if prove_sharded:
+                from pil2gl import parallel
+                parallel.stark_gen_sharded(be_, src, setup_, info_, exprs_, publics_)
+                return
             stark_.stark_gen(be_, src, setup_, info_, exprs_, publics_, timings=stage_times if collect[0] else None)
             return
         if sharded:
@@ -312,10 +354,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = (1 if sharded else world) * N * n_cols / (dt / args.steps)
-    if sharded and rank == 0:
+    value = (1 if (sharded or prove_sharded) else world) * N * n_cols / (dt / args.steps)
+    if (sharded or prove_sharded) and rank == 0:
         dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
-    if prove_ctx is not None and rank == 0:                    # one more, untimed-for-value, proof with a per-stage breakdown
+    if prove_ctx is not None and rank == 0 and not prove_sharded:   # one more, untimed-for-value, proof with a per-stage breakdown
         collect[0] = True
         step(); torch.cuda.synchronize()
         collect[0] = False
@@ -355,8 +397,9 @@ def main():
                     "note": "Poseidon hashing is integer-ALU bound (no 64-bit multiplier on gfx950); its HBM fraction is small by nature, see kernels[]"}
         if prove_ctx is not None:
             metric = "STARK prove time (ms_per_step) and trace-cells/s, synthetic Fibonacci AIR, GL Poseidon Merkle + FRI, blow-up 8"
-            workload = "full proof (commit, Q, evals, FRI %s, %d queries) of 2^%d rows x %d cols -> 2^%d rows, %s linear hash, per GPU" % (
-                "/".join(str(x["nBits"]) for x in prove_ctx[3]["starkStruct"]["steps"]), prove_ctx[3]["starkStruct"]["nQueries"], n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain")
+            workload = "full proof (commit, Q, evals, FRI %s, %d queries) of 2^%d rows x %d cols -> 2^%d rows, %s linear hash, %s" % (
+                "/".join(str(x["nBits"]) for x in prove_ctx[3]["starkStruct"]["steps"]), prove_ctx[3]["starkStruct"]["nQueries"], n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain",
+                "ONE proof split by cosets over the GPUs (q, evaluations, FRI polynomial exchanged)" if prove_sharded else "per GPU")
         elif sharded:
             metric = "trace-cells/s, STARK commit step (extend+merkelize) of ONE trace split by cosets over the GPUs, GL Poseidon Merkle, blow-up 8"
             workload = "extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, %s linear hash, %d of 8 cosets per GPU + all-gather of leaf digests" % (
@@ -367,11 +410,11 @@ def main():
         out = {
             "metric": metric,
             "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded else "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (sharded or prove_sharded) else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "mode": args.mode,
                        "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "GL-Poseidon-12",
-                       "parallelism": ("coset-sharded x%d" % world) if sharded else ("replicas x%d" % world if world > 1 else "single GPU")},
+                       "parallelism": ("coset-sharded x%d" % world) if (sharded or prove_sharded) else ("replicas x%d" % world if world > 1 else "single GPU")},
             "roofline": roofline, "kernels": kernels,
         }
         if prove_ctx is not None:

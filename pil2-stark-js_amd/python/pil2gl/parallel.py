@@ -117,23 +117,32 @@ def coset_slice(be, full, n_bits, ext_bits, cb, cc, width):
     return be.from_torch(t[:, cb:cb + cc, :].contiguous().reshape(-1))
 
 
-def all_gather_rows(be, local, n_bits, cc, width, group=None):
+def all_gather_rows(be, local, n_bits, cc, width, group=None, rehearse_world=None):
     """local slices (N*cc rows x width) of every rank -> the full buffer in natural row order, on every rank"""
-    world = dist.get_world_size(group)
-    mine = _comm_tensor(be, local, group).reshape(-1)
-    parts = [torch.empty_like(mine) for _ in range(world)]
-    dist.all_gather(parts, mine, group=group)
+    if rehearse_world:                                          # one-GPU rehearsal: own slice stands in for the others
+        mine = be.as_torch(local).reshape(-1)
+        parts = [mine] * rehearse_world
+    else:
+        world = dist.get_world_size(group)
+        mine = _comm_tensor(be, local, group).reshape(-1)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
     N = 1 << n_bits
     full = torch.stack([p.reshape(N, cc * width) for p in parts], dim=1).reshape(-1)      # [N][world][cc*width]
     return be.from_torch(full)
 
 
-def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None):
+def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None):
     """pil2gl.stark.stark_gen with stage 1, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
-    single-process one.  Not sharded yet: the Q commitment and the FRI folding run replicated (small next to stage 1)."""
+    single-process one.  Not sharded yet: the Q commitment and the FRI folding run replicated (small next to stage 1).
+    rehearse_world=K: rank 0's share of a K-rank proof run alone (own slices stand in for the gathered ones, so the
+    result is not a valid proof): per-GPU time and memory on one GPU."""
     from . import stark as S
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if rehearse_world:
+        rank, world = 0, int(rehearse_world)
+    else:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
     ss = info["starkStruct"]
     nb, nbe = ss["nBits"], ss["nBitsExt"]
     eb, N, E = nbe - nb, 1 << ss["nBits"], 1 << ss["nBitsExt"]
@@ -149,7 +158,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None):
     transcript.put(setup["constRoot"]); transcript.put(publics)
 
     # stage 1, split by cosets; the tree (all nodes) is on every rank, the rows are not
-    st = extend_and_merkelize_sharded(be, cm1_n, nCm1, nb, nbe, group)
+    st = extend_and_merkelize_sharded(be, cm1_n, nCm1, nb, nbe, group, rehearse_world=rehearse_world)
     root1 = be.root({"nodes": st["nodes"]}); transcript.put(root1)
 
     # quotient: the constraint expression on the local rows, then one all-gather of q
@@ -164,7 +173,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None):
         ops, n_tmp, secs, scalars = S.encode_code(code["code"], "ext", ctx)
         be.eval_program(ops, n_tmp, [(loc[s], widths[s]) for s in secs], scalars, nloc, lb)
     run_local(exprs["expressionsCode"][info["cExpId"]]["code"])
-    q_ext = all_gather_rows(be, loc["q_ext"], nb, cc, qDim, group)
+    q_ext = all_gather_rows(be, loc["q_ext"], nb, cc, qDim, group, rehearse_world)
     del loc["q_ext"]
     # computeQStark (stark_gen_helpers.js:168-208), replicated
     qq1 = be.empty(qDim << nbe)
@@ -202,9 +211,10 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None):
         ev_t = torch.from_numpy(np.array(evals, dtype=np.uint64).reshape(-1).view(np.int64).copy())
         del levs
     owner = 0                                                   # coset 0 always belongs to rank 0
-    if dist.get_backend(group) == "nccl":
-        ev_t = ev_t.to(be.as_torch(loc["cm1_ext"]).device)
-    dist.broadcast(ev_t, src=owner, group=group)
+    if not rehearse_world:
+        if dist.get_backend(group) == "nccl":
+            ev_t = ev_t.to(be.as_torch(loc["cm1_ext"]).device)
+        dist.broadcast(ev_t, src=owner, group=group)
     ctx["evals"] = [[int(v) for v in r] for r in ev_t.cpu().numpy().view(np.uint64).reshape(n_ev, 3)]
     for ev in ctx["evals"]:
         transcript.put(ev)
@@ -215,14 +225,14 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None):
     loc["f_ext"] = be.empty(3 << nloc)
     if not (hasattr(be, "fri_polynomial_fast") and be.fri_polynomial_fast(info, loc, widths, ctx["evals"], ctx["challenges"][3][0], ctx["challenges"][3][1], nloc, loc["f_ext"])):
         run_local(exprs["expressionsCode"][info["friExpId"]]["code"])
-    f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, group)
+    f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, group, rehearse_world)
 
     # folding and its trees, replicated; openings: stage-1 rows from their owners, everything else is local
     friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, f_ext, transcript)
     chq = transcript.getField(); challengesFRI.append(chq)
     tq = be.new_transcript(); tq.put(chq)
     queries = tq.getPermutations(ss["nQueries"], ss["steps"][0]["nBits"])
-    rows1 = open_rows(be, st, queries, group)
+    rows1 = open_rows(be, st, queries, group) if not rehearse_world else np.zeros((len(queries), nCm1), np.uint64)
     sib1 = be.merkle_siblings(st["nodes"], E, queries)
     p2, pc = be.group_proofs(tree2, queries), be.group_proofs(constTree, queries)
     friProof[0]["polQueries"] = [[[[int(v) for v in rows1[i]], sib1[i]], list(p2[i]), list(pc[i])] for i in range(len(queries))]

@@ -69,6 +69,11 @@ int pil2gl_interpolate_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, 
  * One slice per GPU is the multi-GPU partition of extendAndMerkelize; the full range equals interpolate. */
 int pil2gl_interpolate_cosets_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
                                   uint32_t cosetBegin, uint32_t cosetCount, void *stream);
+/* The slice [cosetBegin, cosetBegin+cosetCount) of the PLAIN extension of the columns: src holds their evaluations on the
+ * size-2^nBits subgroup, dst row (pos, j - cosetBegin) = row (pos << b) + j of fft(nBitsExt) applied to their zero-padded
+ * coefficients (no coset shift).  This is how a rank extends its part of the split quotient (stark_gen_helpers.js:192). */
+int pil2gl_extend_cosets_unshifted_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
+                                       uint32_t cosetBegin, uint32_t cosetCount, void *stream);
 /* Same with a caller-provided workspace of 2^nBits x nPols words for the coefficient matrix instead of the library's own
  * scratch; workspace == src is allowed (src is then overwritten): at config 5 a rank holds the 107 GB trace and its
  * 107 GB coset slice and nothing else. */

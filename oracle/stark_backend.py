@@ -39,6 +39,12 @@ class OracleBackend:
         full = orc.interpolate(src.reshape(-1, C), nb, nbe).reshape(1 << nb, 1 << (nbe - nb), C)
         dst[:] = full[:, cb:cb + cc, :].reshape(-1)
 
+    def extend_cosets_unshifted(self, src, C, nb, dst, nbe, cb, cc):
+        coef = orc.ifft_cols(src.reshape(-1, C), nb)
+        pad = np.zeros((1 << nbe, C), np.uint64); pad[:1 << nb] = coef
+        full = orc.fft_cols(pad, nbe).reshape(1 << nb, 1 << (nbe - nb), C)
+        dst[:] = full[:, cb:cb + cc, :].reshape(-1)
+
     def linear_hash_rows(self, buf, w, h):
         return np.concatenate([orc.linear_hash(buf[i * w:(i + 1) * w], self.split) for i in range(h)])
 

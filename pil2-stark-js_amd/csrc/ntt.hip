@@ -190,7 +190,7 @@ __global__ void lde_mid_kernel(LdeParams P) {
         u32 pos = (gt * P.G + (idx >> k)) * K + (idx & (K - 1));
         u32 m = bitrev32(pos, P.n);                 // this row holds coefficient m of the column polynomial
         Uc[idx] = root_pow(P.twf, P.n + P.extBits, m);   // w_E^m : step from coset j to j+1
-        u64 s0 = mul(P.ninv, pow256(P.pow7, m));    // 7^m / N              (coset j = 0)
+        u64 s0 = P.pow7 ? mul(P.ninv, pow256(P.pow7, m)) : P.ninv;    // shift^m / N  (coset j = 0; shift 7, or 1 when pow7 is null)
         if (P.cosetBegin) s0 = mul(s0, root_pow(P.twf, P.n + P.extBits, m * P.cosetBegin));   // (w_E^m)^cosetBegin, m*cb < 2^(n+b)
         Sc[idx] = s0;
     }
@@ -319,7 +319,7 @@ int ntt_launch(const u64 *src, u64 C, u32 n, u64 *dst, bool inverse, hipStream_t
     return PIL2GL_OK;
 }
 
-int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st, u32 cosetBegin, u32 cosetCount, u64 *work) {
+int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st, u32 cosetBegin, u32 cosetCount, u64 *work, bool unitShift) {
     if (C == 0) return PIL2GL_OK;
     u32 eb = nExt - n;
     if (cosetCount == 0) { cosetBegin = 0; cosetCount = 1u << eb; }
@@ -350,7 +350,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
     // 2. mid kernel: last kf iNTT stages + coset scaling + first kf NTT stages, tmp -> dst
     {
         LdeParams P;
-        P.src = coef; P.dst = dst; P.twi = tables().powWi; P.twf = tables().powW; P.pow7 = tables().pow7;
+        P.src = coef; P.dst = dst; P.twi = tables().powWi; P.twf = tables().powW; P.pow7 = unitShift ? nullptr : tables().pow7;
         P.C = C; P.ninv = h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb;
         P.cosetBegin = cosetBegin; P.cosetCount = cosetCount;
         u64 totalGroups = 1ull << (n - kf);
@@ -421,20 +421,28 @@ extern "C" {
 int pil2gl_interpolate_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt, void *stream) {
     P2_TRY(ensure_init());
     P2_TRY(check_ntt_args(src, dst, nBits, nBitsExt));
-    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), 0, 0, nullptr);
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), 0, 0, nullptr, false);
 }
 int pil2gl_interpolate_cosets_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
                                   uint32_t cosetBegin, uint32_t cosetCount, void *stream) {
     P2_TRY(ensure_init());
     P2_TRY(check_coset_args(src, dst, nBits, nBitsExt, cosetBegin, cosetCount));
-    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount, nullptr);
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount, nullptr, false);
+}
+// the same slice of the PLAIN extension (evaluations on w_E^j <w_N>, no coset shift): rows (pos << b) + j of fft_E applied to
+// the zero-padded coefficients of the columns -- how computeQStark extends its split quotient (stark_gen_helpers.js:192)
+int pil2gl_extend_cosets_unshifted_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
+                                       uint32_t cosetBegin, uint32_t cosetCount, void *stream) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_coset_args(src, dst, nBits, nBitsExt, cosetBegin, cosetCount));
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount, nullptr, true);
 }
 int pil2gl_interpolate_cosets_ws_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
                                      uint32_t cosetBegin, uint32_t cosetCount, uint64_t *workspace, void *stream) {
     P2_TRY(ensure_init());
     P2_TRY(check_coset_args(src, dst, nBits, nBitsExt, cosetBegin, cosetCount));
     if (!workspace) return fail(PIL2GL_EINVAL, "null workspace");
-    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount, workspace);
+    return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount, workspace, false);
 }
 int pil2gl_fft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, void *stream) {
     P2_TRY(ensure_init());
@@ -459,7 +467,7 @@ static int host_wrap(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64
     int rc = PIL2GL_OK;
     e = hipMemcpy(dIn, src, nIn * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
-    if (rc == PIL2GL_OK) rc = mode == 0 ? lde_launch(dIn, nPols, nBits, dOut, nBitsOut, 0, 0, 0, nullptr) : ntt_launch(dIn, nPols, nBits, dOut, mode == 2, 0);
+    if (rc == PIL2GL_OK) rc = mode == 0 ? lde_launch(dIn, nPols, nBits, dOut, nBitsOut, 0, 0, 0, nullptr, false) : ntt_launch(dIn, nPols, nBits, dOut, mode == 2, 0);
     if (rc == PIL2GL_OK) { e = hipMemcpy(dst, dOut, nOut * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
     (void)hipFree(dIn); (void)hipFree(dOut);
     return rc;

@@ -62,6 +62,7 @@ SIGNATURES = {
     "pil2gl_interpolate": (_I, [vp, _U64, _U32, vp, _U32]),
     "pil2gl_interpolate_dev": (_I, [vp, _U64, _U32, vp, _U32, vp]),
     "pil2gl_interpolate_cosets_dev": (_I, [vp, _U64, _U32, vp, _U32, _U32, _U32, vp]),
+    "pil2gl_extend_cosets_unshifted_dev": (_I, [vp, _U64, _U32, vp, _U32, _U32, _U32, vp]),
     "pil2gl_interpolate_cosets_ws_dev": (_I, [vp, _U64, _U32, vp, _U32, _U32, _U32, vp, vp]),
     "pil2gl_fft": (_I, [vp, _U64, _U32, vp]),
     "pil2gl_ifft": (_I, [vp, _U64, _U32, vp]),

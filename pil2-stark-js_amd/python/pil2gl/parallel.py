@@ -39,6 +39,23 @@ def _comm_tensor(be, t, group):
     return x
 
 
+def commit_local_slice(be, local, width, n_bits, cc, world, group=None, rehearse_world=None):
+    """leaf digests of a rank's slice (N*cc rows x width), all-gathered and interleaved into natural leaf order, then the
+    levels above them -> the complete node array, on every rank"""
+    N = 1 << n_bits
+    digests = be.linear_hash_rows(local, width, N * cc)              # [N*cc][4], local row = pos*cc + jl
+    if rehearse_world:
+        mine = be.as_torch(digests).reshape(-1)
+        gathered = [mine] * world
+    else:
+        mine = _comm_tensor(be, digests, group).reshape(-1)
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine, group=group)
+    # part r is [N][cc*4]; leaf index = pos*2^eb + r*cc + jl (natural row order of the extension), written straight into
+    # the node array (no stacked / permuted copies: at config 5 the leaf level alone is 17 GB)
+    return be.merkelize_digest_parts(gathered, N, cc)
+
+
 def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None, overwrite_src=False, rehearse_world=None):
     """Sharded extendAndMerkelize.  `src` = the full N x n_pols trace on every rank.
     Returns {"local": N x (cc*n_pols) slice (row pos, coset jl, col c), "nodes": full tree.nodes, "width", "height",
@@ -56,18 +73,8 @@ def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None
     N = 1 << n_bits
     local = be.empty(N * cc * n_pols)
     be.interpolate_cosets(src, n_pols, n_bits, local, n_bits_ext, cb, cc, src if overwrite_src else None)
-    digests = be.linear_hash_rows(local, n_pols, N * cc)             # [N*cc][4], local row = pos*cc + jl
-    if rehearse_world:
-        mine = be.as_torch(digests).reshape(-1)
-        gathered = [mine] * world
-    else:
-        mine = _comm_tensor(be, digests, group).reshape(-1)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine, group=group)
-    # part r is [N][cc*4]; leaf index = pos*2^eb + r*cc + jl (natural row order of the extension), written straight into
-    # the node array (no stacked / permuted copies: at config 5 the leaf level alone is 17 GB)
+    nodes = commit_local_slice(be, local, n_pols, n_bits, cc, world, group, rehearse_world)
     height = N << eb
-    nodes = be.merkelize_digest_parts(gathered, N, cc)
     return {"local": local, "nodes": nodes, "width": n_pols, "height": height,
             "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
 
@@ -135,7 +142,7 @@ def all_gather_rows(be, local, n_bits, cc, width, group=None, rehearse_world=Non
 def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None):
     """pil2gl.stark.stark_gen with stage 1, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
-    single-process one.  Not sharded yet: the Q commitment and the FRI folding run replicated (small next to stage 1).
+    single-process one.  Replicated: the iNTT of q, the levels of the trees above the leaves, and the FRI folding.
     rehearse_world=K: rank 0's share of a K-rank proof run alone (own slices stand in for the gathered ones, so the
     result is not a valid proof): per-GPU time and memory on one GPU."""
     from . import stark as S
@@ -175,16 +182,21 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     run_local(exprs["expressionsCode"][info["cExpId"]]["code"])
     q_ext = all_gather_rows(be, loc["q_ext"], nb, cc, qDim, group, rehearse_world)
     del loc["q_ext"]
-    # computeQStark (stark_gen_helpers.js:168-208), replicated
+    # computeQStark (stark_gen_helpers.js:168-208): the iNTT of q needs all of q and is replicated (3 columns); the split
+    # quotient has degree < N per column, so its extension is again "one coset per rank": evaluations on the subgroup, then
+    # the unshifted coset extension of the own cosets, own leaves, gathered digests
     qq1 = be.empty(qDim << nbe)
     be.ifft(q_ext, qDim, nbe, qq1)
     qq2 = be.q_split(qq1, nb, nbe, qDim, qDeg)
-    cm2_ext = be.empty(nQ << nbe)
-    be.fft(qq2, nQ, nbe, cm2_ext)
-    del qq1, qq2, q_ext
-    tree2 = be.merkelize(cm2_ext, nQ, E)
-    root2 = be.root(tree2); transcript.put(root2)
-    loc["cm2_ext"] = sl(cm2_ext, nQ)
+    del qq1, q_ext
+    q_sub = be.empty(nQ << nb)
+    be.fft(qq2[:nQ << nb], nQ, nb, q_sub)                    # rows >= N of qq2 are zero: these are all its coefficients
+    del qq2
+    loc["cm2_ext"] = be.empty(nQ << nloc)
+    be.extend_cosets_unshifted(q_sub, nQ, nb, loc["cm2_ext"], nbe, cb, cc)
+    nodes2 = commit_local_slice(be, loc["cm2_ext"], nQ, nb, cc, world, group, rehearse_world)
+    st2 = {"local": loc["cm2_ext"], "nodes": nodes2, "width": nQ, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
+    root2 = be.root({"nodes": nodes2}); transcript.put(root2)
 
     # evaluations: only rows k << b are read, i.e. coset 0: its owner computes them and everybody receives them
     xi = transcript.getField()
@@ -233,9 +245,10 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     tq = be.new_transcript(); tq.put(chq)
     queries = tq.getPermutations(ss["nQueries"], ss["steps"][0]["nBits"])
     rows1 = open_rows(be, st, queries, group) if not rehearse_world else np.zeros((len(queries), nCm1), np.uint64)
-    sib1 = be.merkle_siblings(st["nodes"], E, queries)
-    p2, pc = be.group_proofs(tree2, queries), be.group_proofs(constTree, queries)
-    friProof[0]["polQueries"] = [[[[int(v) for v in rows1[i]], sib1[i]], list(p2[i]), list(pc[i])] for i in range(len(queries))]
+    rows2 = open_rows(be, st2, queries, group) if not rehearse_world else np.zeros((len(queries), nQ), np.uint64)
+    sib1, sib2 = be.merkle_siblings(st["nodes"], E, queries), be.merkle_siblings(nodes2, E, queries)
+    pc = be.group_proofs(constTree, queries)
+    friProof[0]["polQueries"] = [[[[int(v) for v in rows1[i]], sib1[i]], [[int(v) for v in rows2[i]], sib2[i]], list(pc[i])] for i in range(len(queries))]
     q = list(queries)
     for step in range(1, len(ss["steps"])):
         q = [qi % (1 << ss["steps"][step]["nBits"]) for qi in q]

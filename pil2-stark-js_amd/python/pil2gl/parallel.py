@@ -39,9 +39,9 @@ def _comm_tensor(be, t, group):
     return x
 
 
-def commit_local_slice(be, local, width, n_bits, cc, world, group=None, rehearse_world=None):
+def commit_local_slice(be, local, width, n_bits, cc, world, group=None, rehearse_world=None, split_tree_rank=None):
     """leaf digests of a rank's slice (N*cc rows x width), all-gathered and interleaved into natural leaf order, then the
-    levels above them -> the complete node array, on every rank"""
+    levels above them -> the complete node array on every rank, or (split_tree_rank = this rank) a ShardedTree"""
     N = 1 << n_bits
     digests = be.linear_hash_rows(local, width, N * cc)              # [N*cc][4], local row = pos*cc + jl
     if rehearse_world:
@@ -53,7 +53,62 @@ def commit_local_slice(be, local, width, n_bits, cc, world, group=None, rehearse
         dist.all_gather(gathered, mine, group=group)
     # part r is [N][cc*4]; leaf index = pos*2^eb + r*cc + jl (natural row order of the extension), written straight into
     # the node array (no stacked / permuted copies: at config 5 the leaf level alone is 17 GB)
+    if split_tree_rank is not None:
+        return ShardedTree(be, gathered, N, cc, split_tree_rank, world, group, rehearse_world)
     return be.merkelize_digest_parts(gathered, N, cc)
+
+
+class ShardedTree:
+    """A Merkle tree (merklehash_p.js layout, power-of-two height) whose levels above the leaves are split by CONTIGUOUS
+    leaf blocks: rank r keeps the subtree over leaves [r*E/w, (r+1)*E/w) (built from the gathered leaf digests), the w
+    subtree roots are exchanged and the log2(w) levels above them are computed by everybody.  Same root and same paths as
+    the single tree; no rank hashes more than 1/w of it (plus w-1 nodes)."""
+
+    def __init__(self, be, parts, N, cc, rank, world, group=None, rehearse_world=None):
+        self.be, self.rank, self.world, self.group, self.rehearse = be, rank, world, group, rehearse_world
+        self.block = N * cc                                     # leaves per rank block: E / world
+        if N % world:
+            raise ValueError("world size must divide the number of rows")
+        self.sub = be.merkelize_digest_block(parts, N, cc, rank)
+        mine = torch.tensor(np.array(be.root({"nodes": self.sub}), dtype=np.uint64).view(np.int64))
+        if rehearse_world:
+            roots = [mine] * world
+        else:
+            if dist.get_backend(group) == "nccl":
+                mine = mine.to(be.as_torch(self.sub).device)
+            roots = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(roots, mine, group=group)
+        cur = [[int(v) for v in r.cpu().numpy().view(np.uint64)] for r in roots]
+        self.top = [cur]
+        while len(cur) > 1:                                     # merklehash_p.js:109-132 on w, w/2, ... nodes
+            cur = [[int(v) for v in be.poseidon(cur[2 * i] + cur[2 * i + 1], [0, 0, 0, 0], 4)] for i in range(len(cur) // 2)]
+            self.top.append(cur)
+        self.root = cur[0]
+
+    def siblings(self, idxs):
+        """sibling digests of the paths to leaves idxs: the lower levels from the rank owning the leaf's block (one
+        all-reduce over zeros elsewhere), the upper log2(w) levels from the replicated top"""
+        low = _log2(self.block)
+        t = torch.zeros((len(idxs), max(low, 1), 4), dtype=torch.int64)
+        mine = [(q, i % self.block) for q, i in enumerate(idxs) if i // self.block == self.rank]
+        if mine and low:
+            sib = self.be.merkle_siblings(self.sub, self.block, [li for _, li in mine])
+            for (q, _), mp in zip(mine, sib):
+                t[q, :low] = torch.from_numpy(np.array(mp, dtype=np.uint64).view(np.int64))
+        if not self.rehearse:
+            if dist.get_backend(self.group) == "nccl":
+                t = t.to(self.be.as_torch(self.sub).device)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        a = t.cpu().numpy().view(np.uint64)
+        out = []
+        for q, i in enumerate(idxs):
+            mp = [[int(v) for v in a[q, l]] for l in range(low)]
+            b = i // self.block
+            for level in self.top[:-1]:
+                mp.append(list(level[b ^ 1]))
+                b >>= 1
+            out.append(mp)
+        return out
 
 
 def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None, overwrite_src=False, rehearse_world=None):
@@ -142,7 +197,8 @@ def all_gather_rows(be, local, n_bits, cc, width, group=None, rehearse_world=Non
 def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None):
     """pil2gl.stark.stark_gen with stage 1, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
-    single-process one.  Replicated: the iNTT of q, the levels of the trees above the leaves, and the FRI folding.
+    single-process one.  Replicated: the iNTT of q (3 columns) and the FRI folding; the trees above the leaves are split
+    by leaf blocks (ShardedTree).
     rehearse_world=K: rank 0's share of a K-rank proof run alone (own slices stand in for the gathered ones, so the
     result is not a valid proof): per-GPU time and memory on one GPU."""
     from . import stark as S
@@ -165,8 +221,11 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     transcript.put(setup["constRoot"]); transcript.put(publics)
 
     # stage 1, split by cosets; the tree (all nodes) is on every rank, the rows are not
-    st = extend_and_merkelize_sharded(be, cm1_n, nCm1, nb, nbe, group, rehearse_world=rehearse_world)
-    root1 = be.root({"nodes": st["nodes"]}); transcript.put(root1)
+    cm1_loc = be.empty(nCm1 << nloc)
+    be.interpolate_cosets(cm1_n, nCm1, nb, cm1_loc, nbe, cb, cc, None)
+    tree1 = commit_local_slice(be, cm1_loc, nCm1, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
+    st = {"local": cm1_loc, "width": nCm1, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
+    root1 = tree1.root; transcript.put(root1)
 
     # quotient: the constraint expression on the local rows, then one all-gather of q
     ctx["challenges"][1] = [transcript.getField()]
@@ -194,9 +253,9 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     del qq2
     loc["cm2_ext"] = be.empty(nQ << nloc)
     be.extend_cosets_unshifted(q_sub, nQ, nb, loc["cm2_ext"], nbe, cb, cc)
-    nodes2 = commit_local_slice(be, loc["cm2_ext"], nQ, nb, cc, world, group, rehearse_world)
-    st2 = {"local": loc["cm2_ext"], "nodes": nodes2, "width": nQ, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
-    root2 = be.root({"nodes": nodes2}); transcript.put(root2)
+    tree2 = commit_local_slice(be, loc["cm2_ext"], nQ, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
+    st2 = {"local": loc["cm2_ext"], "width": nQ, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
+    root2 = tree2.root; transcript.put(root2)
 
     # evaluations: only rows k << b are read, i.e. coset 0: its owner computes them and everybody receives them
     xi = transcript.getField()
@@ -246,7 +305,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     queries = tq.getPermutations(ss["nQueries"], ss["steps"][0]["nBits"])
     rows1 = open_rows(be, st, queries, group) if not rehearse_world else np.zeros((len(queries), nCm1), np.uint64)
     rows2 = open_rows(be, st2, queries, group) if not rehearse_world else np.zeros((len(queries), nQ), np.uint64)
-    sib1, sib2 = be.merkle_siblings(st["nodes"], E, queries), be.merkle_siblings(nodes2, E, queries)
+    sib1, sib2 = tree1.siblings(queries), tree2.siblings(queries)
     pc = be.group_proofs(constTree, queries)
     friProof[0]["polQueries"] = [[[[int(v) for v in rows1[i]], sib1[i]], [[int(v) for v in rows2[i]], sib2[i]], list(pc[i])] for i in range(len(queries))]
     q = list(queries)

@@ -16,6 +16,11 @@ P = 0xFFFFFFFF00000001
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # the built library / addon are git-ignored: build them once if a fresh checkout has none (hipcc cross-compiles on CPU)
+    lib = os.path.join(ROOT, "pil2-stark-js_amd", "lib", "libpil2gl.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+        subprocess.call(["make", "-C", os.path.join(ROOT, "pil2-stark-js_amd"), "-j4", "all"])
 
 
 def golden(name):

@@ -11,12 +11,15 @@ valid one (tests/test_stark_prove.py verifies such proofs and their bit-identity
 --mode commit times only extendAndMerkelize (stark_gen_helpers.js:388-412) on a uniformly random trace.
 Inputs, intermediates, trees and outputs stay on the device (no PCIe in the timed region).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|NBITSxCOLS] [--mode prove|commit]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|NBITSxCOLS]
+                  [--mode prove|commit|commit-sharded|prove-sharded] [--shard-of K]
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same step on its
 own trace (weak scaling, no data-path collective); value = all ranks' cells / max-over-ranks time.
 --mode commit-sharded instead splits ONE trace's extendAndMerkelize by cosets over the ranks (pil2gl.parallel:
-all-gather of leaf digests over RCCL; strong scaling, value = that trace's cells / time).
+all-gather of leaf digests over RCCL; strong scaling, value = that trace's cells / time); --mode prove-sharded does the
+same for ONE whole proof (q, evaluations and the FRI polynomial exchanged as well).  With --shard-of K either sharded mode
+runs rank 0's share of a K-GPU job alone on one GPU (per-GPU time and memory; not a contract line).
 """
 import argparse
 import json

@@ -65,6 +65,11 @@ class OracleBackend:
         leaves = np.stack([p.cpu().numpy().view(np.uint64).reshape(N, cc * 4) for p in parts], axis=1).reshape(-1)
         return self.merkelize_digests(leaves, N * cc * world)
 
+    def get_column(self, buf, width, off, dim, n): return np.ascontiguousarray(buf.reshape(n, width)[:, off:off + dim]).reshape(-1)
+    def set_column(self, buf, width, off, dim, n, col): buf.reshape(n, width)[:, off:off + dim] = col.reshape(n, dim)
+    def gprod(self, num, dn, den, dd): return orc.gprod(num, den, dn, dd)
+    def gsum(self, num, dn, den, dd): return orc.gsum(num, den, dn, dd)
+
     def merkle_siblings(self, nodes, height, idxs):
         return [[[int(x) for x in s] for s in orc.group_proof(nodes, height, i)] for i in idxs]
 

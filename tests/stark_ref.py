@@ -85,15 +85,24 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
             return bn128_oracle.root_from_group_proof(sib, idx, [int(v) for v in vals], arity, custom)
         return [int(v) for v in orc.root_from_proof(np.array(vals, dtype=np.uint64), idx, np.array(sib, dtype=np.uint64), split)]
     same_root = (lambda a, b: int(a) == int(b)) if hash_type == "BN128" else (lambda a, b: list(a) == list(b))
-    # transcript replay, calculateTranscriptVerify.js:7-103 (nStages = 1)
+    # transcript replay, calculateTranscriptVerify.js:7-103
+    nStages = info["nStages"]; qStage = nStages + 1
     t = be.new_transcript()
     t.put(constRoot); t.put(publics)
-    t.put(proof["root1"])
-    vc = t.getField(); t.put(proof["root2"])
-    xi = t.getField()
+    challenges = {}
+    got_ch = [[] for _ in range(nStages + 3)]
+    for st in range(1, qStage + 1):
+        if st > 1:
+            n_ch = sum(1 for c in info["challengesMap"] if c["stage"] == st)
+            got_ch[st - 1] = [t.getField() for _ in range(n_ch)]
+        t.put(proof["root%d" % st])
+    xi = t.getField(); got_ch[qStage] = [xi]
     for ev in proof["evals"]:
         t.put(ev)
-    vf1 = t.getField(); vf2 = t.getField()
+    vf1 = t.getField(); vf2 = t.getField(); got_ch[qStage + 1] = [vf1, vf2]
+    for st, lst in enumerate(got_ch):
+        for k, c in enumerate(lst):
+            challenges[(st + 1, k)] = c
     chF = []
     for step in range(len(steps)):
         chF.append(t.getField())
@@ -103,13 +112,12 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
             for e in proof["fri"][-1]:
                 t.put(e)
     chF.append(t.getField())
-    if check_transcript and not ([vc] == res["challenges"][1] and [xi] == res["challenges"][2] and [vf1, vf2] == res["challenges"][3] and chF == res["challengesFRISteps"]):
+    if check_transcript and not (got_ch == res["challenges"] and chF == res["challengesFRISteps"]):
         return False, "transcript does not reproduce the challenges"
     tq = be.new_transcript(); tq.put(chF[-1])
     queries = tq.getPermutations(ss["nQueries"], steps[0]["nBits"])
     if check_transcript and queries != res["queries"]:
         return False, "query positions differ"
-    challenges = {(2, 0): vc, (3, 0): xi, (4, 0): vf1, (4, 1): vf2}
 
     # evaluations, stark_verify.js:95-152
     xN = _pow3(xi, N)
@@ -124,10 +132,10 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
         if ty == "Zi": return list(Z)
         raise ValueError(ty)
     lhs = exec_code(verifierInfo["qVerifier"]["code"], resolve)
-    nCm1 = info["mapSectionsN"]["cm1"]
+    q_ids = [k for k, pm in enumerate(info["cmPolsMap"]) if pm["stage"] == qStage]
     q = [0, 0, 0]; xAcc = [1, 0, 0]
     for i in range(info["qDeg"]):
-        evId = next(k for k, e in enumerate(info["evMap"]) if e["type"] == "cm" and e["id"] == nCm1 + i)
+        evId = next(k for k, e in enumerate(info["evMap"]) if e["type"] == "cm" and e["id"] == q_ids[i])
         q = _add(q, _mul(xAcc, list(proof["evals"][evId]))); xAcc = _mul(xAcc, xN)
     if _e3(lhs) != q:
         return False, "Invalid evaluations"
@@ -136,7 +144,7 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
     wN, wE = root_of_unity(nb), root_of_unity(nbe)
     for qi, idx in enumerate(queries):
         pq = proof["fri"][0]["polQueries"][qi]
-        for (vals, sib), root in zip(pq, (proof["root1"], proof["root2"], constRoot)):
+        for (vals, sib), root in zip(pq, [proof["root%d" % st] for st in range(1, qStage + 1)] + [constRoot]):
             if not same_root(path_root(vals, idx, sib), root):
                 return False, "Invalid root (query %d)" % qi
         x = SHIFT * pow(wE, idx, P) % P
@@ -151,7 +159,7 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
             if ty == "cm":
                 p = info["cmPolsMap"][r["id"]]; vals = pq[p["stage"] - 1][0]
                 return vals[p["stagePos"]] if p["dim"] == 1 else vals[p["stagePos"]:p["stagePos"] + 3]
-            if ty == "const": return pq[2][0][r["id"]]
+            if ty == "const": return pq[qStage][0][r["id"]]
             if ty == "xDivXSubXi": return list(xdiv[r["id"]])
             return resolve(r)
 

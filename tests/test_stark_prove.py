@@ -165,3 +165,44 @@ def test_gpu_bn128_proof_is_identical_to_oracle_proof(oracle, arity, custom, n_b
     assert r_gpu["proof"] == r_cpu["proof"]
     ok, why = stark_ref.stark_verify(r_gpu, s_gpu["constRoot"], info, vinfo, hash_type="BN128", arity=arity, custom=custom)
     assert ok, why
+
+
+def _perm_case(n_bits=6, steps=(9, 5, 2)):
+    from pil2gl import stark
+    ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
+    info, exprs, vinfo = stark.permutation_air(ss)
+    cm, consts, publics = stark.permutation_trace(n_bits)
+    return stark, info, exprs, vinfo, cm, consts, publics
+
+
+def test_two_stage_proof_with_grand_product_hint_on_oracle_backend(oracle):
+    """stage 2 after its challenge: stage code on the trace domain, the gprod hint (calculateZ), commitment; then the
+    quotient as stage 3.  The proof verifies, and it stops verifying when b is not a permutation of a."""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _perm_case()
+    be = stark_ref.OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    assert set(res["proof"]) == {"root1", "root2", "root3", "evals", "fri"} and len(res["challenges"]) == 5
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    cm2 = cm.copy(); cm2[7, 1] = (int(cm2[7, 1]) + 1) % P          # b no longer a permutation of a: z does not close
+    res2 = stark.stark_gen(be, be.from_host(cm2), setup, info, exprs, publics)
+    assert not stark_ref.stark_verify(res2, setup["constRoot"], info, vinfo)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bits,steps", [(6, (9, 5, 2)), (12, (15, 10, 5))])
+def test_gpu_two_stage_proof_is_identical_to_oracle_proof(oracle, n_bits, steps):
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _perm_case(n_bits, steps)
+    gpu = stark.GpuBackend(0)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    cpu = stark_ref.OracleBackend()
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, publics)
+    assert r_gpu["challenges"] == r_cpu["challenges"] and r_gpu["queries"] == r_cpu["queries"]
+    assert r_gpu["proof"] == r_cpu["proof"]
+    ok, why = stark_ref.stark_verify(r_gpu, s_gpu["constRoot"], info, vinfo)
+    assert ok, why

@@ -53,3 +53,19 @@ def test_proof2zkin_has_the_reference_layout(oracle):
     back = json.loads(txt)
     assert back["publics"] == [str(v) for v in publics] and isinstance(back["root1"][0], str)
     assert int(back["s0_vals1"][3][1]) == z["s0_vals1"][3][1]
+
+
+def test_proof2zkin_two_witness_stages(oracle):
+    """the mapping for nStages = 2 (roots 1..3, stage-0 openings per stage, proof2zkin.js:12-66)"""
+    import stark_ref
+    from pil2gl import stark, io
+    ss = {"nBits": 6, "nBitsExt": 9, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 9}, {"nBits": 5}, {"nBits": 2}]}
+    info, exprs, _ = stark.permutation_air(ss)
+    cm, consts, publics = stark.permutation_trace(6)
+    be = stark_ref.OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    z = io.proof2zkin(res["proof"], info)
+    assert {"root1", "root2", "root3", "s0_vals1", "s0_vals2", "s0_vals3", "s0_valsC", "s0_siblings2", "finalPol"} <= set(z)
+    assert _shape(z["s0_vals2"]) == [8, 9] and _shape(z["s0_vals3"]) == [8, 6] and _shape(z["s0_vals1"]) == [8, 2]
+    assert z["s0_vals2"][0] == res["proof"]["fri"][0]["polQueries"][0][1][0]

@@ -195,7 +195,7 @@ def all_gather_rows(be, local, n_bits, cc, width, group=None, rehearse_world=Non
 
 
 def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None):
-    """pil2gl.stark.stark_gen with stage 1, the constraint evaluation and the FRI polynomial split by cosets over the
+    """pil2gl.stark.stark_gen with every witness stage, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
     single-process one.  Replicated: the iNTT of q (3 columns) and the FRI folding; the trees above the leaves are split
     by leaf blocks (ShardedTree).
@@ -213,31 +213,54 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     lb = _log2(cc)
     nloc = nb + lb                                              # local slices have 2^nloc rows
     qDim, qDeg = info["qDim"], info["qDeg"]
-    nCm1, nQ, nC = info["mapSectionsN"]["cm1"], info["mapSectionsN"]["cm2"], info["nConstants"]
-    assert info["nStages"] == 1 and ss["steps"][0]["nBits"] == nbe
-    ctx = {"pilInfo": info, "publics": list(publics), "challenges": [[], [], [], []], "evals": []}
+    nStages = info["nStages"]
+    qStage = nStages + 1
+    nQ, nC = info["mapSectionsN"]["cm%d" % qStage], info["nConstants"]
+    assert ss["steps"][0]["nBits"] == nbe
+    ctx = {"pilInfo": info, "publics": list(publics), "challenges": [[] for _ in range(nStages + 3)], "evals": []}
     constTree = setup["constTree"]
     transcript = be.new_transcript()
     transcript.put(setup["constRoot"]); transcript.put(publics)
 
-    # stage 1, split by cosets; the tree (all nodes) is on every rank, the rows are not
-    cm1_loc = be.empty(nCm1 << nloc)
-    be.interpolate_cosets(cm1_n, nCm1, nb, cm1_loc, nbe, cb, cc, None)
-    tree1 = commit_local_slice(be, cm1_loc, nCm1, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
-    st = {"local": cm1_loc, "width": nCm1, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
-    root1 = tree1.root; transcript.put(root1)
-
-    # quotient: the constraint expression on the local rows, then one all-gather of q
-    ctx["challenges"][1] = [transcript.getField()]
     sl = lambda full, w: coset_slice(be, full, nb, eb, cb, cc, w)
-    loc = {"const_ext": sl(constTree["elements"], nC), "cm1_ext": st["local"], "x_ext": sl(be.build_x(nbe, S.SHIFT), 1),
-           "Zi_ext#0": sl(be.build_zhinv(nb, nbe), 1), "q_ext": be.empty(qDim << nloc)}
-    widths = {"const_ext": nC, "cm1_ext": nCm1, "cm2_ext": nQ, "q_ext": qDim, "f_ext": 3, "x_ext": 1, "Zi_ext#0": 1,
+    loc = {"const_ext": sl(constTree["elements"], nC), "x_ext": sl(be.build_x(nbe, S.SHIFT), 1),
+           "Zi_ext#0": sl(be.build_zhinv(nb, nbe), 1)}
+    widths = {"const_n": nC, "const_ext": nC, "q_ext": qDim, "f_ext": 3, "x_ext": 1, "x_n": 1, "Zi_ext#0": 1,
               "xDivXSubXi_ext": 3 * len(info["openingPoints"])}
+    for s_ in range(1, qStage + 1):
+        widths["cm%d_n" % s_] = widths["cm%d_ext" % s_] = info["mapSectionsN"]["cm%d" % s_]
 
     def run_local(code):
         ops, n_tmp, secs, scalars = S.encode_code(code["code"], "ext", ctx)
         be.eval_program(ops, n_tmp, [(loc[s], widths[s]) for s in secs], scalars, nloc, lb)
+
+    # witness stages, split by cosets; each tree is split by leaf blocks (ShardedTree), the rows stay with their owners.
+    # From stage 2 on (prover.js:49-77): challenges, stage code and hints on the trace domain, replicated - it is N rows
+    # against the N * 2^b of the extension, and every rank needs the whole stage-s trace for its own cosets anyway
+    trace = {"const_n": setup.get("const_n"), "cm1_n": cm1_n}
+    strees, shards, roots = {}, {}, {}
+    for s_ in range(1, nStages + 1):
+        name, w = "cm%d" % s_, widths["cm%d_n" % s_]
+        if s_ > 1:
+            n_ch = sum(1 for c in info["challengesMap"] if c["stage"] == s_)
+            ctx["challenges"][s_ - 1] = [transcript.getField() for _ in range(n_ch)]
+            trace[name + "_n"] = be.zeros(w << nb)
+            if "x_n" not in trace:
+                trace["x_n"] = be.build_x(nb, 1)
+            for sc in exprs.get("stageCode", {}).get(s_, []):
+                ops, n_tmp, secs, scalars = S.encode_code(sc["code"], "n", ctx)
+                be.eval_program(ops, n_tmp, [(trace[x], widths[x]) for x in secs], scalars, nb, 0)
+            S.resolve_hints(be, info, s_, trace, widths, nb, ctx)
+        loc[name + "_ext"] = be.empty(w << nloc)
+        be.interpolate_cosets(trace[name + "_n"], w, nb, loc[name + "_ext"], nbe, cb, cc, None)
+        strees[s_] = commit_local_slice(be, loc[name + "_ext"], w, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
+        shards[s_] = {"local": loc[name + "_ext"], "width": w, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
+        roots[s_] = strees[s_].root; transcript.put(roots[s_])
+    del trace
+
+    # quotient: the constraint expression on the local rows, then one all-gather of q
+    ctx["challenges"][qStage - 1] = [transcript.getField()]
+    loc["q_ext"] = be.empty(qDim << nloc)
     run_local(exprs["expressionsCode"][info["cExpId"]]["code"])
     q_ext = all_gather_rows(be, loc["q_ext"], nb, cc, qDim, group, rehearse_world)
     del loc["q_ext"]
@@ -251,15 +274,16 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     q_sub = be.empty(nQ << nb)
     be.fft(qq2[:nQ << nb], nQ, nb, q_sub)                    # rows >= N of qq2 are zero: these are all its coefficients
     del qq2
-    loc["cm2_ext"] = be.empty(nQ << nloc)
-    be.extend_cosets_unshifted(q_sub, nQ, nb, loc["cm2_ext"], nbe, cb, cc)
-    tree2 = commit_local_slice(be, loc["cm2_ext"], nQ, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
-    st2 = {"local": loc["cm2_ext"], "width": nQ, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
-    root2 = tree2.root; transcript.put(root2)
+    qname = "cm%d_ext" % qStage
+    loc[qname] = be.empty(nQ << nloc)
+    be.extend_cosets_unshifted(q_sub, nQ, nb, loc[qname], nbe, cb, cc)
+    strees[qStage] = commit_local_slice(be, loc[qname], nQ, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
+    shards[qStage] = {"local": loc[qname], "width": nQ, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
+    roots[qStage] = strees[qStage].root; transcript.put(roots[qStage])
 
     # evaluations: only rows k << b are read, i.e. coset 0: its owner computes them and everybody receives them
     xi = transcript.getField()
-    ctx["challenges"][2] = [xi]
+    ctx["challenges"][qStage] = [xi]
     wN = S.root_of_unity(nb)
     xis, n_ev = [], len(info["evMap"])
     for opening in info["openingPoints"]:
@@ -291,26 +315,30 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         transcript.put(ev)
 
     # FRI polynomial on the local rows, then one all-gather
-    ctx["challenges"][3] = [transcript.getField(), transcript.getField()]
+    vfs = [transcript.getField(), transcript.getField()]
+    ctx["challenges"][qStage + 1] = vfs
     loc["xDivXSubXi_ext"] = sl(be.x_div_x_sub_xi(nbe, xis), widths["xDivXSubXi_ext"])
     loc["f_ext"] = be.empty(3 << nloc)
-    if not (hasattr(be, "fri_polynomial_fast") and be.fri_polynomial_fast(info, loc, widths, ctx["evals"], ctx["challenges"][3][0], ctx["challenges"][3][1], nloc, loc["f_ext"])):
+    if not (hasattr(be, "fri_polynomial_fast") and be.fri_polynomial_fast(info, loc, widths, ctx["evals"], vfs[0], vfs[1], nloc, loc["f_ext"])):
         run_local(exprs["expressionsCode"][info["friExpId"]]["code"])
     f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, group, rehearse_world)
 
-    # folding and its trees, replicated; openings: stage-1 rows from their owners, everything else is local
+    # folding and its trees, replicated; openings: the rows of the committed stages from their owners, everything else is local
     friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, f_ext, transcript)
     chq = transcript.getField(); challengesFRI.append(chq)
     tq = be.new_transcript(); tq.put(chq)
     queries = tq.getPermutations(ss["nQueries"], ss["steps"][0]["nBits"])
-    rows1 = open_rows(be, st, queries, group) if not rehearse_world else np.zeros((len(queries), nCm1), np.uint64)
-    rows2 = open_rows(be, st2, queries, group) if not rehearse_world else np.zeros((len(queries), nQ), np.uint64)
-    sib1, sib2 = tree1.siblings(queries), tree2.siblings(queries)
+    opened = []
+    for s_ in range(1, qStage + 1):
+        w = shards[s_]["width"]
+        rows = open_rows(be, shards[s_], queries, group) if not rehearse_world else np.zeros((len(queries), w), np.uint64)
+        opened.append((rows, strees[s_].siblings(queries)))
     pc = be.group_proofs(constTree, queries)
-    friProof[0]["polQueries"] = [[[[int(v) for v in rows1[i]], sib1[i]], [[int(v) for v in rows2[i]], sib2[i]], list(pc[i])] for i in range(len(queries))]
+    friProof[0]["polQueries"] = [[[[int(v) for v in rows[i]], sib[i]] for rows, sib in opened] + [list(pc[i])] for i in range(len(queries))]
     q = list(queries)
     for step in range(1, len(ss["steps"])):
         q = [qi % (1 << ss["steps"][step]["nBits"]) for qi in q]
         friProof[step]["polQueries"] = [list(p_) for p_ in be.group_proofs(friTrees[step], q)]
-    proof = {"root1": root1, "root2": root2, "evals": ctx["evals"], "fri": friProof}
+    proof = {"root%d" % s_: roots[s_] for s_ in range(1, qStage + 1)}
+    proof["evals"] = ctx["evals"]; proof["fri"] = friProof
     return {"proof": proof, "publics": list(publics), "challenges": ctx["challenges"], "challengesFRISteps": challengesFRI, "queries": queries}

@@ -70,3 +70,13 @@ def test_sharded_proof_equals_single_process_proof_cpu(oracle, world):
 @pytest.mark.parametrize("world,nbits,pairs,steps", [(2, 8, 3, "11,7,3"), (4, 10, 20, "13,9,4")])
 def test_sharded_proof_gpu_ranks(oracle, world, nbits, pairs, steps):
     _launch(world, "--backend", "gpu", "--nbits", str(nbits), "--pairs", str(pairs), "--steps", steps, worker=PROVE_WORKER)
+
+
+def test_sharded_two_stage_proof_cpu(oracle):
+    """two witness stages (stage 2 = challenge + grand-product hint): stage 2 is committed by cosets like stage 1"""
+    _launch(2, "--backend", "oracle", "--air", "perm", worker=PROVE_WORKER)
+
+
+@pytest.mark.gpu
+def test_sharded_two_stage_proof_gpu_ranks(oracle):
+    _launch(4, "--backend", "gpu", "--air", "perm", "--nbits", "10", "--steps", "13,9,4", worker=PROVE_WORKER)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--nbits", type=int, default=6)
     ap.add_argument("--pairs", type=int, default=2)
     ap.add_argument("--steps", default="9,5,2")
+    ap.add_argument("--air", default="fib", help="fib: one witness stage; perm: two (stage 2 = grand-product hint)")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     rank = dist.get_rank()
@@ -29,8 +30,12 @@ def main():
     from pil2gl import stark, parallel
     steps = [int(x) for x in a.steps.split(",")]
     ss = {"nBits": a.nbits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
-    info, exprs, _ = stark.fibonacci_air(a.pairs, ss)
-    cm, consts, publics = stark.fibonacci_trace(a.nbits, a.pairs)
+    if a.air == "perm":
+        info, exprs, _ = stark.permutation_air(ss)
+        cm, consts, publics = stark.permutation_trace(a.nbits)
+    else:
+        info, exprs, _ = stark.fibonacci_air(a.pairs, ss)
+        cm, consts, publics = stark.fibonacci_trace(a.nbits, a.pairs)
     if a.backend == "gpu":
         be = stark.GpuBackend(0)
     else:
@@ -41,7 +46,8 @@ def main():
     want = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
     for k in ("challenges", "challengesFRISteps", "queries", "publics"):
         assert got[k] == want[k], "rank %d: %s differ" % (rank, k)
-    for k in ("root1", "root2", "evals"):
+    assert list(got["proof"]) == list(want["proof"])
+    for k in [k for k in want["proof"] if k != "fri"]:
         assert got["proof"][k] == want["proof"][k], "rank %d: proof.%s differs" % (rank, k)
     assert got["proof"]["fri"] == want["proof"]["fri"], "rank %d: FRI part of the proof differs" % rank
     dist.barrier()

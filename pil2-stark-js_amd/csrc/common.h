@@ -35,6 +35,8 @@ struct Tables {
     const u64 *powWi;     // g = w[32]^-1
     const u64 *pow7;      // g = 7       (coset shift)
     const u64 *pow7i;     // g = 7^-1
+    const u64 *tw1024;    // tw1024[j] = w[10]^j, j < 1024 (tile twiddles of the NTT passes)
+    const u64 *tw1024i;   // w[10]^-j
 };
 const Tables &tables();
 

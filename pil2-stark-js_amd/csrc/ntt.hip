@@ -20,6 +20,7 @@
 //    (or several adjacent rows when C is small): every global access is a coalesced segment.
 #include "common.h"
 #include "gl_field.cuh"
+#include "gl_fermat.cuh"
 #include <stdlib.h>
 #include <algorithm>
 
@@ -36,77 +37,97 @@ __device__ __forceinline__ u64 pow256(const u64 *__restrict__ T, u32 e) {
 // w_(2^logM)^e for the root whose pow256 table is T (1 <= logM <= 32, e < 2^logM)
 __device__ __forceinline__ u64 root_pow(const u64 *__restrict__ T, u32 logM, u32 e) { return pow256(T, e << (32 - logM)); }
 
-// k stages on tile[2^k][S] (column x), Gentleman-Sande: natural in -> bit-reversed out.
-// Two stages at a time: a lane takes 4 rows into registers (radix-4 step = 4 radix-2 butterflies), which halves
-// the LDS traffic and the barriers; an odd k ends with one radix-2 stage.  The last stage's twiddles are all 1.
-__device__ __forceinline__ void dif_stages(u64 *tile, const u64 *TW, u32 k, u32 S, u32 x, u32 y, u32 by) {
-    int s = (int)k - 1;
-    for (; s >= 1; s -= 2) {                        // stages s (half-span h) and s-1 (half-span h/2)
-        const u32 h = 1u << s, q = h >> 1, quarter = 1u << (k - 2);
-        const bool lastTrivial = (s == 1);
-        const u32 qS = q * S, hS = h * S;           // one multiplication per butterfly instead of four
-        for (u32 j = y; j < quarter; j += by) {
-            const u32 off = j & (q - 1);
-            const u32 p = ((j >> (s - 1)) << (s + 1)) + off;
-            const u32 i0 = p * S + x, i1 = i0 + qS, i2 = i0 + hS, i3 = i2 + qS;
-            u64 a0 = tile[i0], a1 = tile[i1], a2 = tile[i2], a3 = tile[i3];
-            const u64 wA = TW[off << (k - 1 - s)], wB = TW[(off + q) << (k - 1 - s)];
-            u64 b0 = add(a0, a2), b2 = mul(sub(a0, a2), wA);
-            u64 b1 = add(a1, a3), b3 = mul(sub(a1, a3), wB);
-            u64 c0 = add(b0, b1), c1 = sub(b0, b1), c2 = add(b2, b3), c3 = sub(b2, b3);
-            if (!lastTrivial) { const u64 wC = TW[off << (k - s)]; c1 = mul(c1, wC); c3 = mul(c3, wC); }
-            tile[i0] = c0; tile[i1] = c1; tile[i2] = c2; tile[i3] = c3;
+// k stages on tile[2^k][S] (column x).  The stages are grouped into register steps of c <= 4 stages: a lane takes the
+// 2^c rows of one sub-transform into registers, runs it in Z/(2^96+1) where its twiddles are constant shifts
+// (gl_fermat.cuh), reduces once, multiplies by the twiddle that joins it to the next group and writes it back: one LDS
+// round trip and one modular multiplication per element per c stages.  TW[j] = w_(2^k)^j for all j < 2^k.
+__host__ __device__ constexpr u32 next_chunk(u32 rem) { return rem <= 4 ? rem : (rem == 5 || rem == 6 || rem == 9) ? 3 : 4; }
+__host__ __device__ constexpr u32 brev_c(u32 i, int c) { u32 r = 0; for (int b = 0; b < c; b++) r |= ((i >> b) & 1u) << (c - 1 - b); return r; }
+
+// Gentleman-Sande group on blocks of 2^lm rows: natural in -> bit-reversed out (within the group's c index bits)
+template <int C, bool INV>
+__device__ __forceinline__ void dif_step(u64 *tile, const u64 *TW, u32 k, u32 lm, u32 S, u32 x, u32 y, u32 by) {
+    constexpr u32 R = 1u << C;
+    const u32 ls = lm - C, nD = 1u << (k - C), st = S << ls;
+    const bool last = ls == 0;
+    for (u32 d = y; d < nD; d += by) {
+        const u32 np = d & ((1u << ls) - 1);
+        u64 *col = tile + (size_t)(((d >> ls) << lm) + np) * S + x;
+        fermat::f128 v[R];
+#pragma unroll
+        for (u32 r = 0; r < R; r++) v[r] = fermat::from_gl(col[r * st]);
+        fermat::dft_dif<C, INV>(v);
+        const u32 e1 = np << (k - lm);                         // w_(2^lm)^np = TW[e1]
+#pragma unroll
+        for (u32 i = 0; i < R; i++) {
+            const u32 q = brev_c(i, C);
+            u64 o = fermat::to_gl_lazy(v[i]);
+            if (last) o = canon(o);
+            else if (q) o = mul_lazy(o, TW[e1 * q]);
+            col[i * st] = o;
         }
-        __syncthreads();
     }
-    if (s == 0) {                                   // odd k: last stage, twiddle 1
-        const u32 half = 1u << (k - 1);
-        for (u32 j = y; j < half; j += by) {
-            const u32 p = j << 1;
-            u64 a = tile[p * S + x], b = tile[(p + 1) * S + x];
-            tile[p * S + x] = add(a, b);
-            tile[(p + 1) * S + x] = sub(a, b);
+    __syncthreads();
+}
+// Cooley-Tukey group joining 2^C finished blocks of 2^lp rows: bit-reversed in -> natural out.  The inputs already carry
+// this group's twiddles (applied when they were stored); the outputs get the next group's (cn = its stage count, 0: none).
+template <int C, bool INV>
+__device__ __forceinline__ void dit_step(u64 *tile, const u64 *TW, u32 k, u32 lp, u32 cn, u32 S, u32 x, u32 y, u32 by) {
+    constexpr u32 R = 1u << C;
+    const u32 lm = lp + C, nD = 1u << (k - C), st = S << lp;
+    for (u32 d = y; d < nD; d += by) {
+        const u32 np = d & ((1u << lp) - 1), blk = d >> lp;
+        u64 *col = tile + (size_t)((blk << lm) + np) * S + x;
+        fermat::f128 v[R];
+#pragma unroll
+        for (u32 r = 0; r < R; r++) v[r] = fermat::from_gl(col[r * st]);
+        fermat::dft_dit<C, INV>(v);
+        if (cn) {
+            const u32 rho = bitrev32(blk & ((1u << cn) - 1), cn), sh = k - lm - cn;
+#pragma unroll
+            for (u32 q = 0; q < R; q++) {
+                u64 o = fermat::to_gl_lazy(v[q]);
+                if (rho) o = mul_lazy(o, TW[(rho * (np + (q << lp))) << sh]);
+                col[q * st] = o;
+            }
+        } else {
+#pragma unroll
+            for (u32 q = 0; q < R; q++) col[q * st] = canon(fermat::to_gl_lazy(v[q]));
         }
-        __syncthreads();
+    }
+    __syncthreads();
+}
+template <bool INV>
+__device__ __forceinline__ void dif_stages(u64 *tile, const u64 *TW, u32 k, u32 S, u32 x, u32 y, u32 by) {
+    for (u32 lm = k; lm > 0;) {
+        const u32 c = next_chunk(lm);
+        switch (c) {
+        case 4: dif_step<4, INV>(tile, TW, k, lm, S, x, y, by); break;
+        case 3: dif_step<3, INV>(tile, TW, k, lm, S, x, y, by); break;
+        case 2: dif_step<2, INV>(tile, TW, k, lm, S, x, y, by); break;
+        default: dif_step<1, INV>(tile, TW, k, lm, S, x, y, by); break;
+        }
+        lm -= c;
     }
 }
-// Cooley-Tukey: bit-reversed in -> natural out (same two-stages-at-a-time structure; the first stage's twiddles are 1)
+template <bool INV>
 __device__ __forceinline__ void dit_stages(u64 *tile, const u64 *TW, u32 k, u32 S, u32 x, u32 y, u32 by) {
-    u32 s = 0;
-    if (k & 1) {                                    // odd k: first stage alone, twiddle 1
-        const u32 half = 1u << (k - 1);
-        for (u32 j = y; j < half; j += by) {
-            const u32 p = j << 1;
-            u64 a = tile[p * S + x], b = tile[(p + 1) * S + x];
-            tile[p * S + x] = add(a, b);
-            tile[(p + 1) * S + x] = sub(a, b);
+    for (u32 lp = 0; lp < k;) {
+        const u32 c = next_chunk(k - lp), cn = next_chunk(k - lp - c);
+        switch (c) {
+        case 4: dit_step<4, INV>(tile, TW, k, lp, cn, S, x, y, by); break;
+        case 3: dit_step<3, INV>(tile, TW, k, lp, cn, S, x, y, by); break;
+        case 2: dit_step<2, INV>(tile, TW, k, lp, cn, S, x, y, by); break;
+        default: dit_step<1, INV>(tile, TW, k, lp, cn, S, x, y, by); break;
         }
-        __syncthreads();
-        s = 1;
-    }
-    for (; s + 1 < k; s += 2) {                     // stages s (half-span h) and s+1 (half-span 2h)
-        const u32 h = 1u << s, quarter = 1u << (k - 2);
-        const bool firstTrivial = (s == 0);
-        const u32 hS = h * S;
-        for (u32 j = y; j < quarter; j += by) {
-            const u32 off = j & (h - 1);
-            const u32 p = ((j >> s) << (s + 2)) + off;
-            const u32 i0 = p * S + x, i1 = i0 + hS, i2 = i1 + hS, i3 = i2 + hS;
-            u64 a0 = tile[i0], a1 = tile[i1], a2 = tile[i2], a3 = tile[i3];
-            if (!firstTrivial) { const u64 wA = TW[off << (k - 1 - s)]; a1 = mul(a1, wA); a3 = mul(a3, wA); }
-            u64 b0 = add(a0, a1), b1 = sub(a0, a1), b2 = add(a2, a3), b3 = sub(a2, a3);
-            const u64 wB = TW[off << (k - 2 - s)], wC = TW[(off + h) << (k - 2 - s)];
-            b2 = mul(b2, wB); b3 = mul(b3, wC);
-            tile[i0] = add(b0, b2); tile[i2] = sub(b0, b2);
-            tile[i1] = add(b1, b3); tile[i3] = sub(b1, b3);
-        }
-        __syncthreads();
+        lp += c;
     }
 }
 
 struct PassParams {
     const u64 *src; u64 *dst;
     const u64 *tw;                  // pow256 table of the transform's 2^32-th root (forward or inverse)
+    const u64 *twK;                 // twK[j] = w_1024^j of the same direction (tile twiddles: w_(2^k)^j = twK[j << (10-k)])
     u64 C;                          // matrix columns
     u64 tStride, gStride, hiStride; // words between tile rows / slot groups / tiles along the outer index
     u64 scale;                      // 0: none; else every output is multiplied by it (1/N of an inverse transform)
@@ -116,11 +137,12 @@ struct PassParams {
     u32 n, scatter;                 // scatter: store row bitrev_n(g*2^k + t) (lo = 0 pass of a natural-order transform)
 };
 
-__global__ void ntt_pass_kernel(PassParams P) {
+template <bool INV, bool DIT>
+__global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     extern __shared__ u64 lds[];
     const u32 k = P.k, K = 1u << k, S = blockDim.x, by = blockDim.y;
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
-    u64 *tile = lds, *TW = tile + ((size_t)S << k), *TWO = TW + (K > 1 ? K / 2 : 1);
+    u64 *tile = lds, *TW = tile + ((size_t)S << k), *TWO = TW + K;
 
     u32 bid = blockIdx.x;
     const u32 cc = bid % P.nColChunks; bid /= P.nColChunks;
@@ -132,7 +154,13 @@ __global__ void ntt_pass_kernel(PassParams P) {
     const u64 g = (u64)gt * P.nbT + gi;
     const u64 base = (u64)hi * P.hiStride + g * P.gStride + c;
 
-    for (u32 j = tid; j < K / 2; j += nth) TW[j] = root_pow(P.tw, k, j);
+    // the first LOADB rows of this lane are requested before the tables are built, so that their latency overlaps it;
+    // all loads of a batch are in flight together (one load per iteration would serialise the HBM latency)
+    constexpr u32 LOADB = 16;
+    u64 vin[LOADB];
+#pragma unroll
+    for (u32 i = 0; i < LOADB; i++) { const u32 t = y + i * by; vin[i] = (valid && t < K) ? P.src[base + (u64)t * P.tStride] : 0; }
+    for (u32 j = tid; j < K; j += nth) TW[j] = P.twK[j << (10 - k)];
     if (P.hasTw) {
         for (u32 idx = tid; idx < P.nbT * K; idx += nth) {
             u32 b = gt * P.nbT + (idx >> k);
@@ -142,17 +170,27 @@ __global__ void ntt_pass_kernel(PassParams P) {
         }
     }
     __syncthreads();
-    for (u32 t = y; t < K; t += by) {
-        u64 v = valid ? P.src[base + (u64)t * P.tStride] : 0;
-        if (P.dit && P.hasTw) v = mul(v, TWO[gi * K + t]);
-        tile[t * S + x] = v;
+    for (u32 t0 = y;;) {
+#pragma unroll
+        for (u32 i = 0; i < LOADB; i++) {
+            const u32 t = t0 + i * by;
+            if (t < K) {
+                u64 v = vin[i];
+                if (DIT && P.hasTw) v = mul_lazy(v, TWO[gi * K + t]);
+                tile[t * S + x] = v;
+            }
+        }
+        t0 += LOADB * by;
+        if (t0 >= K) break;
+#pragma unroll
+        for (u32 i = 0; i < LOADB; i++) { const u32 t = t0 + i * by; vin[i] = (valid && t < K) ? P.src[base + (u64)t * P.tStride] : 0; }
     }
     __syncthreads();
-    if (P.dit) dit_stages(tile, TW, k, S, x, y, by); else dif_stages(tile, TW, k, S, x, y, by);
+    if (DIT) dit_stages<INV>(tile, TW, k, S, x, y, by); else dif_stages<INV>(tile, TW, k, S, x, y, by);
     if (!valid) return;
     for (u32 t = y; t < K; t += by) {
         u64 v = tile[t * S + x];
-        if (P.hasTw) { if (!P.dit) v = mul(v, TWO[gi * K + t]); }
+        if (P.hasTw) { if (!DIT) v = mul(v, TWO[gi * K + t]); }
         else if (P.scale) v = mul(v, P.scale);
         u64 addr = P.scatter ? (u64)bitrev32((u32)(g * K + t), P.n) * P.C + c : base + (u64)t * P.tStride;
         P.dst[addr] = v;
@@ -162,6 +200,7 @@ __global__ void ntt_pass_kernel(PassParams P) {
 struct LdeParams {
     const u64 *src; u64 *dst;
     const u64 *twi, *twf, *pow7;    // pow256 tables: inverse root, forward root, coset shift 7
+    const u64 *twKi, *twKf;         // w_1024^-j, w_1024^j (tile twiddles)
     u64 C, ninv;
     u32 n, k, extBits;
     u32 cosetBegin, cosetCount;     // this call produces cosets [cosetBegin, cosetBegin+cosetCount) of the 2^extBits (multi-GPU: one slice per rank)
@@ -170,11 +209,11 @@ struct LdeParams {
 
 // Finishes the iNTT on bits [0,k), scales by the coset factors and starts the forward NTT (see header).
 template <int EPT>
-__global__ void lde_mid_kernel(LdeParams P) {
+__global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
     extern __shared__ u64 lds[];
     const u32 k = P.k, K = 1u << k, S = blockDim.x, by = blockDim.y;
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
-    u64 *tile = lds, *TWi = tile + ((size_t)S << k), *TWf = TWi + K / 2, *Sc = TWf + K / 2, *Uc = Sc + (size_t)P.G * K;
+    u64 *tile = lds, *TWi = tile + ((size_t)S << k), *TWf = TWi + K, *Sc = TWf + K, *Uc = Sc + (size_t)P.G * K;
 
     u32 bid = blockIdx.x;
     const u32 cc = bid % P.nColChunks;
@@ -185,7 +224,10 @@ __global__ void lde_mid_kernel(LdeParams P) {
     const u64 g = (u64)gt * P.G + gi;               // index of this slot's 2^k-row block
     const u64 base = g * K * P.C + c;
 
-    for (u32 j = tid; j < K / 2; j += nth) { TWi[j] = root_pow(P.twi, k, j); TWf[j] = root_pow(P.twf, k, j); }
+    u64 coef[EPT];                                  // EPT >= K / by rows per lane: all loads in flight while the tables are built
+#pragma unroll
+    for (int i = 0; i < EPT; i++) { const u32 t = y + i * by; coef[i] = (valid && t < K) ? P.src[base + (u64)t * P.C] : 0; }
+    for (u32 j = tid; j < K; j += nth) { TWi[j] = P.twKi[j << (10 - k)]; TWf[j] = P.twKf[j << (10 - k)]; }
     for (u32 idx = tid; idx < P.G * K; idx += nth) {
         u32 pos = (gt * P.G + (idx >> k)) * K + (idx & (K - 1));
         u32 m = bitrev32(pos, P.n);                 // this row holds coefficient m of the column polynomial
@@ -194,19 +236,19 @@ __global__ void lde_mid_kernel(LdeParams P) {
         if (P.cosetBegin) s0 = mul(s0, root_pow(P.twf, P.n + P.extBits, m * P.cosetBegin));   // (w_E^m)^cosetBegin, m*cb < 2^(n+b)
         Sc[idx] = s0;
     }
-    for (u32 t = y; t < K; t += by) tile[t * S + x] = valid ? P.src[base + (u64)t * P.C] : 0;
+#pragma unroll
+    for (int i = 0; i < EPT; i++) { const u32 t = y + i * by; if (t < K) tile[t * S + x] = coef[i]; }
     __syncthreads();
-    dif_stages(tile, TWi, k, S, x, y, by);
-    u64 coef[EPT];
+    dif_stages<true>(tile, TWi, k, S, x, y, by);
 #pragma unroll
     for (int i = 0; i < EPT; i++) { u32 t = y + i * by; coef[i] = t < K ? tile[t * S + x] : 0; }
     __syncthreads();
     const u32 nCosets = P.cosetCount;
     for (u32 j = 0; j < nCosets; j++) {
 #pragma unroll
-        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[t * S + x] = mul(coef[i], Sc[gi * K + t]); }
+        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[t * S + x] = mul_lazy(coef[i], Sc[gi * K + t]); }
         __syncthreads();
-        dit_stages(tile, TWf, k, S, x, y, by);
+        dit_stages<false>(tile, TWf, k, S, x, y, by);
         if (valid) {
 #pragma unroll
             for (int i = 0; i < EPT; i++) {
@@ -250,8 +292,8 @@ Geom make_geom(u32 k, u64 C, u64 totalGroups, u32 maxElems, u32 nThreads) {
         g.nColChunks = (u32)((C + g.Wc - 1) / g.Wc);
     }
     g.S = g.Wc * g.nbT;
-    u32 half = k > 0 ? (1u << (k - 1)) : 1;
-    g.by = std::max<u32>(1, std::min<u32>(nThreads / g.S, half));
+    u32 nSub = 1u << (k - next_chunk(k));          // sub-transforms per column in the widest register step
+    g.by = std::max<u32>(1, std::min<u32>(nThreads / g.S, nSub));
     return g;
 }
 
@@ -266,6 +308,7 @@ int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit,
     PassParams P;
     P.src = src; P.dst = dst;
     P.tw = inverse ? tables().powWi : tables().powW;
+    P.twK = inverse ? tables().tw1024i : tables().tw1024;
     P.C = C; P.scale = scale; P.k = k; P.logM = lo + k; P.hasTw = lo > 0; P.dit = dit; P.n = n; P.scatter = scatter;
     u64 totalGroups;
     u32 nHi;
@@ -274,11 +317,15 @@ int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit,
     Geom g = make_geom(k, C, totalGroups, env_u32("PIL2GL_NTT_TILE", 4096), 256);
     P.Wc = g.Wc; P.nbT = g.nbT; P.nColChunks = g.nColChunks; P.nGroupTiles = (u32)(totalGroups / g.nbT);
     u64 K = 1ull << k;
-    size_t ldsBytes = 8 * ((size_t)g.S * K + std::max<u64>(1, K / 2) + (P.hasTw ? (size_t)g.nbT * K : 0));
-    P2_TRY(set_lds((const void *)ntt_pass_kernel, ldsBytes));
+    size_t ldsBytes = 8 * ((size_t)g.S * K + K + (P.hasTw ? (size_t)g.nbT * K : 0));
     u64 blocks = (u64)nHi * P.nGroupTiles * P.nColChunks;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
-    hipLaunchKernelGGL(ntt_pass_kernel, dim3((unsigned)blocks), dim3(g.S, g.by), ldsBytes, st, P);
+    if (dit && inverse) return fail(PIL2GL_EINVAL, "no inverse decimation-in-time pass");
+#define PASS_CASE(INV_, DIT_)                                                                                     \
+    { P2_TRY(set_lds((const void *)ntt_pass_kernel<INV_, DIT_>, ldsBytes));                                          \
+      hipLaunchKernelGGL((ntt_pass_kernel<INV_, DIT_>), dim3((unsigned)blocks), dim3(g.S, g.by), ldsBytes, st, P); }
+    if (dit) PASS_CASE(false, true) else if (inverse) PASS_CASE(true, false) else PASS_CASE(false, false)
+#undef PASS_CASE
     KERNEL_CHECK();
     return PIL2GL_OK;
 }
@@ -350,7 +397,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
     // 2. mid kernel: last kf iNTT stages + coset scaling + first kf NTT stages, tmp -> dst
     {
         LdeParams P;
-        P.src = coef; P.dst = dst; P.twi = tables().powWi; P.twf = tables().powW; P.pow7 = unitShift ? nullptr : tables().pow7;
+        P.src = coef; P.dst = dst; P.twi = tables().powWi; P.twf = tables().powW; P.twKi = tables().tw1024i; P.twKf = tables().tw1024; P.pow7 = unitShift ? nullptr : tables().pow7;
         P.C = C; P.ninv = h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb;
         P.cosetBegin = cosetBegin; P.cosetCount = cosetCount;
         u64 totalGroups = 1ull << (n - kf);
@@ -360,11 +407,11 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
         u64 K = 1ull << kf;
         u32 maxElems = env_u32("PIL2GL_LDE_TILE", 4096);
         Geom g = make_geom(kf, C, totalGroups, maxElems, nThreads);
-        size_t ldsBytes = 8 * ((size_t)g.S * K + std::max<u64>(2, K) + 2 * (size_t)g.nbT * K);
+        size_t ldsBytes = 8 * ((size_t)g.S * K + 2 * K + 2 * (size_t)g.nbT * K);
         while (ldsBytes > 96 * 1024 && g.nbT > 1) {
             maxElems /= 2;
             g = make_geom(kf, C, totalGroups, maxElems, nThreads);
-            ldsBytes = 8 * ((size_t)g.S * K + std::max<u64>(2, K) + 2 * (size_t)g.nbT * K);
+            ldsBytes = 8 * ((size_t)g.S * K + 2 * K + 2 * (size_t)g.nbT * K);
         }
         P.Wc = g.Wc; P.G = g.nbT; P.nColChunks = g.nColChunks;
         u32 need = (u32)((K + g.by - 1) / g.by);

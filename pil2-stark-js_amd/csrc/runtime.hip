@@ -11,7 +11,7 @@ namespace pil2gl {
 static thread_local char g_err[512] = "";
 static bool g_ready = false;
 static int g_device = -1;
-static Tables g_tables = { nullptr, nullptr, nullptr, nullptr };
+static Tables g_tables = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 static u64 *g_tables_mem = nullptr;
 static const u32 N_SCRATCH = 12;
 static u64 *g_scratch[N_SCRATCH] = { nullptr };
@@ -100,18 +100,25 @@ int pil2gl_init(int device) {
     if (g_ready && g_device == device) return PIL2GL_OK;
     if (g_ready) pil2gl_shutdown();
     HIP_TRY(hipSetDevice(device));
-    std::vector<u64> host(4 * 1024);
+    std::vector<u64> host(6 * 1024);
     u64 w32 = h_root(32);
     fill_pow256(&host[0], w32);
     fill_pow256(&host[1024], h_inv(w32));
     fill_pow256(&host[2048], 7);
     fill_pow256(&host[3072], h_inv(7));
+    {
+        const u64 w10 = h_root(10), w10i = h_inv(w10);
+        u64 a = 1, b = 1;
+        for (int j = 0; j < 1024; j++) { host[4096 + j] = a; host[5120 + j] = b; a = h_mul(a, w10); b = h_mul(b, w10i); }
+    }
     HIP_TRY(hipMalloc((void **)&g_tables_mem, host.size() * 8));
     HIP_TRY(hipMemcpy(g_tables_mem, host.data(), host.size() * 8, hipMemcpyHostToDevice));
     g_tables.powW = g_tables_mem;
     g_tables.powWi = g_tables_mem + 1024;
     g_tables.pow7 = g_tables_mem + 2048;
     g_tables.pow7i = g_tables_mem + 3072;
+    g_tables.tw1024 = g_tables_mem + 4096;
+    g_tables.tw1024i = g_tables_mem + 5120;
     g_device = device;
     g_ready = true;
     return PIL2GL_OK;

@@ -151,7 +151,8 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     const u32 gi = x / P.Wc, ci = x - gi * P.Wc;
     const u64 c = (u64)cc * P.Wc + ci;
     const bool valid = c < P.C;
-    const u64 g = (u64)gt * P.nbT + gi;
+    // slot groups: adjacent blocks; in the scattering pass blocks nGroupTiles apart, whose bit-reversed rows are adjacent
+    const u64 g = P.scatter ? (u64)gi * P.nGroupTiles + gt : (u64)gt * P.nbT + gi;
     const u64 base = (u64)hi * P.hiStride + g * P.gStride + c;
 
     // the first LOADB rows of this lane are requested before the tables are built, so that their latency overlaps it;
@@ -297,6 +298,13 @@ Geom make_geom(u32 k, u64 C, u64 totalGroups, u32 maxElems, u32 nThreads) {
     return g;
 }
 
+// stages per pass: a tile row is S*8 contiguous bytes and S <= 256 / 2^(k-4), so 8 stages keep 128-byte segments for
+// wide matrices; narrow ones (rows under 128 bytes) take 7 so that adjacent rows fill the segment
+u32 pick_kmax(u64 C) {
+    u32 dflt = C * 8 >= 128 ? 8 : 7;
+    return std::min<u32>(10, std::max<u32>(1, env_u32("PIL2GL_NTT_KMAX", dflt)));
+}
+
 int set_lds(const void *fn, size_t bytes) {
     if (bytes > 160 * 1024) return fail(PIL2GL_EINVAL, "tile needs %zu bytes of LDS (>160 KiB)", bytes);
     if (bytes > 48 * 1024) HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
@@ -349,7 +357,7 @@ int ntt_launch(const u64 *src, u64 C, u32 n, u64 *dst, bool inverse, hipStream_t
         if (src != dst) HIP_TRY(hipMemcpyAsync(dst, src, C * 8, hipMemcpyDeviceToDevice, st));
         return PIL2GL_OK;
     }
-    u32 kmax = std::min<u32>(10, std::max<u32>(1, env_u32("PIL2GL_NTT_KMAX", 10)));
+    u32 kmax = pick_kmax(C);
     u32 ks[32];
     int np = split_bits(n, kmax, ks);
     u64 scale = inverse ? h_inv(N % 0xFFFFFFFF00000001ull) : 0;
@@ -377,7 +385,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
         KERNEL_CHECK();
         return PIL2GL_OK;
     }
-    u32 kmax = std::min<u32>(10, std::max<u32>(1, env_u32("PIL2GL_NTT_KMAX", 10)));
+    u32 kmax = pick_kmax(C);
     u32 nfp = (n + kmax - 1) / kmax;
     u32 kf = (n + nfp - 1) / nfp;       // bits done by the mid kernel (both directions)
     // 1. iNTT, decimation in frequency, bits [kf, n) from the top down: src -> tmp, then in place

@@ -102,35 +102,46 @@ __global__ void q_split_kernel(const u64 *__restrict__ qq1, u32 nBits, u32 nBits
     qq2[o] = mul(qq1[(p * N + i) * qDim + k], sPow[p]);
 }
 // stark_gen_helpers.js:302-322: (x_k - xi)^-1 * x_k with F.sub(scalar, triple) (f3g.js:66).
-// A lane takes XD_BATCH rows k, k+T, k+2T, ... (T = threads in the grid: neighbouring lanes stay on neighbouring rows) and
-// inverts their denominators with ONE extension inversion (Montgomery's trick, the device form of the reference's
-// F.batchInverse :316); x advances by the constant w_E^T from row to row.
-constexpr int XD_BATCH = 8;
-__global__ void x_div_x_sub_xi_kernel(u32 nBitsExt, E3 xi, u64 nOpen, u64 iOpen, const u64 *__restrict__ powW, u64 wStep, u64 *__restrict__ out) {
+// The denominator (a, b, c) = (x_k - xi_0, -xi_1, -xi_2) varies in its first component only, so the extension inverse
+// (f3g.js:136-172: adjugate (i1, i2, i3) over the norm t) is a polynomial in a with per-call constants:
+//     u = a (a + 2c);  i1 = m1 - u;  t = a (i1 + 2bc) + k0;  i2 = b a - cc;  i3 = c a + (cc - bb)
+// with m1 = bc + bb - cc, k0 = -b^3 + b c^2 - c^3: four multiplications, and the one inversion per row is of the BASE
+// field element t.  A lane takes XD_BATCH rows k, k+T, k+2T, ... (T = threads in the grid: neighbouring lanes stay on
+// neighbouring rows) and inverts their norms with one field inversion (Montgomery's trick, the device form of the
+// reference's F.batchInverse :316); x advances by the constant w_E^T from row to row.
+constexpr int XD_BATCH = 16;
+struct XDivConst { u64 xi0, b, c, c2, bc2, m1, k0, cc, ccbb; };
+__global__ void __launch_bounds__(256) x_div_x_sub_xi_kernel(u32 nBitsExt, XDivConst K, u64 nOpen, u64 iOpen, const u64 *__restrict__ powW, u64 wStep, u64 *__restrict__ out) {
     const u64 E = 1ull << nBitsExt, T = (u64)gridDim.x * blockDim.x;
     const u64 k0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (k0 >= E) return;
-    u64 xs[XD_BATCH];
-    E3 den[XD_BATCH], pre[XD_BATCH];
+    u64 xs[XD_BATCH], as[XD_BATCH], ts[XD_BATCH], pre[XD_BATCH];
     u64 x = mul(7, root_pow(powW, nBitsExt, (u32)k0));
     int n = 0;
 #pragma unroll
     for (int i = 0; i < XD_BATCH; i++) {
         if (k0 + (u64)i * T < E) {
-            xs[i] = x;
-            den[i] = E3{ { sub(x, xi.v[0]), neg(xi.v[1]), neg(xi.v[2]) } };
-            pre[i] = i ? e3_mul(pre[i - 1], den[i]) : den[i];
+            const u64 a = sub(x, K.xi0);
+            const u64 u = mul(a, add(a, K.c2));
+            const u64 t = add(mul(a, add(sub(K.m1, u), K.bc2)), K.k0);
+            xs[i] = x; as[i] = a; ts[i] = t;
+            pre[i] = i ? mul(pre[i - 1], t) : t;
             x = mul(x, wStep);
             n = i + 1;
         }
     }
-    E3 inv = e3_inv(pre[n - 1]);
+    u64 tinv = inv(pre[n - 1]);
 #pragma unroll
     for (int i = XD_BATCH - 1; i >= 0; i--) {
         if (i < n) {
-            const E3 di = i ? e3_mul(inv, pre[i - 1]) : inv;
-            if (i) inv = e3_mul(inv, den[i]);
-            st3(out + 3 * ((k0 + (u64)i * T) * nOpen + iOpen), e3_scale(di, xs[i]));
+            const u64 ti = i ? mul(tinv, pre[i - 1]) : tinv;          // 1 / t_i
+            if (i) tinv = mul(tinv, ts[i]);
+            const u64 a = as[i], s = mul(ti, xs[i]);                  // x / norm
+            const u64 i1 = sub(K.m1, mul(a, add(a, K.c2)));
+            const u64 i2 = sub(mul(K.b, a), K.cc);
+            const u64 i3 = add(mul(K.c, a), K.ccbb);
+            u64 *o = out + 3 * ((k0 + (u64)i * T) * nOpen + iOpen);
+            o[0] = mul(i1, s); o[1] = mul(i2, s); o[2] = mul(i3, s);
         }
     }
 }
@@ -318,12 +329,19 @@ int pil2gl_compute_q_split_dev(const uint64_t *qq1, uint32_t nBits, uint32_t nBi
 int pil2gl_x_div_x_sub_xi_dev(uint32_t nBitsExt, const uint64_t xi[3], uint64_t nOpen, uint64_t iOpen, uint64_t *out, void *stream) {
     P2_TRY(ensure_init());
     if (!xi || !out || iOpen >= nOpen || nBitsExt > 31) return fail(PIL2GL_EINVAL, "bad xDivXSubXi arguments");
-    E3 x = { { xi[0], xi[1], xi[2] } };
+    const u64 GP = 0xFFFFFFFF00000001ull;
+    const u64 xi0 = xi[0] % GP, b = h_sub(0, xi[1] % GP), c = h_sub(0, xi[2] % GP);
+    const u64 bb = h_mul(b, b), cc = h_mul(c, c), bc = h_mul(b, c);
+    XDivConst K;
+    K.xi0 = xi0; K.b = b; K.c = c; K.c2 = h_add(c, c); K.bc2 = h_add(bc, bc);
+    K.m1 = h_sub(h_add(bc, bb), cc);
+    K.k0 = h_sub(h_sub(h_mul(b, cc), h_mul(bb, b)), h_mul(cc, c));
+    K.cc = cc; K.ccbb = h_sub(cc, bb);
     const u64 E = 1ull << nBitsExt;
     const unsigned blocks = nblk((E + XD_BATCH - 1) / XD_BATCH);
     const u64 T = (u64)blocks * 256;
     const u64 wStep = h_pow(h_root(nBitsExt), T);                                   // w_E^T
-    x_div_x_sub_xi_kernel<<<blocks, 256, 0, as_stream(stream)>>>(nBitsExt, x, nOpen, iOpen, tables().powW, wStep, out);
+    x_div_x_sub_xi_kernel<<<blocks, 256, 0, as_stream(stream)>>>(nBitsExt, K, nOpen, iOpen, tables().powW, wStep, out);
     KERNEL_CHECK();
     return PIL2GL_OK;
 }

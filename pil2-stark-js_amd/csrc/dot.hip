@@ -148,17 +148,26 @@ __global__ void __launch_bounds__(256) cols_dot_kernel(ColsDotParams P) {
 #pragma unroll
             for (int i = 0; i < 6; i++) S[l][k][i] = 0;
     const bool valid = c < P.width;
-    for (u64 k = k0; k < k1; k++) {
-        const u64 p = valid ? P.buf[k * P.rowStep * P.width + c] : 0;
-        const u32 p0 = (u32)p, p1 = (u32)(p >> 32);
+    constexpr int RB = 8;                            // rows whose loads are in flight together
+    const u64 stride = P.rowStep * P.width;
+    for (u64 kb = k0; kb < k1; kb += RB) {
+        u64 pv[RB];
 #pragma unroll
-        for (int l = 0; l < NLEV; l++) {
-            const u32 *L = P.levLimbs + (((u64)l * P.nRows + k) * 9);            // uniform
+        for (int j = 0; j < RB; j++) pv[j] = (valid && kb + j < k1) ? P.buf[(kb + j) * stride + c] : 0;
 #pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const u32 w0 = L[3 * q], w1 = L[3 * q + 1], w2 = L[3 * q + 2];
-                S[l][q][0] += (u64)p0 * w0; S[l][q][1] += (u64)p0 * w1; S[l][q][2] += (u64)p0 * w2;
-                S[l][q][3] += (u64)p1 * w0; S[l][q][4] += (u64)p1 * w1; S[l][q][5] += (u64)p1 * w2;
+        for (int j = 0; j < RB; j++) {
+            const u64 k = kb + j;
+            if (k >= k1) break;
+            const u32 p0 = (u32)pv[j], p1 = (u32)(pv[j] >> 32);
+#pragma unroll
+            for (int l = 0; l < NLEV; l++) {
+                const u32 *L = P.levLimbs + (((u64)l * P.nRows + k) * 9);            // uniform
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const u32 w0 = L[3 * q], w1 = L[3 * q + 1], w2 = L[3 * q + 2];
+                    S[l][q][0] += (u64)p0 * w0; S[l][q][1] += (u64)p0 * w1; S[l][q][2] += (u64)p0 * w2;
+                    S[l][q][3] += (u64)p1 * w0; S[l][q][4] += (u64)p1 * w1; S[l][q][5] += (u64)p1 * w2;
+                }
             }
         }
     }

@@ -220,9 +220,20 @@ __device__ __forceinline__ void lds_store(u32 *S, int tmax, int lane, int buf, i
 #pragma unroll
     for (int l = 0; l < 8; l++) S_AT(buf, j, l) = x[l];
 }
-__device__ __forceinline__ void load_const(const u32 *p, size_t idx, u32 c[8]) {       // wave-uniform address
+// wave-uniform address.  WIDE: the tables live in global memory; saying so (the pointers reach the out-of-line helpers as
+// generic ones) turns the flat loads into global loads, whose counter is separate from the LDS one and in order, so that a
+// request for the next term can stay in flight across the current multiply
+typedef const u32 __attribute__((address_space(1))) *gconst_u32;
+template <bool WIDE>
+__device__ __forceinline__ void load_const(const u32 *p, size_t idx, u32 c[8]) {
+    if constexpr (WIDE) {
+        gconst_u32 q = (gconst_u32)(p + idx * 8);
 #pragma unroll
-    for (int l = 0; l < 8; l++) c[l] = p[idx * 8 + l];
+        for (int l = 0; l < 8; l++) c[l] = q[l];
+    } else {
+#pragma unroll
+        for (int l = 0; l < 8; l++) c[l] = p[idx * 8 + l];
+    }
 }
 __device__ __forceinline__ void pow5(u32 x[8]) {
     u32 x2[8], x4[8];
@@ -231,11 +242,12 @@ __device__ __forceinline__ void pow5(u32 x[8]) {
 
 // x^5 on elements [0, nSbox) after adding constants C[0..t), then the dense n x n matrix A applied to elements
 // [first, first+n) of buffer cur into buffer cur^1 (elements below `first` are copied)
+template <bool WIDE>
 __device__ __noinline__ void add_sbox(u32 *S, int tmax, int lane, int cur, int t, const u32 *C, size_t cOff, int nSbox) {
     for (int j = 0; j < t; j++) {
         u32 x[8], c[8];
         lds_load(S, tmax, lane, cur, j, x);
-        load_const(C, cOff + j, c);
+        load_const<WIDE>(C, cOff + j, c);
         bn::fr_add(x, c);
         if (j < nSbox) pow5(x);
         lds_store(S, tmax, lane, cur, j, x);
@@ -244,17 +256,38 @@ __device__ __noinline__ void add_sbox(u32 *S, int tmax, int lane, int cur, int t
 // In place: every row reads the whole old state, so the n new elements wait in a per-lane private array (scratch memory,
 // 17 x 32 B, a few KB of traffic per permutation against ~10^5 multiply steps) until all rows are done; one LDS buffer per
 // wave then suffices (4 waves per CU at t = 17 instead of 2).
+template <bool WIDE>
 __device__ __noinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, const u32 *A, int n, int first) {
     u32 nw[17 * 8];
     for (int i = 0; i < n; i++) {
         u32 acc[17];
 #pragma unroll
         for (int l = 0; l < 17; l++) acc[l] = 0;
-        for (int j = 0; j < n; j++) {
+        if constexpr (WIDE) {
+            // operands of term j+1 are requested before term j is multiplied: the LDS read and the (wave-uniform) table
+            // load then overlap the ~600 issue cycles of a multiply-accumulate instead of stalling the wave, which at this
+            // width is alone on its SIMD.  One multiply in the loop body: the permutation has to stay in the instruction cache.
             u32 y[8], m[8];
-            lds_load(S, tmax, lane, cur, first + j, y);
-            load_const(A, (size_t)i * n + j, m);
-            bn::mac17(acc, y, m);
+            lds_load(S, tmax, lane, cur, first, y);
+            load_const<true>(A, (size_t)i * n, m);
+            for (int j = 0; j < n; j++) {
+                u32 yn[8], mn[8];
+                if (j + 1 < n) {
+                    lds_load(S, tmax, lane, cur, first + j + 1, yn);
+                    load_const<true>(A, (size_t)i * n + j + 1, mn);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the multiply (the scheduler sinks them otherwise)
+                bn::mac17(acc, y, m);
+#pragma unroll
+                for (int l = 0; l < 8; l++) { y[l] = yn[l]; m[l] = mn[l]; }
+            }
+        } else {
+            for (int j = 0; j < n; j++) {
+                u32 y[8], m[8];
+                lds_load(S, tmax, lane, cur, first + j, y);
+                load_const<false>(A, (size_t)i * n + j, m);
+                bn::mac17(acc, y, m);
+            }
         }
         u32 o[8];
         bn::redc17(o, acc);
@@ -267,54 +300,86 @@ __device__ __noinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, cons
     }
 }
 
+// partial rounds, sparse form, in place: element 0 stays in registers.  WIDE: the next term's requests are pinned ahead of
+// the current term's two products (see dense_mul)
+template <bool WIDE>
+__device__ __noinline__ void partial_rounds(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
+    const int t = A.t;
+    u32 x0[8], m00[8];
+    lds_load(S, tmax, lane, cur, 0, x0);
+#pragma unroll
+    for (int l = 0; l < 8; l++) m00[l] = A.m00[l];
+    const int n = t - 1;
+    for (int k = 0; k < A.rp; k++) {
+        u32 c[8];
+        load_const<WIDE>(A.S, (size_t)k, c);
+        bn::fr_add(x0, c);
+        pow5(x0);
+        u32 acc[17];
+#pragma unroll
+        for (int l = 0; l < 17; l++) acc[l] = 0;
+        bn::mac17(acc, x0, m00);
+        if constexpr (WIDE) {
+            u32 y[8], vv[8], ww[8];
+            lds_load(S, tmax, lane, cur, 1, y);
+            load_const<true>(A.V, (size_t)k * n, vv);
+            load_const<true>(A.W, (size_t)k * n, ww);
+            for (int j = 0; j < n; j++) {
+                u32 yn[8], vn[8], wn[8], p[8];
+                if (j + 1 < n) {
+                    lds_load(S, tmax, lane, cur, 2 + j, yn);
+                    load_const<true>(A.V, (size_t)k * n + j + 1, vn);
+                    load_const<true>(A.W, (size_t)k * n + j + 1, wn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bn::mac17(acc, y, vv);               // row 0:   m00*x0 + sum V_kj * y_j
+                bn::fr_mul(p, x0, ww);               // column:  y_j + W_kj * x0
+                bn::fr_add(y, p);
+                lds_store(S, tmax, lane, cur, 1 + j, y);
+#pragma unroll
+                for (int l = 0; l < 8; l++) { y[l] = yn[l]; vv[l] = vn[l]; ww[l] = wn[l]; }
+            }
+        } else {
+            for (int j = 0; j < n; j++) {
+                u32 y[8], vv[8], ww[8], p[8];
+                lds_load(S, tmax, lane, cur, 1 + j, y);
+                load_const<false>(A.V, (size_t)k * n + j, vv);
+                bn::mac17(acc, y, vv);               // row 0:   m00*x0 + sum V_kj * y_j
+                load_const<false>(A.W, (size_t)k * n + j, ww);
+                bn::fr_mul(p, x0, ww);               // column:  y_j + W_kj * x0
+                bn::fr_add(y, p);
+                lds_store(S, tmax, lane, cur, 1 + j, y);
+            }
+        }
+        bn::redc17(x0, acc);
+    }
+    lds_store(S, tmax, lane, cur, 0, x0);
+}
+
 // permutation of the t elements in buffer `cur`; returns the buffer holding the result
+template <bool WIDE>
 __device__ __noinline__ int bn_perm(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
     const int t = A.t;
     if (A.dense) {                                   // poseidon.circom:22-44 as written (tests)
         for (int r = 0; r < N_ROUNDS_F + A.rp; r++) {
             const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
-            add_sbox(S, tmax, lane, cur, t, A.Cd, (size_t)r * t, full ? t : 1);
-            dense_mul(S, tmax, lane, cur, A.M, t, 0);
+            add_sbox<WIDE>(S, tmax, lane, cur, t, A.Cd, (size_t)r * t, full ? t : 1);
+            dense_mul<WIDE>(S, tmax, lane, cur, A.M, t, 0);
         }
         return cur;
     }
     for (int r = 0; r < 4; r++) {
-        add_sbox(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
-        dense_mul(S, tmax, lane, cur, A.M, t, 0);
+        add_sbox<WIDE>(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
+        dense_mul<WIDE>(S, tmax, lane, cur, A.M, t, 0);
     }
-    {   // partial rounds, sparse form, in place: element 0 stays in registers
-        u32 x0[8], m00[8];
-        lds_load(S, tmax, lane, cur, 0, x0);
-#pragma unroll
-        for (int l = 0; l < 8; l++) m00[l] = A.m00[l];
+    {
         const int n = t - 1;
-        for (int k = 0; k < A.rp; k++) {
-            u32 c[8];
-            load_const(A.S, (size_t)k, c);
-            bn::fr_add(x0, c);
-            pow5(x0);
-            u32 acc[17];
-#pragma unroll
-            for (int l = 0; l < 17; l++) acc[l] = 0;
-            bn::mac17(acc, x0, m00);
-            for (int j = 0; j < n; j++) {
-                u32 y[8], vv[8], ww[8], p[8];
-                lds_load(S, tmax, lane, cur, 1 + j, y);
-                load_const(A.V, (size_t)k * n + j, vv);
-                bn::mac17(acc, y, vv);               // row 0:   m00*x0 + sum V_kj * y_j
-                load_const(A.W, (size_t)k * n + j, ww);
-                bn::fr_mul(p, x0, ww);               // column:  y_j + W_kj * x0
-                bn::fr_add(y, p);
-                lds_store(S, tmax, lane, cur, 1 + j, y);
-            }
-            bn::redc17(x0, acc);
-        }
-        lds_store(S, tmax, lane, cur, 0, x0);
-        dense_mul(S, tmax, lane, cur, A.D, n, 1);    // diag(1, Mh^RP)
+        partial_rounds<WIDE>(S, tmax, lane, cur, A);
+        dense_mul<WIDE>(S, tmax, lane, cur, A.D, n, 1);    // diag(1, Mh^RP)
     }
     for (int r = 4; r < 8; r++) {
-        add_sbox(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
-        dense_mul(S, tmax, lane, cur, A.M, t, 0);
+        add_sbox<WIDE>(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
+        dense_mul<WIDE>(S, tmax, lane, cur, A.M, t, 0);
     }
     return cur;
 }
@@ -338,6 +403,7 @@ __device__ __forceinline__ void digest_out(const u32 *S, int tmax, int lane, int
 }
 
 // leaf digests (merklehash_bn128_worker.js:42-98): one row per lane
+template <bool WIDE>
 __global__ void __launch_bounds__(BN_BLOCK) bn_linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int arity, int custom,
                                                                     PermArgs full, PermArgs last, u64 *__restrict__ out) {
     extern __shared__ u32 S[];
@@ -361,11 +427,11 @@ __global__ void __launch_bounds__(BN_BLOCK) bn_linear_hash_kernel(const u64 *__r
                 for (int q = 0; q < 3; q++) { const u64 idx = 3 * (e + k) + q; if (idx < width) w[q] = v[idx]; }
                 to_mont_store(S, tmax, lane, cur, 1 + (int)k, w);
             }
-            if (n == (u64)arity) cur = bn_perm(S, tmax, lane, cur, full);
+            if (n == (u64)arity) cur = bn_perm<WIDE>(S, tmax, lane, cur, full);
             else if (custom) {                       // :87-93: zero-pad the last chunk to `arity` inputs
                 for (u64 k = n; k < (u64)arity; k++) zero_store(S, tmax, lane, cur, 1 + (int)k);
-                cur = bn_perm(S, tmax, lane, cur, full);
-            } else cur = bn_perm(S, tmax, lane, cur, last);      // :85-86: t = nLast + 1
+                cur = bn_perm<WIDE>(S, tmax, lane, cur, full);
+            } else cur = bn_perm<WIDE>(S, tmax, lane, cur, last);      // :85-86: t = nLast + 1
             e += n;
         }
     }
@@ -373,6 +439,7 @@ __global__ void __launch_bounds__(BN_BLOCK) bn_linear_hash_kernel(const u64 *__r
 }
 
 // parents (merklehash_bn128_worker.js:104-144): out[i] = Poseidon(0; in[arity*i .. arity*i+arity-1])[0]
+template <bool WIDE>
 __global__ void __launch_bounds__(BN_BLOCK) bn_merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, int arity, PermArgs full, u64 *__restrict__ out) {
     extern __shared__ u32 S[];
     const int lane = threadIdx.x, tmax = arity + 1;
@@ -384,11 +451,12 @@ __global__ void __launch_bounds__(BN_BLOCK) bn_merkle_level_kernel(const u64 *__
 #pragma unroll
         for (int q = 0; q < 4; q++) { const u64 w = v[4 * k + q]; S_AT(0, 1 + k, 2 * q) = (u32)w; S_AT(0, 1 + k, 2 * q + 1) = (u32)(w >> 32); }
     }
-    const int cur = bn_perm(S, tmax, lane, 0, full);
+    const int cur = bn_perm<WIDE>(S, tmax, lane, 0, full);
     if (live) digest_out(S, tmax, lane, cur, 0, out + 4 * i0);
 }
 
 // circomlibjs poseidon(inputs, initState, nOut): normal-form words in and out (transcript, verification, tests)
+template <bool WIDE>
 __global__ void __launch_bounds__(BN_BLOCK) bn_poseidon_kernel(const u64 *__restrict__ in, const u64 *__restrict__ init, u64 count, int nIn, int nOut,
                                                                  PermArgs full, u64 *__restrict__ out) {
     extern __shared__ u32 S[];
@@ -403,7 +471,7 @@ __global__ void __launch_bounds__(BN_BLOCK) bn_poseidon_kernel(const u64 *__rest
         for (int q = 0; q < 4; q++) w[q] = in[(i * nIn + k) * 4 + q];
         to_mont_store(S, tmax, lane, 0, 1 + k, w);
     }
-    const int cur = bn_perm(S, tmax, lane, 0, full);
+    const int cur = bn_perm<WIDE>(S, tmax, lane, 0, full);
     if (!live) return;
     for (int k = 0; k < nOut; k++) {                 // out of Montgomery form: multiply by 1
         u32 x[8], one[8] = { 1, 0, 0, 0, 0, 0, 0, 0 }, o[8];
@@ -441,6 +509,10 @@ int set_lds_attr(K kernel, size_t bytes) {
     return PIL2GL_OK;
 }
 
+// a state of t elements takes t * 2 KB of LDS per wave: from t = 10 on only one wave fits per SIMD, and the kernels
+// that prefetch their operands (more registers, no cost in occupancy there) are the faster ones
+bool wide_state(int t) { return t >= 10; }
+
 int check_arity(uint32_t arity) {
     if (arity < 2 || arity > 16 || (arity & (arity - 1))) return fail(PIL2GL_EINVAL, "arity must be 2, 4, 8 or 16 (got %u)", arity);
     return PIL2GL_OK;
@@ -472,10 +544,15 @@ int pil2gl_bn128_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64
     const uint64_t nEl = (width + 2) / 3, nLast = nEl % arity;
     if (width > 4 && !custom && nLast) P2_TRY(get_params((int)nLast + 1, &pl));
     const size_t lds = lds_bytes((int)arity + 1);
-    P2_TRY(set_lds_attr(bn_linear_hash_kernel, lds));
     const uint64_t blocks = (height + BN_BLOCK - 1) / BN_BLOCK;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
-    bn_linear_hash_kernel<<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
+    if (wide_state((int)arity + 1)) {
+        P2_TRY(set_lds_attr(bn_linear_hash_kernel<true>, lds));
+        bn_linear_hash_kernel<true><<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
+    } else {
+        P2_TRY(set_lds_attr(bn_linear_hash_kernel<false>, lds));
+        bn_linear_hash_kernel<false><<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
+    }
     KERNEL_CHECK();
     return PIL2GL_OK;
 }
@@ -488,10 +565,15 @@ int pil2gl_bn128_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint32_t
     const Params *pf;
     P2_TRY(get_params((int)arity + 1, &pf));
     const size_t lds = lds_bytes((int)arity + 1);
-    P2_TRY(set_lds_attr(bn_merkle_level_kernel, lds));
     const uint64_t blocks = (nOps + BN_BLOCK - 1) / BN_BLOCK;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
-    bn_merkle_level_kernel<<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
+    if (wide_state((int)arity + 1)) {
+        P2_TRY(set_lds_attr(bn_merkle_level_kernel<true>, lds));
+        bn_merkle_level_kernel<true><<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
+    } else {
+        P2_TRY(set_lds_attr(bn_merkle_level_kernel<false>, lds));
+        bn_merkle_level_kernel<false><<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
+    }
     KERNEL_CHECK();
     return PIL2GL_OK;
 }
@@ -525,8 +607,14 @@ int pil2gl_bn128_poseidon_dev(const uint64_t *in, const uint64_t *init, uint64_t
     const Params *pf;
     P2_TRY(get_params((int)nIn + 1, &pf));
     const size_t lds = lds_bytes((int)nIn + 1);
-    P2_TRY(set_lds_attr(bn_poseidon_kernel, lds));
-    bn_poseidon_kernel<<<(unsigned)((count + BN_BLOCK - 1) / BN_BLOCK), BN_BLOCK, lds, as_stream(stream)>>>(in, init, count, (int)nIn, (int)nOut, perm_args(pf), out);
+    const unsigned pblocks = (unsigned)((count + BN_BLOCK - 1) / BN_BLOCK);
+    if (wide_state((int)nIn + 1)) {
+        P2_TRY(set_lds_attr(bn_poseidon_kernel<true>, lds));
+        bn_poseidon_kernel<true><<<pblocks, BN_BLOCK, lds, as_stream(stream)>>>(in, init, count, (int)nIn, (int)nOut, perm_args(pf), out);
+    } else {
+        P2_TRY(set_lds_attr(bn_poseidon_kernel<false>, lds));
+        bn_poseidon_kernel<false><<<pblocks, BN_BLOCK, lds, as_stream(stream)>>>(in, init, count, (int)nIn, (int)nOut, perm_args(pf), out);
+    }
     KERNEL_CHECK();
     return PIL2GL_OK;
 }

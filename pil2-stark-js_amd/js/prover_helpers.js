@@ -40,7 +40,7 @@ function encode(code, dom, ctx, global) {
                 return { kind: SEC, dim: r.dim, section: section("q_ext", info.qDim), prime: 0, index: 0 };
             case "f": if (dom !== "ext") throw new Error("Accessing q in domain n");
                 return { kind: SEC, dim: 3, section: section("f_ext", 3), prime: 0, index: 0 };
-            case "x": return { kind: SEC, dim: 1, section: section("x_" + dom, 1), prime: 0, index: 0 };
+            case "x": return { kind: SEC, dim: r.dim || 1, section: section("x_" + dom, r.dim || 1), prime: 0, index: 0 };
             case "Zi": {
                 const boundary = info.boundaries[r.boundaryId];
                 const ziIndex = boundary.name === "everyFrame"

@@ -124,6 +124,15 @@ __device__ __forceinline__ void dit_stages(u64 *tile, const u64 *TW, u32 k, u32 
     }
 }
 
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share one, each XCD has its own L2).  Tiles that are
+// neighbours in memory -- the column chunks of the same rows, whose row segments share cache lines when the row length is
+// not a multiple of 128 bytes -- are consecutive logical indices; this maps consecutive logical indices to one XCD, so the
+// second half of a straddled line is found (reads) or completed (writes) in the same L2.
+__device__ __forceinline__ u32 xcd_local_block() {
+    const u32 b = blockIdx.x, per = gridDim.x >> 3;
+    return b < (per << 3) ? (b & 7) * per + (b >> 3) : b;
+}
+
 struct PassParams {
     const u64 *src; u64 *dst;
     const u64 *tw;                  // pow256 table of the transform's 2^32-th root (forward or inverse)
@@ -144,7 +153,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
     u64 *tile = lds, *TW = tile + ((size_t)S << k), *TWO = TW + K;
 
-    u32 bid = blockIdx.x;
+    u32 bid = xcd_local_block();
     const u32 cc = bid % P.nColChunks; bid /= P.nColChunks;
     const u32 gt = bid % P.nGroupTiles;
     const u32 hi = bid / P.nGroupTiles;
@@ -216,7 +225,7 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
     u64 *tile = lds, *TWi = tile + ((size_t)S << k), *TWf = TWi + K, *Sc = TWf + K, *Uc = Sc + (size_t)P.G * K;
 
-    u32 bid = blockIdx.x;
+    u32 bid = xcd_local_block();
     const u32 cc = bid % P.nColChunks;
     const u32 gt = bid / P.nColChunks;
     const u32 gi = x / P.Wc, ci = x - gi * P.Wc;

@@ -255,15 +255,22 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
     __syncthreads();
     const u32 nCosets = P.cosetCount;
     for (u32 j = 0; j < nCosets; j++) {
+        // the per-row offsets do not depend on j: left alone the compiler computes them all once and keeps ~4 registers per
+        // row alive across the loop; the opaque copies make it redo the few additions in every coset instead
+        u64 dstOff = ((g * K + y) * P.cosetCount + j) * P.C + c;
+        u32 tileOff = y * S + x, scOff = gi * K + y;
+        asm volatile("" : "+v"(dstOff), "+v"(tileOff), "+v"(scOff));
+        const u64 dstStep = (u64)by * P.cosetCount * P.C;
 #pragma unroll
-        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[t * S + x] = mul_lazy(coef[i], Sc[gi * K + t]); }
+        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[tileOff + i * by * S] = mul_lazy(coef[i], Sc[scOff + i * by]); }
         __syncthreads();
         dit_stages<false>(tile, TWf, k, S, x, y, by);
+        asm volatile("" : "+v"(dstOff), "+v"(tileOff));
         if (valid) {
 #pragma unroll
             for (int i = 0; i < EPT; i++) {
                 u32 t = y + i * by;
-                if (t < K) P.dst[((g * K + t) * P.cosetCount + j) * P.C + c] = tile[t * S + x];
+                if (t < K) P.dst[dstOff + i * dstStep] = tile[tileOff + i * by * S];
             }
         }
         for (u32 idx = tid; idx < P.G * K; idx += nth) Sc[idx] = mul(Sc[idx], Uc[idx]);

@@ -64,20 +64,30 @@ __global__ void __launch_bounds__(256) rows_dot_kernel(RowsDotParams P) {
     // fetched into registers while the current one is consumed from LDS (the mads of a tile take far less time than
     // its loads are in flight, so without the overlap a wave mostly waits).
     u64 nxt[CW];
+    // row (lane >> 4) + 4 i, column c0 + (lane & 15): the 16 row offsets do not depend on c0 -- an opaque copy of the first
+    // one per tile keeps the compiler from holding all of them (and the LDS offsets) in registers across the column loop,
+    // which costs the kernel its fourth wave
+    const u32 lr = lane >> 4, lc = lane & 15;
     auto fetch = [&](u64 c0) {
         const u32 cw = (u32)min((u64)CW, P.width - c0);
+        u64 off = (row0 + lr) * P.width + c0 + lc;
+        asm volatile("" : "+v"(off));
+        const u64 step = 4 * P.width;
 #pragma unroll
         for (u32 i = 0; i < CW; i++) {
-            const u32 e = lane + 64 * i, r = e >> 4, c = e & 15;
-            const u64 gr = row0 + r;
-            nxt[i] = (c < cw && gr < P.nRows) ? P.buf[gr * P.width + c0 + c] : 0;
+            const u64 gr = row0 + lr + 4 * i;
+            nxt[i] = (lc < cw && gr < P.nRows) ? P.buf[off + i * step] : 0;
         }
     };
     fetch(0);
     for (u64 c0 = 0; c0 < P.width; c0 += CW) {
         const u32 cw = (u32)min((u64)CW, P.width - c0);
+        {
+            u32 to = lr * LD + lc;
+            asm volatile("" : "+v"(to));
 #pragma unroll
-        for (u32 i = 0; i < CW; i++) { const u32 e = lane + 64 * i; T[(e >> 4) * LD + (e & 15)] = nxt[i]; }
+            for (u32 i = 0; i < CW; i++) T[to + i * 4 * LD] = nxt[i];
+        }
         if (c0 + CW < P.width) fetch(c0 + CW);
         // wave-local hand-off through LDS: every lane of this wave wrote, every lane reads; no other wave involved
         __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0)

@@ -4,10 +4,12 @@
 // result is, per column, F.fft / F.ifft / extendPol (test/fft_p.test.js:47-229).
 //
 // Design (not the reference's block/transposition scheme):
-//  * A transform of 2^n rows is cut into passes of k <= 10 index bits.  One workgroup owns a
-//    tile of 2^k rows (stride 2^lo rows) x S column slots in LDS, runs the k radix-2 stages
-//    there, and applies the inter-pass twiddle w_(2^(lo+k))^(b*j) from a per-tile LDS table that
-//    is shared by all columns of the tile.  All passes are in place.
+//  * A transform of 2^n rows is cut into passes of k index bits (8, or 7 for matrices whose rows are
+//    shorter than 128 bytes; at most 10).  One workgroup owns a tile of 2^k rows (stride 2^lo rows)
+//    x S column slots in LDS, runs the k stages there as register steps of up to four stages (16-row
+//    sub-transforms in Z/(2^96+1), see below), and applies the inter-pass twiddle w_(2^(lo+k))^(b*j)
+//    from a per-tile LDS table that is shared by all columns of the tile.  All passes are in place.
+//    Workgroups are numbered so that the column chunks of one row block run on one XCD (one L2).
 //  * Forward/inverse transforms run decimation-in-frequency (natural in -> bit-reversed out);
 //    the last pass scatters rows to their bit-reversed index so the caller sees natural order.
 //  * interpolate (LDE) never reorders anything: iNTT as DIF leaves coefficient m at row

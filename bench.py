@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default=os.environ.get("PIL2GL_BENCH_MODE", "prove"), choices=["prove", "commit", "commit-sharded", "prove-sharded"])
     ap.add_argument("--split", action="store_true", help="splitLinearHash leaves (linearhash_gpu.js)")
+    ap.add_argument("--full-tree", action="store_true", help="commit-sharded: every rank builds the whole tree above the gathered leaves (default: the tree is split by leaf blocks, pil2gl.parallel.ShardedTree)")
     ap.add_argument("--shard-of", type=int, default=0, help="commit-sharded on ONE GPU: run rank 0's share of a K-GPU job (per-GPU time/memory rehearsal, e.g. --workload c5 --shard-of 8)")
     return ap.parse_args()
 
@@ -198,7 +199,7 @@ def rehearse_shard(args):
     times = []
     for i in range(args.warmup + args.steps):
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        st = parallel.extend_and_merkelize_sharded(be, src, n_cols, n_bits, n_bits + EXT_BITS, overwrite_src=True, rehearse_world=K)
+        st = parallel.extend_and_merkelize_sharded(be, src, n_cols, n_bits, n_bits + EXT_BITS, overwrite_src=True, rehearse_world=K, split_tree=not args.full_tree)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         if i >= args.warmup:
             times.append(dt)
@@ -210,7 +211,7 @@ def rehearse_shard(args):
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
                       "dtype": "u64", "data": "synthetic",
                       "config": {"workload": "extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, %d of %d cosets on this GPU" % (n_bits, n_cols, n_bits + EXT_BITS, (1 << EXT_BITS) // K, 1 << EXT_BITS),
-                                 "mode": "commit-sharded rehearsal", "shard_of": K},
+                                 "mode": "commit-sharded rehearsal", "shard_of": K, "tree": "full on every rank" if args.full_tree else "split by leaf blocks"},
                       "peak_torch_GB": torch.cuda.max_memory_allocated() / 1e9, "device_GB_in_use_at_end": (total - free) / 1e9}), flush=True)
 
 
@@ -329,7 +330,7 @@ def main():
             return
         if sharded:
             parallel.extend_and_merkelize_sharded(shard_be, src, n_cols, n_bits, n_bits + EXT_BITS,
-                                                  overwrite_src=bool(args.shard_of), rehearse_world=args.shard_of or None)
+                                                  overwrite_src=bool(args.shard_of), rehearse_world=args.shard_of or None, split_tree=not args.full_tree)
             return
         pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
         pil2gl.call("pil2gl_merkelize_dev", pil2gl._ptr(dst), n_cols, E, int(args.split), pil2gl._ptr(nodes), C.c_void_p(stream))

@@ -111,14 +111,16 @@ class ShardedTree:
         return out
 
 
-def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None, overwrite_src=False, rehearse_world=None):
+def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None, overwrite_src=False, rehearse_world=None, split_tree=False):
     """Sharded extendAndMerkelize.  `src` = the full N x n_pols trace on every rank.
     Returns {"local": N x (cc*n_pols) slice (row pos, coset jl, col c), "nodes": full tree.nodes, "width", "height",
     "cosetBegin", "cosetCount", "extBits"}; tree root = last 4 words of nodes, identical on all ranks and to the
     single-GPU merkelize of the full extension.
     overwrite_src: let the LDE use the trace buffer for its coefficient matrix (config 5: 107 GB trace + 107 GB slice per
     GPU, no third buffer).  rehearse_world=K: run rank 0's share of a K-rank job alone, standing in copies of the own
-    digests for the gathered ones (a one-GPU rehearsal of the per-GPU time and memory; the tree is not a real root)."""
+    digests for the gathered ones (a one-GPU rehearsal of the per-GPU time and memory; the tree is not a real root).
+    split_tree: instead of the full node array on every rank ("nodes"), return "tree": a ShardedTree -- each rank builds the
+    subtree over its block of leaves only and the top log2(world) levels are replicated (same root, same paths)."""
     if rehearse_world:
         rank, world = 0, int(rehearse_world)
     else:
@@ -128,10 +130,11 @@ def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None
     N = 1 << n_bits
     local = be.empty(N * cc * n_pols)
     be.interpolate_cosets(src, n_pols, n_bits, local, n_bits_ext, cb, cc, src if overwrite_src else None)
-    nodes = commit_local_slice(be, local, n_pols, n_bits, cc, world, group, rehearse_world)
+    tree = commit_local_slice(be, local, n_pols, n_bits, cc, world, group, rehearse_world, split_tree_rank=rank if split_tree else None)
     height = N << eb
-    return {"local": local, "nodes": nodes, "width": n_pols, "height": height,
-            "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
+    out = {"local": local, "width": n_pols, "height": height, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
+    out["tree" if split_tree else "nodes"] = tree
+    return out
 
 
 def owner_of_row(idx, ext_bits, world):

@@ -57,6 +57,16 @@ def main():
         t1 = be.merkelize(full, C, 1 << nbe)
         assert np.array_equal(be.to_host(t1["nodes"]), got_nodes)
     idxs = [0, 1, (1 << nbe) - 1, 37 % (1 << nbe), (5 << a.extbits) + 3]
+    # the same commit with the tree split by leaf blocks: same root, and the sibling paths of the full tree
+    st2 = parallel.extend_and_merkelize_sharded(be, be.from_host(trace), C, nb, nbe, split_tree=True)
+    assert [int(v) for v in st2["tree"].root] == [int(v) for v in want_nodes[-4:]], "rank %d: split-tree root differs" % rank
+    sib = st2["tree"].siblings(idxs)
+    for k, i in enumerate(idxs):
+        want_sib, off, n, j = [], 0, 1 << nbe, i
+        while n > 1:
+            want_sib.append([int(v) for v in want_nodes[off + 4 * (j ^ 1): off + 4 * (j ^ 1) + 4]])
+            off += 4 * (n + (n & 1)); n = (n + 1) // 2; j //= 2
+        assert [[int(v) for v in s_] for s_ in sib[k]] == want_sib, "rank %d: split-tree path of leaf %d differs" % (rank, i)
     rows = parallel.open_rows(be, st, idxs)
     assert np.array_equal(rows, ext[idxs]), "rank %d: opened rows differ" % rank
     for i in idxs:

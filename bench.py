@@ -242,11 +242,13 @@ def rehearse_prove(args):
         if i >= args.warmup:
             times.append(dt)
     dt = sum(times) / len(times)
+    stages = {}
+    parallel.stark_gen_sharded(be, src, setup, info, exprs, publics, rehearse_world=K, timings=stages)      # one more, instrumented
     print(json.dumps({"metric": "per-GPU time of ONE proof split over %d GPUs (rank 0's share run alone, exchanges stood in)" % K,
                       "value": (1 << n_bits) * n_cols / dt, "unit": "trace-cells/s (the job rate if the %d ranks run in parallel and the exchanges are free)" % K,
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "u64", "data": "synthetic",
                       "config": {"workload": "full proof of 2^%d rows x %d cols, blow-up 8, %d of %d cosets on this GPU" % (n_bits, n_cols, (1 << EXT_BITS) // K, 1 << EXT_BITS),
-                                 "mode": "prove-sharded rehearsal", "shard_of": K},
+                                 "mode": "prove-sharded rehearsal", "shard_of": K}, "stages_s": {k: round(v, 4) for k, v in stages.items()},
                       "peak_torch_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
 
 

@@ -197,14 +197,20 @@ def all_gather_rows(be, local, n_bits, cc, width, group=None, rehearse_world=Non
     return be.from_torch(full)
 
 
-def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None):
+def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None, timings=None):
     """pil2gl.stark.stark_gen with every witness stage, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
     single-process one.  Replicated: the iNTT of q (3 columns) and the FRI folding; the trees above the leaves are split
     by leaf blocks (ShardedTree).
     rehearse_world=K: rank 0's share of a K-rank proof run alone (own slices stand in for the gathered ones, so the
-    result is not a valid proof): per-GPU time and memory on one GPU."""
+    result is not a valid proof): per-GPU time and memory on one GPU.  timings: dict that receives seconds per stage."""
     from . import stark as S
+    import time
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if timings is not None:
+            be.sync(); now = time.perf_counter(); timings[name] = timings.get(name, 0.0) + now - t_last[0]; t_last[0] = now
     if rehearse_world:
         rank, world = 0, int(rehearse_world)
     else:
@@ -237,6 +243,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         ops, n_tmp, secs, scalars = S.encode_code(code["code"], "ext", ctx)
         be.eval_program(ops, n_tmp, [(loc[s], widths[s]) for s in secs], scalars, nloc, lb)
 
+    lap("tables")
     # witness stages, split by cosets; each tree is split by leaf blocks (ShardedTree), the rows stay with their owners.
     # From stage 2 on (prover.js:49-77): challenges, stage code and hints on the trace domain, replicated - it is N rows
     # against the N * 2^b of the extension, and every rank needs the whole stage-s trace for its own cosets anyway
@@ -256,15 +263,18 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
             S.resolve_hints(be, info, s_, trace, widths, nb, ctx)
         loc[name + "_ext"] = be.empty(w << nloc)
         be.interpolate_cosets(trace[name + "_n"], w, nb, loc[name + "_ext"], nbe, cb, cc, None)
+        lap("stage%d_lde" % s_)
         strees[s_] = commit_local_slice(be, loc[name + "_ext"], w, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
         shards[s_] = {"local": loc[name + "_ext"], "width": w, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
         roots[s_] = strees[s_].root; transcript.put(roots[s_])
+        lap("stage%d_merkle" % s_)
     del trace
 
     # quotient: the constraint expression on the local rows, then one all-gather of q
     ctx["challenges"][qStage - 1] = [transcript.getField()]
     loc["q_ext"] = be.empty(qDim << nloc)
     run_local(exprs["expressionsCode"][info["cExpId"]]["code"])
+    lap("q_expr")
     q_ext = all_gather_rows(be, loc["q_ext"], nb, cc, qDim, group, rehearse_world)
     del loc["q_ext"]
     # computeQStark (stark_gen_helpers.js:168-208): the iNTT of q needs all of q and is replicated (3 columns); the split
@@ -280,9 +290,11 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     qname = "cm%d_ext" % qStage
     loc[qname] = be.empty(nQ << nloc)
     be.extend_cosets_unshifted(q_sub, nQ, nb, loc[qname], nbe, cb, cc)
+    lap("q_ntt")
     strees[qStage] = commit_local_slice(be, loc[qname], nQ, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
     shards[qStage] = {"local": loc[qname], "width": nQ, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
     roots[qStage] = strees[qStage].root; transcript.put(roots[qStage])
+    lap("q_merkle")
 
     # evaluations: only rows k << b are read, i.e. coset 0: its owner computes them and everybody receives them
     xi = transcript.getField()
@@ -305,7 +317,8 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
             else:
                 p = info["cmPolsMap"][ev["id"]]
                 descs.append((loc["cm%d_ext" % p["stage"]], widths["cm%d_ext" % p["stage"]], p["stagePos"], p["dim"], li))
-        evals = be.compute_evals(descs, nb, lb, levs)          # row k of the domain is local row k << log2(cc)
+        # row k of the domain is local row k << log2(cc)
+        evals = be.evals_fast(info, loc, widths, nb, lb, levs) if hasattr(be, "evals_fast") else be.compute_evals(descs, nb, lb, levs)
         ev_t = torch.from_numpy(np.array(evals, dtype=np.uint64).reshape(-1).view(np.int64).copy())
         del levs
     owner = 0                                                   # coset 0 always belongs to rank 0
@@ -317,6 +330,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     for ev in ctx["evals"]:
         transcript.put(ev)
 
+    lap("evals")
     # FRI polynomial on the local rows, then one all-gather
     vfs = [transcript.getField(), transcript.getField()]
     ctx["challenges"][qStage + 1] = vfs
@@ -326,8 +340,10 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         run_local(exprs["expressionsCode"][info["friExpId"]]["code"])
     f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, group, rehearse_world)
 
+    lap("fri_expr")
     # folding and its trees, replicated; openings: the rows of the committed stages from their owners, everything else is local
     friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, f_ext, transcript)
+    lap("fri_fold")
     chq = transcript.getField(); challengesFRI.append(chq)
     tq = be.new_transcript(); tq.put(chq)
     queries = tq.getPermutations(ss["nQueries"], ss["steps"][0]["nBits"])
@@ -342,6 +358,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     for step in range(1, len(ss["steps"])):
         q = [qi % (1 << ss["steps"][step]["nBits"]) for qi in q]
         friProof[step]["polQueries"] = [list(p_) for p_ in be.group_proofs(friTrees[step], q)]
+    lap("queries")
     proof = {"root%d" % s_: roots[s_] for s_ in range(1, qStage + 1)}
     proof["evals"] = ctx["evals"]; proof["fri"] = friProof
     return {"proof": proof, "publics": list(publics), "challenges": ctx["challenges"], "challengesFRISteps": challengesFRI, "queries": queries}

@@ -351,10 +351,13 @@ def main():
         step()
     barrier()
     t0 = time.perf_counter()
+    step_marks = []
     for _ in range(args.steps):
         step()
+        step_marks.append(time.perf_counter())               # host clock only: no extra synchronisation inside the timed region
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -424,7 +427,7 @@ def main():
             "roofline": roofline, "kernels": kernels,
         }
         if prove_ctx is not None:
-            out["prove"] = {"seconds": ms_per_step / 1e3, "stages_s": {k: round(v, 4) for k, v in stage_times.items()}}
+            out["prove"] = {"seconds": ms_per_step / 1e3, "stages_s": {k: round(v, 4) for k, v in stage_times.items()}, "host_ms_of_each_step": step_ms}
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_prove(n_cols, args.split) if prove_ctx is not None else cpu_baseline(n_cols, args.split)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]

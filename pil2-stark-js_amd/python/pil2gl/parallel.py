@@ -64,12 +64,17 @@ class ShardedTree:
     subtree roots are exchanged and the log2(w) levels above them are computed by everybody.  Same root and same paths as
     the single tree; no rank hashes more than 1/w of it (plus w-1 nodes)."""
 
-    def __init__(self, be, parts, N, cc, rank, world, group=None, rehearse_world=None):
+    def __init__(self, be, parts, N, cc, rank, world, group=None, rehearse_world=None, block_digests=None):
+        """parts: the all-gathered coset-ordered leaf digests of a committed stage (commit_local_slice); or block_digests:
+        the digests of this rank's own contiguous block of N*cc leaves (nothing to gather: the first FRI tree)"""
         self.be, self.rank, self.world, self.group, self.rehearse = be, rank, world, group, rehearse_world
         self.block = N * cc                                     # leaves per rank block: E / world
-        if N % world:
-            raise ValueError("world size must divide the number of rows")
-        self.sub = be.merkelize_digest_block(parts, N, cc, rank)
+        if block_digests is not None:
+            self.sub = be.merkelize_digests(block_digests, self.block)
+        else:
+            if N % world:
+                raise ValueError("world size must divide the number of rows")
+            self.sub = be.merkelize_digest_block(parts, N, cc, rank)
         mine = torch.tensor(np.array(be.root({"nodes": self.sub}), dtype=np.uint64).view(np.int64))
         if rehearse_world:
             roots = [mine] * world
@@ -342,7 +347,20 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
 
     lap("fri_expr")
     # folding and its trees, replicated; openings: the rows of the committed stages from their owners, everything else is local
-    friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, f_ext, transcript)
+    # the first FRI tree (2^steps[1].nBits leaves of 3 * 2^(bits0 - bits1) words: as many leaf permutations as a 12-column stage)
+    # is split by contiguous leaf blocks: every rank holds the whole transposed polynomial, hashes its block of leaves and
+    # builds the subtree over them; only the subtree roots are exchanged.  The later trees are 32x smaller and replicated.
+    fri_sharded = {}
+
+    def fri_tree(step, tb, w, h):
+        blk = h // world
+        if step != 1 or h % world or blk < 2:
+            return None
+        lo = rank * blk * w
+        dig = be.linear_hash_rows(tb[lo:lo + blk * w], w, blk)
+        fri_sharded[step] = (tb, w, ShardedTree(be, None, blk, 1, rank, world, group, rehearse_world, block_digests=dig))
+        return fri_sharded[step][2]
+    friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, f_ext, transcript, tree_builder=fri_tree)
     lap("fri_fold")
     chq = transcript.getField(); challengesFRI.append(chq)
     tq = be.new_transcript(); tq.put(chq)
@@ -357,7 +375,12 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     q = list(queries)
     for step in range(1, len(ss["steps"])):
         q = [qi % (1 << ss["steps"][step]["nBits"]) for qi in q]
-        friProof[step]["polQueries"] = [list(p_) for p_ in be.group_proofs(friTrees[step], q)]
+        if step in fri_sharded:
+            tb, w, stree = fri_sharded[step]
+            sib = stree.siblings(q)
+            friProof[step]["polQueries"] = [[[int(v) for v in np.asarray(be.to_host(tb[qi * w:(qi + 1) * w])).view(np.uint64)], sib[i]] for i, qi in enumerate(q)]
+        else:
+            friProof[step]["polQueries"] = [list(p_) for p_ in be.group_proofs(friTrees[step], q)]
     lap("queries")
     proof = {"root%d" % s_: roots[s_] for s_ in range(1, qStage + 1)}
     proof["evals"] = ctx["evals"]; proof["fri"] = friProof

@@ -103,28 +103,61 @@ __device__ __forceinline__ void acc_add(u64 &lo, u32 &hi, u32 x) {
 }
 __device__ __forceinline__ void acc_shift(u64 &lo, u32 &hi) { lo = (lo >> 32) | ((u64)hi << 32); hi = 0; }
 
+// Up to eight products accumulated by ONE asm statement.  gfx950's hazard recogniser gives every instruction that reads a
+// register written by an asm statement a wait state (it cannot rule out a partial-register write inside), so a chain of
+// one-product statements carries an s_nop per product -- with one wave per SIMD a lost issue slot each; a column's products
+// in one statement carry one.
+#define BN_MA(X, Y) "v_mad_u64_u32 %0, vcc, %" #X ", %" #Y ", %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc\n\t"
+template <int N>
+__device__ __forceinline__ void acc_madn(u64 &lo, u32 &hi, const u32 *x, const u32 *y) {
+    static_assert(N >= 0 && N <= 9, "up to nine products");
+    if constexpr (N == 1) asm(BN_MA(2, 3) : "+v"(lo), "+v"(hi) : "v"(x[0]), "v"(y[0]) : "vcc");
+    if constexpr (N == 2) asm(BN_MA(2, 3) BN_MA(4, 5) : "+v"(lo), "+v"(hi) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]) : "vcc");
+    if constexpr (N == 3) asm(BN_MA(2, 3) BN_MA(4, 5) BN_MA(6, 7) : "+v"(lo), "+v"(hi) : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]) : "vcc");
+    if constexpr (N == 4) asm(BN_MA(2, 3) BN_MA(4, 5) BN_MA(6, 7) BN_MA(8, 9) : "+v"(lo), "+v"(hi)
+        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]) : "vcc");
+    if constexpr (N == 5) asm(BN_MA(2, 3) BN_MA(4, 5) BN_MA(6, 7) BN_MA(8, 9) BN_MA(10, 11) : "+v"(lo), "+v"(hi)
+        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]) : "vcc");
+    if constexpr (N == 6) asm(BN_MA(2, 3) BN_MA(4, 5) BN_MA(6, 7) BN_MA(8, 9) BN_MA(10, 11) BN_MA(12, 13) : "+v"(lo), "+v"(hi)
+        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]) : "vcc");
+    if constexpr (N == 7) asm(BN_MA(2, 3) BN_MA(4, 5) BN_MA(6, 7) BN_MA(8, 9) BN_MA(10, 11) BN_MA(12, 13) BN_MA(14, 15) : "+v"(lo), "+v"(hi)
+        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]) : "vcc");
+    if constexpr (N == 8) asm(BN_MA(2, 3) BN_MA(4, 5) BN_MA(6, 7) BN_MA(8, 9) BN_MA(10, 11) BN_MA(12, 13) BN_MA(14, 15) BN_MA(16, 17) : "+v"(lo), "+v"(hi)
+        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]) : "vcc");
+    if constexpr (N == 9) asm(BN_MA(2, 3) BN_MA(4, 5) BN_MA(6, 7) BN_MA(8, 9) BN_MA(10, 11) BN_MA(12, 13) BN_MA(14, 15) BN_MA(16, 17) BN_MA(18, 19) : "+v"(lo), "+v"(hi)
+        : "v"(x[0]), "v"(y[0]), "v"(x[1]), "v"(y[1]), "v"(x[2]), "v"(y[2]), "v"(x[3]), "v"(y[3]), "v"(x[4]), "v"(y[4]), "v"(x[5]), "v"(y[5]), "v"(x[6]), "v"(y[6]), "v"(x[7]), "v"(y[7]), "v"(x[8]), "v"(y[8]) : "vcc");
+}
+// column K of x * y (the products x_j * y_(K-j) with both indices in 0..7, j < JMAX), preceded by the word `w` when WITH_W:
+// one statement per column
+template <int K, int JMAX, bool WITH_W>
+__device__ __forceinline__ void acc_column(u64 &lo, u32 &hi, const u32 *x, const u32 *y, u32 w = 0) {
+    constexpr int J0 = K > 7 ? K - 7 : 0, J1 = (K < JMAX - 1 ? K : JMAX - 1) < 7 ? (K < JMAX - 1 ? K : JMAX - 1) : 7;
+    constexpr int NP = J1 >= J0 ? J1 - J0 + 1 : 0, N = NP + (WITH_W ? 1 : 0);
+    if constexpr (N > 0) {
+        u32 xs[N], ys[N];
+        if constexpr (WITH_W) { xs[0] = w; ys[0] = 1u; }
+#pragma unroll
+        for (int i = 0; i < NP; i++) { xs[(WITH_W ? 1 : 0) + i] = x[J0 + i]; ys[(WITH_W ? 1 : 0) + i] = y[K - J0 - i]; }
+        acc_madn<N>(lo, hi, xs, ys);
+    }
+}
+
 // out = a * b / 2^256 mod r   (finely integrated product scanning; a < 2^256, b < r => out < r after one subtraction)
+template <int I>
+__device__ __forceinline__ void fr_mul_col(u64 &lo, u32 &hi, const u32 a[8], const u32 b[8], u32 m[8], const u32 rl[8], u32 t[9]) {
+    acc_column<I, 8, false>(lo, hi, a, b);           // a_j b_(I-j)
+    acc_column<I, (I < 8 ? I : 8), false>(lo, hi, m, rl);   // m_j r_(I-j), j < I: only the m already known
+    if constexpr (I < 8) { m[I] = (u32)lo * N0INV; acc_mad(lo, hi, m[I], rl[0]); }      // low word becomes 0
+    else t[I - 8] = (u32)lo;
+    acc_shift(lo, hi);
+    if constexpr (I < 15) fr_mul_col<I + 1>(lo, hi, a, b, m, rl, t);
+}
 __device__ __forceinline__ void fr_mul(u32 out[8], const u32 a[8], const u32 b[8]) {
     u32 m[8], t[9], rl[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) rl[i] = r_limb(i);
     u64 lo = 0; u32 hi = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-#pragma unroll
-        for (int j = 0; j < i; j++) { acc_mad(lo, hi, a[j], b[i - j]); acc_mad(lo, hi, m[j], rl[i - j]); }
-        acc_mad(lo, hi, a[i], b[0]);
-        m[i] = (u32)lo * N0INV;
-        acc_mad(lo, hi, m[i], rl[0]);                // low word becomes 0
-        acc_shift(lo, hi);
-    }
-#pragma unroll
-    for (int i = 8; i < 16; i++) {
-#pragma unroll
-        for (int j = i - 7; j < 8; j++) { acc_mad(lo, hi, a[j], b[i - j]); acc_mad(lo, hi, m[j], rl[i - j]); }
-        t[i - 8] = (u32)lo;
-        acc_shift(lo, hi);
-    }
+    fr_mul_col<0>(lo, hi, a, b, m, rl, t);
     t[8] = (u32)lo;
     cond_sub_r(t);
 #pragma unroll
@@ -154,19 +187,16 @@ __device__ __forceinline__ void fr_mul_os(u32 out[8], const u32 a[8], const u32 
 }
 
 // acc (17 limbs) += a * b, column by column: column k takes the old limb k and the products a_j * b_(k-j)
+template <int K>
+__device__ __forceinline__ void mac17_col(u64 &lo, u32 &hi, u32 acc[17], const u32 a[8], const u32 b[8]) {
+    acc_column<K, 8, true>(lo, hi, a, b, acc[K]);
+    acc[K] = (u32)lo;
+    acc_shift(lo, hi);
+    if constexpr (K < 15) mac17_col<K + 1>(lo, hi, acc, a, b);
+}
 __device__ __forceinline__ void mac17(u32 acc[17], const u32 a[8], const u32 b[8]) {
     u64 lo = 0; u32 hi = 0;
-#pragma unroll
-    for (int k = 0; k < 15; k++) {
-        acc_add(lo, hi, acc[k]);
-#pragma unroll
-        for (int j = (k > 7 ? k - 7 : 0); j <= (k < 7 ? k : 7); j++) acc_mad(lo, hi, a[j], b[k - j]);
-        acc[k] = (u32)lo;
-        acc_shift(lo, hi);
-    }
-    acc_add(lo, hi, acc[15]);
-    acc[15] = (u32)lo;
-    acc_shift(lo, hi);
+    mac17_col<0>(lo, hi, acc, a, b);
     acc[16] += (u32)lo;
 }
 // operand-scanning form (reference implementation for tests)
@@ -188,28 +218,20 @@ __device__ __forceinline__ void mac17_os(u32 acc[17], const u32 a[8], const u32 
 }
 
 // Montgomery reduction of a 17-limb accumulator T < 32 * r^2:  out = T / 2^256 mod r   (product scanning)
+template <int K>
+__device__ __forceinline__ void redc17_col(u64 &lo, u32 &hi, const u32 acc[17], u32 m[8], const u32 rl[8], u32 t[9]) {
+    acc_column<K, (K < 8 ? K : 8), true>(lo, hi, m, rl, acc[K]);      // acc_K + m_j r_(K-j), j < K
+    if constexpr (K < 8) { m[K] = (u32)lo * N0INV; acc_mad(lo, hi, m[K], rl[0]); }
+    else t[K - 8] = (u32)lo;
+    acc_shift(lo, hi);
+    if constexpr (K < 15) redc17_col<K + 1>(lo, hi, acc, m, rl, t);
+}
 __device__ __forceinline__ void redc17(u32 out[8], u32 acc[17]) {
     u32 m[8], t[9], rl[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) rl[i] = r_limb(i);
     u64 lo = 0; u32 hi = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        acc_add(lo, hi, acc[k]);
-#pragma unroll
-        for (int j = 0; j < k; j++) acc_mad(lo, hi, m[j], rl[k - j]);
-        m[k] = (u32)lo * N0INV;
-        acc_mad(lo, hi, m[k], rl[0]);
-        acc_shift(lo, hi);
-    }
-#pragma unroll
-    for (int k = 8; k < 16; k++) {
-        acc_add(lo, hi, acc[k]);
-#pragma unroll
-        for (int j = k - 7; j < 8; j++) acc_mad(lo, hi, m[j], rl[k - j]);
-        t[k - 8] = (u32)lo;
-        acc_shift(lo, hi);
-    }
+    redc17_col<0>(lo, hi, acc, m, rl, t);
     t[8] = (u32)lo + acc[16];                        // T/2^256 + r < 2^261: the ninth limb cannot overflow
     // T < 17 r^2 in every caller (at most 17 products): T/2^256 + r < 17*0.19 r + r < 5 r, so five subtractions at most
 #pragma unroll

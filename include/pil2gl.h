@@ -119,6 +119,11 @@ int pil2gl_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_
  * `width` row words followed by nLevels x 4 sibling words; one gather kernel, one device-to-host copy. */
 int pil2gl_group_proofs_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height,
                             const uint64_t *hostIdxs, uint32_t nIdx, uint64_t *hostOut, uint32_t *nLevels);
+/* verifier side: MerkleHash.calculateRootFromGroupProof  merklehash_p.js:169-203 for a batch of openings in
+ * the packed layout pil2gl_group_proofs_dev writes (per opening: width values, then `levels` x 4 sibling words):
+ * hostRoots[q] = the root the path of leaf hostIdxs[q] leads to; verifyGroupProof :212-215 is the comparison with the root. */
+int pil2gl_roots_from_group_proofs(const uint64_t *hostProofs, uint64_t width, uint32_t levels, const uint64_t *hostIdxs, uint32_t nIdx,
+                                   int splitLinearHash, uint64_t *hostRoots /* nIdx x 4 */);
 
 /* ---- FRI: src/stark/fri.js ------------------------------------------------ */
 /* FRI.fold(step>0, pol, challenge)  fri.js:22-61: pol has 2^polBits extension elements, out 2^outBits;

@@ -146,6 +146,12 @@ FN(GroupProofDev) {  // (devElems, devNodes, width, height, idx, vals BigUint64A
     napi_value v; napi_create_uint32(env, nl, &v); return v;
 }
 
+FN(RootsFromGroupProofs) {  // (packed BigUint64Array(n*(width+4*levels)), width, levels, idxs BigUint64Array(n), n, split, roots BigUint64Array(4n))
+    Args a(env, info); uint64_t w = a.u64(1), lv = a.u64(2), n = a.u64(4); int split = (int)a.u64(5);
+    uint64_t *packed = a.arr(0, n * (w + 4 * lv)), *idx = a.arr(3, n), *roots = a.arr(6, 4 * n); if (!a.ok) return nullptr;
+    P2(env, pil2gl_roots_from_group_proofs(packed, w, (uint32_t)lv, idx, (uint32_t)n, split, roots)); return mk_undefined(env);
+}
+
 // ---- STARK step helpers and stage-2 hints (device pointers; js/stark_gen_helpers.js and js/polutils.js stage host buffers) ----
 #define DP(i) ((uint64_t *)(uintptr_t)a.u64(i))
 FN(BuildXDev) {        // (nBits, shift, dX)  stark_gen_helpers.js:111-116,139-144
@@ -272,6 +278,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "interpolateDev", InterpolateDev }, { "fftDev", FftDev }, { "ifftDev", IfftDev },
         { "poseidon", Poseidon }, { "linearHashRows", LinearHashRows }, { "merkelizeLevel", MerkelizeLevel },
         { "merkleNumNodes", MerkleNumNodes }, { "merkelize", Merkelize }, { "merkelizeDev", MerkelizeDev }, { "groupProofDev", GroupProofDev },
+        { "rootsFromGroupProofs", RootsFromGroupProofs },
         { "bn128Poseidon", Bn128Poseidon }, { "bn128LinearHashRows", Bn128LinearHashRows }, { "bn128MerkleNumNodes", Bn128MerkleNumNodes },
         { "bn128Merkelize", Bn128Merkelize }, { "bn128MerkelizeDev", Bn128MerkelizeDev }, { "bn128Convert", Bn128Convert },
         { "buildXDev", BuildXDev }, { "buildZhInvDev", BuildZhInvDev }, { "buildOneRowZerofierInvDev", BuildOneRowZerofierInvDev },

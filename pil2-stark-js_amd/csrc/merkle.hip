@@ -11,6 +11,8 @@
 // The MDS layers run on the matrix cores (poseidon_mds_mfma.cuh), which takes the operands of all 64 lanes
 // in one instruction: no lane leaves early -- out-of-range lanes hash a clamped (valid) index and skip the store.
 #include "common.h"
+#include <vector>
+#include <string.h>
 #include "poseidon_gl.cuh"
 #include <algorithm>
 
@@ -79,6 +81,36 @@ __global__ void __launch_bounds__(256, 2) merkle_level_kernel(const u64 *__restr
     if (!live) return;
     u64 *o = out + 4 * i;
     o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];
+}
+
+// merklehash_p.js:187-203 (calculateRootFromGroupProof, after the leaf hash): one lane walks one path; level l hashes
+// (cur, sibling) or (sibling, cur) by bit l of the leaf index
+__global__ void __launch_bounds__(256, 2) merkle_path_roots_kernel(const u64 *__restrict__ leaf, const u64 *__restrict__ sib, const u64 *__restrict__ idx,
+                                                                  u64 count, u32 levels, u64 *__restrict__ roots) {
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < count;
+    const u64 i = live ? i0 : count - 1;
+    MdsMfma m;
+    mds_mfma_init(m);
+    u64 cur[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) cur[j] = canon(leaf[4 * i + j]);
+    u64 pos = idx[i];
+    for (u32 l = 0; l < levels; l++) {
+        const u64 *s = sib + (i * levels + l) * 4;
+        const bool right = pos & 1;                  // this node is the right child: the sibling goes first
+        u64 st[12];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const u64 sv = canon(s[j]); st[j] = right ? sv : cur[j]; st[4 + j] = right ? cur[j] : sv; }
+        st[8] = st[9] = st[10] = st[11] = 0;
+        poseidon_perm(st, m);
+#pragma unroll
+        for (int j = 0; j < 4; j++) cur[j] = st[j];
+        pos >>= 1;
+    }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < 4; j++) roots[4 * i + j] = cur[j];
 }
 
 // batch of independent permutations (glwasm.js:216 `poseidon`, hash/poseidon/poseidon.js:57)
@@ -246,6 +278,32 @@ int pil2gl_group_proofs_dev(const uint64_t *elems, const uint64_t *nodes, uint64
     KERNEL_CHECK();
     HIP_TRY(hipMemcpy(hostOut, d, (u64)nIdx * stride * 8, hipMemcpyDeviceToHost));
     if (nLevels) *nLevels = lv;
+    return PIL2GL_OK;
+}
+
+// Verifier side: calculateRootFromGroupProof (merklehash_p.js:169-203) for a batch of openings in the
+// packed layout pil2gl_group_proofs_dev writes: per opening `width` values, then `levels` sibling digests.
+int pil2gl_roots_from_group_proofs(const uint64_t *hostProofs, uint64_t width, uint32_t levels, const uint64_t *hostIdxs, uint32_t nIdx,
+                                   int splitLinearHash, uint64_t *hostRoots) {
+    P2_TRY(ensure_init());
+    if (!nIdx) return PIL2GL_OK;
+    if (!hostProofs || !hostIdxs || !hostRoots) return fail(PIL2GL_EINVAL, "null buffer");
+    if (levels > 64) return fail(PIL2GL_EINVAL, "too many levels");
+    const u64 stride = width + 4ull * levels, nv = (u64)nIdx * width, ns = (u64)nIdx * levels * 4;
+    std::vector<u64> h(nv + ns + nIdx + 1);
+    for (u32 q = 0; q < nIdx; q++) {
+        memcpy(h.data() + (u64)q * width, hostProofs + q * stride, width * 8);
+        memcpy(h.data() + nv + (u64)q * levels * 4, hostProofs + q * stride + width, 4ull * levels * 8);
+        h[nv + ns + q] = hostIdxs[q];
+    }
+    u64 *d;
+    P2_TRY(scratch(6, nv + ns + nIdx + 8ull * nIdx + 1, &d));
+    u64 *dVals = d, *dSib = d + nv, *dIdx = dSib + ns, *dLeaf = dIdx + nIdx, *dRoots = dLeaf + 4ull * nIdx;
+    HIP_TRY(hipMemcpy(d, h.data(), (nv + ns + nIdx) * 8, hipMemcpyHostToDevice));
+    P2_TRY(pil2gl_linear_hash_rows_dev(dVals, width, nIdx, splitLinearHash, dLeaf, nullptr));
+    merkle_path_roots_kernel<<<(nIdx + 255) / 256, 256>>>(dLeaf, dSib, dIdx, nIdx, levels, dRoots);
+    KERNEL_CHECK();
+    HIP_TRY(hipMemcpy(hostRoots, dRoots, 4ull * nIdx * 8, hipMemcpyDeviceToHost));
     return PIL2GL_OK;
 }
 

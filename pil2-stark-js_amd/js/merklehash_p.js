@@ -95,6 +95,26 @@ class MerkleHash {
         return value;
     }
 
+    // batch form for the verifier's loops over queries (stark_verify.js:165-178, fri.js:140): proofs = [[vals, siblings], ...]
+    // of one tree -> their roots, leaf hashes and path walks on the device in one call
+    calculateRootsFromGroupProofs(proofs, idxs) {
+        if (proofs.length === 0) return [];
+        const width = proofs[0][0].length, nl = proofs[0][1].length, stride = width + 4 * nl, n = proofs.length;
+        const packed = new BigUint64Array(n * stride), ii = new BigUint64Array(n), roots = new BigUint64Array(4 * n);
+        for (let q = 0; q < n; q++) {
+            const [vals, sib] = proofs[q];
+            if (vals.length !== width || sib.length !== nl) throw new Error("openings of different shapes in one batch");
+            for (let i = 0; i < width; i++) packed[q * stride + i] = BigInt(vals[i]);
+            for (let l = 0; l < nl; l++) for (let k = 0; k < 4; k++) packed[q * stride + width + 4 * l + k] = BigInt(sib[l][k]);
+            ii[q] = BigInt(idxs[q]);
+        }
+        addon.rootsFromGroupProofs(packed, width, nl, ii, n, this.splitLinearHash ? 1 : 0, roots);
+        const out = [];
+        for (let q = 0; q < n; q++) out.push([roots[4 * q], roots[4 * q + 1], roots[4 * q + 2], roots[4 * q + 3]]);
+        return out;
+    }
+    verifyGroupProofs(root, proofs, idxs) { return this.calculateRootsFromGroupProofs(proofs, idxs).every((r) => this.eqRoot(r, root)); }
+
     eqRoot(r1, r2) { for (let k = 0; k < 4; k++) if (BigInt(r1[k]) !== BigInt(r2[k])) return false; return true; }
     verifyGroupProof(root, mp, idx, groupElements) { return this.eqRoot(this.calculateRootFromGroupProof(mp, idx, groupElements), root); }
     root(tree) { return [...tree.nodes.slice(-4)]; }

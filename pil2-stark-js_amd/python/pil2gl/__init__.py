@@ -304,6 +304,25 @@ class MerkleHash:
             idx >>= 1
         return value
 
+    def calculateRootsFromGroupProofs(self, proofs, idxs):
+        """calculateRootFromGroupProof for a batch of openings [(vals, siblings), ...] of one tree (the verifier checks every
+        query of a tree: stark_verify.js:165-178, fri.js:140): leaf hashes and path walks on the device, one call"""
+        if not proofs:
+            return []
+        width, nl = len(proofs[0][0]), len(proofs[0][1])
+        packed = np.zeros((len(proofs), width + 4 * nl), np.uint64)
+        for q, (vals, sib) in enumerate(proofs):
+            if len(vals) != width or len(sib) != nl:
+                raise Pil2glError("openings of different shapes in one batch")
+            packed[q, :width] = [int(v) % P for v in vals]
+            packed[q, width:] = [int(x) % P for s_ in sib for x in s_]
+        ii = np.array([int(i) for i in idxs], dtype=np.uint64); roots = np.zeros((len(proofs), 4), np.uint64)
+        call("pil2gl_roots_from_group_proofs", _ptr(packed), width, nl, _ptr(ii), len(proofs), int(self.splitLinearHash), _ptr(roots))
+        return [[int(v) for v in r] for r in roots]
+
+    def verifyGroupProofs(self, root, proofs, idxs):
+        return all(self.eqRoot(r, root) for r in self.calculateRootsFromGroupProofs(proofs, idxs))
+
     def eqRoot(self, r1, r2):
         return all(int(a) % P == int(b) % P for a, b in zip(r1, r2))
 

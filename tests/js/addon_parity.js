@@ -65,6 +65,12 @@ class ChunkedBuffer {
         groupElements[0] ^= 1n;
         assert(!MH.verifyGroupProof(MH.root(tree), mp, idx, groupElements));
         assert.throws(() => MH.getGroupProof(tree, N), /Out of range/);
+        {   // batch verification of several openings in one call
+            const idxs = [0, N - 1, Math.floor(N / 2)], proofs = idxs.map((i) => { const [v, m] = MH.getGroupProof(tree, i); return [v, m]; });
+            assert(MH.verifyGroupProofs(MH.root(tree), proofs, idxs));
+            proofs[1][0][0] ^= 1n;
+            assert(!MH.verifyGroupProofs(MH.root(tree), proofs, idxs));
+        }
         if (N === 256 && w === 9) {     // chunked container + file round trip
             const cb = new ChunkedBuffer(N * w, 100); cb.set(pols, 0);
             const t2 = await MH.merkelize(cb, w, N);

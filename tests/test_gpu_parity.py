@@ -177,6 +177,30 @@ def test_merkle_tree(gl, oracle, N, nPols, idx, split):
         MH.getGroupProof(tree, N)
 
 
+@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("N,nPols", [(256, 3), (256, 9), (33, 6), (1000, 100), (2, 9)])
+def test_batch_root_from_group_proofs(gl, oracle, N, nPols, split):
+    """verifier side (merklehash_p.js:169-215 for all queries of a tree in one call): the batch equals the one-by-one walk,
+    reaches the root for every leaf asked, and a wrong value or a wrong sibling is caught"""
+    rng = np.random.default_rng(N * 7 + nPols)
+    pols = rand_field(rng, (N, nPols))
+    MH = gl.buildMerkleHash(split)
+    tree = MH.merkelize(pols, nPols, N)
+    root = MH.root(tree)
+    idxs = sorted({0, N - 1, N // 2, 1 % N, 5 % N, (N - 2) % N})
+    proofs = MH.getGroupProofs(tree, idxs)
+    roots = MH.calculateRootsFromGroupProofs(proofs, idxs)
+    assert roots == [[int(v) for v in MH.calculateRootFromGroupProof(mp, i, vals)] for (vals, mp), i in zip(proofs, idxs)]
+    assert all(r == [int(v) for v in root] for r in roots) and MH.verifyGroupProofs(root, proofs, idxs)
+    bad = [(list(v), [list(s_) for s_ in mp]) for v, mp in proofs]
+    bad[1][0][0] = (bad[1][0][0] + 1) % P
+    assert not MH.verifyGroupProofs(root, bad, idxs)
+    bad = [(list(v), [list(s_) for s_ in mp]) for v, mp in proofs]
+    bad[-1][1][-1][3] ^= 1
+    assert not MH.verifyGroupProofs(root, bad, idxs)
+    assert MH.calculateRootsFromGroupProofs([], []) == []
+
+
 def test_merkle_roots_golden(gl):
     for N, w, split, root, leaf0, leaf_last in H(golden("merkle.json")):
         elems = np.ascontiguousarray(np.arange(N, dtype=np.uint64)[:, None] + np.uint64(1000) * np.arange(w, dtype=np.uint64)[None, :])
@@ -243,6 +267,15 @@ def test_reference_proof_through_gpu(gl):
     for q, idx in enumerate(queries):
         for name, root in (("1", z["root1"]), ("2", z["root2"]), ("3", z["root3"]), ("4", z["root4"]), ("C", trp.ROOT_C)):
             assert MH.verifyGroupProof(root, z["s0_siblings" + name][q], idx, z["s0_vals" + name][q])
+    # the same openings through the batch entry point: all eight queries of a tree in one call, for the five stage trees
+    # and the two FRI trees the reference prover committed
+    for name, root in (("1", z["root1"]), ("2", z["root2"]), ("3", z["root3"]), ("4", z["root4"]), ("C", trp.ROOT_C)):
+        proofs = [(z["s0_vals" + name][q], z["s0_siblings" + name][q]) for q in range(len(queries))]
+        assert MH.calculateRootsFromGroupProofs(proofs, queries) == [[int(v) for v in root]] * len(queries), name
+    for s in (1, 2):
+        idxs = [i % (1 << trp.STEPS[s]) for i in queries]
+        proofs = [(z["s%d_vals" % s][q], z["s%d_siblings" % s][q]) for q in range(len(queries))]
+        assert MH.verifyGroupProofs(z["s%d_root" % s], proofs, idxs), s
     # FRI fold of the opened groups (fri.js:107-150) on the GPU
     pol_bits = trp.STEPS[0]
     for s in (1, 2):

@@ -404,6 +404,16 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom["hbm_frac"], "traffic": load_pmc_traffic(dom["kernel"].split(" ")[0]),
                     "note": "Poseidon hashing is integer-ALU bound (no 64-bit multiplier on gfx950); its HBM fraction is small by nature, see kernels[]"}
+        # what does bind it: the committed SQ counters of the same kernel (profiles/r01_valu_utilisation.json, tools/pmc_valu.py):
+        # share of a wave's cycles spent issuing vector-ALU instructions x waves per SIMD ~ share of the SIMD's issue slots
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_valu_utilisation.json")) as f:
+                pm = json.load(f).get(dom["kernel"].split(" ")[0])
+            if pm:
+                roofline["valu"] = {"active_frac_of_wave_cycles": round(pm["valu_frac_of_wave_cycles"], 3), "wait_frac": round(pm["wait_any_frac"], 3),
+                                    "source": "profiles/r01_valu_utilisation.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, rocprofv3 --pmc, config 3)"}
+        except Exception:
+            pass
         if prove_ctx is not None:
             metric = "STARK prove time (ms_per_step) and trace-cells/s, synthetic Fibonacci AIR, GL Poseidon Merkle + FRI, blow-up 8"
             workload = "full proof (commit, Q, evals, FRI %s, %d queries) of 2^%d rows x %d cols -> 2^%d rows, %s linear hash, %s" % (

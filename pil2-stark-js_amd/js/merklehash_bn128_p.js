@@ -129,6 +129,47 @@ class MerkleHash {
         return value;
     }
 
+    // batch form for the verifier's loops over queries: every sponge chunk and every level is one batched permutation call
+    // over all the openings (one BN254 permutation alone has the latency of a wave of them)
+    calculateRootsFromGroupProofs(proofs, idxs) {
+        const n = proofs.length;
+        if (n === 0) return [];
+        const batch = (rows, init) => {         // rows: n x nIn BigInt -> n outputs
+            const nIn = rows[0].length, out = new BigUint64Array(4 * n);
+            addon.bn128Poseidon(toWords([].concat(...rows)), init ? toWords(init) : null, n, nIn, 1, out);
+            const res = [];
+            for (let q = 0; q < n; q++) res.push(fromWords(out, q));
+            return res;
+        };
+        const els = proofs.map(([vals]) => {
+            const flat = [];
+            for (const v of vals) { if (Array.isArray(v)) for (const x of v) flat.push(BigInt(x)); else flat.push(BigInt(v)); }
+            const e = [];
+            for (let i = 0; i < flat.length; i += 3) { let acc = 0n; for (let k = 0; k < 3 && i + k < flat.length; k++) acc += flat[i + k] << BigInt(64 * k); e.push(acc % R); }
+            return e;
+        });
+        const nEl = els[0].length, nl = proofs[0][1].length;
+        if (els.some((e) => e.length !== nEl) || proofs.some((p) => p[1].length !== nl)) throw new Error("openings of different shapes in one batch");
+        let value;
+        if (nEl === 0) value = els.map(() => 0n);
+        else if (nEl === 1) value = els.map((e) => e[0]);
+        else {
+            value = els.map(() => 0n);
+            for (let i = 0; i < nEl; i += this.arity) {
+                let chunks = els.map((e) => e.slice(i, i + this.arity));
+                if (chunks[0].length < this.arity && this.custom) chunks = chunks.map((c) => c.concat(new Array(this.arity - c.length).fill(0n)));
+                value = batch(chunks, value);
+            }
+        }
+        const nBitsArity = Math.ceil(Math.log2(this.arity)), pos = idxs.map((i) => Number(i));
+        for (let o = 0; o < nl; o++) {
+            const groups = proofs.map(([, mp], q) => { const g = mp[o].map((x) => BigInt(x)); g[pos[q] & (this.arity - 1)] = value[q]; pos[q] = pos[q] >> nBitsArity; return g; });
+            value = batch(groups, null);
+        }
+        return value;
+    }
+    verifyGroupProofs(root, proofs, idxs) { return this.calculateRootsFromGroupProofs(proofs, idxs).every((r) => this.eqRoot(r, root)); }
+
     eqRoot(r1, r2) { return BigInt(r1) === BigInt(r2); }
 
     verifyGroupProof(root, mp, idx, groupElements) {

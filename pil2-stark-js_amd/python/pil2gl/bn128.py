@@ -149,6 +149,48 @@ class MerkleHashBN128:
             value = poseidon(group, 0, 1)[0]
         return value
 
+    def calculateRootsFromGroupProofs(self, proofs, idxs):
+        """calculateRootFromGroupProof for a batch of openings [(vals, siblings), ...] of one tree: every sponge chunk and
+        every tree level is ONE batched permutation call over all the openings (a single BN254 permutation has the
+        latency of a whole wave of them)"""
+        if not proofs:
+            return []
+        flat = []
+        for vals, _ in proofs:
+            f = []
+            for v in vals:
+                f.extend(int(x) for x in v) if isinstance(v, (list, tuple, np.ndarray)) else f.append(int(v))
+            flat.append(f)
+        if len({len(f) for f in flat}) != 1 or len({len(mp) for _, mp in proofs}) != 1:
+            raise Pil2glError("openings of different shapes in one batch")
+        els = [[sum(x << (64 * k) for k, x in enumerate(f[i:i + 3])) % R for i in range(0, len(f), 3)] for f in flat]
+        n_el = len(els[0])
+        if n_el == 0:
+            value = [0] * len(proofs)
+        elif n_el == 1:
+            value = [e[0] for e in els]
+        else:                                                   # linearhash.bn128.js:46-57, all openings per chunk
+            value = [0] * len(proofs)
+            for i in range(0, n_el, self.arity):
+                chunks = [e[i:i + self.arity] for e in els]
+                if len(chunks[0]) < self.arity and self.custom:
+                    chunks = [c + [0] * (self.arity - len(c)) for c in chunks]
+                value = [r[0] for r in poseidon_batch(chunks, value, 1)]
+        nbits = (self.arity - 1).bit_length()
+        pos = [int(i) for i in idxs]
+        for level in range(len(proofs[0][1])):                  # merklehash_bn128_p.js:207-231
+            groups = []
+            for q, (_, mp) in enumerate(proofs):
+                g = [int(s_) % R for s_ in mp[level]]
+                g[pos[q] & (self.arity - 1)] = value[q]
+                groups.append(g)
+                pos[q] >>= nbits
+            value = [r[0] for r in poseidon_batch(groups, None, 1)]
+        return value
+
+    def verifyGroupProofs(self, root, proofs, idxs):
+        return all(self.eqRoot(r, root) for r in self.calculateRootsFromGroupProofs(proofs, idxs))
+
     def eqRoot(self, r1, r2):
         return int(r1) == int(r2)
 

@@ -261,6 +261,11 @@ class ChunkedBuffer {
                 const [v, mp] = MH.getGroupProof(tree, t.idx);
                 assert.deepStrictEqual(mp.map((l) => l.map(String)), t.proof);
                 assert(MH.verifyGroupProof(MH.root(tree), mp, t.idx, v));
+                {   // batch form over several openings
+                    const idxs = [0, t.N - 1, t.idx], proofs = idxs.map((i) => MH.getGroupProof(tree, i));
+                    assert(MH.verifyGroupProofs(MH.root(tree), proofs, idxs));
+                    assert.deepStrictEqual(MH.calculateRootsFromGroupProofs(proofs, idxs).map(String), idxs.map(() => t.root));
+                }
                 v[0] = v[0] + 1n;
                 assert(!MH.verifyGroupProof(MH.root(tree), mp, t.idx, v));
                 if (buf === pols) {

@@ -131,6 +131,16 @@ def test_reference_final_proof_through_gpu(bn):
         for s, bits in ((1, 14), (2, 11), (3, 7), (4, 4)):
             assert MH.verifyGroupProof(int(p["s%d_root" % s]), p["s%d_siblings" % s][q], ys[q] % (1 << bits),
                                        [int(x) for x in p["s%d_vals" % s][q]]), (s, q)
+    # the same 32 x 8 openings through the batch form: one batched permutation call per sponge chunk and per level
+    for vk, sk, rt in (("s0_vals1", "s0_siblings1", int(p["root1"])), ("s0_vals3", "s0_siblings3", int(p["root3"])),
+                       ("s0_valsQ", "s0_siblingsQ", int(p["rootQ"])), ("s0_valsC", "s0_siblingsC", ROOT_C)):
+        proofs = [([int(x) for x in p[vk][q]], p[sk][q]) for q in range(32)]
+        assert MH.calculateRootsFromGroupProofs(proofs, ys) == [rt] * 32, vk
+    for s, bits in ((1, 14), (2, 11), (3, 7), (4, 4)):
+        proofs = [([int(x) for x in p["s%d_vals" % s][q]], p["s%d_siblings" % s][q]) for q in range(32)]
+        assert MH.verifyGroupProofs(int(p["s%d_root" % s]), proofs, [y % (1 << bits) for y in ys]), s
+    bad = [(list(v), m) for v, m in proofs]; bad[5][0][0] += 1
+    assert not MH.verifyGroupProofs(int(p["s4_root"]), bad, [y % 16 for y in ys])
 
 
 def test_config4_shape_tree_opens(bn):

@@ -177,6 +177,31 @@ def test_merkle_tree(gl, oracle, N, nPols, idx, split):
         MH.getGroupProof(tree, N)
 
 
+def test_ntt_random_shapes_and_pass_splits(gl, oracle, monkeypatch):
+    """interpolate / fft / ifft on random shapes with the pass planner forced to every split it can take (PIL2GL_NTT_KMAX:
+    passes of up to 4, 6, 9, 10 stages besides the default 8 / 7), i.e. every register-step chunking of gl_fermat.cuh"""
+    rng = np.random.default_rng(2024)
+    n_cases = 0
+    while n_cases < 40:
+        nb = int(rng.integers(1, 14)); C = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 17, 33, 64, 100])); eb = int(rng.integers(0, 4))
+        if (C << (nb + eb)) > (1 << 22):
+            continue
+        kmax = rng.choice(["", "4", "6", "9", "10"])
+        if kmax:
+            monkeypatch.setenv("PIL2GL_NTT_KMAX", str(kmax))
+        else:
+            monkeypatch.delenv("PIL2GL_NTT_KMAX", raising=False)
+        a = rand_field(rng, ((1 << nb), C))
+        dst = np.zeros(((1 << (nb + eb)), C), np.uint64)
+        gl.interpolate(a, C, nb, dst, nb + eb)
+        assert np.array_equal(dst, oracle.interpolate(a, nb, nb + eb)), (nb, C, eb, kmax)
+        f = np.zeros_like(a); gl.fft(a, C, nb, f)
+        assert np.array_equal(f, oracle.fft_cols(a, nb)), (nb, C, kmax)
+        g = np.zeros_like(a); gl.ifft(a, C, nb, g)
+        assert np.array_equal(g, oracle.ifft_cols(a, nb)), (nb, C, kmax)
+        n_cases += 1
+
+
 @pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("N,nPols", [(256, 3), (256, 9), (33, 6), (1000, 100), (2, 9)])
 def test_batch_root_from_group_proofs(gl, oracle, N, nPols, split):

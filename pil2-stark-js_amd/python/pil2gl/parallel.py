@@ -301,7 +301,10 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     roots[qStage] = strees[qStage].root; transcript.put(roots[qStage])
     lap("q_merkle")
 
-    # evaluations: only rows k << b are read, i.e. coset 0: its owner computes them and everybody receives them
+    # evaluations (computeEvalsStark :210-273).  The reference reads rows k << b, i.e. coset 0 with LEv = iNTT of (xi w/7)^k;
+    # any coset 7 w_E^c of the subgroup determines the same polynomial values with LEv_c = iNTT of (xi w / (7 w_E^c))^k, so
+    # the opening points are dealt over the ranks: rank i mod world takes opening i on its own first coset, the others
+    # contribute zeros, one all-reduce
     xi = transcript.getField()
     ctx["challenges"][qStage] = [xi]
     wN = S.root_of_unity(nb)
@@ -311,26 +314,33 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         if opening < 0:
             w = S._inv(w)
         xis.append(S.ext_scale(xi, w))
+    mine = [i for i in range(len(xis)) if i % world == rank]
     ev_t = torch.zeros(n_ev * 3, dtype=torch.int64)
-    if cb == 0:
-        levs = [be.build_lev(nb, S.ext_scale(x, S._inv(S.SHIFT))) for x in xis]
-        descs = []
-        for ev in info["evMap"]:
-            li = info["openingPoints"].index(ev["prime"])
-            if ev["type"] == "const":
-                descs.append((loc["const_ext"], nC, ev["id"], 1, li))
-            else:
-                p = info["cmPolsMap"][ev["id"]]
-                descs.append((loc["cm%d_ext" % p["stage"]], widths["cm%d_ext" % p["stage"]], p["stagePos"], p["dim"], li))
-        # row k of the domain is local row k << log2(cc)
-        evals = be.evals_fast(info, loc, widths, nb, lb, levs) if hasattr(be, "evals_fast") else be.compute_evals(descs, nb, lb, levs)
-        ev_t = torch.from_numpy(np.array(evals, dtype=np.uint64).reshape(-1).view(np.int64).copy())
+    if mine:
+        g_inv = S._inv(S.SHIFT * pow(S.root_of_unity(nbe), cb, S.P) % S.P)          # 1 / (7 w_E^cb): this rank's first coset
+        levs = [be.build_lev(nb, S.ext_scale(xis[i], g_inv)) for i in mine]
+        sel = [k for k, ev in enumerate(info["evMap"]) if info["openingPoints"].index(ev["prime"]) in mine]
+        sub = dict(info); sub["evMap"] = [info["evMap"][k] for k in sel]; sub["openingPoints"] = [info["openingPoints"][i] for i in mine]
+        if hasattr(be, "evals_fast"):
+            evals = be.evals_fast(sub, loc, widths, nb, lb, levs)          # row k of the coset is local row k << log2(cc)
+        else:
+            descs = []
+            for ev in sub["evMap"]:
+                li = sub["openingPoints"].index(ev["prime"])
+                if ev["type"] == "const":
+                    descs.append((loc["const_ext"], nC, ev["id"], 1, li))
+                else:
+                    p = info["cmPolsMap"][ev["id"]]
+                    descs.append((loc["cm%d_ext" % p["stage"]], widths["cm%d_ext" % p["stage"]], p["stagePos"], p["dim"], li))
+            evals = be.compute_evals(descs, nb, lb, levs)
+        full = np.zeros((n_ev, 3), dtype=np.uint64)
+        full[sel] = np.array(evals, dtype=np.uint64).reshape(len(sel), 3)
+        ev_t = torch.from_numpy(full.reshape(-1).view(np.int64).copy())
         del levs
-    owner = 0                                                   # coset 0 always belongs to rank 0
     if not rehearse_world:
         if dist.get_backend(group) == "nccl":
             ev_t = ev_t.to(be.as_torch(loc["cm1_ext"]).device)
-        dist.broadcast(ev_t, src=owner, group=group)
+        dist.all_reduce(ev_t, op=dist.ReduceOp.SUM, group=group)          # every entry is non-zero on one rank only
     ctx["evals"] = [[int(v) for v in r] for r in ev_t.cpu().numpy().view(np.uint64).reshape(n_ev, 3)]
     for ev in ctx["evals"]:
         transcript.put(ev)

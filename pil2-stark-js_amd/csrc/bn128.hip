@@ -332,8 +332,7 @@ __device__ __noinline__ void partial_rounds(u32 *S, int tmax, int lane, int cur,
                     load_const<true>(A.W, (size_t)k * n + j + 1, wn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                bn::mac17(acc, y, vv);               // row 0:   m00*x0 + sum V_kj * y_j
-                bn::fr_mul(p, x0, ww);               // column:  y_j + W_kj * x0
+                bn::mac17_and_fr_mul(acc, y, vv, p, x0, ww);   // row 0: m00*x0 + sum V_kj * y_j;  column: y_j + W_kj * x0
                 bn::fr_add(y, p);
                 lds_store(S, tmax, lane, cur, 1 + j, y);
 #pragma unroll

@@ -144,12 +144,16 @@ __device__ __forceinline__ void acc_column(u64 &lo, u32 &hi, const u32 *x, const
 
 // out = a * b / 2^256 mod r   (finely integrated product scanning; a < 2^256, b < r => out < r after one subtraction)
 template <int I>
-__device__ __forceinline__ void fr_mul_col(u64 &lo, u32 &hi, const u32 a[8], const u32 b[8], u32 m[8], const u32 rl[8], u32 t[9]) {
+__device__ __forceinline__ void fr_mul_step(u64 &lo, u32 &hi, const u32 a[8], const u32 b[8], u32 m[8], const u32 rl[8], u32 t[9]) {
     acc_column<I, 8, false>(lo, hi, a, b);           // a_j b_(I-j)
     acc_column<I, (I < 8 ? I : 8), false>(lo, hi, m, rl);   // m_j r_(I-j), j < I: only the m already known
     if constexpr (I < 8) { m[I] = (u32)lo * N0INV; acc_mad(lo, hi, m[I], rl[0]); }      // low word becomes 0
     else t[I - 8] = (u32)lo;
     acc_shift(lo, hi);
+}
+template <int I>
+__device__ __forceinline__ void fr_mul_col(u64 &lo, u32 &hi, const u32 a[8], const u32 b[8], u32 m[8], const u32 rl[8], u32 t[9]) {
+    fr_mul_step<I>(lo, hi, a, b, m, rl, t);
     if constexpr (I < 15) fr_mul_col<I + 1>(lo, hi, a, b, m, rl, t);
 }
 __device__ __forceinline__ void fr_mul(u32 out[8], const u32 a[8], const u32 b[8]) {
@@ -188,16 +192,41 @@ __device__ __forceinline__ void fr_mul_os(u32 out[8], const u32 a[8], const u32 
 
 // acc (17 limbs) += a * b, column by column: column k takes the old limb k and the products a_j * b_(k-j)
 template <int K>
-__device__ __forceinline__ void mac17_col(u64 &lo, u32 &hi, u32 acc[17], const u32 a[8], const u32 b[8]) {
+__device__ __forceinline__ void mac17_step(u64 &lo, u32 &hi, u32 acc[17], const u32 a[8], const u32 b[8]) {
     acc_column<K, 8, true>(lo, hi, a, b, acc[K]);
     acc[K] = (u32)lo;
     acc_shift(lo, hi);
+}
+template <int K>
+__device__ __forceinline__ void mac17_col(u64 &lo, u32 &hi, u32 acc[17], const u32 a[8], const u32 b[8]) {
+    mac17_step<K>(lo, hi, acc, a, b);
     if constexpr (K < 15) mac17_col<K + 1>(lo, hi, acc, a, b);
 }
 __device__ __forceinline__ void mac17(u32 acc[17], const u32 a[8], const u32 b[8]) {
     u64 lo = 0; u32 hi = 0;
     mac17_col<0>(lo, hi, acc, a, b);
     acc[16] += (u32)lo;
+}
+// acc += a * b  and  out = c * d / 2^256 mod r  together, column by column in turn: the two chains are independent, so
+// the wait state each asm statement owes its successor (see acc_madn) is filled by the other chain's statement
+template <int K>
+__device__ __forceinline__ void mac17_fr_mul_col(u64 &lo1, u32 &hi1, u32 acc[17], const u32 a[8], const u32 b[8],
+                                                 u64 &lo2, u32 &hi2, const u32 c[8], const u32 d[8], u32 m[8], const u32 rl[8], u32 t[9]) {
+    mac17_step<K>(lo1, hi1, acc, a, b);
+    fr_mul_step<K>(lo2, hi2, c, d, m, rl, t);
+    if constexpr (K < 15) mac17_fr_mul_col<K + 1>(lo1, hi1, acc, a, b, lo2, hi2, c, d, m, rl, t);
+}
+__device__ __forceinline__ void mac17_and_fr_mul(u32 acc[17], const u32 a[8], const u32 b[8], u32 out[8], const u32 c[8], const u32 d[8]) {
+    u32 m[8], t[9], rl[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rl[i] = r_limb(i);
+    u64 lo1 = 0, lo2 = 0; u32 hi1 = 0, hi2 = 0;
+    mac17_fr_mul_col<0>(lo1, hi1, acc, a, b, lo2, hi2, c, d, m, rl, t);
+    acc[16] += (u32)lo1;
+    t[8] = (u32)lo2;
+    cond_sub_r(t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = t[i];
 }
 // operand-scanning form (reference implementation for tests)
 __device__ __forceinline__ void mac17_os(u32 acc[17], const u32 a[8], const u32 b[8]) {

@@ -662,14 +662,15 @@ int pil2gl_bn128_poseidon(const uint64_t *in, const uint64_t *init, uint64_t cou
     if (!in || !out) return fail(PIL2GL_EINVAL, "null buffer");
     u64 *d = nullptr;
     const u64 nI = count * nIn * 4, nS = init ? count * 4 : 0, nO = count * nOut * 4;
-    HIP_TRY(hipMalloc((void **)&d, (nI + nS + nO + 1) * 8));
+    bool owned = false;
+    P2_TRY(stage_acquire(nI + nS + nO, &d, &owned));
     int rc = PIL2GL_OK;
     hipError_t e = hipMemcpy(d, in, nI * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess && nS) e = hipMemcpy(d + nI, init, nS * 8, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
     if (rc == PIL2GL_OK) rc = pil2gl_bn128_poseidon_dev(d, nS ? d + nI : nullptr, count, nIn, nOut, d + nI + nS, nullptr);
     if (rc == PIL2GL_OK) { e = hipMemcpy(out, d + nI + nS, nO * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
-    (void)hipFree(d);
+    stage_release(d, owned);
     return rc;
 }
 
@@ -679,13 +680,14 @@ int pil2gl_bn128_merkelize(const uint64_t *elems, uint64_t width, uint64_t heigh
     P2_TRY(check_arity(arity));
     const u64 nE = width * height, nN = pil2gl_bn128_merkle_num_nodes(height, arity) * 4;
     u64 *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, (nE + nN + 1) * 8));
+    bool owned = false;
+    P2_TRY(stage_acquire(nE + nN, &d, &owned));
     int rc = PIL2GL_OK;
     hipError_t e = nE ? hipMemcpy(d, elems, nE * 8, hipMemcpyHostToDevice) : hipSuccess;
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
     if (rc == PIL2GL_OK) rc = pil2gl_bn128_merkelize_dev(d, width, height, arity, custom, d + nE, nullptr);
     if (rc == PIL2GL_OK) { e = hipMemcpy(nodes, d + nE, nN * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
-    (void)hipFree(d);
+    stage_release(d, owned);
     return rc;
 }
 
@@ -694,13 +696,14 @@ int pil2gl_bn128_linear_hash_rows(const uint64_t *in, uint64_t width, uint64_t h
     if (height == 0) return PIL2GL_OK;
     const u64 nE = width * height, nO = height * 4;
     u64 *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, (nE + nO + 1) * 8));
+    bool owned = false;
+    P2_TRY(stage_acquire(nE + nO, &d, &owned));
     int rc = PIL2GL_OK;
     hipError_t e = nE ? hipMemcpy(d, in, nE * 8, hipMemcpyHostToDevice) : hipSuccess;
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
     if (rc == PIL2GL_OK) rc = pil2gl_bn128_linear_hash_rows_dev(d, width, height, arity, custom, d + nE, nullptr);
     if (rc == PIL2GL_OK) { e = hipMemcpy(out, d + nE, nO * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
-    (void)hipFree(d);
+    stage_release(d, owned);
     return rc;
 }
 

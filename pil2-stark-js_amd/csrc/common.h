@@ -43,6 +43,12 @@ const Tables &tables();
 // scratch (grown on demand, kept across calls) ------------------------------------------
 int scratch(u32 slot, u64 nWords, u64 **out);
 
+// device staging for the host-pointer entry points: small requests (<= 16 MB) come from a persistent slot -- a hipMalloc /
+// hipFree pair per call costs a device synchronisation each, which dominated the transcript's single permutations --
+// larger ones are allocated and released per call.  stage_release() frees only what stage_acquire() allocated.
+int stage_acquire(u64 nWords, u64 **out, bool *owned);
+void stage_release(u64 *p, bool owned);
+
 hipStream_t as_stream(void *s);
 
 // internal launchers shared between translation units --------------------------------------

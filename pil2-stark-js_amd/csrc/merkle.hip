@@ -311,8 +311,8 @@ int pil2gl_roots_from_group_proofs(const uint64_t *hostProofs, uint64_t width, u
 static int with_dev(const uint64_t *hIn, u64 nIn, const uint64_t *hIn2, u64 nIn2, uint64_t *hOut, u64 nOut,
                     int (*fn)(const u64 *, const u64 *, u64 *, void *), void *arg) {
     P2_TRY(ensure_init());
-    u64 *d = nullptr;
-    HIP_TRY(hipMalloc((void **)&d, (nIn + nIn2 + nOut + 1) * 8));
+    u64 *d = nullptr; bool owned = false;
+    P2_TRY(stage_acquire(nIn + nIn2 + nOut, &d, &owned));
     int rc = PIL2GL_OK;
     hipError_t e = hipSuccess;
     if (nIn) e = hipMemcpy(d, hIn, nIn * 8, hipMemcpyHostToDevice);
@@ -320,7 +320,7 @@ static int with_dev(const uint64_t *hIn, u64 nIn, const uint64_t *hIn2, u64 nIn2
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
     if (rc == PIL2GL_OK) rc = fn(d, nIn2 ? d + nIn : nullptr, d + nIn + nIn2, arg);
     if (rc == PIL2GL_OK && nOut) { e = hipMemcpy(hOut, d + nIn + nIn2, nOut * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
-    (void)hipFree(d);
+    stage_release(d, owned);
     return rc;
 }
 struct LhArgs { u64 width, height; int split; };

@@ -83,6 +83,14 @@ int scratch(u32 slot, u64 nWords, u64 **out) {
     return PIL2GL_OK;
 }
 
+int stage_acquire(u64 nWords, u64 **out, bool *owned) {
+    if (nWords <= (2ull << 20)) { *owned = false; return scratch(11, nWords + 1, out); }
+    *owned = true;
+    HIP_TRY(hipMalloc((void **)out, (nWords + 1) * 8));
+    return PIL2GL_OK;
+}
+void stage_release(u64 *p, bool owned) { if (owned && p) (void)hipFree(p); }
+
 }  // namespace pil2gl
 
 using namespace pil2gl;

@@ -92,6 +92,10 @@ int pil2gl_ifft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_
  * `count` independent permutations: in = count x 8, cap = count x 4 (NULL = zeros), out = count x nOut. */
 int pil2gl_poseidon(const uint64_t *in, const uint64_t *cap, uint64_t count, uint32_t nOut, uint64_t *out);
 int pil2gl_poseidon_dev(const uint64_t *in, const uint64_t *cap, uint64_t count, uint32_t nOut, uint64_t *out, void *stream);
+/* Transcript.put of a list (transcript.js:49-66): nBlocks full blocks of 8 elements absorbed one after the other, the
+ * first with capacity hostCap, each next one with the previous output's first four words; hostOut12 = the last
+ * permutation's twelve outputs.  One launch for the whole chain (twelve lanes share each permutation). */
+int pil2gl_sponge_absorb(const uint64_t *hostBlocks, uint64_t nBlocks, const uint64_t hostCap[4], uint64_t hostOut12[12]);
 /* worker linearHash(buffIn,width,st_i,st_n,splitLinearHash)  merklehash_worker.js:37-82
  * (= WASM multiLinearHash glwasm.js:1124-1218 / multiLinearHashGPU :1089-1122, with the
  * width<=4 raw copy of merklehash_worker.js:42-49): out = height x 4 digests. */

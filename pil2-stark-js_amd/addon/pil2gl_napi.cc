@@ -146,6 +146,11 @@ FN(GroupProofDev) {  // (devElems, devNodes, width, height, idx, vals BigUint64A
     napi_value v; napi_create_uint32(env, nl, &v); return v;
 }
 
+FN(SpongeAbsorb) {  // (blocks BigUint64Array(8*n), n, cap BigUint64Array(4), out BigUint64Array(12))  transcript.js:49-66 for a list
+    Args a(env, info); uint64_t n = a.u64(1);
+    uint64_t *blocks = a.arr(0, 8 * n), *cap = a.arr(2, 4), *out = a.arr(3, 12); if (!a.ok) return nullptr;
+    P2(env, pil2gl_sponge_absorb(blocks, n, cap, out)); return mk_undefined(env);
+}
 FN(RootsFromGroupProofs) {  // (packed BigUint64Array(n*(width+4*levels)), width, levels, idxs BigUint64Array(n), n, split, roots BigUint64Array(4n))
     Args a(env, info); uint64_t w = a.u64(1), lv = a.u64(2), n = a.u64(4); int split = (int)a.u64(5);
     uint64_t *packed = a.arr(0, n * (w + 4 * lv)), *idx = a.arr(3, n), *roots = a.arr(6, 4 * n); if (!a.ok) return nullptr;
@@ -278,7 +283,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "interpolateDev", InterpolateDev }, { "fftDev", FftDev }, { "ifftDev", IfftDev },
         { "poseidon", Poseidon }, { "linearHashRows", LinearHashRows }, { "merkelizeLevel", MerkelizeLevel },
         { "merkleNumNodes", MerkleNumNodes }, { "merkelize", Merkelize }, { "merkelizeDev", MerkelizeDev }, { "groupProofDev", GroupProofDev },
-        { "rootsFromGroupProofs", RootsFromGroupProofs },
+        { "rootsFromGroupProofs", RootsFromGroupProofs }, { "spongeAbsorb", SpongeAbsorb },
         { "bn128Poseidon", Bn128Poseidon }, { "bn128LinearHashRows", Bn128LinearHashRows }, { "bn128MerkleNumNodes", Bn128MerkleNumNodes },
         { "bn128Merkelize", Bn128Merkelize }, { "bn128MerkelizeDev", Bn128MerkelizeDev }, { "bn128Convert", Bn128Convert },
         { "buildXDev", BuildXDev }, { "buildZhInvDev", BuildZhInvDev }, { "buildOneRowZerofierInvDev", BuildOneRowZerofierInvDev },

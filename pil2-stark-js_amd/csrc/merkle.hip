@@ -113,6 +113,49 @@ __global__ void __launch_bounds__(256, 2) merkle_path_roots_kernel(const u64 *__
     for (int j = 0; j < 4; j++) roots[4 * i + j] = cur[j];
 }
 
+// A chain of dependent permutations -- the Fiat-Shamir transcript absorbing a list (transcript.js:49-66: every full block of 8
+// is permuted with the previous output's first four words as capacity).  One permutation per lane would leave the chain at
+// one wave-alone permutation (~50 us) per block; here twelve lanes hold one state word each: S-boxes in parallel (lane 0
+// alone in the partial rounds), the MDS row of a lane from the twelve words exchanged through LDS, textbook round schedule
+// (constants of round r added to every word).  out12 = the last permutation's twelve outputs.
+__global__ void __launch_bounds__(64) sponge_chain_kernel(const u64 *__restrict__ blocks, u64 nBlocks, const u64 *__restrict__ cap, u64 *__restrict__ out12) {
+    constexpr u32 MC[12] = { 17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20 };
+    __shared__ u64 sh[12];
+    const u32 lane = threadIdx.x;
+    const bool act = lane < 12;
+    const u32 l = act ? lane : 0;
+    u32 mrow[12];                                    // row `l` of the MDS matrix: circ(MC) + 8 at (0,0)
+#pragma unroll
+    for (int j = 0; j < 12; j++) mrow[j] = MC[(j + 12 - l) % 12] + ((l == 0 && j == 0) ? 8u : 0u);
+    u64 carry = (act && l >= 8) ? canon(cap[l - 8]) : 0;          // lanes 8..11 hold the capacity words
+    u64 s = 0;
+    for (u64 b = 0; b < nBlocks; b++) {
+        s = l < 8 ? canon(blocks[8 * b + l]) : carry;
+        for (int r = 0; r < 30; r++) {
+            s = add_lazy_canon(s, POSEIDON_GL_RC[r * 12 + l]);
+            const bool full = r < 4 || r >= 26;
+            if (full || l == 0) s = pow7_lazy(s);
+            if (act) sh[l] = s;
+            __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): the writes of this wave have landed
+            __builtin_amdgcn_wave_barrier();
+            u64 al = 0, ah = 0;                      // sum of low halves * m and of high halves * m (each < 2^42)
+#pragma unroll
+            for (int j = 0; j < 12; j++) { const u64 v = sh[j]; al += (u64)(u32)v * mrow[j]; ah += (u64)(u32)(v >> 32) * mrow[j]; }
+            __builtin_amdgcn_wave_barrier();
+            const u64 lo = al + (ah << 32);
+            const u64 hi = (ah >> 32) + (lo < al ? 1 : 0);
+            s = reduce128_lazy(lo, hi);
+        }
+        s = canon(s);
+        if (act) sh[l] = s;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        carry = (l >= 8) ? sh[l - 8] : 0;            // next capacity = outputs 0..3
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (act) out12[l] = s;
+}
+
 // batch of independent permutations (glwasm.js:216 `poseidon`, hash/poseidon/poseidon.js:57)
 __global__ void __launch_bounds__(256, 2) poseidon_batch_kernel(const u64 *__restrict__ in, const u64 *__restrict__ cap, u64 count, u32 nOut, u64 *__restrict__ out) {
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -305,6 +348,27 @@ int pil2gl_roots_from_group_proofs(const uint64_t *hostProofs, uint64_t width, u
     KERNEL_CHECK();
     HIP_TRY(hipMemcpy(hostRoots, dRoots, 4ull * nIdx * 8, hipMemcpyDeviceToHost));
     return PIL2GL_OK;
+}
+
+// transcript.js:49-66 for a list: nBlocks full blocks of 8 absorbed one after the other, starting from capacity cap[4]
+int pil2gl_sponge_absorb(const uint64_t *hostBlocks, uint64_t nBlocks, const uint64_t hostCap[4], uint64_t hostOut12[12]) {
+    P2_TRY(ensure_init());
+    if (!hostBlocks || !hostCap || !hostOut12) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nBlocks == 0) return fail(PIL2GL_EINVAL, "nothing to absorb");
+    u64 *d; bool owned;
+    P2_TRY(stage_acquire(8 * nBlocks + 4 + 12, &d, &owned));
+    int rc = PIL2GL_OK;
+    hipError_t e = hipMemcpy(d, hostBlocks, 8 * nBlocks * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + 8 * nBlocks, hostCap, 32, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
+    if (rc == PIL2GL_OK) {
+        sponge_chain_kernel<<<1, 64>>>(d, nBlocks, d + 8 * nBlocks, d + 8 * nBlocks + 4);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(hostOut12, d + 8 * nBlocks + 4, 96, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = hip_fail(e, "sponge_chain_kernel");
+    }
+    stage_release(d, owned);
+    return rc;
 }
 
 // ---- host-pointer forms ----

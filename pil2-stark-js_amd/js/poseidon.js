@@ -15,4 +15,12 @@ function poseidon(inputs, capacity, nOuts) {
     addon.poseidon(i, c, 1, nOuts, out);
     return Array.from(out);
 }
+// not in the reference: a list of full blocks absorbed one after the other in one device call (each permutation takes the
+// previous one's first four outputs as capacity), for js/transcript.js; -> the last permutation's twelve outputs
+poseidon.absorbChain = function absorbChain(blocks, capacity) {
+    if (blocks.length === 0 || blocks.length % 8 !== 0) throw new Error("Invalid Input size (must be a multiple of 8)");
+    const out = new BigUint64Array(12);
+    addon.spongeAbsorb(BigUint64Array.from(blocks, e), blocks.length / 8, BigUint64Array.from(capacity || [0n, 0n, 0n, 0n], e), out);
+    return Array.from(out);
+};
 module.exports = function getPoseidon() { return poseidon; };

@@ -8,6 +8,7 @@ module.exports = class Transcript {
     constructor(poseidon) {
         this.poseidon = poseidon;
         this.core = new Duplex((block, st) => poseidon(block, st, 12), 8, [0n, 0n, 0n, 0n], (out) => out.slice(0, 4));
+        if (poseidon.absorbChain) this.core.chain = (blocks, st) => poseidon.absorbChain(blocks, st);     // the drop-in poseidon.js has it
     }
     get state() { return this.core.state; }
     put(a) { absorbAll(this.core, a, BigInt); }

@@ -49,7 +49,24 @@ function indicesFromFields(nextField, n, nBits, usable) {
     }
     return out;
 }
+// A (nested) list is absorbed block-wise: with a `chain(blocks, state) -> outputs` callback on the core (the Goldilocks
+// transcript has one: a single device call for all the full blocks the list completes) the state and outbox end up exactly
+// as element-by-element absorbs leave them; without it, element by element.
 function absorbAll(core, a, convert) {
-    if (Array.isArray(a)) for (const x of a) absorbAll(core, x, convert); else core.absorb(convert(a));
+    if (!core.chain) { if (Array.isArray(a)) for (const x of a) absorbAll(core, x, convert); else core.absorb(convert(a)); return; }
+    const flat = [];
+    (function walk(v) { if (Array.isArray(v)) for (const x of v) walk(x); else flat.push(convert(v)); })(a);
+    let i = 0;
+    while (i < flat.length) {
+        const need = core.rate - core.inbox.length;
+        if (flat.length - i < need) { for (; i < flat.length; i++) core.inbox.push(flat[i]); core.outbox = []; return; }
+        const nFull = 1 + Math.floor((flat.length - i - need) / core.rate), take = need + core.rate * (nFull - 1);
+        const blocks = core.inbox.concat(flat.slice(i, i + take));
+        core.inbox = [];
+        core.outbox = nFull === 1 ? core.permute(blocks, core.state) : core.chain(blocks, core.state);
+        core.state = core.carry(core.outbox);
+        if (core.onPermute) for (let k = 0; k < nFull; k++) core.onPermute();
+        i += take;
+    }
 }
 module.exports = { Duplex, indicesFromFields, absorbAll };

@@ -388,11 +388,34 @@ class Transcript:
         return self.out.pop(0)
 
     def put(self, a):
-        if isinstance(a, (list, tuple, np.ndarray)):
-            for v in a:
-                self.put(v)
-        else:
-            self._add1(int(a))
+        """transcript.js:49-66.  A list is absorbed block-wise: all the full blocks of 8 it completes go through ONE device
+        call (pil2gl_sponge_absorb chains their permutations), which leaves exactly the state element-by-element `put`s leave"""
+        flat = []
+
+        def walk(v):
+            if isinstance(v, (list, tuple, np.ndarray)):
+                for x in v:
+                    walk(x)
+            else:
+                flat.append(int(v) % P)
+        walk(a)
+        i = 0
+        while i < len(flat):
+            need = 8 - len(self.pending)
+            if len(flat) - i < need:
+                self.pending.extend(flat[i:]); self.out = []
+                return
+            n_full = 1 + (len(flat) - i - need) // 8
+            take = need + 8 * (n_full - 1)
+            blocks = np.array(self.pending + flat[i:i + take], dtype=np.uint64)
+            if n_full == 1:
+                self.out = poseidon(blocks.tolist(), self.state, 12)
+            else:
+                cap = np.array([int(x) % P for x in self.state], dtype=np.uint64); out = np.zeros(12, np.uint64)
+                call("pil2gl_sponge_absorb", _ptr(blocks), n_full, _ptr(cap), _ptr(out))
+                self.out = [int(v) for v in out]
+            self.pending = []; self.state = self.out[:4]
+            i += take
 
     def updateState(self):
         while len(self.pending) < 8:

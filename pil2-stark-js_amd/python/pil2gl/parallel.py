@@ -342,8 +342,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
             ev_t = ev_t.to(be.as_torch(loc["cm1_ext"]).device)
         dist.all_reduce(ev_t, op=dist.ReduceOp.SUM, group=group)          # every entry is non-zero on one rank only
     ctx["evals"] = [[int(v) for v in r] for r in ev_t.cpu().numpy().view(np.uint64).reshape(n_ev, 3)]
-    for ev in ctx["evals"]:
-        transcript.put(ev)
+    transcript.put(ctx["evals"])
 
     lap("evals")
     # FRI polynomial on the local rows, then one all-gather

@@ -177,6 +177,34 @@ def test_merkle_tree(gl, oracle, N, nPols, idx, split):
         MH.getGroupProof(tree, N)
 
 
+def test_transcript_list_absorption(gl, oracle):
+    """Transcript.put of a list goes through one chained device call (pil2gl_sponge_absorb: twelve lanes per permutation):
+    same challenges as the oracle's element-by-element transcript, for every alignment of the list against the blocks"""
+    from pil2gl import _lib
+    rng = np.random.default_rng(5)
+    for pre in (0, 1, 3, 7, 8, 9):
+        for n in (0, 1, 7, 8, 15, 16, 17, 40, 96 * 8 + 5):
+            vals = [int(v) for v in rand_field(rng, n)]
+            head = [int(v) for v in rand_field(rng, pre)]
+            t, o = gl.Transcript(), oracle.Transcript()
+            for v in head:
+                t.put(v)
+            if head:
+                o.put(np.array(head, dtype=np.uint64))
+            t.put(vals if n % 2 else [vals[:n // 2], [vals[n // 2:]]])          # nested lists flatten in order
+            if vals:
+                o.put(np.array(vals, dtype=np.uint64))
+            assert [int(x) for x in t.getField()] == [int(x) for x in o.get_field()], (pre, n)
+            assert t.getPermutations(8, 11) == [int(x) for x in o.get_permutations(8, 11)]
+    blocks = rand_field(rng, 5 * 8); cap = rand_field(rng, 4); out = np.zeros(12, np.uint64)
+    _lib.call("pil2gl_sponge_absorb", gl._ptr(blocks), 5, gl._ptr(cap), gl._ptr(out))
+    st = [int(v) for v in cap]
+    for b in range(5):
+        st12 = gl.poseidon([int(v) for v in blocks[8 * b:8 * b + 8]], st[:4], 12)
+        st = st12
+    assert [int(v) for v in out] == [int(v) for v in st]
+
+
 def test_ntt_random_shapes_and_pass_splits(gl, oracle, monkeypatch):
     """interpolate / fft / ifft on random shapes with the pass planner forced to every split it can take (PIL2GL_NTT_KMAX:
     passes of up to 4, 6, 9, 10 stages besides the default 8 / 7), i.e. every register-step chunking of gl_fermat.cuh"""

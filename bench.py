@@ -347,6 +347,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # set-up, not a timed or counted step: on a box that has just been handed out the first pass after process start has
+    # been seen ~180 ms (13 %) slower than the following ones (clock ramp, first touch of 150 GB); one untimed pass ahead of the
+    # W warm-up steps keeps that out of a short run's mean.  PIL2GL_BENCH_PREWARM=0 skips it.
+    if os.environ.get("PIL2GL_BENCH_PREWARM", "1") != "0":
+        step()
     for _ in range(args.warmup):
         step()
     barrier()

@@ -215,6 +215,11 @@ FN(Bn128Poseidon) {  // (in BigUint64Array(4*nIn*count) normal form, init BigUin
     uint64_t *in = a.arr(0, 4 * nIn * count), *init = a.is_nullish(1) ? nullptr : a.arr(1, 4 * count), *out = a.arr(5, 4 * nOut * count); if (!a.ok) return nullptr;
     P2(env, pil2gl_bn128_poseidon(in, init, count, (uint32_t)nIn, (uint32_t)nOut, out)); return mk_undefined(env);
 }
+FN(Bn128SpongeAbsorb) {  // (blocks BigUint64Array(4*nIn*n) normal form, n, nIn, init BigUint64Array(4), out BigUint64Array(4*(nIn+1)))  transcript.bn128.js:56-83 for a list
+    Args a(env, info); uint64_t n = a.u64(1), nIn = a.u64(2);
+    uint64_t *blocks = a.arr(0, 4 * nIn * n), *init = a.arr(3, 4), *out = a.arr(4, 4 * (nIn + 1)); if (!a.ok) return nullptr;
+    P2(env, pil2gl_bn128_sponge_absorb(blocks, n, (uint32_t)nIn, init, out)); return mk_undefined(env);
+}
 FN(Bn128LinearHashRows) { // (in, width, height, arity, custom, out(4*height) Montgomery)  merklehash_bn128_worker.js:13
     Args a(env, info); uint64_t w = a.u64(1), h = a.u64(2), arity = a.u64(3); int custom = (int)a.u64(4);
     uint64_t *in = a.arr(0, w * h), *out = a.arr(5, 4 * h); if (!a.ok) return nullptr;
@@ -284,7 +289,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "poseidon", Poseidon }, { "linearHashRows", LinearHashRows }, { "merkelizeLevel", MerkelizeLevel },
         { "merkleNumNodes", MerkleNumNodes }, { "merkelize", Merkelize }, { "merkelizeDev", MerkelizeDev }, { "groupProofDev", GroupProofDev },
         { "rootsFromGroupProofs", RootsFromGroupProofs }, { "spongeAbsorb", SpongeAbsorb },
-        { "bn128Poseidon", Bn128Poseidon }, { "bn128LinearHashRows", Bn128LinearHashRows }, { "bn128MerkleNumNodes", Bn128MerkleNumNodes },
+        { "bn128Poseidon", Bn128Poseidon }, { "bn128SpongeAbsorb", Bn128SpongeAbsorb }, { "bn128LinearHashRows", Bn128LinearHashRows }, { "bn128MerkleNumNodes", Bn128MerkleNumNodes },
         { "bn128Merkelize", Bn128Merkelize }, { "bn128MerkelizeDev", Bn128MerkelizeDev }, { "bn128Convert", Bn128Convert },
         { "buildXDev", BuildXDev }, { "buildZhInvDev", BuildZhInvDev }, { "buildOneRowZerofierInvDev", BuildOneRowZerofierInvDev },
         { "buildFrameZerofierDev", BuildFrameZerofierDev }, { "computeQSplitDev", ComputeQSplitDev }, { "xDivXSubXiDev", XDivXSubXiDev },

@@ -29,6 +29,15 @@ function poseidon(inputs, initState, nOut) {
     for (let i = 0; i < nOut; i++) res.push(fromWords(out, i));
     return nOut === 1 ? res[0] : res;
 }
+// transcript.bn128.js:56-66 for a list: the full blocks of nIn elements in `flat` absorbed one after the other (each
+// permutation's output 0 is the next one's state element 0) in one device call -> the nIn+1 outputs of the last one
+poseidon.absorbChain = function (flat, initState, nIn) {
+    const out = new BigUint64Array(4 * (nIn + 1));
+    addon.bn128SpongeAbsorb(toWords(flat), flat.length / nIn, nIn, toWords([initState || 0n]), out);
+    const res = [];
+    for (let i = 0; i <= nIn; i++) res.push(fromWords(out, i));
+    return res;
+};
 function fromMontgomery(words) {
     const n = words.length / 4, out = new BigUint64Array(words.length);
     addon.bn128Convert(words, n, 0, out);

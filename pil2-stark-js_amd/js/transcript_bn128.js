@@ -15,6 +15,7 @@ module.exports = class Transcript {
         this.limbs = [];                        // 64-bit words of the output currently being cut up (the reference's out3)
         // a permutation drops limbs still waiting (transcript.bn128.js:62); absorbing alone does not (:78-83)
         this.core = new Duplex((block, st) => this.poseidon(block, st, this.nInputs + 1), this.nInputs, 0n, (out) => out[0], () => { this.limbs = []; });
+        if (this.poseidon.absorbChain) this.core.chain = (blocks, st) => this.poseidon.absorbChain(blocks, st, this.nInputs);   // lists: one device call
     }
     get state() { return this.core.state; }
     put(a) { absorbAll(this.core, a, BigInt); }

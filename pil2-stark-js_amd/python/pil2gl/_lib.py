@@ -82,6 +82,7 @@ SIGNATURES = {
     "pil2gl_group_proofs_dev": (_I, [vp, vp, _U64, _U64, vp, _U32, vp, C.POINTER(_U32)]),
     "pil2gl_roots_from_group_proofs": (_I, [vp, _U64, _U32, vp, _U32, C.c_int, vp]),
     "pil2gl_sponge_absorb": (_I, [vp, _U64, vp, vp]),
+    "pil2gl_bn128_sponge_absorb": (_I, [vp, _U64, _U32, vp, vp]),
     "pil2gl_fri_fold": (_I, [vp, _U32, _U32, _U64, vp, vp]),
     "pil2gl_fri_fold_dev": (_I, [vp, _U32, _U32, _U64, vp, vp, vp]),
     "pil2gl_fri_transpose": (_I, [vp, _U32, _U32, vp]),

@@ -36,6 +36,15 @@ def poseidon(inputs, initState=0, nOut=1):
     return _ints(o)
 
 
+def poseidon_chain(blocks, initState=0):
+    """blocks: [nBlocks][nIn] ints absorbed one after the other, each permutation's output 0 being the next one's state
+    element 0 (transcript.bn128.js:56-66) -> the nIn+1 outputs of the last permutation; one launch, nIn+1 lanes"""
+    nB, nIn = len(blocks), len(blocks[0])
+    i = _words([v for row in blocks for v in row]); s = _words([initState]); o = np.zeros((nIn + 1, 4), np.uint64)
+    call("pil2gl_bn128_sponge_absorb", _ptr(i), nB, nIn, _ptr(s), _ptr(o))
+    return _ints(o)
+
+
 def poseidon_batch(inputs, init=None, nOut=1):
     """inputs: [count][nIn] ints, init: [count] ints or None -> [count][nOut] ints"""
     count, nIn = len(inputs), len(inputs[0])
@@ -259,14 +268,31 @@ class Transcript:
         self.state = self.out[0]
 
     def put(self, a):
-        for v in (a if isinstance(a, (list, tuple)) else [a]):
+        flat = []
+
+        def walk(v):
             if isinstance(v, (list, tuple)):
-                self.put(v)
+                for x in v:
+                    walk(x)
             else:
+                flat.append(int(v) % R)
+        walk(a)
+        if not flat:
+            return
+        n = self.nInputs
+        if (len(self.pending) + len(flat)) // n >= 2:      # a chain of dependent permutations: one launch for all of them
+            allv = self.pending + flat
+            nb = len(allv) // n
+            self.out = poseidon_chain([allv[k * n:(k + 1) * n] for k in range(nb)], self.state)
+            self.state, self.out3, self.pending = self.out[0], [], allv[nb * n:]
+            if self.pending:
                 self.out = []
-                self.pending.append(int(v) % R)
-                if len(self.pending) == self.nInputs:
-                    self.updateState()
+            return
+        for v in flat:
+            self.out = []
+            self.pending.append(v)
+            if len(self.pending) == n:
+                self.updateState()
 
     def getPermutations(self, n, nBits):
         total = n * nBits

@@ -289,6 +289,20 @@ class ChunkedBuffer {
         for (let s = 1; s <= 4; s++) { T.put(BigInt(p[`s${s}_root`])); T.getField(); }
         T.put(p.finalPol.map((e) => e.map(BigInt)));
         const ys = T.getPermutations(32, 17);
+        {   // lists go through the chained kernel: same state and outputs as element-by-element absorption
+            const plain = (i, st, n) => buildMHBN.poseidon(i, st, n);       // no absorbChain on this one
+            for (const nIn of [4, 16]) {
+                const A = new TranscriptBN(nIn), B = new TranscriptBN(plain, nIn);
+                assert(A.core.chain && !B.core.chain);
+                const vals = []; for (let i = 0; i < 5 * nIn + 3; i++) vals.push((BigInt(i + 1) << 200n) + 12345n ** BigInt(i % 9 + 1));
+                for (const step of [vals.slice(0, 2), vals, [vals.slice(0, nIn), [vals[1], [vals[2]]]], vals.slice(0, 2 * nIn - 2)]) {
+                    A.put(step); B.put(step);
+                    assert.deepStrictEqual([A.core.state, A.core.inbox, A.core.outbox, A.limbs], [B.core.state, B.core.inbox, B.core.outbox, B.limbs]);
+                    assert.deepStrictEqual(A.getField(), B.getField());
+                }
+                assert.deepStrictEqual(A.getPermutations(8, 20), B.getPermutations(8, 20));
+            }
+        }
         const MH4 = await buildMHBN(4, false);
         for (const q of [0, 13, 31]) {
             assert(MH4.verifyGroupProof(BigInt(p.root1), p.s0_siblings1[q], ys[q], p.s0_vals1[q].map(BigInt)), "final proof root1 q" + q);

@@ -143,6 +143,33 @@ def test_reference_final_proof_through_gpu(bn):
     assert not MH.verifyGroupProofs(int(p["s4_root"]), bad, [y % 16 for y in ys])
 
 
+def test_transcript_chain_kernel(bn, orc):
+    """lists go through the chained kernel (nIn+1 lanes share each permutation): the same state and the same challenges as
+    the oracle's element-by-element transcript, for every sponge width and for lists that straddle block boundaries"""
+    rng = np.random.default_rng(17)
+    rnd = lambda n: [int.from_bytes(rng.bytes(32), "little") % orc.R for _ in range(n)]
+    for n_in in (1, 2, 3, 4, 7, 8, 12, 15, 16):
+        for nb in (1, 2, 5):
+            blocks = [rnd(n_in) for _ in range(nb)]
+            st = rnd(1)[0]
+            want = None
+            s = st
+            for b in blocks:
+                want = orc.poseidon(b, s, n_in + 1); s = want[0]
+            assert bn.poseidon_chain(blocks, st) == want, (n_in, nb)
+    assert bn.poseidon_chain([[orc.R - 1] * 16, [0] * 16], 0) == orc.poseidon([0] * 16, orc.poseidon([orc.R - 1] * 16, 0, 1)[0], 17)
+    with pytest.raises(bn.Pil2glError):
+        bn.poseidon_chain([[1] * 17], 0)
+    for n_in in (4, 16):
+        T, O = bn.Transcript(n_in), orc.TranscriptBN128(n_in)
+        for step in ([3], rnd(2 * n_in), [rnd(3) for _ in range(n_in)], rnd(1)[0], rnd(5 * n_in - 1), [], rnd(n_in - 2), [[rnd(2), rnd(1)[0]]] * 7):
+            T.put(step); O.put(step)
+            assert (T.pending, T.out, T.out3, T.state) == (O.pending, O.out, O.out3, O.state)
+            if not isinstance(step, int) and len(step) % 2:
+                assert T.getField() == O.getField()
+        assert T.getPermutations(20, 13) == O.getPermutations(20, 13) and T.getState() == O.getState()
+
+
 def test_config4_shape_tree_opens(bn):
     """BASELINE config 4's shape (100 columns, BN128 linear hash, arity 16; 2^24 extended rows here, 2^27 in the config):
     every opened path of the device-built tree recomputes the root through the host-side verification rule"""

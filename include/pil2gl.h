@@ -136,6 +136,13 @@ int pil2gl_fri_fold(const uint64_t *pol, uint32_t polBits, uint32_t outBits, uin
                     const uint64_t challenge[3], uint64_t *out);
 int pil2gl_fri_fold_dev(const uint64_t *pol, uint32_t polBits, uint32_t outBits, uint64_t shiftInv,
                         const uint64_t challenge[3], uint64_t *out, void *stream);
+/* FRI.verify, the per-query step of one layer for all queries at once  fri.js:121-127:
+ * groups = 2^foldBits x (nQueries*3) row-major (row i = element i of every query's opened group),
+ * sinv[q] = 1 / (shift * w_polBits^idx_q); out[q] = evalPol(ifft(group_q), challenge * sinv[q]). */
+int pil2gl_fri_verify_fold(const uint64_t *groups, uint32_t foldBits, uint32_t nQueries, const uint64_t *sinv,
+                           const uint64_t challenge[3], uint64_t *out /* nQueries x 3 */);
+int pil2gl_fri_verify_fold_dev(const uint64_t *groups, uint32_t foldBits, uint32_t nQueries, const uint64_t *sinv,
+                               const uint64_t challenge[3], uint64_t *out, void *stream);
 /* getTransposedBuffer(pol, trasposeBits)  fri.js:187-202 */
 int pil2gl_fri_transpose(const uint64_t *pol, uint32_t polBits, uint32_t transposeBits, uint64_t *out);
 int pil2gl_fri_transpose_dev(const uint64_t *pol, uint32_t polBits, uint32_t transposeBits, uint64_t *out, void *stream);

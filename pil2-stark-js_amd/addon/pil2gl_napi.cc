@@ -248,6 +248,12 @@ FN(FriFold) {        // (pol, polBits, outBits, shiftInv, challenge[3], out)  fr
     uint64_t *pol = a.arr(0, a.ok ? 3ull << pb : 0), *ch = a.arr(4, 3), *out = a.arr(5, a.ok ? 3ull << ob : 0); if (!a.ok) return nullptr;
     P2(env, pil2gl_fri_fold(pol, pb, ob, sinv, ch, out)); return mk_undefined(env);
 }
+FN(FriVerifyFold) {  // (groups BigUint64Array(3*2^foldBits*nQ), foldBits, nQ, sinv BigUint64Array(nQ), challenge[3], out BigUint64Array(3*nQ))  fri.js:121-127
+    Args a(env, info); uint32_t fb = (uint32_t)a.u64(1), nq = (uint32_t)a.u64(2);
+    if (fb > 20 || nq == 0) a.fail("Invalid group size or query count");
+    uint64_t *g = a.arr(0, a.ok ? (3ull << fb) * nq : 0), *sinv = a.arr(3, nq), *ch = a.arr(4, 3), *out = a.arr(5, 3ull * nq); if (!a.ok) return nullptr;
+    P2(env, pil2gl_fri_verify_fold(g, fb, nq, sinv, ch, out)); return mk_undefined(env);
+}
 FN(FriTranspose) {   // (pol, polBits, transposeBits, out)  fri.js:187
     Args a(env, info); uint32_t pb = (uint32_t)a.u64(1), tb = (uint32_t)a.u64(2);
     if (pb > 40) a.fail("Invalid polynomial size");
@@ -295,7 +301,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "buildFrameZerofierDev", BuildFrameZerofierDev }, { "computeQSplitDev", ComputeQSplitDev }, { "xDivXSubXiDev", XDivXSubXiDev },
         { "buildLevDev", BuildLevDev }, { "computeEvalsDev", ComputeEvalsDev }, { "gprodDev", GprodDev }, { "gsumDev", GsumDev }, { "h1h2Dev", H1H2Dev },
         { "friFoldDev", FriFoldDev }, { "friTransposeDev", FriTransposeDev },
-        { "friFold", FriFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
+        { "friFold", FriFold }, { "friVerifyFold", FriVerifyFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
     };
     for (auto &f : fns) {
         napi_value v;

@@ -23,12 +23,13 @@ __device__ __forceinline__ void st3(u64 *p, const E3 &v) { p[0] = v.v[0]; p[1] =
 
 // fri.js:45-60 after the group iNTT: out[g] = sum_i coef[i][g] * (sinv_g * challenge)^i, sinv_g = shiftInv * wi^g.
 // coef is the nX x (pol2N*3) matrix of iNTT'd groups (row i, column g): lanes walk consecutive g.
-__global__ void fri_horner_kernel(const u64 *__restrict__ coef, u32 polBits, u32 outBits, u64 shiftInv, E3 challenge,
-                                  const u64 *__restrict__ powWi, u64 *__restrict__ out) {
+// With sinvOf (the verifier, fri.js:125-127: one opened group per query, each with its own position) the pol2N columns
+// are unrelated groups and sinv_g = sinvOf[g]; pol2N need not be a power of two then.
+__global__ void fri_horner_kernel(const u64 *__restrict__ coef, u32 polBits, u64 pol2N, u64 nX, u64 shiftInv, E3 challenge,
+                                  const u64 *__restrict__ powWi, const u64 *__restrict__ sinvOf, u64 *__restrict__ out) {
     const u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    const u64 pol2N = 1ull << outBits, nX = 1ull << (polBits - outBits);
     if (g >= pol2N) return;
-    const u64 sinv = mul(shiftInv, root_pow(powWi, polBits, (u32)g));
+    const u64 sinv = sinvOf ? sinvOf[g] : mul(shiftInv, root_pow(powWi, polBits, (u32)g));
     const E3 Y = e3_scale(challenge, sinv);
     E3 acc = ld3(coef + ((nX - 1) * pol2N + g) * 3);                 // polutils.js:9-16 evalPol
     for (u64 i = nX - 1; i-- > 0;) acc = e3_add(e3_mul(acc, Y), ld3(coef + (i * pol2N + g) * 3));
@@ -214,7 +215,29 @@ int pil2gl_fri_fold_dev(const uint64_t *pol, uint32_t polBits, uint32_t outBits,
     // group iNTT (fri.js:51-55): pol is an nX x (pol2N*3) row-major matrix, transform along its rows' index
     P2_TRY(ntt_launch(pol, 3ull << outBits, polBits - outBits, coef, true, st));
     E3 ch = { { challenge[0], challenge[1], challenge[2] } };
-    fri_horner_kernel<<<nblk(1ull << outBits), 256, 0, st>>>(coef, polBits, outBits, shiftInv, ch, tables().powWi, out);
+    fri_horner_kernel<<<nblk(1ull << outBits), 256, 0, st>>>(coef, polBits, 1ull << outBits, 1ull << (polBits - outBits), shiftInv, ch, tables().powWi, nullptr, out);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+// FRI.verify's inner step for all queries of a layer (fri.js:121-127): groups = 2^foldBits x (nQueries*3) row-major (row i =
+// element i of every query's opened group), sinv[q] = 1 / (shift * w_polBits^idx_q); out[q] = evalPol(ifft(group_q), challenge * sinv[q])
+int pil2gl_fri_verify_fold_dev(const uint64_t *groups, uint32_t foldBits, uint32_t nQueries, const uint64_t *sinv,
+                               const uint64_t challenge[3], uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (!groups || !sinv || !out || !challenge) return fail(PIL2GL_EINVAL, "null buffer");
+    if (foldBits > 20 || nQueries == 0) return fail(PIL2GL_EINVAL, "Invalid group size or query count");
+    hipStream_t st = as_stream(stream);
+    const u64 nX = 1ull << foldBits;
+    const u64 *coef = groups;
+    if (foldBits > 0) {
+        u64 *c;
+        P2_TRY(scratch(1, 3 * nX * nQueries, &c));
+        P2_TRY(ntt_launch(groups, 3ull * nQueries, foldBits, c, true, st));
+        coef = c;
+    }
+    E3 ch = { { challenge[0], challenge[1], challenge[2] } };
+    fri_horner_kernel<<<nblk(nQueries), 256, 0, st>>>(coef, 0, nQueries, nX, 0, ch, tables().powWi, sinv, out);
     KERNEL_CHECK();
     return PIL2GL_OK;
 }
@@ -246,6 +269,23 @@ int pil2gl_fri_fold(const uint64_t *pol, uint32_t polBits, uint32_t outBits, uin
     FoldArgs a = { polBits, outBits, shiftInv, challenge };
     return host3(pol, 3ull << polBits, out, 3ull << outBits,
                  [](const u64 *i, u64 *o, void *p) { FoldArgs *a = (FoldArgs *)p; return pil2gl_fri_fold_dev(i, a->polBits, a->outBits, a->shiftInv, a->ch, o, nullptr); }, &a);
+}
+int pil2gl_fri_verify_fold(const uint64_t *groups, uint32_t foldBits, uint32_t nQueries, const uint64_t *sinv,
+                           const uint64_t challenge[3], uint64_t *out) {
+    P2_TRY(ensure_init());
+    if (!groups || !sinv || !out || !challenge) return fail(PIL2GL_EINVAL, "null buffer");
+    if (foldBits > 20 || nQueries == 0) return fail(PIL2GL_EINVAL, "Invalid group size or query count");
+    const u64 nG = (3ull << foldBits) * nQueries;
+    u64 *d = nullptr;
+    HIP_TRY(hipMalloc((void **)&d, (nG + 4ull * nQueries) * 8));
+    int rc = PIL2GL_OK;
+    hipError_t e = hipMemcpy(d, groups, nG * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + nG, sinv, nQueries * 8ull, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
+    if (rc == PIL2GL_OK) rc = pil2gl_fri_verify_fold_dev(d, foldBits, nQueries, d + nG, challenge, d + nG + nQueries, nullptr);
+    if (rc == PIL2GL_OK) { e = hipMemcpy(out, d + nG + nQueries, 3ull * nQueries * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
+    (void)hipFree(d);
+    return rc;
 }
 int pil2gl_fri_transpose(const uint64_t *pol, uint32_t polBits, uint32_t transposeBits, uint64_t *out) {
     if (transposeBits > polBits || polBits > 31) return fail(PIL2GL_EINVAL, "Invalid polynomial size");

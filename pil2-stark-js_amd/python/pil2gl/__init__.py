@@ -454,8 +454,15 @@ def _inv(a):
     return pow(int(a), P - 2, P)
 
 
+def _root_of_unity(bits):
+    w = 7277203076849721926                              # f3g.js:40: F.w[32]; w[k] = w[k+1]^2 (fft.js:45-50)
+    for _ in range(32 - bits):
+        w = w * w % P
+    return w
+
+
 class FRI:
-    """fri.js:7-105.  Polynomials are (n,3) uint64 arrays / int64 CUDA tensors of extension elements."""
+    """fri.js:7-175.  Polynomials are (n,3) uint64 arrays / int64 CUDA tensors of extension elements."""
 
     def __init__(self, starkStruct, MH):
         if not starkStruct:
@@ -505,6 +512,62 @@ class FRI:
         else:                                           # fri.js:72-75
             proof = [[int(x) for x in row] for row in _to_host(pol2_e).reshape(-1, 3)]
         return {"pol": pol2_e, "tree": tree, "proof": proof}
+
+    def verify(self, friChallenges, friQueries, proof, checkQuery):
+        """fri.js:107-174.  checkQuery(polQuery, idx) -> the step-0 group of a query ([value], stark_verify.js:158-215) or a false
+        value.  Per layer the openings of all queries are checked in one device call (MH.verifyGroupProofs) and their groups
+        folded in one (pil2gl_fri_verify_fold); friQueries is reduced in place, as the reference does."""
+        assert len(proof) == len(self.steps) + 1, "Invalid proof size"
+        nQ = self.nQueries
+        polBits, shift = self.inNBits, SHIFT
+        for si in range(len(self.steps)):
+            item = proof[si]
+            reductionBits = polBits - self.steps[si]["nBits"]
+            if si == 0:
+                groups = []
+                for i in range(nQ):
+                    g = checkQuery(item["polQueries"][i], friQueries[i])
+                    if g is None or g is False:
+                        return False
+                    groups.append(g)
+            else:
+                pq = item["polQueries"]
+                if not self.MH.verifyGroupProofs(item["root"], [(q[0], q[1]) for q in pq[:nQ]], list(friQueries[:nQ])):
+                    return False
+                groups = [np.array([int(v) % P for v in q[0]], dtype=np.uint64).reshape(-1, 3) for q in pq[:nQ]]   # split3, fri.js:179-185
+            G = np.array([[[int(c) % P for c in e] for e in g] for g in groups], dtype=np.uint64).reshape(nQ, -1, 3)
+            nX = G.shape[1]
+            foldBits = nX.bit_length() - 1
+            assert (1 << foldBits) == nX, "Invalid group size"
+            w = _root_of_unity(polBits)
+            sinv = np.array([_inv(shift * pow(w, int(friQueries[i]), P) % P) for i in range(nQ)], dtype=np.uint64)   # fri.js:126
+            ch = np.array([int(c) % P for c in friChallenges[si]], dtype=np.uint64)
+            ev = np.zeros((nQ, 3), np.uint64)
+            Gt = np.ascontiguousarray(G.transpose(1, 0, 2))      # row i = element i of every query's group
+            call("pil2gl_fri_verify_fold", _ptr(Gt), foldBits, nQ, _ptr(sinv), _ptr(ch), _ptr(ev))
+            for i in range(nQ):
+                if si < len(self.steps) - 1:
+                    groupIdx = int(friQueries[i]) // (1 << self.steps[si + 1]["nBits"])
+                    query = proof[si + 1]["polQueries"][i][0]
+                    nxt = [int(v) % P for v in query[3 * groupIdx:3 * groupIdx + 3]]
+                else:
+                    nxt = [int(v) % P for v in proof[si + 1][int(friQueries[i])]]
+                if nxt != [int(v) for v in ev[i]]:
+                    return False
+            polBits = self.steps[si]["nBits"]
+            for _ in range(reductionBits):
+                shift = shift * shift % P
+            if si < len(self.steps) - 1:
+                for i in range(len(friQueries)):
+                    friQueries[i] = friQueries[i] % (1 << self.steps[si + 1]["nBits"])
+        last = np.array([[int(c) % P for c in e] for e in proof[-1]], dtype=np.uint64).reshape(-1, 3)
+        maxDeg = 0 if polBits - (self.inNBits - self.maxDegNBits) < 0 else 1 << (polBits - (self.inNBits - self.maxDegNBits))
+        if last.shape[0] > 1:                            # the extension iNTT is the base-field one on each of the three coordinates
+            coef = np.zeros_like(last)
+            ifft(last, 3, last.shape[0].bit_length() - 1, coef)
+            if coef[maxDeg + 1:].any():                  # no division by the shift needed to look for zeros (fri.js:166)
+                return False
+        return True
 
     def proofQueries(self, proof, trees, friQueries):
         """fri.js:83-105"""

@@ -85,6 +85,8 @@ SIGNATURES = {
     "pil2gl_bn128_sponge_absorb": (_I, [vp, _U64, _U32, vp, vp]),
     "pil2gl_fri_fold": (_I, [vp, _U32, _U32, _U64, vp, vp]),
     "pil2gl_fri_fold_dev": (_I, [vp, _U32, _U32, _U64, vp, vp, vp]),
+    "pil2gl_fri_verify_fold": (_I, [vp, _U32, _U32, vp, vp, vp]),
+    "pil2gl_fri_verify_fold_dev": (_I, [vp, _U32, _U32, vp, vp, vp, vp]),
     "pil2gl_fri_transpose": (_I, [vp, _U32, _U32, vp]),
     "pil2gl_fri_transpose_dev": (_I, [vp, _U32, _U32, vp, vp]),
     "pil2gl_build_x_dev": (_I, [_U32, _U64, vp, vp]),

@@ -98,6 +98,34 @@ class ChunkedBuffer {
         assert(MHf.verifyGroupProof(r0.proof.root, gp[1], nGroups - 1, gp[0]));
         for (let j = 0; j < pol.length / nGroups; j++) assert.strictEqual(gp[0][3 * j], pol[j * nGroups + nGroups - 1][0]);
     }
+    // --- FRI commit -> queries -> verify (fri.js:22-174) on a polynomial of degree < 2^5 over the 2^8 coset
+    for (const [MHv, name] of [[MHf, "GL"], [await require(path.join(root, "pil2-stark-js_amd/js/merklehash_bn128_p.js"))(4, false), "BN128"]]) {
+        const nBits = 5, nBitsExt = 8, ss = { nBits, nBitsExt, nQueries: 6, steps: [{ nBits: 8 }, { nBits: 5 }, { nBits: 2 }] };
+        const src = new BigUint64Array(3 << nBits); for (let i = 0; i < src.length; i++) src[i] = BigInt(i * i * 7919 + 13) ** 3n % 0xFFFFFFFF00000001n;
+        const ext = new BigUint64Array(3 << nBitsExt);
+        await interpolate(src, 3, nBits, ext, nBitsExt);
+        let cur = []; for (let i = 0; i < (1 << nBitsExt); i++) cur.push([ext[3 * i], ext[3 * i + 1], ext[3 * i + 2]]);
+        const fri = new FRI(ss, MHv), tree0 = await MHv.merkelize(ext, 3, 1 << nBitsExt), root0 = MHv.root(tree0);
+        const friProof = [{}], friTrees = [[tree0]], chs = [];
+        for (let step = 0; step < 3; step++) {                                  // computeFRIFolding, stark_gen_helpers.js:337-356
+            chs.push([BigInt(step + 3), 5n, 0xFFFFFFFF00000000n]);
+            const r = await fri.fold(step, cur, chs[step]);
+            cur = r.pol; friProof[step + 1] = r.proof; if (step < 2) friTrees[step + 1] = r.tree;
+        }
+        const queries = [3, 200, 77, 255, 0, 128];
+        fri.proofQueries(friProof, friTrees, queries.slice());
+        const checkQuery = (pq, idx) => MHv.verifyGroupProof(root0, pq[0][1], idx, pq[0][0]) ? [pq[0][0]] : false;   // stark_verify.js:158-215
+        assert.strictEqual(fri.verify(chs, queries.slice(), friProof, checkQuery), true, name + " FRI verify");
+        const bump = (arr, i) => { const old = arr[i]; arr[i] = (BigInt(old) + 1n) % 0xFFFFFFFF00000001n; return () => { arr[i] = old; }; };
+        for (const [what, undo] of [["layer value", () => bump(friProof[1].polQueries[2][0], 4)], ["layer sibling", () => bump(friProof[2].polQueries[1][1][0], 1)],
+                                    ["last polynomial", () => bump(friProof[3][1], 2)], ["step-0 value", () => bump(friProof[0].polQueries[5][0][0], 1)]]) {
+            const restore = undo();
+            assert.strictEqual(fri.verify(chs, queries.slice(), friProof, checkQuery), false, name + " FRI verify accepts a bad " + what);
+            restore();
+        }
+        assert.strictEqual(fri.verify(chs, queries.slice(), friProof, checkQuery), true);
+        assert.throws(() => fri.verify(chs, queries.slice(), friProof.slice(0, 3), checkQuery), /Invalid proof size/);
+    }
     // --- callCalculateExps: a small op-list over a fake ctx (prover_helpers.js:23-259 operand kinds), checked by BigInt math
     {
         const { callCalculateExps } = require(path.join(root, "pil2-stark-js_amd/js/prover_helpers.js"));

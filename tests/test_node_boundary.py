@@ -16,7 +16,7 @@ def test_addon_loads_and_exports():
     assert os.path.exists(ADDON), "addon not built (make -C pil2-stark-js_amd)"
     js = ("const m=require(%r);const a=m.native;"
           "for (const k of ['interpolate','fft','ifft','merkelize','merkelizeLevel','linearHashRows','poseidon','friFold',"
-          "'friTranspose','buildXDev','buildZhInvDev','computeQSplitDev','xDivXSubXiDev','buildLevDev','computeEvalsDev','gprodDev','gsumDev','h1h2Dev','bn128Poseidon','bn128Merkelize','bn128MerkelizeDev','bn128LinearHashRows','bn128Convert','devAlloc','devFree','devUpload','devDownload','interpolateDev','merkelizeDev','groupProofDev','rootsFromGroupProofs','spongeAbsorb','bn128SpongeAbsorb','evalProgramDev'])"
+          "'friTranspose','buildXDev','buildZhInvDev','computeQSplitDev','xDivXSubXiDev','buildLevDev','computeEvalsDev','gprodDev','gsumDev','h1h2Dev','bn128Poseidon','bn128Merkelize','bn128MerkelizeDev','bn128LinearHashRows','bn128Convert','devAlloc','devFree','devUpload','devDownload','interpolateDev','merkelizeDev','groupProofDev','rootsFromGroupProofs','spongeAbsorb','bn128SpongeAbsorb','friVerifyFold','evalProgramDev'])"
           " if (typeof a[k] !== 'function') throw new Error('missing '+k);"
           "if (a.merkleNumNodes(256) !== 2044) throw new Error('merkleNumNodes');"
           "if (a.bn128MerkleNumNodes(256, 16) !== 273) throw new Error('bn128MerkleNumNodes');"

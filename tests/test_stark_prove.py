@@ -70,6 +70,70 @@ def test_gpu_proof_is_bit_identical_to_oracle_proof(oracle, n_bits, n_pairs, ste
     assert ok, why
 
 
+def _tampered(res, what):
+    import copy
+    bad = copy.deepcopy(res["proof"])
+    if what == "eval":
+        bad["evals"][1][0] = (bad["evals"][1][0] + 1) % P
+    elif what == "opened value":
+        bad["fri"][0]["polQueries"][3][0][0][0] = (int(bad["fri"][0]["polQueries"][3][0][0][0]) + 1) % P
+    elif what == "sibling":
+        sib = bad["fri"][0]["polQueries"][2][1][1]
+        sib[0][0] = (int(sib[0][0]) + 1) % P
+    elif what == "fri layer value":
+        v = bad["fri"][1]["polQueries"][-1][0]; v[4] = (int(v[4]) + 1) % P
+    elif what == "fri layer sibling":
+        sib = bad["fri"][2]["polQueries"][0][1]; sib[0][0] = (int(sib[0][0]) + 1) % P
+    elif what == "last polynomial":
+        bad["fri"][-1][1][2] = (bad["fri"][-1][1][2] + 1) % P
+    elif what == "root":
+        bad["root2"] = list(bad["root2"]); bad["root2"][0] = (int(bad["root2"][0]) + 1) % P
+    return bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bits,n_pairs,steps,split,nq", [(8, 2, [11, 7, 3], False, 8), (10, 4, [13, 9, 4], True, 13), (12, 5, [15, 11, 7, 3], False, 32)])
+def test_device_verifier_agrees_with_restated_verifier(oracle, n_bits, n_pairs, steps, split, nq):
+    """pil2gl.stark.stark_verify (batched openings, device evaluator on the query rows, FRI.verify) accepts what the
+    restated stark_verify.js accepts and rejects each kind of tampering it rejects"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _setup(n_bits, n_pairs, steps, n_queries=nq)
+    gpu = stark.GpuBackend(0, split)
+    setup = stark.build_const_tree(gpu, consts, info)
+    res = stark.stark_gen(gpu, gpu.from_host(cm), setup, info, exprs, publics)
+    ok, why = stark.stark_verify(gpu, res["proof"], publics, setup["constRoot"], info, exprs, vinfo)
+    assert ok, why
+    assert stark_ref.stark_verify(res, setup["constRoot"], info, vinfo, split)[0]
+    for what in ("eval", "opened value", "sibling", "fri layer value", "fri layer sibling", "last polynomial", "root"):
+        bad = _tampered(res, what)
+        ok_ref = stark_ref.stark_verify({**res, "proof": bad}, setup["constRoot"], info, vinfo, split, check_transcript=False)[0]
+        ok_dev, why = stark.stark_verify(gpu, bad, publics, setup["constRoot"], info, exprs, vinfo)
+        assert not ok_ref and not ok_dev, (what, why)
+    wrong_publics = list(publics); wrong_publics[0] = (wrong_publics[0] + 1) % P
+    assert not stark.stark_verify(gpu, res["proof"], wrong_publics, setup["constRoot"], info, exprs, vinfo)[0]
+
+
+@pytest.mark.gpu
+def test_fri_verify_fold_batch(oracle):
+    """pil2gl_fri_verify_fold: per query evalPol(ifft(group), challenge * sinv) (fri.js:121-127) against the oracle's fold of
+    the same group, for group sizes 1..64 and a query count that is not a power of two"""
+    import gl_oracle as orc
+    import pil2gl
+    pil2gl.init(0)
+    rng = np.random.default_rng(23)
+    from conftest import rand_field
+    for fold_bits, nq in ((0, 5), (1, 1), (3, 13), (4, 64), (6, 7)):
+        G = rand_field(rng, (nq, 1 << fold_bits, 3)); sinv = rand_field(rng, nq); ch = rand_field(rng, 3)
+        out = np.zeros((nq, 3), np.uint64)
+        Gt = np.ascontiguousarray(G.transpose(1, 0, 2))
+        pil2gl.call("pil2gl_fri_verify_fold", pil2gl._ptr(Gt), fold_bits, nq, pil2gl._ptr(sinv), pil2gl._ptr(ch), pil2gl._ptr(out))
+        for q in range(nq):
+            want = orc.fri_fold(G[q], 0, int(sinv[q]), ch)[0]
+            assert [int(v) for v in out[q]] == [int(v) for v in want], (fold_bits, q)
+    with pytest.raises(pil2gl.Pil2glError):
+        pil2gl.call("pil2gl_fri_verify_fold", pil2gl._ptr(Gt), 21, 1, pil2gl._ptr(sinv), pil2gl._ptr(ch), pil2gl._ptr(out))
+
+
 @pytest.mark.gpu
 def test_synthetic_trace_kernel_matches_reference_recurrence():
     import ctypes as C
@@ -165,6 +229,11 @@ def test_gpu_bn128_proof_is_identical_to_oracle_proof(oracle, arity, custom, n_b
     assert r_gpu["proof"] == r_cpu["proof"]
     ok, why = stark_ref.stark_verify(r_gpu, s_gpu["constRoot"], info, vinfo, hash_type="BN128", arity=arity, custom=custom)
     assert ok, why
+    # the device verifier over BN128 trees and transcript
+    ok, why = stark.stark_verify(gpu, r_gpu["proof"], publics, s_gpu["constRoot"], info, exprs, vinfo)
+    assert ok, why
+    for what in ("opened value", "fri layer value", "last polynomial"):
+        assert not stark.stark_verify(gpu, _tampered(r_gpu, what), publics, s_gpu["constRoot"], info, exprs, vinfo)[0], what
 
 
 def _perm_case(n_bits=6, steps=(9, 5, 2)):
@@ -206,3 +275,6 @@ def test_gpu_two_stage_proof_is_identical_to_oracle_proof(oracle, n_bits, steps)
     assert r_gpu["proof"] == r_cpu["proof"]
     ok, why = stark_ref.stark_verify(r_gpu, s_gpu["constRoot"], info, vinfo)
     assert ok, why
+    ok, why = stark.stark_verify(gpu, r_gpu["proof"], publics, s_gpu["constRoot"], info, exprs, vinfo)   # stage-2 challenges, three opening points
+    assert ok, why
+    assert not stark.stark_verify(gpu, _tampered(r_gpu, "eval"), publics, s_gpu["constRoot"], info, exprs, vinfo)[0]

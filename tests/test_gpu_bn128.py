@@ -119,9 +119,10 @@ def test_reference_final_proof_through_gpu(bn):
     T.put(int(p["root2"])); T.getField(); T.getField()
     T.put(int(p["root3"])); T.getField()
     T.put(int(p["rootQ"])); T.getField()
-    T.put([[int(x) for x in e] for e in p["evals"]]); T.getField(); T.getField(); T.getField()
+    T.put([[int(x) for x in e] for e in p["evals"]]); T.getField(); T.getField()
+    fri_ch = [T.getField()]
     for s in range(1, 5):
-        T.put(int(p["s%d_root" % s])); T.getField()
+        T.put(int(p["s%d_root" % s])); fri_ch.append(T.getField())
     T.put([[int(x) for x in e] for e in p["finalPol"]])
     ys = T.getPermutations(32, 17)
     for q in range(32):
@@ -141,6 +142,26 @@ def test_reference_final_proof_through_gpu(bn):
         assert MH.verifyGroupProofs(int(p["s%d_root" % s]), proofs, [y % (1 << bits) for y in ys]), s
     bad = [(list(v), m) for v, m in proofs]; bad[5][0][0] += 1
     assert not MH.verifyGroupProofs(int(p["s4_root"]), bad, [y % 16 for y in ys])
+    # FRI.verify (fri.js:107-174) on the reference prover's layers: BN128 trees, Goldilocks folds.  nBits 13 (verifier.circom:303),
+    # steps 17/14/11/7/4; step 0 hands over the value layer 1 opened (the FRI polynomial needs the circuit's own program).
+    import pil2gl
+    ss = {"nBits": 13, "nBitsExt": 17, "nQueries": 32, "steps": [{"nBits": b} for b in (17, 14, 11, 7, 4)]}
+
+    def ref_proof():
+        layers = [{"root": int(p["s%d_root" % s]), "polQueries": [[[int(x) for x in p["s%d_vals" % s][q]], p["s%d_siblings" % s][q]] for q in range(32)]}
+                  for s in range(1, 5)]
+        return [{"polQueries": list(range(32))}] + layers + [[[int(x) for x in e] for e in p["finalPol"]]]
+
+    def step0(q, idx):
+        g = idx // (1 << 14)
+        return [[int(x) for x in p["s1_vals"][q][3 * g:3 * g + 3]]]
+    fri = pil2gl.FRI(ss, MH)
+    assert fri.verify(fri_ch, list(ys), ref_proof(), step0)
+    bad = ref_proof(); bad[3]["polQueries"][7][0][2] += 1
+    assert not fri.verify(fri_ch, list(ys), bad, step0)
+    bad = ref_proof(); bad[-1][5][1] += 1
+    assert not fri.verify(fri_ch, list(ys), bad, step0)
+    assert not fri.verify(fri_ch[:4] + [[1, 2, 3]], list(ys), ref_proof(), step0)
 
 
 def test_transcript_chain_kernel(bn, orc):

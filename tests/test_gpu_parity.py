@@ -349,6 +349,28 @@ def test_reference_proof_through_gpu(gl):
             else:
                 assert z["finalPol"][idx] == out[0].tolist()
         pol_bits = out_bits
+    # ... and through FRI.verify itself (fri.js:107-174): the layer trees, the folds and the last polynomial are the reference
+    # prover's.  The FRI polynomial's value at a query needs the circuit's verifier program, which is not part of the
+    # fixture, so step 0 hands over the value layer 1 opened; every later layer is checked for real.
+    nq = len(queries)
+    ss = {"nBits": 10, "nBitsExt": trp.STEPS[0], "nQueries": nq, "steps": [{"nBits": b} for b in trp.STEPS]}
+
+    def ref_proof():
+        layers = [{"root": z["s%d_root" % s_], "polQueries": [[list(z["s%d_vals" % s_][q]), z["s%d_siblings" % s_][q]] for q in range(nq)]}
+                  for s_ in range(1, len(trp.STEPS))]
+        return [{"polQueries": list(range(nq))}] + layers + [[list(e) for e in z["finalPol"]]]
+
+    def step0(q, idx):
+        return [[int(v) for v in np.array(z["s1_vals"][q], dtype=np.uint64).reshape(-1, 3)[idx // (1 << trp.STEPS[1])]]]
+    fri = gl.FRI(ss, MH)
+    assert fri.verify(fri_steps, list(queries), ref_proof(), step0)
+    bad = ref_proof(); bad[2]["polQueries"][3][0][5] = (int(bad[2]["polQueries"][3][0][5]) + 1) % P
+    assert not fri.verify(fri_steps, list(queries), bad, step0)
+    bad = ref_proof(); bad[-1][2][0] = (int(bad[-1][2][0]) + 1) % P
+    assert not fri.verify(fri_steps, list(queries), bad, step0)
+    bad = ref_proof(); bad[1]["root"] = [int(v) ^ 1 for v in bad[1]["root"]]
+    assert not fri.verify(fri_steps, list(queries), bad, step0)
+    assert not fri.verify(fri_steps, list(queries), ref_proof(), lambda q, idx: [[1, 2, 3]])
 
 
 def gl_root(bits):

@@ -672,17 +672,21 @@ def test_rows_and_cols_dot_ext(gl, oracle):
     import torch
     from pil2gl import _lib
     rng = np.random.default_rng(31)
-    for n_rows, width, n_out in [(1000, 37, 2), (64, 1, 1), (4097, 100, 3), (300, 16, 4)]:
+    # every row is checked; widths around the 16-column tile, row counts around the 256-row block, and a buffer that does not
+    # start on a 128-byte line
+    for n_rows, width, n_out, skew in [(1000, 37, 2, 0), (64, 1, 1, 0), (4097, 100, 3, 0), (300, 16, 4, 0), (515, 12, 1, 0), (1030, 20, 4, 0),
+                                       (256, 4, 2, 0), (777, 36, 2, 0), (3, 100, 1, 0), (700, 100, 2, 1), (259, 44, 3, 0)]:
         m = rand_field(rng, (n_rows, width)); m[0, 0] = P - 1; m[-1, -1] = 0
         coef = rand_field(rng, (n_out, width, 3)); coef[0, 0] = [P - 1, P - 1, P - 1]
-        dm = torch.from_numpy(m.view(np.int64)).cuda(); acc = torch.zeros(n_rows * n_out * 3, dtype=torch.int64, device="cuda")
+        store = torch.zeros(n_rows * width + skew, dtype=torch.int64, device="cuda")
+        dm = store[skew:]; dm.copy_(torch.from_numpy(m.view(np.int64).reshape(-1)))
+        assert dm.data_ptr() % 128 == 8 * skew
+        acc = torch.zeros(n_rows * n_out * 3, dtype=torch.int64, device="cuda")
         _lib.call("pil2gl_rows_dot_ext_dev", gl._ptr(dm), width, n_rows, gl._ptr(coef), n_out, gl._ptr(acc), 0, None)
         _lib.call("pil2gl_rows_dot_ext_dev", gl._ptr(dm), width, n_rows, gl._ptr(coef), n_out, gl._ptr(acc), 1, None)   # accumulate: 2x
         got = acc.cpu().numpy().view(np.uint64).reshape(n_rows, n_out, 3)
-        for r in (0, 1, n_rows // 2, n_rows - 1):
-            for o in range(n_out):
-                exp = [2 * sum(int(m[r, c]) * int(coef[o, c, k]) for c in range(width)) % P for k in range(3)]
-                assert got[r, o].tolist() == exp
+        want = (2 * (m.astype(object) @ coef.astype(object).transpose(1, 0, 2).reshape(width, n_out * 3))) % P
+        assert (got.reshape(n_rows, n_out * 3).astype(object) == want).all(), (n_rows, width, n_out, skew)
     # column sums against the oracle's per-column evaluation (stark_gen_helpers.js:250-264)
     nb, eb, width = 11, 3, 9
     buf = rand_field(rng, (1 << (nb + eb), width)); dbuf = torch.from_numpy(buf.view(np.int64)).cuda()

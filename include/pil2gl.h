@@ -209,7 +209,7 @@ int pil2gl_h1h2_dev(const uint64_t *f, const uint64_t *t, uint64_t n, uint32_t d
 int pil2gl_bn128_poseidon(const uint64_t *in, const uint64_t *init, uint64_t count, uint32_t nIn, uint32_t nOut, uint64_t *out);
 /* TranscriptBN128.put of a list (transcript.bn128.js:56-83): nBlocks full blocks of nIn elements (normal form, 4 words each)
  * absorbed one after the other, state element 0 = hostInit, then each permutation's output 0; hostOut = the nIn+1 outputs
- * of the last permutation.  One launch for the chain, nIn+1 lanes sharing each permutation. */
+ * of the last permutation.  One launch for the chain, 3*(nIn+1) lanes sharing each permutation. */
 int pil2gl_bn128_sponge_absorb(const uint64_t *hostBlocks, uint64_t nBlocks, uint32_t nIn, const uint64_t hostInit[4], uint64_t *hostOut);
 int pil2gl_bn128_poseidon_dev(const uint64_t *in, const uint64_t *init, uint64_t count, uint32_t nIn, uint32_t nOut, uint64_t *out, void *stream);
 /* worker linearHash(buffIn,width,st_i,st_n,arity,custom)  merklehash_bn128_worker.js:13-100 -> height x 4 words */

@@ -482,17 +482,20 @@ __global__ void __launch_bounds__(BN_BLOCK) bn_poseidon_kernel(const u64 *__rest
 
 // A chain of dependent permutations (transcript.bn128.js:56-66 absorbing a list: each full block of nIn elements is permuted
 // with the previous output 0 as state element 0).  One permutation per lane leaves such a chain at one wave-alone
-// permutation (~3 ms) per block; here t lanes hold one state element each and run the round function as poseidon.circom:22-44
-// states it: constants and S-boxes in parallel (lane 0 alone in the partial rounds), every lane its own row of the dense MDS
-// product from the t elements exchanged through LDS.  Normal-form words in and out.  Measured: 0.76 ms per permutation at
-// t = 17 against 3.1 ms for a call per block; the wave is issue-bound on its 17 multiply-accumulates per round (requesting
-// the operands a term ahead changes nothing), so the next step would be to split each row over more lanes.
+// permutation (~3 ms) per block; here the wave shares each permutation and runs the round function as poseidon.circom:22-44
+// states it: lane (l, s), l < t, s < 3, holds state element l (the three copies stay equal); constants and S-boxes in
+// parallel (element 0 alone in the partial rounds); of row l of the dense MDS product, lane (l, s) accumulates the terms
+// j = s, s+3, ... unreduced in 17 limbs, the three partial sums are added through LDS and reduced once.  Normal-form words
+// in and out.  Measured at t = 17: 3.1 ms per permutation for a call per block, 0.76 ms with one lane per row (issue-bound
+// on its 17 multiply-accumulates per round; requesting operands a term ahead changes nothing), 0.49 ms with the row split.
+constexpr int CHAIN_SUB = 3;
 __global__ void __launch_bounds__(64) bn_sponge_chain_kernel(const u64 *__restrict__ blocks, u64 nBlocks, int nIn, const u64 *__restrict__ init,
                                                             PermArgs A, u64 *__restrict__ out) {
     __shared__ u32 sh[17 * 8];
+    __shared__ u32 part[CHAIN_SUB * 17 * 17];
     const int t = nIn + 1, lane = threadIdx.x;
-    const bool act = lane < t;
-    const int l = act ? lane : 0;
+    const bool act = lane < CHAIN_SUB * t;
+    const int sub = act ? lane / t : 0, l = act ? lane - sub * t : 0;
     u32 r2[8], x[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) r2[i] = bn::r2_limb(i);
@@ -512,7 +515,7 @@ __global__ void __launch_bounds__(64) bn_sponge_chain_kernel(const u64 *__restri
             bn::fr_add(x, c);
             const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
             if (full || l == 0) pow5(x);
-            if (act) {
+            if (act && sub == 0) {
 #pragma unroll
                 for (int i = 0; i < 8; i++) sh[l * 8 + i] = x[i];
             }
@@ -521,18 +524,36 @@ __global__ void __launch_bounds__(64) bn_sponge_chain_kernel(const u64 *__restri
             u32 acc[17];
 #pragma unroll
             for (int i = 0; i < 17; i++) acc[i] = 0;
-            for (int j = 0; j < t; j++) {
+            for (int j = sub; j < t; j += CHAIN_SUB) {
                 u32 y[8], m[8];
 #pragma unroll
                 for (int i = 0; i < 8; i++) y[i] = sh[j * 8 + i];
                 load_const<true>(A.M, (size_t)l * t + j, m);
                 bn::mac17(acc, y, m);
             }
+            if (act) {
+#pragma unroll
+                for (int i = 0; i < 17; i++) part[(sub * 17 + l) * 17 + i] = acc[i];
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            // every copy adds the three partial sums (together at most t products: they fit the 17 limbs as one row did)
+#pragma unroll
+            for (int i = 0; i < 17; i++) acc[i] = part[l * 17 + i];
+#pragma unroll
+            for (int q = 1; q < CHAIN_SUB; q++) {
+                u64 cy = 0;
+#pragma unroll
+                for (int i = 0; i < 17; i++) {
+                    const u64 v = (u64)acc[i] + part[(q * 17 + l) * 17 + i] + cy;
+                    acc[i] = (u32)v; cy = v >> 32;
+                }
+            }
             __builtin_amdgcn_wave_barrier();
             bn::redc17(x, acc);
         }
     }
-    if (!act) return;
+    if (!act || sub != 0) return;
     u32 one[8] = { 1, 0, 0, 0, 0, 0, 0, 0 }, o[8];
     bn::fr_mul(o, x, one);                           // out of Montgomery form
 #pragma unroll

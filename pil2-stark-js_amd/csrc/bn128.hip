@@ -489,11 +489,18 @@ __global__ void __launch_bounds__(BN_BLOCK) bn_poseidon_kernel(const u64 *__rest
 // in and out.  Measured at t = 17: 3.1 ms per permutation for a call per block, 0.76 ms with one lane per row (issue-bound
 // on its 17 multiply-accumulates per round; requesting operands a term ahead changes nothing), 0.49 ms with the row split.
 constexpr int CHAIN_SUB = 3;
+// One workgroup (one wave) per chain: chain g reads nBlocks*nIn elements at blocks + g*nBlocks*nIn*4, state element 0 from
+// init + 4g (zero if init is null), and writes its first nOut outputs at out + g*nOut*4 -- with nBlocks = 1 this is a batch of
+// independent permutations, the faster form while there are fewer of them than SIMDs to give a whole wave each.
 __global__ void __launch_bounds__(64) bn_sponge_chain_kernel(const u64 *__restrict__ blocks, u64 nBlocks, int nIn, const u64 *__restrict__ init,
-                                                            PermArgs A, u64 *__restrict__ out) {
+                                                            PermArgs A, int nOut, u64 *__restrict__ out) {
     __shared__ u32 sh[17 * 8];
     __shared__ u32 part[CHAIN_SUB * 17 * 17];
     const int t = nIn + 1, lane = threadIdx.x;
+    blocks += (u64)blockIdx.x * nBlocks * nIn * 4;
+    out += (u64)blockIdx.x * nOut * 4;
+    const u64 zero4[4] = { 0, 0, 0, 0 };
+    if (init) init += (u64)blockIdx.x * 4;
     const bool act = lane < CHAIN_SUB * t;
     const int sub = act ? lane / t : 0, l = act ? lane - sub * t : 0;
     u32 r2[8], x[8];
@@ -505,7 +512,7 @@ __global__ void __launch_bounds__(64) bn_sponge_chain_kernel(const u64 *__restri
         for (int q = 0; q < 4; q++) { v[2 * q] = (u32)w[q]; v[2 * q + 1] = (u32)(w[q] >> 32); }
         bn::fr_mul(x, v, r2);
     };
-    if (l == 0) load_mont(init);
+    if (l == 0) load_mont(init ? init : zero4);
     const int nRounds = N_ROUNDS_F + A.rp;
     for (u64 b = 0; b < nBlocks; b++) {
         if (l > 0) load_mont(blocks + (b * nIn + (l - 1)) * 4);
@@ -553,7 +560,7 @@ __global__ void __launch_bounds__(64) bn_sponge_chain_kernel(const u64 *__restri
             bn::redc17(x, acc);
         }
     }
-    if (!act || sub != 0) return;
+    if (!act || sub != 0 || l >= nOut) return;
     u32 one[8] = { 1, 0, 0, 0, 0, 0, 0, 0 }, o[8];
     bn::fr_mul(o, x, one);                           // out of Montgomery form
 #pragma unroll
@@ -687,6 +694,14 @@ int pil2gl_bn128_poseidon_dev(const uint64_t *in, const uint64_t *init, uint64_t
     P2_TRY(get_params((int)nIn + 1, &pf));
     const size_t lds = lds_bytes((int)nIn + 1);
     const unsigned pblocks = (unsigned)((count + BN_BLOCK - 1) / BN_BLOCK);
+    // few permutations (a transcript squeeze, the levels of a handful of Merkle paths): a lane each would leave them at the
+    // latency of one wave working alone (~3 ms at t = 17); a wave each runs them in ~0.5 ms while the SIMDs outnumber them
+    static const long chainMax = getenv("PIL2GL_BN128_WAVE_PER_PERM_MAX") ? atol(getenv("PIL2GL_BN128_WAVE_PER_PERM_MAX")) : 2048;
+    if ((long)count <= chainMax) {
+        bn_sponge_chain_kernel<<<(unsigned)count, 64, 0, as_stream(stream)>>>(in, 1, (int)nIn, init, perm_args(pf), (int)nOut, out);
+        KERNEL_CHECK();
+        return PIL2GL_OK;
+    }
     if (wide_state((int)nIn + 1)) {
         P2_TRY(set_lds_attr(bn_poseidon_kernel<true>, lds));
         bn_poseidon_kernel<true><<<pblocks, BN_BLOCK, lds, as_stream(stream)>>>(in, init, count, (int)nIn, (int)nOut, perm_args(pf), out);
@@ -771,7 +786,7 @@ int pil2gl_bn128_sponge_absorb(const uint64_t *hostBlocks, uint64_t nBlocks, uin
     if (e == hipSuccess) e = hipMemcpy(d + nB, hostInit, 32, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
     if (rc == PIL2GL_OK) {
-        bn_sponge_chain_kernel<<<1, 64>>>(d, nBlocks, (int)nIn, d + nB, perm_args(pf), d + nB + 4);
+        bn_sponge_chain_kernel<<<1, 64>>>(d, nBlocks, (int)nIn, d + nB, perm_args(pf), (int)nIn + 1, d + nB + 4);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpy(hostOut, d + nB + 4, nO * 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = hip_fail(e, "bn_sponge_chain_kernel");

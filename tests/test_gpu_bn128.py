@@ -40,6 +40,17 @@ def test_poseidon_every_width(bn, orc):
             assert g == orc.poseidon(a, s, n_out), n_in
     # inputs above the modulus are reduced like F.e()
     assert bn.poseidon([orc.R + 5, 7], orc.R + 1, 2) == orc.poseidon([5, 7], 1, 2)
+    # batches up to 2048 permutations get a wave each (the row-split kernel of the transcript chain), larger ones a lane
+    # each: the same inputs through both, and a sample against the oracle
+    for n_in, n_out in ((2, 1), (8, 9), (16, 3)):
+        ins = [[int.from_bytes(rng.bytes(32), "little") % orc.R for _ in range(n_in)] for _ in range(2100)]
+        init = [int.from_bytes(rng.bytes(32), "little") % orc.R for _ in ins]
+        big = bn.poseidon_batch(ins, init, n_out)
+        small = sum((bn.poseidon_batch(ins[k:k + 700], init[k:k + 700], n_out) for k in range(0, 2100, 700)), [])
+        assert big == small, n_in
+        for k in (0, 1234, 2099):
+            assert big[k] == orc.poseidon(ins[k], init[k], n_out), (n_in, k)
+    assert bn.poseidon_batch([[3, 4]] * 3, None, 1) == [[orc.poseidon([3, 4], 0, 1)[0]]] * 3          # no initial states given
 
 
 def test_dense_statement_of_the_permutation_agrees():

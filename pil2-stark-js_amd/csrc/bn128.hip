@@ -493,7 +493,7 @@ constexpr int CHAIN_SUB = 3;
 // init + 4g (zero if init is null), and writes its first nOut outputs at out + g*nOut*4 -- with nBlocks = 1 this is a batch of
 // independent permutations, the faster form while there are fewer of them than SIMDs to give a whole wave each.
 __global__ void __launch_bounds__(64) bn_sponge_chain_kernel(const u64 *__restrict__ blocks, u64 nBlocks, int nIn, const u64 *__restrict__ init,
-                                                            PermArgs A, int nOut, u64 *__restrict__ out) {
+                                                            PermArgs A, int nOut, int mont, u64 *__restrict__ out) {
     __shared__ u32 sh[17 * 8];
     __shared__ u32 part[CHAIN_SUB * 17 * 17];
     const int t = nIn + 1, lane = threadIdx.x;
@@ -506,11 +506,14 @@ __global__ void __launch_bounds__(64) bn_sponge_chain_kernel(const u64 *__restri
     u32 r2[8], x[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) r2[i] = bn::r2_limb(i);
-    auto load_mont = [&](const u64 *w) {             // frm_toMontgomery
+    auto load_mont = [&](const u64 *w) {             // frm_toMontgomery; mont: the words are in Montgomery form already (tree nodes)
         u32 v[8];
 #pragma unroll
         for (int q = 0; q < 4; q++) { v[2 * q] = (u32)w[q]; v[2 * q + 1] = (u32)(w[q] >> 32); }
-        bn::fr_mul(x, v, r2);
+        if (mont) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) x[i] = v[i];
+        } else bn::fr_mul(x, v, r2);
     };
     if (l == 0) load_mont(init ? init : zero4);
     const int nRounds = N_ROUNDS_F + A.rp;
@@ -562,7 +565,10 @@ __global__ void __launch_bounds__(64) bn_sponge_chain_kernel(const u64 *__restri
     }
     if (!act || sub != 0 || l >= nOut) return;
     u32 one[8] = { 1, 0, 0, 0, 0, 0, 0, 0 }, o[8];
-    bn::fr_mul(o, x, one);                           // out of Montgomery form
+    if (mont) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) o[i] = x[i];
+    } else bn::fr_mul(o, x, one);                    // out of Montgomery form
 #pragma unroll
     for (int q = 0; q < 4; q++) out[l * 4 + q] = (u64)o[2 * q] | ((u64)o[2 * q + 1] << 32);
 }
@@ -643,6 +649,10 @@ int pil2gl_bn128_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64
     return PIL2GL_OK;
 }
 
+static long wave_per_perm_max() {
+    static const long v = getenv("PIL2GL_BN128_WAVE_PER_PERM_MAX") ? atol(getenv("PIL2GL_BN128_WAVE_PER_PERM_MAX")) : 2048;
+    return v;
+}
 int pil2gl_bn128_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint32_t arity, uint64_t *out, void *stream) {
     P2_TRY(ensure_init());
     if (nOps == 0) return PIL2GL_OK;
@@ -653,6 +663,11 @@ int pil2gl_bn128_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint32_t
     const size_t lds = lds_bytes((int)arity + 1);
     const uint64_t blocks = (nOps + BN_BLOCK - 1) / BN_BLOCK;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
+    if ((long)nOps <= wave_per_perm_max()) {          // the levels near the root: a wave per parent (see pil2gl_bn128_poseidon_dev)
+        bn_sponge_chain_kernel<<<(unsigned)nOps, 64, 0, as_stream(stream)>>>(in, 1, (int)arity, nullptr, perm_args(pf), 1, 1, out);
+        KERNEL_CHECK();
+        return PIL2GL_OK;
+    }
     if (wide_state((int)arity + 1)) {
         P2_TRY(set_lds_attr(bn_merkle_level_kernel<true>, lds));
         bn_merkle_level_kernel<true><<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
@@ -696,9 +711,8 @@ int pil2gl_bn128_poseidon_dev(const uint64_t *in, const uint64_t *init, uint64_t
     const unsigned pblocks = (unsigned)((count + BN_BLOCK - 1) / BN_BLOCK);
     // few permutations (a transcript squeeze, the levels of a handful of Merkle paths): a lane each would leave them at the
     // latency of one wave working alone (~3 ms at t = 17); a wave each runs them in ~0.5 ms while the SIMDs outnumber them
-    static const long chainMax = getenv("PIL2GL_BN128_WAVE_PER_PERM_MAX") ? atol(getenv("PIL2GL_BN128_WAVE_PER_PERM_MAX")) : 2048;
-    if ((long)count <= chainMax) {
-        bn_sponge_chain_kernel<<<(unsigned)count, 64, 0, as_stream(stream)>>>(in, 1, (int)nIn, init, perm_args(pf), (int)nOut, out);
+    if ((long)count <= wave_per_perm_max()) {
+        bn_sponge_chain_kernel<<<(unsigned)count, 64, 0, as_stream(stream)>>>(in, 1, (int)nIn, init, perm_args(pf), (int)nOut, 0, out);
         KERNEL_CHECK();
         return PIL2GL_OK;
     }
@@ -786,7 +800,7 @@ int pil2gl_bn128_sponge_absorb(const uint64_t *hostBlocks, uint64_t nBlocks, uin
     if (e == hipSuccess) e = hipMemcpy(d + nB, hostInit, 32, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
     if (rc == PIL2GL_OK) {
-        bn_sponge_chain_kernel<<<1, 64>>>(d, nBlocks, (int)nIn, d + nB, perm_args(pf), (int)nIn + 1, d + nB + 4);
+        bn_sponge_chain_kernel<<<1, 64>>>(d, nBlocks, (int)nIn, d + nB, perm_args(pf), (int)nIn + 1, 0, d + nB + 4);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpy(hostOut, d + nB + 4, nO * 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = hip_fail(e, "bn_sponge_chain_kernel");

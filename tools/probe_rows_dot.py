@@ -1,4 +1,6 @@
-"""rows_dot_kernel on the config-3 stage matrix (2^27 x 100): line-aligned row mapping against the plain one."""
+"""rows_dot_kernel on the config-3 stage matrix (2^27 x 100).  Used once to compare a line-aligned row mapping (a wave owning
+rows 4j + w; switch PIL2GL_ROWS_DOT_LINES) with the plain one: 48.0 ms against 44.7 ms, so that variant was not kept
+ and the switch no longer exists; the script now just times the kernel."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "pil2-stark-js_amd", "python"))
 import numpy as np, torch
@@ -15,4 +17,4 @@ torch.cuda.synchronize(); t0 = time.time()
 for _ in range(5):
     _lib.call("pil2gl_rows_dot_ext_dev", pil2gl._ptr(dm), width, n_rows, pil2gl._ptr(coef), n_out, pil2gl._ptr(acc), 0, None)
 torch.cuda.synchronize(); dt = (time.time() - t0) / 5
-print("PIL2GL_ROWS_DOT_LINES=%s: %.2f ms per call, %.2f TB/s of matrix" % (os.environ.get("PIL2GL_ROWS_DOT_LINES", "1"), dt * 1e3, n_rows * width * 8 / dt / 1e12), "checksum", int(acc.sum()))
+print("rows_dot_kernel<%d>: %.2f ms per call, %.2f TB/s of matrix" % (n_out, dt * 1e3, n_rows * width * 8 / dt / 1e12), "checksum", int(acc.sum()))

@@ -292,7 +292,8 @@ class MerkleHash:
             n = ((n - 1) // 8 + 1) * 4; nl += 1
         ii = np.array(idxs, dtype=np.uint64); out = np.zeros((len(idxs), width + 4 * nl), np.uint64); lv = C.c_uint32()
         call("pil2gl_group_proofs_dev", _ptr(tree["elements"]), _ptr(tree["nodes"]), width, height, _ptr(ii), len(idxs), _ptr(out), C.byref(lv))
-        return [([int(v) for v in r[:width]], [[int(x) for x in r[width + 4 * l:width + 4 * l + 4]] for l in range(nl)]) for r in out]
+        vals, sibs = out[:, :width].tolist(), out[:, width:].reshape(len(idxs), nl, 4).tolist()      # python ints, as getGroupProof gives
+        return list(zip(vals, sibs))
 
     def calculateRootFromGroupProof(self, mp, idx, vals):
         value = self.lh.hash(vals)                      # merklehash_p.js:170-210

@@ -42,7 +42,7 @@ __device__ __forceinline__ void linear_hash_plain(const u64 *__restrict__ v, u32
     sponge(v, width, digest, m);
 }
 
-__global__ void __launch_bounds__(256, 2) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int split, u64 *__restrict__ out) {
+__global__ void __launch_bounds__(256, 3) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int split, u64 *__restrict__ out) {
     const u64 row0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = row0 < height;
     const u64 row = live ? row0 : height - 1;       // width, split are uniform: every lane takes the same path
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256, 2) linear_hash_kernel(const u64 *__restri
 }
 
 // glwasm.js:1220-1254: out[i] = Poseidon(in[8i..8i+7], capacity 0)[0..3]
-__global__ void __launch_bounds__(256, 2) merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, u64 *__restrict__ out) {
+__global__ void __launch_bounds__(256, 3) merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, u64 *__restrict__ out) {
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i0 < nOps;
     const u64 i = live ? i0 : nOps - 1;

@@ -110,6 +110,36 @@ def test_poseidon_kats(gl):
         gl.poseidon([1, 2, 3])
 
 
+def test_poseidon_sbox_borrow_path(gl, oracle):
+    """the hand-written S-box product flags a lane whose last subtraction borrows (probability ~2^-32 per product) and the
+    kernel recomputes it the slow way.  2^63 squared is 2^126 = 2^30 * 2^96: low words zero, so the borrow is certain; states
+    whose round-0 S-box inputs (state + round constant, glwasm.js:377) are 2^63 exercise that path in every lane, in some
+    lanes only (mixed with random states: the fallback must not disturb the other lanes), and in single elements"""
+    import os, re
+    from conftest import ROOT
+    with open(os.path.join(ROOT, "oracle", "poseidon_gl_constants.h")) as f:
+        rc = [int(x, 16) for x in re.findall(r"0x([0-9a-f]{16})ull", f.read())[:12]]
+    trig = [((1 << 63) - c) % P for c in rc]
+    rng = np.random.default_rng(5)
+    states = []
+    for k in range(600):
+        s = [int(x) % P for x in rng.integers(0, 1 << 63, 12, dtype=np.uint64)]
+        if k % 3 == 0:
+            s = list(trig)
+        elif k % 3 == 1:
+            j = k % 12
+            s[j] = trig[j]
+        states.append(s)
+    a = np.array(states, dtype=np.uint64)
+    got = gl.poseidon_batch(np.ascontiguousarray(a[:, :8]), np.ascontiguousarray(a[:, 8:]), 12)
+    for k, s in enumerate(states):
+        assert [int(v) for v in got[k]] == [int(v) for v in oracle.poseidon(s[:8], s[8:], 12)], k
+    # the same rows through the leaf kernel (sponge) and the tree-level kernel
+    rows = np.ascontiguousarray(a[:, :8])
+    assert (gl.linearHash(rows, 8).reshape(-1, 4) == np.array([oracle.linear_hash(r) for r in rows])).all()
+    assert (gl.merkelizeLevel(rows).reshape(-1, 4) == np.array([oracle.poseidon(r, None, 4) for r in rows])).all()
+
+
 @pytest.mark.parametrize("mfma", [1, 0])
 def test_mds_layer_structured_inputs(gl, mfma):
     """the MDS layer alone (matrix-core and vector-ALU forms) on inputs the hash never produces by chance: zero and

@@ -1,29 +1,34 @@
 #!/usr/bin/env python3
 """bench.py -- STARK prove time and trace-cells/s on MI355X.
 
-One "step" (default --mode prove) = one full proof of a synthetic AIR whose witness is already resident in HBM:
-the stage loop of src/prover/prover.js:7-127 -- extendAndMerkelize (LDE blow-up 8 + Poseidon Merkle tree),
-constraint polynomial Q (expression evaluation on the extended domain, iNTT/split/NTT, tree), evaluations,
-FRI polynomial, FRI folding with trees, query openings -- driven by pil2gl.stark.stark_gen through the C ABI
-(libpil2gl.so).  The AIR is K = cols/2 copies of the reference's Fibonacci machine
-(test/state_machines/sm_fibonacci/fibonacci.pil), so the trace satisfies its constraints and the proof is a
-valid one (tests/test_stark_prove.py verifies such proofs and their bit-identity with the CPU oracle's).
---mode commit times only extendAndMerkelize (stark_gen_helpers.js:388-412) on a uniformly random trace.
-Inputs, intermediates, trees and outputs stay on the device (no PCIe in the timed region).
+One "step" = one pass of the hot path over one synthetic input that is already resident in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c5|NBITSxCOLS]
-                  [--mode prove|commit|commit-sharded|prove-sharded] [--shard-of K]
+  N = 1 (default)   --mode prove: one full proof -- the stage loop of src/prover/prover.js:7-127: extendAndMerkelize (LDE
+                    blow-up 8 + Poseidon Merkle tree), constraint polynomial Q (expression evaluation on the extended
+                    domain, iNTT/split/NTT, tree), evaluations, FRI polynomial, FRI folding with trees, query openings --
+                    driven by pil2gl.stark.stark_gen through the C ABI (libpil2gl.so), at config 3 of BASELINE.json
+                    (2^24 rows x 100 cols, GL Poseidon + FRI).  The AIR is K = cols/2 copies of the reference's Fibonacci
+                    machine (test/state_machines/sm_fibonacci/fibonacci.pil): a valid trace, so the proof verifies.
+  N > 1 (default)   --mode prove-sharded: ONE proof of the same config-3 trace, split by cosets over the N ranks
+                    (pil2gl.parallel): strong scaling, value = that trace's cells / max-over-ranks time.
+                    Exchanges (leaf digests, q, FRI polynomial, a few sums) go over RCCL when every rank has its own GPU
+                    and through HIP IPC windows when ranks share one (one-GPU rehearsal).
+  --mode commit / commit-sharded: only extendAndMerkelize (stark_gen_helpers.js:388-412) on a uniformly random trace;
+                    commit-sharded on 8 ranks takes config 5 (2^26 x 200), which only fits sharded.
+  --replicas        N > 1: every rank proves its own trace (weak scaling, no data-path exchange) -- the proving-farm mode.
+  --workload c4     BN128 Poseidon (arity 16) commit of the config-4 trace; --workload c2: config 2.
+  --shard-of K      (with a sharded mode, one GPU) rank 0's share of a K-rank job run alone; not a contract line.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank runs the same step on its
-own trace (weak scaling, no data-path collective); value = all ranks' cells / max-over-ranks time.
---mode commit-sharded instead splits ONE trace's extendAndMerkelize by cosets over the ranks (pil2gl.parallel:
-all-gather of leaf digests over RCCL; strong scaling, value = that trace's cells / time); --mode prove-sharded does the
-same for ONE whole proof (q, evaluations and the FRI polynomial exchanged as well).  With --shard-of K either sharded mode
-runs rank 0's share of a K-GPU job alone on one GPU (per-GPU time and memory; not a contract line).
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload auto|c2|c3|c4|c5|NBITSxCOLS] [--mode ...]
+
+`python bench.py --gpus N` without a launcher starts the N ranks itself (torch.distributed.run, 127.0.0.1) and relays
+rank 0's JSON line; under torchrun WORLD_SIZE must equal --gpus.
 """
 import argparse
+import gc
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -34,8 +39,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-WORKLOADS = {"c2": (20, 8), "c3": (24, 100), "c5": (26, 200)}      # BASELINE.json configs[1], configs[2], configs[4] (c5: sharded only)
+CLOCK_HZ = 2.4e9             # MI355X_MICROARCH.md: max clock (the clock held under an all-integer load is lower: conservative)
+N_SIMD = 256 * 4
+WORKLOADS = {"c2": (20, 8), "c3": (24, 100), "c4": (24, 100), "c5": (26, 200)}      # BASELINE.json configs[1..4] (c5: sharded only)
 EXT_BITS = 3
+# measured issue cost of the instructions the integer floor is priced in (tools/microbench.hip, tools/mfma_mds.hip, MI355X)
+CYC_MAD_U64_U32 = 4.5
+CYC_MFMA_ISSUE = 8.0
 
 
 def parse():
@@ -45,10 +55,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("PIL2GL_BENCH_WORKLOAD", "auto"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default=os.environ.get("PIL2GL_BENCH_MODE", "prove"), choices=["prove", "commit", "commit-sharded", "prove-sharded"])
+    ap.add_argument("--mode", default=os.environ.get("PIL2GL_BENCH_MODE", "auto"),
+                    choices=["auto", "prove", "commit", "commit-sharded", "prove-sharded"])
+    ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per rank (weak scaling) instead of ONE sharded proof")
     ap.add_argument("--split", action="store_true", help="splitLinearHash leaves (linearhash_gpu.js)")
     ap.add_argument("--full-tree", action="store_true", help="commit-sharded: every rank builds the whole tree above the gathered leaves (default: the tree is split by leaf blocks, pil2gl.parallel.ShardedTree)")
-    ap.add_argument("--shard-of", type=int, default=0, help="commit-sharded on ONE GPU: run rank 0's share of a K-GPU job (per-GPU time/memory rehearsal, e.g. --workload c5 --shard-of 8)")
+    ap.add_argument("--shard-of", type=int, default=0, help="a sharded mode on ONE GPU: run rank 0's share of a K-GPU job (per-GPU time/memory rehearsal, e.g. --workload c5 --shard-of 8)")
     return ap.parse_args()
 
 
@@ -66,7 +78,7 @@ def make_trace(n_rows, n_cols, seed, device):
     return out
 
 
-def fibonacci_trace_gpu(torch, dev, n_bits, n_pairs, rank):
+def fibonacci_trace_gpu(dev, n_bits, n_pairs, rank):
     """witness of K Fibonacci machines (sm_fibonacci.js:12-23), generated on the device (one lane per machine,
     the recurrence is sequential in the row index), plus the constant columns L1/LLAST and the publics"""
     import ctypes as C
@@ -95,27 +107,46 @@ def ev_time(fn, iters):
     return s.elapsed_time(e) / iters
 
 
-def cpu_baseline_prove(n_cols, split, fri_delta=5):
+def host_cores():
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    return min(cores, int(os.environ.get("PIL2GL_CPU_THREADS", "16")))      # the GPU box grants a 16-CPU share per GPU
+
+
+def port_calibration():
+    """how the C/OpenMP port relates to the reference's own JavaScript (measured in the build container, one thread, on the
+    reference's dependency-free twins of the path: oracle/calibrate_ref.js, oracle/calibrate_port.py)"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_cpu_port_vs_reference_js.json")) as f:
+            c = json.load(f)
+        return {"source": "profiles/r01_cpu_port_vs_reference_js.json (build container, 1 thread)", "data": c}
+    except Exception:
+        return None
+
+
+def fri_steps_for(n_bits_ext):
+    steps = [n_bits_ext]
+    while steps[-1] > 10:                              # decreasing by <= 5 bits, as zkevm.starkstruct.json does
+        steps.append(max(steps[-1] - 5, 6))
+    return steps
+
+
+def cpu_baseline_prove(n_cols, split):
     """the same full proof by the prove loop over the CPU oracle backend (C/OpenMP port) on a bounded sample"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gl_oracle
     from stark_backend import OracleBackend
     from pil2gl import stark
     gl_oracle.build()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    cores = min(cores, int(os.environ.get("PIL2GL_CPU_THREADS", "16")))
+    cores = host_cores()
     gl_oracle.set_threads(cores)
     n_bits = 11 if n_cols > 16 else 14
 
     def run(nb):
-        steps = [nb + EXT_BITS]
-        while steps[-1] > 10:
-            steps.append(max(steps[-1] - fri_delta, 6))
-        ss = {"nBits": nb, "nBitsExt": nb + EXT_BITS, "nQueries": 64, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
+        ss = {"nBits": nb, "nBitsExt": nb + EXT_BITS, "nQueries": 64, "verificationHashType": "GL", "steps": [{"nBits": b} for b in fri_steps_for(nb + EXT_BITS)]}
         info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
         cm, consts, publics = stark.fibonacci_trace(nb, n_cols // 2)
         be = OracleBackend(split)
@@ -129,20 +160,16 @@ def cpu_baseline_prove(n_cols, split, fri_delta=5):
         t = run(n_bits)
     cells = (1 << n_bits) * n_cols
     return {"value": cells / t, "unit": "trace-cells/s", "cores": cores, "kind": "port",
-            "sample": "full proof of 2^%d x %d Fibonacci AIR, blow-up 8, prove loop over the OpenMP C oracle backend, %.1f s" % (n_bits, n_cols, t)}
+            "sample": "full proof of 2^%d x %d Fibonacci AIR, blow-up 8, prove loop over the OpenMP C oracle backend, %.1f s" % (n_bits, n_cols, t),
+            "port_vs_reference_js": port_calibration()}
 
 
-def cpu_baseline(n_cols, split):
+def cpu_baseline_commit(n_cols, split):
     """extend+merkelize by the CPU oracle (a C/OpenMP port of the reference algorithms) on a bounded sample"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gl_oracle
     gl_oracle.build()
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
-    cores = min(cores, int(os.environ.get("PIL2GL_CPU_THREADS", "16")))      # the GPU box grants a 16-CPU share per GPU
+    cores = host_cores()
     gl_oracle.set_threads(cores)
     n_bits = 14 if n_cols > 16 else 17
     rng = np.random.default_rng(1)
@@ -159,35 +186,101 @@ def cpu_baseline(n_cols, split):
         t = run(n_bits)
     cells = (1 << n_bits) * n_cols
     return {"value": cells / t, "unit": "trace-cells/s", "cores": cores, "kind": "port",
-            "sample": "extend+merkelize of 2^%d x %d random trace, blow-up 8, OpenMP C oracle, %.1f s" % (n_bits, n_cols, t)}
+            "sample": "extend+merkelize of 2^%d x %d random trace, blow-up 8, OpenMP C oracle, %.1f s" % (n_bits, n_cols, t),
+            "port_vs_reference_js": port_calibration()}
 
 
-def load_pmc_lde_traffic():
-    """HBM bytes of ONE interpolate from the committed PMC summary: all ntt_pass_kernel + lde_mid_kernel launches of the
-    profiled run divided by the number of LDEs in it (one lde_mid launch each)"""
+def cpu_baseline_bn128(n_cols, arity):
+    """config 4's commit on the CPU: LDE by the C port, BN128 tree by the Python-integer oracle (bn128_oracle.py; the
+    reference's arithmetic here is third-party WASM, absent from its tree) on a bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gl_oracle
+    import bn128_oracle
+    gl_oracle.build(); gl_oracle.set_threads(host_cores())
+    rng = np.random.default_rng(1)
+    nb = 2
+
+    def run(nb):
+        a = rng.integers(0, 0xFFFFFFFF00000001, size=(1 << nb, n_cols), dtype=np.uint64)
+        t0 = time.perf_counter()
+        e = gl_oracle.interpolate(a, nb, nb + EXT_BITS)
+        bn128_oracle.merkelize([[int(v) for v in r] for r in e], arity, False)
+        return time.perf_counter() - t0
+    t = run(nb)
+    while t < 8.0 and nb < 12:
+        nb += 1
+        t = run(nb)
+    return {"value": (1 << nb) * n_cols / t, "unit": "trace-cells/s", "cores": 1, "kind": "port",
+            "sample": "extend (C port) + BN128 arity-%d merkelize (Python-integer oracle, one thread) of 2^%d x %d, blow-up 8, %.1f s" % (arity, nb, n_cols, t)}
+
+
+def load_pmc(name, kernel):
+    """HBM bytes per launch from a committed rocprofv3 --pmc summary under profiles/, if any"""
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            sb = json.load(f)["_sum_bytes"]
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f).get(kernel)
+    except Exception:
+        return None
+
+
+def load_pmc_lde_traffic(name):
+    """HBM bytes of ONE interpolate from a committed PMC summary: all NTT-family launches of the profiled run divided by
+    the number of LDEs in it"""
+    try:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            d = json.load(f)
+        if "_interpolate_bytes" in d:
+            return int(d["_interpolate_bytes"])
+        sb = d["_sum_bytes"]
         n = sb["lde_mid_kernel"]["launches"]
         return int((sb["lde_mid_kernel"]["bytes"] + sb["ntt_pass_kernel"]["bytes"]) / n)
     except Exception:
         return None
 
 
-def load_pmc_traffic(kernel):
-    """HBM bytes per launch from the committed rocprofv3 --pmc summary (profiles/pmc_traffic.json), if any"""
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    try:
-        with open(p) as f:
-            return json.load(f).get(kernel)
-    except Exception:
-        return None
+def pmc_file():
+    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+        if os.path.exists(os.path.join(ROOT, "profiles", name)):
+            return name
+    return "pmc_traffic.json"
+
+
+def poseidon_int_roofline(perms, ms):
+    """integer-issue roofline of the Goldilocks Poseidon kernels (118 S-boxes x 4 = 472 modular
+    multiplications + 30 MDS layers per permutation).  achieved = SIMD cycles per wave of 64 permutations; floor = what the
+    multiplications and the matrix-core MDS cost if nothing but their irreducible instructions were issued:
+    472 x 5 v_mad_u64_u32 (four 32x32 partial products + the multiply by 2^32-1 that folds the high half; gfx950 has no
+    64-bit multiplier) + 30 x 18 v_mfma_i32_32x32x32_i8, priced at their measured issue costs."""
+    achieved = N_SIMD * CLOCK_HZ * (ms * 1e-3) / (perms / 64.0)
+    floor = 472 * 5 * CYC_MAD_U64_U32 + 30 * 18 * CYC_MFMA_ISSUE
+    return {"bound": "int-issue", "kernel": "linear_hash_kernel", "achieved": achieved, "floor": floor, "unit": "SIMD issue cycles per wave of 64 permutations",
+            "frac": floor / achieved, "clock_GHz_assumed": CLOCK_HZ / 1e9,
+            "floor_terms": {"v_mad_u64_u32": 472 * 5, "cycles_each": CYC_MAD_U64_U32, "v_mfma_i32_32x32x32_i8": 30 * 18, "issue_cycles_each": CYC_MFMA_ISSUE},
+            "note": "reductions, carries, byte-plane recombination and round constants are overhead by this definition"}
+
+
+def bn128_mads(t):
+    """v_mad_u64_u32 steps of one BN254 Poseidon permutation of width t as bn128.hip computes it (Montgomery product 128,
+    an unreduced 64 per accumulated product + 64 per reduction), RF = 8, RP from poseidon.circom:7-9"""
+    rp = [56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68][t - 2]
+    full = 8 * (t * 3 * 128 + t * (t * 64 + 64))
+    partial = rp * (3 * 128 + (t * 64 + 64) + (t - 1) * 128)
+    return full + partial
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher: start the N ranks as children (never exec after touching the GPU) and
+    relay their output; rank 0 prints the JSON line"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
 
 
 def rehearse_shard(args):
     """--mode commit-sharded --shard-of K on one GPU: rank 0's share of a K-GPU sharded commit (its cosets of the LDE in the
     trace's own memory, its leaves, a tree over stand-in digests), to show the per-GPU time and memory of e.g. config 5."""
-    import pil2gl
     from pil2gl import stark, parallel
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -218,21 +311,17 @@ def rehearse_shard(args):
 def rehearse_prove(args):
     """--mode prove-sharded --shard-of K on one GPU: rank 0's share of a K-GPU sharded proof (own slices standing in for the
     gathered q / FRI polynomial / digests; the evaluations are computed here anyway because rank 0 owns coset 0)"""
-    import pil2gl
     from pil2gl import stark, parallel
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     n_bits, n_cols = WORKLOADS[args.workload] if args.workload in WORKLOADS else (int(v) for v in args.workload.lower().split("x"))
     n_cols -= n_cols & 1
     K = args.shard_of
-    fri_steps = [n_bits + EXT_BITS]
-    while fri_steps[-1] > 10:
-        fri_steps.append(max(fri_steps[-1] - 5, 6))
     ss = {"nBits": n_bits, "nBitsExt": n_bits + EXT_BITS, "nQueries": 64, "verificationHashType": "GL", "splitLinearHash": bool(args.split),
-          "steps": [{"nBits": b} for b in fri_steps]}
+          "steps": [{"nBits": b} for b in fri_steps_for(n_bits + EXT_BITS)]}
     info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
     be = stark.GpuBackend(0, args.split)
-    src, consts, publics = fibonacci_trace_gpu(torch, dev, n_bits, n_cols // 2, 0)
+    src, consts, publics = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
     setup = stark.build_const_tree(be, consts, info)
     times = []
     for i in range(args.warmup + args.steps):
@@ -243,103 +332,190 @@ def rehearse_prove(args):
             times.append(dt)
     dt = sum(times) / len(times)
     stages = {}
-    parallel.stark_gen_sharded(be, src, setup, info, exprs, publics, rehearse_world=K, timings=stages)      # one more, instrumented
+    r = parallel.stark_gen_sharded(be, src, setup, info, exprs, publics, rehearse_world=K, timings=stages)      # one more, instrumented
     print(json.dumps({"metric": "per-GPU time of ONE proof split over %d GPUs (rank 0's share run alone, exchanges stood in)" % K,
                       "value": (1 << n_bits) * n_cols / dt, "unit": "trace-cells/s (the job rate if the %d ranks run in parallel and the exchanges are free)" % K,
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "u64", "data": "synthetic",
                       "config": {"workload": "full proof of 2^%d rows x %d cols, blow-up 8, %d of %d cosets on this GPU" % (n_bits, n_cols, (1 << EXT_BITS) // K, 1 << EXT_BITS),
                                  "mode": "prove-sharded rehearsal", "shard_of": K}, "stages_s": {k: round(v, 4) for k, v in stages.items()},
-                      "peak_torch_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+                      "exchange_per_proof": r["exchange"], "peak_torch_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+
+
+def h2d_sample(dev, total_bytes):
+    """what a caller that holds the witness in host memory pays before the timed step: pinned host -> HBM copy rate on a
+    bounded sample (1 GiB), and the time that rate gives for the whole witness.  Reported beside the step, never inside it."""
+    try:
+        n = 1 << 27
+        h = torch.empty(n, dtype=torch.int64).pin_memory()
+        d = torch.empty(n, dtype=torch.int64, device=dev)
+        d.copy_(h, non_blocking=True); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            d.copy_(h, non_blocking=True)
+        torch.cuda.synchronize()
+        gbs = 3 * n * 8 / (time.perf_counter() - t0) / 1e9
+        return {"pinned_h2d_GBps": round(gbs, 1), "sample_GB": round(n * 8 / 1e9, 2), "witness_GB": round(total_bytes / 1e9, 2),
+                "witness_upload_ms_at_that_rate": round(total_bytes / gbs / 1e6, 1)}
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)}
+
+
+def bench_bn128(args, dev, wl, n_bits, n_cols):
+    """config 4: extendAndMerkelize with the BN128 MerkleHash (merklehash_bn128_p.js:47-129, arity 16, non-custom): the GL
+    LDE of the 2^24 x 100 trace and the BN254-Poseidon linear hash + 16-ary tree over all 2^27 extended rows"""
+    import pil2gl
+    from pil2gl import bn128
+    arity = 16
+    N, E = 1 << n_bits, 1 << (n_bits + EXT_BITS)
+    src = make_trace(N, n_cols, 0x5EED0000, dev)
+    dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
+    MH = bn128.buildMerkleHash(arity, False)
+    MH.merkelize(src[:n_cols * 64], n_cols, 64); torch.cuda.synchronize()          # parameter generation
+    times = {}
+
+    def step():
+        pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
+        return MH.merkelize(dst, n_cols, E)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tree = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    t_lde = ev_time(lambda: pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS), 1)
+    t_tree = ev_time(lambda: MH.merkelize(dst, n_cols, E), 1)
+    n_el = (n_cols + 2) // 3
+    chunks = [min(arity, n_el - o) for o in range(0, n_el, arity)]
+    leaf_mads = sum(bn128_mads(c + 1) for c in chunks)                              # last chunk: t = nLast + 1 (non-custom)
+    leaf_perms = E * len(chunks)
+    tree_perms, n = 0, E
+    while n > 1:
+        n = (n - 1) // arity + 1; tree_perms += n
+    mads = E * leaf_mads + tree_perms * bn128_mads(arity + 1)
+    floor_cyc = mads * CYC_MAD_U64_U32 / 64.0 / N_SIMD                              # chip-wide: a v_mad_u64_u32 serves 64 lanes of one of 1024 SIMDs
+    floor_ms = floor_cyc / CLOCK_HZ * 1e3
+    alg = 8 * E * n_cols + 32 * (E + tree_perms)
+    out = {"metric": "trace-cells/s, STARK commit step (extend + BN128 Poseidon Merkle tree, arity 16), blow-up 8",
+           "value": N * n_cols / dt, "unit": "trace-cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fr, Montgomery) + u64 (Goldilocks LDE)", "data": "synthetic",
+           "config": {"workload": "config 4: extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, BN128 Poseidon linear hash + %d-ary tree over all 2^%d extended rows" % (n_bits, n_cols, n_bits + EXT_BITS, arity, n_bits + EXT_BITS),
+                      "mode": "commit", "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "BN128-Poseidon (t = 17, 17, 3 per row; t = 17 in the tree)", "parallelism": "single GPU"},
+           "roofline": {"bound": "hbm", "kernel": "bn_linear_hash_kernel + bn_merkle_level_kernel", "achieved": alg / t_tree / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg / t_tree / 1e6 / HBM_PEAK_GBS, "traffic": None,
+                        "note": "BN254 Poseidon is integer-issue bound by three orders of magnitude; see roofline_int_issue"},
+           "roofline_int_issue": {"bound": "int-issue", "kernel": "bn_linear_hash_kernel", "achieved": t_tree, "floor": floor_ms, "unit": "ms per tree at %.1f GHz" % (CLOCK_HZ / 1e9),
+                                  "frac": floor_ms / t_tree, "v_mad_u64_u32_per_row": leaf_mads, "cycles_each": CYC_MAD_U64_U32,
+                                  "note": "floor = every 32x32 product of the Montgomery multiplications and reductions (bn128_mads) issued back to back at the measured 4.5 cycles, nothing else"},
+           "kernels": [{"kernel": "BN128 merkelize (leaf hash + tree)", "ms": t_tree, "perms": leaf_perms + tree_perms, "Mperm_s": (leaf_perms + tree_perms) / t_tree / 1e3},
+                       {"kernel": "interpolate", "ms": t_lde, "alg_bytes": 8 * N * n_cols * (1 + (1 << EXT_BITS)), "GBps": 8 * N * n_cols * 9 / t_lde / 1e6}],
+           "root": hex(MH.root(tree))}
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_bn128(n_cols, arity)
+        out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out), flush=True)
 
 
 def main():
     args = parse()
-    if args.mode == "commit-sharded" and args.shard_of:
-        return rehearse_shard(args)
-    if args.mode == "prove-sharded" and args.shard_of:
-        return rehearse_prove(args)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1 and not args.shard_of:
+        sys.exit(self_launch(args))                            # nothing has touched the GPU yet
+    world = int(env_world or "1")
+    if env_world is not None and args.gpus not in (1, world):
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    mode = args.mode
+    if mode == "auto":
+        mode = "prove" if (world == 1 or args.replicas) else "prove-sharded"
+        if args.shard_of:
+            mode = "prove-sharded"
+    elif mode == "commit" and world > 1 and not args.replicas:
+        mode = "commit-sharded"
+    if args.shard_of:
+        if args.workload == "auto":
+            args.workload = "c3"
+        return rehearse_shard(args) if mode == "commit-sharded" else rehearse_prove(args)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    local_rank %= max(1, torch.cuda.device_count())            # rehearsing N ranks on fewer GPUs: ranks share devices
+    n_dev = max(1, torch.cuda.device_count())
+    shared_gpu = world > n_dev                                 # rehearsing N ranks on fewer GPUs: ranks share devices
+    local_rank %= n_dev
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or (args.mode in ("commit-sharded", "prove-sharded") and not args.shard_of):
+    sharded_mode = mode in ("commit-sharded", "prove-sharded")
+    backend = None
+    if world > 1 or sharded_mode:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        backend = os.environ.get("PIL2GL_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path with ranks sharing a GPU
+        backend = os.environ.get("PIL2GL_BENCH_BACKEND", "gloo" if shared_gpu else "nccl")   # RCCL wants one device per rank
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     import pil2gl
     pil2gl.init(local_rank)
-    dev = torch.device("cuda", local_rank)
 
     wl = args.workload
     if wl == "auto":
         free, _ = torch.cuda.mem_get_info()
-        wl = "c3" if free > 170e9 else "c2"
+        if mode == "commit-sharded" and world == 8 and free > 235e9:
+            wl = "c5"                                          # 2^26 x 200: 221 GB per GPU, fits only sharded
+        else:
+            wl = "c3" if free > (170e9 if not sharded_mode else 100e9) * (world if shared_gpu else 1) else "c2"
     if wl in WORKLOADS:
         n_bits, n_cols = WORKLOADS[wl]
     else:
         n_bits, n_cols = (int(v) for v in wl.lower().split("x"))
     N, E = 1 << n_bits, 1 << (n_bits + EXT_BITS)
+    if wl == "c4":
+        if world > 1:
+            raise SystemExit("--workload c4 is a single-GPU line")
+        return bench_bn128(args, dev, wl, n_bits, n_cols)
+    if sharded_mode and (1 << EXT_BITS) % world:
+        raise SystemExit("a sharded mode needs a world size dividing the %d cosets" % (1 << EXT_BITS))
+    if mode == "prove-sharded" and n_bits + EXT_BITS > 27:
+        raise SystemExit("--mode prove-sharded needs nBitsExt <= 27 (the quotient's iNTT and the first fold are replicated); use --mode commit-sharded for %s" % wl)
 
+    from pil2gl import stark, parallel
+    comm = parallel.Comm() if dist is not None else None
     prove_ctx = None
-    prove_sharded = args.mode == "prove-sharded"
-    if args.mode in ("prove", "prove-sharded"):
-        from pil2gl import stark
+    be = stark.GpuBackend(local_rank, args.split)
+    if mode in ("prove", "prove-sharded"):
         n_cols -= n_cols & 1                                   # pairs of columns
-        fri_steps = [n_bits + EXT_BITS]
-        while fri_steps[-1] > 10:                              # decreasing by <= 5 bits, as zkevm.starkstruct.json does
-            fri_steps.append(max(fri_steps[-1] - 5, 6))
         ss = {"nBits": n_bits, "nBitsExt": n_bits + EXT_BITS, "nQueries": 64, "verificationHashType": "GL",
-              "splitLinearHash": bool(args.split), "steps": [{"nBits": b} for b in fri_steps]}
+              "splitLinearHash": bool(args.split), "steps": [{"nBits": b} for b in fri_steps_for(n_bits + EXT_BITS)]}
         info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
-        be = stark.GpuBackend(local_rank, args.split)
-        src, consts, publics = fibonacci_trace_gpu(torch, dev, n_bits, n_cols // 2, 0 if prove_sharded else rank)   # sharded: ONE trace
+        src, consts, publics = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0 if mode == "prove-sharded" else rank)   # sharded: ONE trace
         setup = stark.build_const_tree(be, consts, info)
-        prove_ctx = (stark, be, setup, info, exprs, publics)
-    elif args.mode == "commit-sharded":                        # ONE trace, replicated; the cosets of its extension are split
-        from pil2gl import stark, parallel
-        if (1 << EXT_BITS) % (args.shard_of or world):
-            raise SystemExit("commit-sharded needs a world size dividing %d" % (1 << EXT_BITS))
-        shard_be = stark.GpuBackend(local_rank, args.split)
+        prove_ctx = (setup, info, exprs, publics)
+    elif mode == "commit-sharded":                             # ONE trace, replicated; the cosets of its extension are split
         src = make_trace(N, n_cols, 0x5EED0000, dev)
     else:
         src = make_trace(N, n_cols, 0x5EED0000 + rank, dev)
-    sharded = args.mode == "commit-sharded"
-    dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
     MH = pil2gl.buildMerkleHash(args.split)
-    nodes = torch.empty(MH._getNNodes(E * 4), dtype=torch.int64, device=dev)
+    dst = nodes = None
+    if mode == "commit":
+        dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
+        nodes = torch.empty(MH._getNNodes(E * 4), dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     import ctypes as C
 
-    stage_times = {}
-
-    def step():
-        if prove_ctx is not None:
-            stark_, be_, setup_, info_, exprs_, publics_ = prove_ctx
-            if prove_sharded:
-                from pil2gl import parallel
-                parallel.stark_gen_sharded(be_, src, setup_, info_, exprs_, publics_)
-                return
-            stark_.stark_gen(be_, src, setup_, info_, exprs_, publics_, timings=stage_times if collect[0] else None)
-            return
-        if sharded:
-            parallel.extend_and_merkelize_sharded(shard_be, src, n_cols, n_bits, n_bits + EXT_BITS,
-                                                  overwrite_src=bool(args.shard_of), rehearse_world=args.shard_of or None, split_tree=not args.full_tree)
-            return
+    def step(timings=None):
+        if mode == "prove":
+            setup_, info_, exprs_, publics_ = prove_ctx
+            return stark.stark_gen(be, src, setup_, info_, exprs_, publics_, timings=timings)
+        if mode == "prove-sharded":
+            setup_, info_, exprs_, publics_ = prove_ctx
+            return parallel.stark_gen_sharded(be, src, setup_, info_, exprs_, publics_, comm=comm, timings=timings)
+        if mode == "commit-sharded":
+            return parallel.extend_and_merkelize_sharded(be, src, n_cols, n_bits, n_bits + EXT_BITS, overwrite_src=(wl == "c5"), split_tree=not args.full_tree, comm=comm)
         pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
         pil2gl.call("pil2gl_merkelize_dev", pil2gl._ptr(dst), n_cols, E, int(args.split), pil2gl._ptr(nodes), C.c_void_p(stream))
-    collect = [False]
-    if prove_ctx is not None or sharded:
-        del dst, nodes                                         # the prove loop allocates its own buffers
-        dst = nodes = None
+        return None
 
     def barrier():
         torch.cuda.synchronize()
@@ -354,6 +530,11 @@ def main():
         step()
     for _ in range(args.warmup):
         step()
+    # the interpreter's cycle collector stays out of the timed region (round 1's line showed one step in eight or nine 43 ms
+    # slower than its neighbours: a generation-2 collection walking the proof objects); collected once here instead
+    gc.collect(); gc.disable()
+    if comm is not None:
+        comm.reset_stats()
     barrier()
     t0 = time.perf_counter()
     step_marks = []
@@ -362,69 +543,75 @@ def main():
         step_marks.append(time.perf_counter())               # host clock only: no extra synchronisation inside the timed region
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     step_ms = [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = (1 if (sharded or prove_sharded) else world) * N * n_cols / (dt / args.steps)
-    if (sharded or prove_sharded) and rank == 0:
-        dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
-    if prove_ctx is not None and rank == 0 and not prove_sharded:   # one more, untimed-for-value, proof with a per-stage breakdown
-        collect[0] = True
-        step(); torch.cuda.synchronize()
-        collect[0] = False
-        dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
+    value = (1 if sharded_mode else world) * N * n_cols / (dt / args.steps)
+    exchange = None
+    if comm is not None and sharded_mode:
+        exchange = comm.stats()
+        for k in ("collectives", "bytes_sent_per_rank", "bytes_received_per_rank"):
+            exchange[k] = exchange[k] // args.steps            # per step
+        exchange["backend"] = backend + (" + HIP IPC windows (ranks share a GPU)" if exchange["mode"] == "ipc" else (" (RCCL over xGMI)" if backend == "nccl" else ""))
+    # one more pass, outside the timed region, with a synchronisation after every stage (collective in the sharded mode: all ranks)
+    stage_times = {}
+    if mode in ("prove", "prove-sharded") and (rank == 0 or mode == "prove-sharded"):
+        step(timings=stage_times); torch.cuda.synchronize()
 
-    out = None
     if rank == 0:
-        # ---- per-kernel timing with HIP events on the launch stream (each call below is exactly one kernel,
-        #      or one kernel family named in DESIGN.md) ----
+        # ---- per-kernel timing with HIP events on the launch stream (each call below is exactly one kernel, or one kernel
+        #      family named in DESIGN.md), at the size this rank runs them: the whole extension, or its cosets ----
+        cc = ((1 << EXT_BITS) // world) if sharded_mode else (1 << EXT_BITS)
+        rows = N * cc
+        if dst is None or dst.numel() != rows * n_cols:
+            dst = None
+            dst = torch.empty(rows * n_cols, dtype=torch.int64, device=dev)
         iters = max(1, min(3, args.steps))
-        digests = torch.empty(E * 4, dtype=torch.int64, device=dev)
+        digests = torch.empty(rows * 4, dtype=torch.int64, device=dev)
+        if sharded_mode:
+            ws = src if wl == "c5" else None
+            lde = lambda: be.interpolate_cosets(src, n_cols, n_bits, dst, n_bits + EXT_BITS, 0, cc, ws)
+        else:
+            lde = lambda: pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
+        t_lde = ev_time(lde, iters)
         t_leaf = ev_time(lambda: pil2gl.linearHash(dst, n_cols, args.split, digests), iters)
-        t_lde = ev_time(lambda: pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS), iters)
-        lvl = torch.empty(E * 2, dtype=torch.int64, device=dev)
+        lvl = torch.empty(rows * 2, dtype=torch.int64, device=dev)
         t_lvl = ev_time(lambda: pil2gl.merkelizeLevel(digests, lvl), iters)
-        leaf_perms = E * ((n_cols + 7) // 8) if n_cols > 4 else 0
+        leaf_perms = rows * ((n_cols + 7) // 8) if n_cols > 4 else 0
         if args.split and n_cols > 4:
             batch = max(8, (n_cols + 3) // 4); nb = (n_cols + batch - 1) // batch
-            leaf_perms = E * (sum((min(batch, n_cols - b * batch) + 7) // 8 if min(batch, n_cols - b * batch) > 4 else 0 for b in range(nb)) + (((4 * nb) + 7) // 8 if nb > 1 else 0))
+            leaf_perms = rows * (sum((min(batch, n_cols - b * batch) + 7) // 8 if min(batch, n_cols - b * batch) > 4 else 0 for b in range(nb)) + (((4 * nb) + 7) // 8 if nb > 1 else 0))
         kernels = [
-            {"kernel": "linear_hash_kernel", "ms": t_leaf, "alg_bytes": 8 * E * n_cols + 32 * E, "perms": leaf_perms},
-            {"kernel": "interpolate (ntt_pass_kernel x / lde_mid_kernel)", "ms": t_lde, "alg_bytes": 8 * N * n_cols * (1 + (1 << EXT_BITS))},
-            {"kernel": "merkle_level_kernel (first level)", "ms": t_lvl, "alg_bytes": 32 * E + 16 * E, "perms": E // 2},
+            {"kernel": "linear_hash_kernel", "ms": t_leaf, "alg_bytes": 8 * rows * n_cols + 32 * rows, "perms": leaf_perms},
+            {"kernel": "interpolate (ntt_pass_kernel x / lde_mid_kernel)", "ms": t_lde, "alg_bytes": 8 * N * n_cols * (1 + cc)},
+            {"kernel": "merkle_level_kernel (first level)", "ms": t_lvl, "alg_bytes": 32 * rows + 16 * rows, "perms": rows // 2},
         ]
-        if wl == "c3":                                          # the committed PMC passes were taken at config 3
-            kernels[0]["traffic"] = load_pmc_traffic("linear_hash_kernel")
-            kernels[1]["traffic"] = load_pmc_lde_traffic()
-            kernels[2]["traffic"] = load_pmc_traffic("merkle_level_kernel")
+        if wl == "c3" and not sharded_mode:                    # the committed PMC passes were taken at config 3, one GPU
+            pf = pmc_file()
+            kernels[0]["traffic"] = load_pmc(pf, "linear_hash_kernel")
+            kernels[1]["traffic"] = load_pmc_lde_traffic(pf)
+            kernels[2]["traffic"] = load_pmc(pf, "merkle_level_kernel")
         for k in kernels:
             k["GBps"] = k["alg_bytes"] / k["ms"] / 1e6
             k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS
-            if "perms" in k:
+            if k.get("perms"):
                 k["Gperm_s"] = k["perms"] / k["ms"] / 1e6
         dom = max(kernels, key=lambda k: k["ms"])
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": dom["hbm_frac"], "traffic": load_pmc_traffic(dom["kernel"].split(" ")[0]),
-                    "note": "Poseidon hashing is integer-ALU bound (no 64-bit multiplier on gfx950); its HBM fraction is small by nature, see kernels[]"}
-        # what does bind it: the committed SQ counters of the same kernel (profiles/r01_valu_utilisation.json, tools/pmc_valu.py):
-        # share of a wave's cycles spent issuing vector-ALU instructions x waves per SIMD ~ share of the SIMD's issue slots
-        try:
-            with open(os.path.join(ROOT, "profiles", "r01_valu_utilisation.json")) as f:
-                pm = json.load(f).get(dom["kernel"].split(" ")[0])
-            if pm:
-                roofline["valu"] = {"active_frac_of_wave_cycles": round(pm["valu_frac_of_wave_cycles"], 3), "wait_frac": round(pm["wait_any_frac"], 3),
-                                    "source": "profiles/r01_valu_utilisation.json (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES, rocprofv3 --pmc, config 3)"}
-        except Exception:
-            pass
+                    "frac": dom["hbm_frac"], "traffic": dom.get("traffic"),
+                    "note": "Poseidon hashing is integer-issue bound (no 64-bit multiplier on gfx950): its HBM fraction is small by nature; roofline_int_issue prices it against its own roof, kernels[1] is the HBM-bound LDE"}
+        out = {}
         if prove_ctx is not None:
+            info = prove_ctx[1]
             metric = "STARK prove time (ms_per_step) and trace-cells/s, synthetic Fibonacci AIR, GL Poseidon Merkle + FRI, blow-up 8"
             workload = "full proof (commit, Q, evals, FRI %s, %d queries) of 2^%d rows x %d cols -> 2^%d rows, %s linear hash, %s" % (
-                "/".join(str(x["nBits"]) for x in prove_ctx[3]["starkStruct"]["steps"]), prove_ctx[3]["starkStruct"]["nQueries"], n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain",
-                "ONE proof split by cosets over the GPUs (q, evaluations, FRI polynomial exchanged)" if prove_sharded else "per GPU")
-        elif sharded:
+                "/".join(str(x["nBits"]) for x in info["starkStruct"]["steps"]), info["starkStruct"]["nQueries"], n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain",
+                "ONE proof split by cosets over the GPUs (leaf digests, q, evaluations, FRI polynomial exchanged)" if mode == "prove-sharded" else "per GPU")
+        elif mode == "commit-sharded":
             metric = "trace-cells/s, STARK commit step (extend+merkelize) of ONE trace split by cosets over the GPUs, GL Poseidon Merkle, blow-up 8"
             workload = "extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, %s linear hash, %d of 8 cosets per GPU + all-gather of leaf digests" % (
                 n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain", (1 << EXT_BITS) // world)
@@ -434,17 +621,29 @@ def main():
         out = {
             "metric": metric,
             "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (sharded or prove_sharded) else "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": workload, "mode": args.mode,
+            "config": {"workload": workload, "mode": mode, "config": wl,
                        "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "GL-Poseidon-12",
-                       "parallelism": ("coset-sharded x%d" % world) if (sharded or prove_sharded) else ("replicas x%d" % world if world > 1 else "single GPU")},
-            "roofline": roofline, "kernels": kernels,
+                       "parallelism": ("coset-sharded x%d" % world) if sharded_mode else ("replicas x%d" % world if world > 1 else "single GPU")},
+            "roofline": roofline, "roofline_int_issue": poseidon_int_roofline(kernels[0]["perms"], kernels[0]["ms"]) if kernels[0]["perms"] else None,
+            "kernels": kernels,
         }
+        if dist is not None:
+            out["n_ranks"] = dist.get_world_size()
+            out["ranks_share_gpus"] = bool(shared_gpu)
+        if exchange is not None:
+            out["exchange_per_step"] = exchange
         if prove_ctx is not None:
-            out["prove"] = {"seconds": ms_per_step / 1e3, "stages_s": {k: round(v, 4) for k, v in stage_times.items()}, "host_ms_of_each_step": step_ms}
+            cexp = prove_ctx[2]["expressionsCode"][prove_ctx[1]["cExpId"]]["code"]["code"]
+            fexp = prove_ctx[2]["expressionsCode"][prove_ctx[1]["friExpId"]]["code"]["code"]
+            out["prove"] = {"seconds": ms_per_step / 1e3, "stages_s": {k: round(v, 4) for k, v in stage_times.items()}, "host_ms_of_each_step": step_ms,
+                            "air": {"machines": n_cols // 2, "constraint_ops_per_extended_row": len(cexp), "fri_ops_per_extended_row": len(fexp),
+                                    "openings": len(prove_ctx[1]["openingPoints"]), "evaluations": len(prove_ctx[1]["evMap"])}}
+        if world == 1:
+            out["witness_upload"] = h2d_sample(dev, 8 * N * n_cols)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_prove(n_cols, args.split) if prove_ctx is not None else cpu_baseline(n_cols, args.split)
+            out["cpu_baseline"] = cpu_baseline_prove(n_cols, args.split) if prove_ctx is not None else cpu_baseline_commit(n_cols, args.split)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -31,30 +31,177 @@ def coset_range(rank, world, ext_bits):
     return rank * cc, cc
 
 
-def _comm_tensor(be, t, group):
-    """tensor handed to the collective: device tensor for nccl, host tensor for gloo"""
-    x = be.as_torch(t)
-    if dist.get_backend(group) != "nccl" and x.is_cuda:
-        x = x.cpu()
-    return x
+class _Done:
+    """handle of an exchange that has already completed"""
+    def __init__(self, parts): self.parts = parts
+    def wait(self): return self.parts
 
 
-def commit_local_slice(be, local, width, n_bits, cc, world, group=None, rehearse_world=None, split_tree_rank=None):
-    """leaf digests of a rank's slice (N*cc rows x width), all-gathered and interleaved into natural leaf order, then the
-    levels above them -> the complete node array on every rank, or (split_tree_rank = this rank) a ShardedTree"""
+class _Pending:
+    def __init__(self, work, parts): self.work, self.parts = work, parts
+    def wait(self):
+        if self.work is not None:
+            self.work.wait()                                    # nccl: the current stream waits for the collective's stream
+            self.work = None
+        return self.parts
+
+
+class Comm:
+    """Exchange layer of the sharded prover: the few collectives SURVEY.md 8e names (all-gather of leaf digests, of q and of
+    the FRI polynomial; sums of a few opened rows / evaluations), with the bytes they move counted.
+
+    mode "nccl"  one rank per GPU: torch.distributed's nccl backend, which on ROCm is RCCL over xGMI.  Every tensor stays on
+                 the device; an all-gather may be started asynchronously (it runs on RCCL's stream) so that the next
+                 chunk of leaf hashing overlaps it.
+    mode "gloo"  host tensors (the CPU tests on the checker backend).
+    mode "ipc"   several ranks SHARING one GPU (the one-GPU rehearsal of an N-rank job: RCCL refuses two ranks on one device,
+                 and staging through host memory and gloo costs hundreds of ms).  Each rank exposes two windows of device
+                 memory to the others (HIP IPC, through torch's CUDA tensor sharing); an all-gather is then: copy into the
+                 own window, stream synchronise, one host barrier, `world` device-to-device copies out of the peers'
+                 windows.  The windows alternate, so a window is only rewritten after every rank has passed the barrier of
+                 the following exchange, i.e. has finished reading it (each rank synchronises its stream before a barrier).
+                 Small sums travel through gloo on the host.
+    mode "rehearse"  rank 0 of a K-rank job run alone: its own data stands in for the other ranks' (timing / memory only).
+    """
+
+    def __init__(self, group=None, rehearse_world=None, mode=None):
+        self.group = group
+        self.bytes_sent = self.bytes_received = self.collectives = 0
+        self._auto_ipc = False
+        if rehearse_world:
+            self.mode, self.rank, self.world = "rehearse", 0, int(rehearse_world)
+            return
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        backend = dist.get_backend(group)
+        import os
+        self.mode = mode or ("nccl" if backend == "nccl" else "gloo")
+        # device tensors under a gloo group = ranks sharing a GPU: exchange through IPC windows unless told to stage through the host
+        self._auto_ipc = mode is None and backend != "nccl" and self.world > 1 and os.environ.get("PIL2GL_EXCHANGE", "ipc") == "ipc"
+        if self.mode == "ipc" and self.world == 1:
+            self.mode = "gloo"
+        self._win, self._peer, self._turn = [None, None], [None, None], 0
+
+    # ---- helpers
+    def _count(self, sent, received):
+        self.collectives += 1; self.bytes_sent += int(sent); self.bytes_received += int(received)
+
+    def stats(self):
+        return {"mode": self.mode, "ranks": self.world, "collectives": self.collectives,
+                "bytes_sent_per_rank": self.bytes_sent, "bytes_received_per_rank": self.bytes_received}
+
+    def reset_stats(self):
+        self.bytes_sent = self.bytes_received = self.collectives = 0
+
+    def barrier(self):
+        if self.mode != "rehearse":
+            dist.barrier(group=self.group)
+
+    def _windows(self, n, device):
+        """both windows hold at least n words on every rank (n is the same on every rank)"""
+        if self._win[0] is not None and self._win[0].numel() >= n:
+            return
+        from torch.multiprocessing.reductions import reduce_tensor
+        torch.cuda.synchronize()
+        dist.barrier(group=self.group)                          # nobody still reads the old windows
+        self._peer = [None, None]
+        cap = max(n, 1 << 16)
+        self._win = [torch.empty(cap, dtype=torch.int64, device=device) for _ in range(2)]
+        mine = [reduce_tensor(w) for w in self._win]
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine, group=self.group)
+        self._peer = [[(self._win[k] if r == self.rank else everyone[r][k][0](*everyone[r][k][1])) for r in range(self.world)] for k in range(2)]
+
+    # ---- collectives
+    def all_gather_start(self, mine, outs=None):
+        """mine: 1-D int64 tensor (same length on every rank).  -> handle whose wait() returns the list of every rank's
+        tensor (rank order), written into `outs` when given (a list of `world` contiguous tensors)"""
+        n = mine.numel()
+        if self.mode == "rehearse":
+            self._count(8 * n, 8 * n * (self.world - 1))
+            if outs is not None:
+                for o in outs:
+                    o.copy_(mine)
+                return _Done(outs)
+            return _Done([mine] * self.world)
+        self._count(8 * n, 8 * n * (self.world - 1))
+        if self.mode == "gloo" and self._auto_ipc and mine.is_cuda:
+            self.mode = "ipc"                                    # every rank takes this branch at the same exchange
+        if self.mode == "ipc" and mine.is_cuda:
+            self._windows(n, mine.device)
+            k = self._turn; self._turn ^= 1
+            self._win[k][:n].copy_(mine)
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)
+            if outs is None:
+                outs = [torch.empty_like(mine) for _ in range(self.world)]
+            for r in range(self.world):
+                outs[r].copy_(mine if r == self.rank else self._peer[k][r][:n])
+            return _Done(outs)
+        x = mine
+        if self.mode != "nccl" and x.is_cuda:                  # gloo with device data: through the host (slow; tests only)
+            x = x.cpu()
+        host_staged = x is not mine
+        parts = outs if (outs is not None and not host_staged) else [torch.empty_like(x) for _ in range(self.world)]
+        if self.mode == "nccl":
+            work = dist.all_gather(parts, x, group=self.group, async_op=True)
+            return _Pending(work, parts)
+        dist.all_gather(parts, x, group=self.group)
+        if host_staged:
+            if outs is not None:
+                for o, p_ in zip(outs, parts):
+                    o.copy_(p_)
+                parts = outs
+            else:
+                parts = [p_.to(mine.device) for p_ in parts]
+        return _Done(parts)
+
+    def all_gather(self, mine, outs=None):
+        return self.all_gather_start(mine, outs).wait()
+
+    def all_reduce_sum(self, t):
+        """sum over the ranks of a SMALL int64 tensor (every entry is non-zero on one rank only, so the sum is exact);
+        returns a host tensor"""
+        if self.mode == "rehearse":
+            return t.cpu()
+        self._count(8 * t.numel(), 8 * t.numel())
+        if self.mode == "nccl":
+            x = t if t.is_cuda else t.cuda()
+            dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+            return x.cpu()
+        x = t.cpu() if t.is_cuda else t
+        dist.all_reduce(x, op=dist.ReduceOp.SUM, group=self.group)
+        return x
+
+
+def _comm_of(comm, group, rehearse_world):
+    return comm if comm is not None else Comm(group, rehearse_world)
+
+
+def commit_local_slice(be, local, width, n_bits, cc, comm, split_tree=False, chunks=None):
+    """leaf digests of a rank's slice (N*cc rows x width), all-gathered, then the levels above them -> the complete node
+    array on every rank, or (split_tree) a ShardedTree.  Under RCCL the rows are hashed in `chunks` pieces and the
+    all-gather of a piece runs (on RCCL's stream) while the next piece is being hashed."""
     N = 1 << n_bits
-    digests = be.linear_hash_rows(local, width, N * cc)              # [N*cc][4], local row = pos*cc + jl
-    if rehearse_world:
-        mine = be.as_torch(digests).reshape(-1)
-        gathered = [mine] * world
+    rows = N * cc
+    if chunks is None:
+        chunks = 4 if (comm.mode == "nccl" and rows >= (1 << 16) and hasattr(be, "linear_hash_rows_into")) else 1
+    if chunks == 1:
+        digests = be.linear_hash_rows(local, width, rows)       # [N*cc][4], local row = pos*cc + jl
+        gathered = comm.all_gather(be.as_torch(digests).reshape(-1))
     else:
-        mine = _comm_tensor(be, digests, group).reshape(-1)
-        gathered = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(gathered, mine, group=group)
+        mine = be.empty(rows * 4)
+        gathered = [be.empty(rows * 4) for _ in range(comm.world)]
+        pending = []
+        for k in range(chunks):
+            r0, r1 = rows * k // chunks, rows * (k + 1) // chunks
+            be.linear_hash_rows_into(local[r0 * width:r1 * width], width, r1 - r0, mine[r0 * 4:r1 * 4])
+            pending.append(comm.all_gather_start(mine[r0 * 4:r1 * 4], [g[r0 * 4:r1 * 4] for g in gathered]))
+        for h in pending:
+            h.wait()
     # part r is [N][cc*4]; leaf index = pos*2^eb + r*cc + jl (natural row order of the extension), written straight into
     # the node array (no stacked / permuted copies: at config 5 the leaf level alone is 17 GB)
-    if split_tree_rank is not None:
-        return ShardedTree(be, gathered, N, cc, split_tree_rank, world, group, rehearse_world)
+    if split_tree:
+        return ShardedTree(be, gathered, N, cc, comm)
     return be.merkelize_digest_parts(gathered, N, cc)
 
 
@@ -64,35 +211,30 @@ class ShardedTree:
     subtree roots are exchanged and the log2(w) levels above them are computed by everybody.  Same root and same paths as
     the single tree; no rank hashes more than 1/w of it (plus w-1 nodes)."""
 
-    def __init__(self, be, parts, N, cc, rank, world, group=None, rehearse_world=None, block_digests=None):
+    def __init__(self, be, parts, N, cc, comm, block_digests=None):
         """parts: the all-gathered coset-ordered leaf digests of a committed stage (commit_local_slice); or block_digests:
         the digests of this rank's own contiguous block of N*cc leaves (nothing to gather: the first FRI tree)"""
-        self.be, self.rank, self.world, self.group, self.rehearse = be, rank, world, group, rehearse_world
+        self.be, self.comm, self.rank, self.world = be, comm, comm.rank, comm.world
         self.block = N * cc                                     # leaves per rank block: E / world
         if block_digests is not None:
             self.sub = be.merkelize_digests(block_digests, self.block)
         else:
-            if N % world:
+            if N % self.world:
                 raise ValueError("world size must divide the number of rows")
-            self.sub = be.merkelize_digest_block(parts, N, cc, rank)
-        mine = torch.tensor(np.array(be.root({"nodes": self.sub}), dtype=np.uint64).view(np.int64))
-        if rehearse_world:
-            roots = [mine] * world
-        else:
-            if dist.get_backend(group) == "nccl":
-                mine = mine.to(be.as_torch(self.sub).device)
-            roots = [torch.empty_like(mine) for _ in range(world)]
-            dist.all_gather(roots, mine, group=group)
-        cur = [[int(v) for v in r.cpu().numpy().view(np.uint64)] for r in roots]
+            self.sub = be.merkelize_digest_block(parts, N, cc, self.rank)
+        mine = torch.zeros(self.world * 4, dtype=torch.int64)
+        mine[self.rank * 4:self.rank * 4 + 4] = torch.tensor(np.array(be.root({"nodes": self.sub}), dtype=np.uint64).view(np.int64))
+        roots = comm.all_reduce_sum(mine) if comm.mode != "rehearse" else mine[:4].repeat(self.world)
+        cur = [[int(v) for v in roots[4 * r:4 * r + 4].numpy().view(np.uint64)] for r in range(self.world)]
         self.top = [cur]
         while len(cur) > 1:                                     # merklehash_p.js:109-132 on w, w/2, ... nodes
             cur = [[int(v) for v in be.poseidon(cur[2 * i] + cur[2 * i + 1], [0, 0, 0, 0], 4)] for i in range(len(cur) // 2)]
             self.top.append(cur)
         self.root = cur[0]
 
-    def siblings(self, idxs):
-        """sibling digests of the paths to leaves idxs: the lower levels from the rank owning the leaf's block (one
-        all-reduce over zeros elsewhere), the upper log2(w) levels from the replicated top"""
+    def siblings_local(self, idxs):
+        """this rank's share of the lower levels of the paths to leaves idxs (zeros for leaves of other blocks): host tensor
+        [len(idxs)][log2(block)][4]"""
         low = _log2(self.block)
         t = torch.zeros((len(idxs), max(low, 1), 4), dtype=torch.int64)
         mine = [(q, i % self.block) for q, i in enumerate(idxs) if i // self.block == self.rank]
@@ -100,11 +242,13 @@ class ShardedTree:
             sib = self.be.merkle_siblings(self.sub, self.block, [li for _, li in mine])
             for (q, _), mp in zip(mine, sib):
                 t[q, :low] = torch.from_numpy(np.array(mp, dtype=np.uint64).view(np.int64))
-        if not self.rehearse:
-            if dist.get_backend(self.group) == "nccl":
-                t = t.to(self.be.as_torch(self.sub).device)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-        a = t.cpu().numpy().view(np.uint64)
+        return t
+
+    def siblings_finish(self, idxs, summed):
+        """summed: the sum over the ranks of siblings_local (host tensor) -> the sibling digests of every path: the lower
+        levels from the owners, the upper log2(w) levels from the replicated top"""
+        low = _log2(self.block)
+        a = summed.numpy().view(np.uint64).reshape(len(idxs), max(low, 1), 4)
         out = []
         for q, i in enumerate(idxs):
             mp = [[int(v) for v in a[q, l]] for l in range(low)]
@@ -115,8 +259,12 @@ class ShardedTree:
             out.append(mp)
         return out
 
+    def siblings(self, idxs):
+        """sibling digests of the paths to leaves idxs (one sum over the ranks)"""
+        return self.siblings_finish(idxs, self.comm.all_reduce_sum(self.siblings_local(idxs)))
 
-def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None, overwrite_src=False, rehearse_world=None, split_tree=False):
+
+def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None, overwrite_src=False, rehearse_world=None, split_tree=False, comm=None):
     """Sharded extendAndMerkelize.  `src` = the full N x n_pols trace on every rank.
     Returns {"local": N x (cc*n_pols) slice (row pos, coset jl, col c), "nodes": full tree.nodes, "width", "height",
     "cosetBegin", "cosetCount", "extBits"}; tree root = last 4 words of nodes, identical on all ranks and to the
@@ -125,17 +273,16 @@ def extend_and_merkelize_sharded(be, src, n_pols, n_bits, n_bits_ext, group=None
     GPU, no third buffer).  rehearse_world=K: run rank 0's share of a K-rank job alone, standing in copies of the own
     digests for the gathered ones (a one-GPU rehearsal of the per-GPU time and memory; the tree is not a real root).
     split_tree: instead of the full node array on every rank ("nodes"), return "tree": a ShardedTree -- each rank builds the
-    subtree over its block of leaves only and the top log2(world) levels are replicated (same root, same paths)."""
-    if rehearse_world:
-        rank, world = 0, int(rehearse_world)
-    else:
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    subtree over its block of leaves only and the top log2(world) levels are replicated (same root, same paths).
+    comm: the exchange layer (Comm); built from group / rehearse_world when not given."""
+    comm = _comm_of(comm, group, rehearse_world)
+    rank, world = comm.rank, comm.world
     eb = n_bits_ext - n_bits
     cb, cc = coset_range(rank, world, eb)
     N = 1 << n_bits
     local = be.empty(N * cc * n_pols)
     be.interpolate_cosets(src, n_pols, n_bits, local, n_bits_ext, cb, cc, src if overwrite_src else None)
-    tree = commit_local_slice(be, local, n_pols, n_bits, cc, world, group, rehearse_world, split_tree_rank=rank if split_tree else None)
+    tree = commit_local_slice(be, local, n_pols, n_bits, cc, comm, split_tree=split_tree)
     height = N << eb
     out = {"local": local, "width": n_pols, "height": height, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
     out["tree" if split_tree else "nodes"] = tree
@@ -149,10 +296,9 @@ def owner_of_row(idx, ext_bits, world):
     return j // cc, (idx >> ext_bits) * cc + (j % cc)
 
 
-def open_rows(be, stree, idxs, group=None):
-    """values of the extended rows idxs (fri.js:83-105 opens every tree at the query rows): each rank fills the rows of
-    its own cosets, one all-reduce (sum with zeros, exact) completes them everywhere.  -> numpy [len(idxs)][width]"""
-    rank, world = dist.get_rank(group), dist.get_world_size(group)
+def open_rows_local(be, stree, idxs, rank, world):
+    """this rank's rows among the extended rows idxs (zeros for rows of other ranks' cosets): int64 tensor [len(idxs)][width]
+    on the slice's device"""
     w = stree["width"]
     loc = be.as_torch(stree["local"]).reshape(-1, w)
     sel = [(q, owner_of_row(i, stree["extBits"], world)) for q, i in enumerate(idxs)]
@@ -162,9 +308,14 @@ def open_rows(be, stree, idxs, group=None):
         qi = torch.tensor([q for q, _ in own], device=loc.device)
         li = torch.tensor([lr for _, lr in own], device=loc.device)
         out[qi] = loc[li].to(torch.int64)
-    x = out if dist.get_backend(group) == "nccl" or not out.is_cuda else out.cpu()
-    dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group)
-    return x.cpu().numpy().view(np.uint64)
+    return out
+
+
+def open_rows(be, stree, idxs, group=None, comm=None):
+    """values of the extended rows idxs (fri.js:83-105 opens every tree at the query rows): each rank fills the rows of
+    its own cosets, one sum (with zeros, exact) completes them everywhere.  -> numpy [len(idxs)][width]"""
+    comm = _comm_of(comm, group, None)
+    return comm.all_reduce_sum(open_rows_local(be, stree, idxs, comm.rank, comm.world)).numpy().view(np.uint64)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -187,22 +338,15 @@ def coset_slice(be, full, n_bits, ext_bits, cb, cc, width):
     return be.from_torch(t[:, cb:cb + cc, :].contiguous().reshape(-1))
 
 
-def all_gather_rows(be, local, n_bits, cc, width, group=None, rehearse_world=None):
+def all_gather_rows(be, local, n_bits, cc, width, comm):
     """local slices (N*cc rows x width) of every rank -> the full buffer in natural row order, on every rank"""
-    if rehearse_world:                                          # one-GPU rehearsal: own slice stands in for the others
-        mine = be.as_torch(local).reshape(-1)
-        parts = [mine] * rehearse_world
-    else:
-        world = dist.get_world_size(group)
-        mine = _comm_tensor(be, local, group).reshape(-1)
-        parts = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(parts, mine, group=group)
+    parts = comm.all_gather(be.as_torch(local).reshape(-1))
     N = 1 << n_bits
     full = torch.stack([p.reshape(N, cc * width) for p in parts], dim=1).reshape(-1)      # [N][world][cc*width]
     return be.from_torch(full)
 
 
-def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None, timings=None):
+def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None, timings=None, comm=None):
     """pil2gl.stark.stark_gen with every witness stage, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
     single-process one.  Replicated: the iNTT of q (3 columns) and the FRI folding; the trees above the leaves are split
@@ -216,11 +360,14 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     def lap(name):
         if timings is not None:
             be.sync(); now = time.perf_counter(); timings[name] = timings.get(name, 0.0) + now - t_last[0]; t_last[0] = now
-    if rehearse_world:
-        rank, world = 0, int(rehearse_world)
-    else:
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    comm = _comm_of(comm, group, rehearse_world)
+    rank, world = comm.rank, comm.world
+    rehearse_world = world if comm.mode == "rehearse" else None
     ss = info["starkStruct"]
+    if ss["nBitsExt"] > 27 and comm.mode != "rehearse":
+        # the replicated steps (iNTT of q, first FRI fold) run on the whole extended domain; the library's transforms stop at 2^27 rows
+        raise ValueError("a sharded PROOF needs nBitsExt <= 27 (got %d): the quotient's iNTT and the first FRI fold are replicated; "
+                         "the sharded COMMIT (extend_and_merkelize_sharded) has no such limit" % ss["nBitsExt"])
     nb, nbe = ss["nBits"], ss["nBitsExt"]
     eb, N, E = nbe - nb, 1 << ss["nBits"], 1 << ss["nBitsExt"]
     cb, cc = coset_range(rank, world, eb)
@@ -269,7 +416,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         loc[name + "_ext"] = be.empty(w << nloc)
         be.interpolate_cosets(trace[name + "_n"], w, nb, loc[name + "_ext"], nbe, cb, cc, None)
         lap("stage%d_lde" % s_)
-        strees[s_] = commit_local_slice(be, loc[name + "_ext"], w, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
+        strees[s_] = commit_local_slice(be, loc[name + "_ext"], w, nb, cc, comm, split_tree=True)
         shards[s_] = {"local": loc[name + "_ext"], "width": w, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
         roots[s_] = strees[s_].root; transcript.put(roots[s_])
         lap("stage%d_merkle" % s_)
@@ -280,7 +427,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     loc["q_ext"] = be.empty(qDim << nloc)
     run_local(exprs["expressionsCode"][info["cExpId"]]["code"])
     lap("q_expr")
-    q_ext = all_gather_rows(be, loc["q_ext"], nb, cc, qDim, group, rehearse_world)
+    q_ext = all_gather_rows(be, loc["q_ext"], nb, cc, qDim, comm)
     del loc["q_ext"]
     # computeQStark (stark_gen_helpers.js:168-208): the iNTT of q needs all of q and is replicated (3 columns); the split
     # quotient has degree < N per column, so its extension is again "one coset per rank": evaluations on the subgroup, then
@@ -296,7 +443,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     loc[qname] = be.empty(nQ << nloc)
     be.extend_cosets_unshifted(q_sub, nQ, nb, loc[qname], nbe, cb, cc)
     lap("q_ntt")
-    strees[qStage] = commit_local_slice(be, loc[qname], nQ, nb, cc, world, group, rehearse_world, split_tree_rank=rank)
+    strees[qStage] = commit_local_slice(be, loc[qname], nQ, nb, cc, comm, split_tree=True)
     shards[qStage] = {"local": loc[qname], "width": nQ, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
     roots[qStage] = strees[qStage].root; transcript.put(roots[qStage])
     lap("q_merkle")
@@ -337,11 +484,8 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         full[sel] = np.array(evals, dtype=np.uint64).reshape(len(sel), 3)
         ev_t = torch.from_numpy(full.reshape(-1).view(np.int64).copy())
         del levs
-    if not rehearse_world:
-        if dist.get_backend(group) == "nccl":
-            ev_t = ev_t.to(be.as_torch(loc["cm1_ext"]).device)
-        dist.all_reduce(ev_t, op=dist.ReduceOp.SUM, group=group)          # every entry is non-zero on one rank only
-    ctx["evals"] = [[int(v) for v in r] for r in ev_t.cpu().numpy().view(np.uint64).reshape(n_ev, 3)]
+    ev_t = comm.all_reduce_sum(ev_t)                                      # every entry is non-zero on one rank only
+    ctx["evals"] = [[int(v) for v in r] for r in ev_t.numpy().view(np.uint64).reshape(n_ev, 3)]
     transcript.put(ctx["evals"])
 
     lap("evals")
@@ -352,7 +496,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     loc["f_ext"] = be.empty(3 << nloc)
     if not (hasattr(be, "fri_polynomial_fast") and be.fri_polynomial_fast(info, loc, widths, ctx["evals"], vfs[0], vfs[1], nloc, loc["f_ext"])):
         run_local(exprs["expressionsCode"][info["friExpId"]]["code"])
-    f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, group, rehearse_world)
+    f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, comm)
 
     lap("fri_expr")
     # folding and its trees, replicated; openings: the rows of the committed stages from their owners, everything else is local
@@ -367,18 +511,31 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
             return None
         lo = rank * blk * w
         dig = be.linear_hash_rows(tb[lo:lo + blk * w], w, blk)
-        fri_sharded[step] = (tb, w, ShardedTree(be, None, blk, 1, rank, world, group, rehearse_world, block_digests=dig))
+        fri_sharded[step] = (tb, w, ShardedTree(be, None, blk, 1, comm, block_digests=dig))
         return fri_sharded[step][2]
     friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, f_ext, transcript, tree_builder=fri_tree)
     lap("fri_fold")
     chq = transcript.getField(); challengesFRI.append(chq)
     tq = be.new_transcript(); tq.put(chq)
     queries = tq.getPermutations(ss["nQueries"], ss["steps"][0]["nBits"])
-    opened = []
+    # every opened row and every lower sibling comes from the one rank that owns it: all of them (the witness stages, the
+    # quotient, the split FRI tree) travel in ONE sum over the ranks
+    q1 = [qi % (1 << ss["steps"][1]["nBits"]) for qi in queries] if len(ss["steps"]) > 1 else []
+    pieces = []
     for s_ in range(1, qStage + 1):
         w = shards[s_]["width"]
-        rows = open_rows(be, shards[s_], queries, group) if not rehearse_world else np.zeros((len(queries), w), np.uint64)
-        opened.append((rows, strees[s_].siblings(queries)))
+        pieces.append(open_rows_local(be, shards[s_], queries, rank, world).cpu().reshape(-1) if not rehearse_world else torch.zeros(len(queries) * w, dtype=torch.int64))
+        pieces.append(strees[s_].siblings_local(queries).reshape(-1))
+    if 1 in fri_sharded:
+        pieces.append(fri_sharded[1][2].siblings_local(q1).reshape(-1))
+    summed = comm.all_reduce_sum(torch.cat(pieces))
+    parts, o = [], 0
+    for p_ in pieces:
+        parts.append(summed[o:o + p_.numel()]); o += p_.numel()
+    opened = []
+    for k, s_ in enumerate(range(1, qStage + 1)):
+        rows = parts[2 * k].numpy().view(np.uint64).reshape(len(queries), shards[s_]["width"])
+        opened.append((rows, strees[s_].siblings_finish(queries, parts[2 * k + 1])))
     pc = be.group_proofs(constTree, queries)
     friProof[0]["polQueries"] = [[[[int(v) for v in rows[i]], sib[i]] for rows, sib in opened] + [list(pc[i])] for i in range(len(queries))]
     q = list(queries)
@@ -386,11 +543,14 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         q = [qi % (1 << ss["steps"][step]["nBits"]) for qi in q]
         if step in fri_sharded:
             tb, w, stree = fri_sharded[step]
-            sib = stree.siblings(q)
-            friProof[step]["polQueries"] = [[[int(v) for v in np.asarray(be.to_host(tb[qi * w:(qi + 1) * w])).view(np.uint64)], sib[i]] for i, qi in enumerate(q)]
+            sib = stree.siblings_finish(q, parts[-1])
+            tt = be.as_torch(tb).reshape(-1, w)
+            vals = tt[torch.tensor(q, device=tt.device)].cpu().numpy().view(np.uint64).reshape(len(q), w)      # one gather for all queries
+            friProof[step]["polQueries"] = [[[int(v) for v in vals[i]], sib[i]] for i in range(len(q))]
         else:
             friProof[step]["polQueries"] = [list(p_) for p_ in be.group_proofs(friTrees[step], q)]
     lap("queries")
     proof = {"root%d" % s_: roots[s_] for s_ in range(1, qStage + 1)}
     proof["evals"] = ctx["evals"]; proof["fri"] = friProof
-    return {"proof": proof, "publics": list(publics), "challenges": ctx["challenges"], "challengesFRISteps": challengesFRI, "queries": queries}
+    return {"proof": proof, "publics": list(publics), "challenges": ctx["challenges"], "challengesFRISteps": challengesFRI, "queries": queries,
+            "exchange": comm.stats()}

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include "../../include/pil2gl.h"
 
 namespace pil2gl {
@@ -18,6 +19,8 @@ int  hip_fail(hipError_t e, const char *what);      // -> PIL2GL_EHIP
 #define KERNEL_CHECK() HIP_TRY(hipGetLastError())
 
 int ensure_init();                                   // pil2gl_init(current device) on first use
+std::recursive_mutex &runtime_lock();                // guards the process-global runtime state (tables, scratch, kernel cache)
+void jit_clear();                                    // unloads the run-time compiled expression kernels (expr.hip)
 
 // host-side Goldilocks (table construction and scalar parameters only) ---------
 u64 h_mul(u64 a, u64 b);

@@ -36,7 +36,8 @@ __device__ __forceinline__ u64 fold6(const u64 S[6]) {
 }
 
 struct RowsDotParams {
-    const u64 *buf; u64 width; u64 nRows;
+    const u64 *buf; u64 width; u64 nRows;       // width: columns of THIS launch's window [col0, col0 + width) -- at most 1024 (the unreduced sums hold 1024 terms)
+    u64 stride, col0;                           // row length of the matrix, first column of the window
     const u32 *coefLimbs;       // [nOut][width][3 comps][3 limbs]
     u32 nOut;
     u64 *acc;                   // [nRows][nOut][3]
@@ -70,9 +71,9 @@ __global__ void __launch_bounds__(256) rows_dot_kernel(RowsDotParams P) {
     const u32 lr = lane >> 4, lc = lane & 15;
     auto fetch = [&](u64 c0) {
         const u32 cw = (u32)min((u64)CW, P.width - c0);
-        u64 off = (row0 + lr) * P.width + c0 + lc;
+        u64 off = (row0 + lr) * P.stride + P.col0 + c0 + lc;
         asm volatile("" : "+v"(off));
-        const u64 step = 4 * P.width;
+        const u64 step = 4 * P.stride;
 #pragma unroll
         for (u32 i = 0; i < CW; i++) {
             const u64 gr = row0 + lr + 4 * i;
@@ -97,7 +98,7 @@ __global__ void __launch_bounds__(256) rows_dot_kernel(RowsDotParams P) {
             const u32 p0 = (u32)p, p1 = (u32)(p >> 32);
 #pragma unroll
             for (int o = 0; o < NOUT; o++) {
-                const u32 *L = P.coefLimbs + (((u64)o * P.width + c0 + c) * 9);   // wave-uniform -> scalar loads
+                const u32 *L = P.coefLimbs + (((u64)o * P.stride + P.col0 + c0 + c) * 9);   // wave-uniform -> scalar loads
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const u32 w0 = L[3 * k], w1 = L[3 * k + 1], w2 = L[3 * k + 2];
@@ -230,15 +231,19 @@ int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
     u64 *d;
     P2_TRY(scratch(7, (limbs.size() * 4 + 7) / 8 + 1, &d));
     HIP_TRY(hipMemcpyAsync(d, limbs.data(), limbs.size() * 4, hipMemcpyHostToDevice, st));
-    RowsDotParams P = { buf, width, nRows, (const u32 *)d, nOut, acc, (u32)(accumulate != 0) };
     const unsigned blocks = (unsigned)((nRows + 255) / 256);
-    switch (nOut) {
-    case 1: rows_dot_kernel<1><<<blocks, 256, 0, st>>>(P); break;
-    case 2: rows_dot_kernel<2><<<blocks, 256, 0, st>>>(P); break;
-    case 3: rows_dot_kernel<3><<<blocks, 256, 0, st>>>(P); break;
-    default: rows_dot_kernel<4><<<blocks, 256, 0, st>>>(P); break;
+    // a lane's six partial sums take one term below 2^54 per column and are folded once per launch: windows of at most
+    // 1024 columns, the later ones accumulating onto the first one's result
+    for (u64 col0 = 0; col0 < width; col0 += 1024) {
+        RowsDotParams P = { buf, std::min<u64>(1024, width - col0), nRows, width, col0, (const u32 *)d, nOut, acc, (u32)(accumulate != 0 || col0 != 0) };
+        switch (nOut) {
+        case 1: rows_dot_kernel<1><<<blocks, 256, 0, st>>>(P); break;
+        case 2: rows_dot_kernel<2><<<blocks, 256, 0, st>>>(P); break;
+        case 3: rows_dot_kernel<3><<<blocks, 256, 0, st>>>(P); break;
+        default: rows_dot_kernel<4><<<blocks, 256, 0, st>>>(P); break;
+        }
+        KERNEL_CHECK();
     }
-    KERNEL_CHECK();
     HIP_TRY(hipStreamSynchronize(st));      // `limbs` is a host temporary and the scratch slot is reused by the next call
     return PIL2GL_OK;
 }

@@ -404,7 +404,14 @@ struct JitArgs {            // kernel argument block (by value)
     const u64 *scalars; const u32 *limbs; u64 *sec[GLX_MAX_SECTIONS]; u32 nBits; u32 pad_;
 };
 struct JitEntry { hipModule_t mod; hipFunction_t fn; };
-static std::map<std::string, JitEntry> g_jit_cache;
+static std::map<std::string, JitEntry> g_jit_cache;       // modules of the device the library is initialised on (cleared by pil2gl_shutdown)
+namespace pil2gl {
+void jit_clear() {
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
+    for (auto &kv : g_jit_cache) (void)hipModuleUnload(kv.second.mod);
+    g_jit_cache.clear();
+}
+}
 
 static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx_ctx *ctx) {
     std::ostringstream o;
@@ -482,10 +489,24 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
     return o.str();
 }
 
+// target of the run-time compiled kernels: the device the library is initialised on (gfx950 when no device is present:
+// the host-only compile hook of the CPU tests)
+static std::string jit_arch() {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.gcnArchName[0]) {
+        std::string a(pr.gcnArchName);
+        return a.substr(0, a.find(':'));
+    }
+    (void)hipGetLastError();
+    return "gfx950";
+}
+
 static int jit_build(const std::string &src, std::vector<char> &code) {
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "pil2gl_expr.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail(PIL2GL_EHIP, "hiprtcCreateProgram failed");
-    const char *opts[] = { "--offload-arch=gfx950", "-O3", "-ffp-contract=off" };
+    const std::string arch = "--offload-arch=" + jit_arch();
+    const char *opts[] = { arch.c_str(), "-O3", "-ffp-contract=off" };
     hiprtcResult rc = hiprtcCompileProgram(prog, 3, opts);
     if (rc != HIPRTC_SUCCESS) {
         size_t n = 0; hiprtcGetProgramLogSize(prog, &n);
@@ -499,6 +520,7 @@ static int jit_build(const std::string &src, std::vector<char> &code) {
     return PIL2GL_OK;
 }
 static int jit_get(const std::string &src, hipFunction_t *fn) {
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
     auto it = g_jit_cache.find(src);
     if (it != g_jit_cache.end()) { *fn = it->second.fn; return PIL2GL_OK; }
     std::vector<char> code;

@@ -72,7 +72,14 @@ int ensure_init() {
     return pil2gl_init(dev);
 }
 
+// The reference issues its operator calls one after the other from one JS thread and the ABI is specified for
+// that: ONE caller at a time, any stream.  The lock below only keeps the process-global state (device tables, scratch slots,
+// compiled-kernel cache) consistent if two host threads do enter at once; it does not make one scratch slot serve two
+// concurrent calls.
+std::recursive_mutex &runtime_lock() { static std::recursive_mutex m; return m; }
+
 int scratch(u32 slot, u64 nWords, u64 **out) {
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
     if (slot >= N_SCRATCH) return fail(PIL2GL_EINVAL, "bad scratch slot");
     if (g_scratch_words[slot] < nWords) {
         if (g_scratch[slot]) { HIP_TRY(hipDeviceSynchronize()); HIP_TRY(hipFree(g_scratch[slot])); g_scratch[slot] = nullptr; g_scratch_words[slot] = 0; }
@@ -101,6 +108,7 @@ int pil2gl_version(void) { return 1; }
 const char *pil2gl_last_error(void) { return g_err; }
 
 int pil2gl_init(int device) {
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n == 0) { (void)hipGetLastError(); return fail(PIL2GL_ENODEV, "no HIP device available (libpil2gl has no CPU fallback)"); }
@@ -133,8 +141,10 @@ int pil2gl_init(int device) {
 }
 
 void pil2gl_shutdown(void) {
+    std::lock_guard<std::recursive_mutex> lk(runtime_lock());
     if (!g_ready) return;
     (void)hipDeviceSynchronize();
+    jit_clear();                                          // compiled expression kernels belong to the device being left
     for (u32 i = 0; i < N_SCRATCH; i++) { if (g_scratch[i]) (void)hipFree(g_scratch[i]); g_scratch[i] = nullptr; g_scratch_words[i] = 0; }
     if (g_tables_mem) (void)hipFree(g_tables_mem);
     g_tables_mem = nullptr;

@@ -468,7 +468,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         levs = [be.build_lev(nb, S.ext_scale(xis[i], g_inv)) for i in mine]
         sel = [k for k, ev in enumerate(info["evMap"]) if info["openingPoints"].index(ev["prime"]) in mine]
         sub = dict(info); sub["evMap"] = [info["evMap"][k] for k in sel]; sub["openingPoints"] = [info["openingPoints"][i] for i in mine]
-        if hasattr(be, "evals_fast"):
+        if hasattr(be, "evals_fast") and len(levs) <= 4:
             evals = be.evals_fast(sub, loc, widths, nb, lb, levs)          # row k of the coset is local row k << log2(cc)
         else:
             descs = []

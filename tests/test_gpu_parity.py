@@ -717,6 +717,17 @@ def test_rows_and_cols_dot_ext(gl, oracle):
         got = acc.cpu().numpy().view(np.uint64).reshape(n_rows, n_out, 3)
         want = (2 * (m.astype(object) @ coef.astype(object).transpose(1, 0, 2).reshape(width, n_out * 3))) % P
         assert (got.reshape(n_rows, n_out * 3).astype(object) == want).all(), (n_rows, width, n_out, skew)
+    # stages wider than the 1024 terms a lane's unreduced sums can hold (the library cuts them into windows): values and
+    # weights whose every limb is at its maximum, so that a window one column too long would wrap the 64-bit partial sums
+    for n_rows, width, n_out in [(130, 1500, 2), (70, 5000, 4), (64, 1024, 1), (64, 1025, 1)]:
+        m = np.full((n_rows, width), P - 1, dtype=np.uint64); m[1::2] = rand_field(rng, (len(m[1::2]), width))
+        coef = np.full((n_out, width, 3), P - 1, dtype=np.uint64); coef[:, ::3] = rand_field(rng, coef[:, ::3].shape)
+        dm = torch.from_numpy(m.view(np.int64).reshape(-1)).cuda()
+        acc = torch.zeros(n_rows * n_out * 3, dtype=torch.int64, device="cuda")
+        _lib.call("pil2gl_rows_dot_ext_dev", gl._ptr(dm), width, n_rows, gl._ptr(coef), n_out, gl._ptr(acc), 0, None)
+        got = acc.cpu().numpy().view(np.uint64).reshape(n_rows, n_out * 3)
+        want = (m.astype(object) @ coef.astype(object).transpose(1, 0, 2).reshape(width, n_out * 3)) % P
+        assert (got.astype(object) == want).all(), (n_rows, width, n_out)
     # column sums against the oracle's per-column evaluation (stark_gen_helpers.js:250-264)
     nb, eb, width = 11, 3, 9
     buf = rand_field(rng, (1 << (nb + eb), width)); dbuf = torch.from_numpy(buf.view(np.int64)).cuda()

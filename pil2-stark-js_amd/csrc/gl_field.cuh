@@ -77,6 +77,37 @@ __device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
     const u64 w = (u64)a1 * b1 + (u >> 32) + (v >> 32);      // <= 2^64 - 1
     return reduce128_lazy((v << 32) | (u32)t, w);
 }
+
+// The same product with the carries taken where the hardware leaves them -- the multiply-add's carry-out and the
+// subtraction's borrow, as lane masks in SGPRs -- instead of re-derived by 64-bit compares: 13 vector instructions
+// against the 22 hipcc emits for mul_lazy (tools/sbox_bench.hip: an x^7 chain 331 -> 203 issue cycles per wave, the Poseidon
+// permutation 2.28 -> 2.72 G/s).
+//   t = a0 b0;  u = a0 b1 + (t >> 32);  v = a1 b0 + u  (the WHOLE u as addend: the 65th bit is the carry-out);
+//   w = a1 b1 + (v >> 32) + carry 2^32;     z = w0 (2^32-1) + (v0:t0)  (carry c);  z += c (2^32-1)  (cannot wrap);  r = z - w1.
+// The last subtraction borrows with probability ~2^-32 (z < w1 < 2^32): the lane's bit is OR-ed into `bad`, a wave-level
+// value, and the CALLER recomputes the flagged work with mul_lazy (a branch on `bad` is uniform for the wave).
+// Each asm statement is one instruction (plus the two wait states gfx950 wants between a vector instruction that writes
+// an SGPR and one that reads it: hipcc pads its own carry chains the same way, nobody pads an asm string), so register
+// allocation and scheduling stay the compiler's.  Measured, not assumed: where independent work surrounds the products
+// (the NTT tiles) the plain form schedules better and stays; a branch per product, or folding the borrow back in place
+// (three more instructions), both lose the gain.
+__device__ __forceinline__ u64 mul_lazy_b(u64 a, u64 b, u64 &bad) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    u64 v, cy, z, c, br; u32 c01, c201, r0, r1;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v), "=s"(cy) : "v"(a1), "v"(b0), "v"(u));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c01) : "s"(cy));
+    const u64 w = (u64)a1 * b1 + (((u64)c01 << 32) | (v >> 32));   // <= 2^64 - 1: the full product is < 2^128
+    const u64 lo = (v << 32) | (u32)t;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)w), "v"(lo));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c201) : "s"(c));
+    const u64 z2 = (u64)c201 * 0xFFFFFFFFu + z;
+    asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\ts_nop 1\n\tv_subbrev_co_u32_e64 %1, %2, 0, %4, %2"
+        : "=&v"(r0), "=&v"(r1), "=&s"(br) : "v"((u32)z2), "v"((u32)(z2 >> 32)), "v"((u32)(w >> 32)));
+    bad |= br;
+    return ((u64)r1 << 32) | r0;
+}
 // any x any -> canonical
 __device__ __forceinline__ u64 mul(u64 a, u64 b) { return canon(mul_lazy(a, b)); }
 __device__ __forceinline__ u64 sqr(u64 a) { return mul(a, a); }

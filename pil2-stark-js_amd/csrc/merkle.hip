@@ -42,6 +42,7 @@ __device__ __forceinline__ void linear_hash_plain(const u64 *__restrict__ v, u32
     sponge(v, width, digest, m);
 }
 
+// three waves per SIMD (168 VGPRs); held to four (128 VGPRs, 114 spilled) it runs at the same rate
 __global__ void __launch_bounds__(256, 3) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int split, u64 *__restrict__ out) {
     const u64 row0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = row0 < height;
@@ -157,7 +158,7 @@ __global__ void __launch_bounds__(64) sponge_chain_kernel(const u64 *__restrict_
 }
 
 // batch of independent permutations (glwasm.js:216 `poseidon`, hash/poseidon/poseidon.js:57)
-__global__ void __launch_bounds__(256, 2) poseidon_batch_kernel(const u64 *__restrict__ in, const u64 *__restrict__ cap, u64 count, u32 nOut, u64 *__restrict__ out) {
+__global__ void __launch_bounds__(256, 4) poseidon_batch_kernel(const u64 *__restrict__ in, const u64 *__restrict__ cap, u64 count, u32 nOut, u64 *__restrict__ out) {
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i0 < count;
     const u64 i = live ? i0 : count - 1;

@@ -18,33 +18,18 @@ namespace gl {
 #include "poseidon_gl_constants.inc"     // POSEIDON_GL_RC[360]: round r, lane i at [12*r+i]
 #undef POSEIDON_GL_RC_QUAL
 
+// x^7 with the 13-instruction products; a lane flagged in `bad` (probability ~2^-30) must be recomputed with pow7_lazy
+__device__ __forceinline__ u64 pow7_b(u64 x, u64 &bad) {
+    u64 x2 = mul_lazy_b(x, x, bad);
+    u64 x3 = mul_lazy_b(x2, x, bad);
+    u64 x4 = mul_lazy_b(x2, x2, bad);
+    return mul_lazy_b(x3, x4, bad);
+}
 __device__ __forceinline__ u64 pow7_lazy(u64 x) {
     u64 x2 = mul_lazy(x, x);
     u64 x3 = mul_lazy(x2, x);
     u64 x4 = mul_lazy(x2, x2);
     return mul_lazy(x3, x4);
-}
-
-// x^7 in hand-written assembly (gen_sbox_asm.py documents the sequence: 13 vector instructions per product against the
-// 22 hipcc emits).  A product whose last subtraction borrows (probability about 2^-32) sets the lane's bit in `bad`; the
-// callers then recompute with pow7_lazy -- `bad` is a wave-level value, so that branch is uniform.
-#include "poseidon_sbox_asm.inc"
-__device__ __forceinline__ u64 pow7_asm(u64 x, u64 &bad) {
-    u32 y0, y1, a0, a1, b0, b1;
-    asm(GL_SBOX1_TEXT : "=&v"(y0), "=&v"(y1), "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "+s"(bad)
-        : "v"((u32)x), "v"((u32)(x >> 32)) : GL_SBOX1_CLOBBERS);
-    return ((u64)y1 << 32) | y0;
-}
-// three independent S-boxes, interleaved instruction by instruction (each chain's carries in its own SGPR pair)
-__device__ __forceinline__ void pow7x3_asm(u64 &xa, u64 &xb, u64 &xc, u64 &bad) {
-    u32 y[6], t[12];
-    u64 c0, c1, c2;
-    asm(GL_SBOX3_TEXT
-        : "=&v"(y[0]), "=&v"(y[1]), "=&v"(y[2]), "=&v"(y[3]), "=&v"(y[4]), "=&v"(y[5]),
-          "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]), "=&v"(t[8]), "=&v"(t[9]), "=&v"(t[10]), "=&v"(t[11]),
-          "=&s"(c0), "=&s"(c1), "=&s"(c2), "+s"(bad)
-        : "v"((u32)xa), "v"((u32)(xa >> 32)), "v"((u32)xb), "v"((u32)(xb >> 32)), "v"((u32)xc), "v"((u32)(xc >> 32)) : GL_SBOX3_CLOBBERS);
-    xa = ((u64)y[1] << 32) | y[0]; xb = ((u64)y[3] << 32) | y[2]; xc = ((u64)y[5] << 32) | y[4];
 }
 
 // out = M * st with the 6-bit circulant.  The low and high 32-bit halves of the 12 lanes are accumulated
@@ -73,21 +58,21 @@ __device__ __forceinline__ void mds_layer(u64 st[12]) {
     }
 }
 
-// S-box layers of the matrix-core form: hand-written products (pow7_asm / pow7x3_asm); a lane whose product needed the
-// rare borrow path is recomputed with pow7_lazy (the branch is wave-uniform: every lane recomputes, same values)
+// S-box layers of the matrix-core form, on the 13-instruction products (pow7_b): a full layer is checked once, and a
+// wave in which some lane hit the rare borrow recomputes the layer with pow7_lazy (the branch is wave-uniform: every
+// lane recomputes, same values)
 __device__ __forceinline__ void sbox_full(u64 st[12], const u64 *__restrict__ rc) {
-    u64 bad = 0;
+    u64 bad = 0, in[12];
 #pragma unroll
-    for (int i = 0; i < 12; i += 3) {
-        const u64 a = add_lazy_canon(st[i], rc[i]), b = add_lazy_canon(st[i + 1], rc[i + 1]), c = add_lazy_canon(st[i + 2], rc[i + 2]);
-        st[i] = a; st[i + 1] = b; st[i + 2] = c;
-        pow7x3_asm(st[i], st[i + 1], st[i + 2], bad);
-        if (__builtin_expect(bad != 0, 0)) { st[i] = pow7_lazy(a); st[i + 1] = pow7_lazy(b); st[i + 2] = pow7_lazy(c); bad = 0; }
+    for (int i = 0; i < 12; i++) { in[i] = add_lazy_canon(st[i], rc[i]); st[i] = pow7_b(in[i], bad); }
+    if (__builtin_expect(bad != 0, 0)) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = pow7_lazy(in[i]);
     }
 }
 __device__ __forceinline__ u64 sbox_one(u64 x) {
     u64 bad = 0;
-    u64 y = pow7_asm(x, bad);
+    u64 y = pow7_b(x, bad);
     if (__builtin_expect(bad != 0, 0)) y = pow7_lazy(x);
     return y;
 }

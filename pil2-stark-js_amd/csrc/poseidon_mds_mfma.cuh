@@ -63,6 +63,11 @@ __device__ __forceinline__ void mds_layer_mfma(u64 st[12], const MdsMfma &m) {
             Bl[t][e] = (int)((u32)st[4 * t + e] ^ 0x80808080u);
             Bh[t][e] = (int)((u32)(st[4 * t + e] >> 32) ^ 0x80808080u);
         }
+    // the last addition of an element's recombination carries out of 64 bits with probability ~2^-20 (see below): the carry
+    // masks (lane masks in SGPRs, straight from the add) are only OR-ed together here and patched after the layer in a
+    // branch that is uniform for the wave and rarely taken -- three vector instructions per element less than selecting
+    // between r and r + 2^32-1 every time
+    u64 cm[12], any = 0;
 #pragma unroll
     for (int s = 0; s < 3; s++) {
         v16i L = m.C, H = m.C;
@@ -84,12 +89,21 @@ __device__ __forceinline__ void mds_layer_mfma(u64 st[12], const MdsMfma &m) {
             }
             const u64 X = (u64)xc * m.sh16 + xa;
             const u64 Y = (u64)yc * m.sh16 + ya;
-            // X + Y*2^32 = X + Y_hi*2^64 + Y_lo*2^32 = (X + Y_hi*(2^32-1)) + Y_lo*2^32   (mod p)
+            // X + Y*2^32 = X + Y_hi*2^64 + Y_lo*2^32 = (X + Y_hi*(2^32-1)) + Y_lo*2^32   (mod p); the bracket is < 2^44, so the
+            // high word of the sum wraps only when Y_lo >= 2^32 - 2^12
             const u64 tt = (u64)(u32)(Y >> 32) * EPS + X;
             u32 th;
-            const bool c = __builtin_uadd_overflow((u32)(tt >> 32), (u32)Y, &th);
-            const u64 r = ((u64)th << 32) | (u32)tt;
-            st[4 * s + ii] = c ? r + EPS : r;
+            asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(th), "=s"(cm[4 * s + ii]) : "v"((u32)(tt >> 32)), "v"((u32)Y));
+            any |= cm[4 * s + ii];
+            st[4 * s + ii] = ((u64)th << 32) | (u32)tt;
+        }
+    }
+    if (__builtin_expect(any != 0, 0)) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            u32 e;
+            asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(e) : "s"(cm[i]));
+            st[i] += e;                                        // wrapped once: the value is small, + 2^32-1 cannot wrap again
         }
     }
 }

@@ -153,6 +153,21 @@ def test_mds_layer_structured_inputs(gl, mfma):
     for j in range(12):
         for v in (1, 0xFF, 1 << 63, (1 << 64) - 1, 0x80, 0x100):
             s = [0] * 12; s[j] = v; states.append(s)
+    # states that make the LAST addition of an element's recombination carry out of 64 bits (probability ~2^-20 on random
+    # data; the matrix-core form patches those lanes in a rarely taken branch): one non-zero high word v in column j with
+    # M[i][j] * v = (k + 1) 2^32 - 1 - r and k - 1 > r, alone and together with random other elements
+    hit = 0
+    for j in range(12):
+        for i in range(12):
+            mij = M[i][j]
+            for k in range(mij - 1, 0, -1):
+                v = ((k + 1) * 2 ** 32 - 1) // mij
+                if v < 2 ** 32 and ((mij * v >> 32) * (2 ** 32 - 1) >> 32) + (mij * v & 0xFFFFFFFF) >= 2 ** 32:
+                    s = [0] * 12; s[j] = v << 32; states.append(s)
+                    s2 = [int(x) for x in rng.integers(0, 1 << 20, 12, dtype=np.uint64)]; s2[j] = v << 32; states.append(s2)
+                    hit += 1
+                    break
+    assert hit > 50
     for _ in range(300):                     # random sparse bytes
         s = []
         for j in range(12):

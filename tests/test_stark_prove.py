@@ -179,7 +179,7 @@ def test_config3_size_proof_verifies(oracle):
           "steps": [{"nBits": b} for b in (27, 22, 17, 12, 7)]}
     info, exprs, vinfo = stark.fibonacci_air(n_cols // 2, ss)
     gpu = stark.GpuBackend(0, False)
-    cm, consts, publics = bench.fibonacci_trace_gpu(torch, torch.device("cuda", 0), n_bits, n_cols // 2, 0)
+    cm, consts, publics = bench.fibonacci_trace_gpu(torch.device("cuda", 0), n_bits, n_cols // 2, 0)
     setup = stark.build_const_tree(gpu, consts, info)
     res = stark.stark_gen(gpu, cm, setup, info, exprs, publics)
     del cm

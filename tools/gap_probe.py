@@ -7,7 +7,7 @@ n_bits, n_cols = 24, 100
 ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 64, "verificationHashType": "GL", "splitLinearHash": False, "steps": [{"nBits": b} for b in (27, 22, 17, 12, 7)]}
 info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
 be = stark.GpuBackend(0, False)
-src, consts, publics = bench.fibonacci_trace_gpu(torch, dev, n_bits, n_cols // 2, 0)
+src, consts, publics = bench.fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
 setup = stark.build_const_tree(be, consts, info)
 for i in range(5):
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -48,6 +48,52 @@ __global__ void __launch_bounds__(256) k_hazard(u64 *out, int iters, u64 seed) {
     out[id] = ((u64)(a[0] ^ a[2]) << 32) | (a[1] ^ a[3]);
 }
 
+// ---- a Goldilocks product from SMALL asm statements (registers stay the compiler's): the carries hipcc re-derives with
+// 64-bit compares come out of the multiply-adds as lane masks
+__device__ __forceinline__ u64 mul_s(u64 a, u64 b, u64 &bad) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    u64 v, cy; u32 c01;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v), "=s"(cy) : "v"(a1), "v"(b0), "v"(u));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c01) : "s"(cy));
+    const u64 w = (u64)a1 * b1 + (((u64)c01 << 32) | (v >> 32));
+    const u64 lo = (v << 32) | (u32)t;
+    u64 z, c2; u32 c201;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c2) : "v"((u32)w), "v"(lo));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c201) : "s"(c2));
+    const u64 z2 = (u64)c201 * 0xFFFFFFFFu + z;
+    u32 r0, r1; u64 br;
+    asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\ts_nop 1\n\tv_subbrev_co_u32_e64 %1, %2, 0, %4, %2" : "=&v"(r0), "=&v"(r1), "=&s"(br) : "v"((u32)z2), "v"((u32)(z2 >> 32)), "v"((u32)(w >> 32)));
+    bad |= br;
+    return ((u64)r1 << 32) | r0;
+}
+__device__ __forceinline__ u64 pow7_s(u64 x, u64 &bad) { u64 x2 = mul_s(x, x, bad), x3 = mul_s(x2, x, bad), x4 = mul_s(x2, x2, bad); return mul_s(x3, x4, bad); }
+// exact variant: the borrow is folded back in place (three more instructions, no fallback)
+__device__ __forceinline__ u64 mul_e(u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    u64 v, cy; u32 c01;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v), "=s"(cy) : "v"(a1), "v"(b0), "v"(u));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c01) : "s"(cy));
+    const u64 w = (u64)a1 * b1 + (((u64)c01 << 32) | (v >> 32));
+    const u64 lo = (v << 32) | (u32)t;
+    u64 z, c2; u32 c201;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c2) : "v"((u32)w), "v"(lo));
+    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c201) : "s"(c2));
+    const u64 z2 = (u64)c201 * 0xFFFFFFFFu + z;
+    u32 r0, r1, m;
+    // r = z2 - w1; on a borrow the true value is r - (2^32 - 1) = (r0 + 1, r1 - 1 + carry)
+    asm("v_sub_co_u32 %0, vcc, %3, %5\n\ts_nop 1\n\tv_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\ts_nop 1\n\t"
+        "v_cndmask_b32 %2, 0, -1, vcc\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc"
+        : "=&v"(r0), "=&v"(r1), "=&v"(m) : "v"((u32)z2), "v"((u32)(z2 >> 32)), "v"((u32)(w >> 32)) : "vcc");
+    return ((u64)r1 << 32) | r0;
+}
+__device__ __forceinline__ u64 pow7_e(u64 x) { u64 x2 = mul_e(x, x), x3 = mul_e(x2, x), x4 = mul_e(x2, x2); return mul_e(x3, x4); }
+
+__device__ __forceinline__ u64 pow7_c(u64 x) { return pow7_lazy(x); }
+
 // ---- S-box variants ----
 template <int V>
 __global__ void __launch_bounds__(256) k_sbox(u64 *out, int iters, u64 seed, int dump) {
@@ -59,23 +105,19 @@ __global__ void __launch_bounds__(256) k_sbox(u64 *out, int iters, u64 seed, int
     for (int it = 0; it < iters; it++) {
         if (V == 0) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) x[i] = pow7_lazy(x[i]);
+            for (int i = 0; i < 12; i++) x[i] = pow7_c(x[i]);
         }
-        if (V == 1) {
+        if (V == 3) {
 #pragma unroll
             for (int i = 0; i < 12; i++) {
                 const u64 in = x[i];
-                x[i] = pow7_asm(in, bad);
+                x[i] = pow7_s(in, bad);
                 if (__builtin_expect(bad != 0, 0)) { x[i] = pow7_lazy(in); bad = 0; nbad++; }
             }
         }
-        if (V == 2) {
+        if (V == 4) {
 #pragma unroll
-            for (int i = 0; i < 12; i += 3) {
-                const u64 i0 = x[i], i1 = x[i + 1], i2 = x[i + 2];
-                pow7x3_asm(x[i], x[i + 1], x[i + 2], bad);
-                if (__builtin_expect(bad != 0, 0)) { x[i] = pow7_lazy(i0); x[i + 1] = pow7_lazy(i1); x[i + 2] = pow7_lazy(i2); bad = 0; nbad++; }
-            }
+            for (int i = 0; i < 12; i++) x[i] = pow7_e(x[i]);
         }
         // a cheap lane-local shuffle between rounds so that the twelve values do not stay in a fixed orbit
         const u64 t = x[0];
@@ -98,15 +140,17 @@ __device__ inline void perm_v(u64 st[12], const MdsMfma &m) {
         if (V == 0) {
 #pragma unroll
             for (int i = 0; i < 12; i++) st[i] = pow7_lazy(st[i]);
-        } else if (V == 1) {
+        } else if (V == 4) {
 #pragma unroll
-            for (int i = 0; i < 12; i++) { const u64 in = st[i]; st[i] = pow7_asm(in, bad); if (__builtin_expect(bad != 0, 0)) { st[i] = pow7_lazy(in); bad = 0; } }
-        } else {
+            for (int i = 0; i < 12; i++) { const u64 in = st[i]; st[i] = pow7_b(in, bad); if (__builtin_expect(bad != 0, 0)) { st[i] = pow7_lazy(in); bad = 0; } }
+        } else if (V == 5) {
+            u64 in[12];
 #pragma unroll
-            for (int i = 0; i < 12; i += 3) {
-                const u64 i0 = st[i], i1 = st[i + 1], i2 = st[i + 2];
-                pow7x3_asm(st[i], st[i + 1], st[i + 2], bad);
-                if (__builtin_expect(bad != 0, 0)) { st[i] = pow7_lazy(i0); st[i + 1] = pow7_lazy(i1); st[i + 2] = pow7_lazy(i2); bad = 0; }
+            for (int i = 0; i < 12; i++) { in[i] = st[i]; st[i] = pow7_b(in[i], bad); }
+            if (__builtin_expect(bad != 0, 0)) {
+#pragma unroll
+                for (int i = 0; i < 12; i++) st[i] = pow7_lazy(in[i]);
+                bad = 0;
             }
         }
         mds_layer_mfma(st, m);
@@ -117,7 +161,7 @@ __device__ inline void perm_v(u64 st[12], const MdsMfma &m) {
     for (int r = 0; r < 22; r++) {
         const u64 in = add_lazy_canon(st[0], POSEIDON_GL_PARTIAL_C0[r]);
         if (V == 0) st[0] = pow7_lazy(in);
-        else { st[0] = pow7_asm(in, bad); if (__builtin_expect(bad != 0, 0)) { st[0] = pow7_lazy(in); bad = 0; } }
+        else { st[0] = pow7_b(in, bad); if (__builtin_expect(bad != 0, 0)) { st[0] = pow7_lazy(in); bad = 0; } }
         mds_layer_mfma(st, m);
     }
 #pragma unroll 1
@@ -182,12 +226,13 @@ int main() {
         float t2 = timeit([&] { hipLaunchKernelGGL(k_hazard<2>, dim3(blocks), dim3(256), 0, 0, out, it, 99ull); });
         printf("time: unpadded vcc %.2f ms, padded vcc %.2f ms, unpadded sgpr %.2f ms\n", t0, t1, t2);
     }
-    // 2. S-box variants: values
+    // 2. S-box variants: values (0 = gl::mul_lazy as hipcc compiles it, 3 = carry-out products + fallback per S-box,
+    //    4 = carry-out products with the borrow folded back in place)
     for (int dump = 1; dump <= 2; dump++) {
         hipLaunchKernelGGL(k_sbox<0>, dim3(blocks), dim3(256), 0, 0, out, 7, 4242ull, dump); CHECK(hipMemcpy(h0, out, 8 * n * 12, hipMemcpyDeviceToHost));
-        for (int v = 1; v <= 2; v++) {
-            if (v == 1) hipLaunchKernelGGL(k_sbox<1>, dim3(blocks), dim3(256), 0, 0, out, 7, 4242ull, dump);
-            else hipLaunchKernelGGL(k_sbox<2>, dim3(blocks), dim3(256), 0, 0, out, 7, 4242ull, dump);
+        for (int v = 3; v <= 4; v++) {
+            if (v == 3) hipLaunchKernelGGL(k_sbox<3>, dim3(blocks), dim3(256), 0, 0, out, 7, 4242ull, dump);
+            else hipLaunchKernelGGL(k_sbox<4>, dim3(blocks), dim3(256), 0, 0, out, 7, 4242ull, dump);
             CHECK(hipMemcpy(h1, out, 8 * n * 12, hipMemcpyDeviceToHost));
             size_t bad = 0; for (size_t i = 0; i < n * 12; i++) bad += h0[i] != h1[i];
             printf("sbox variant %d vs pow7_lazy (inputs %s): %zu of %zu values differ\n", v, dump == 1 ? "random" : "edge", bad, n * 12);
@@ -198,37 +243,35 @@ int main() {
         const int it = 200;
         float t[3];
         t[0] = timeit([&] { hipLaunchKernelGGL(k_sbox<0>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
-        t[1] = timeit([&] { hipLaunchKernelGGL(k_sbox<1>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
-        t[2] = timeit([&] { hipLaunchKernelGGL(k_sbox<2>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
-        const char *nm[3] = { "pow7_lazy (hipcc)", "pow7_asm (1 chain, vcc, padded)", "pow7x3_asm (3 chains, sgpr carries)" };
+        t[1] = timeit([&] { hipLaunchKernelGGL(k_sbox<3>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
+        t[2] = timeit([&] { hipLaunchKernelGGL(k_sbox<4>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
+        const char *nm[3] = { "pow7_lazy (hipcc's plain-C product)", "carry-out products + fallback per S-box", "carry-out products, borrow folded in place" };
         for (int v = 0; v < 3; v++) {
             double ops = (double)n * it * 12;
-            printf("%-40s %8.3f ms  %7.2f G sbox/s  (%.1f cyc per wave-sbox per SIMD @2.4GHz)\n", nm[v], t[v], ops / t[v] / 1e6, 2.4e9 * 1024 * 64 / (ops / (t[v] * 1e-3)));
+            printf("%-44s %8.3f ms  %7.2f G sbox/s  (%.1f cyc per wave-sbox per SIMD @2.4GHz)\n", nm[v], t[v], ops / t[v] / 1e6, 2.4e9 * 1024 * 64 / (ops / (t[v] * 1e-3)));
         }
     }
-    // 4. permutation: values and rates
+    // 4. permutation: values and rates (0 = pow7_lazy, 4 = pow7_b checked per S-box, 5 = pow7_b checked per layer)
     {
         hipLaunchKernelGGL(k_perm<0>, dim3(blocks), dim3(256), 0, 0, out, 3, 77ull, 1); CHECK(hipMemcpy(h0, out, 8 * n * 12, hipMemcpyDeviceToHost));
-        hipLaunchKernelGGL(k_perm<1>, dim3(blocks), dim3(256), 0, 0, out, 3, 77ull, 1); CHECK(hipMemcpy(h1, out, 8 * n * 12, hipMemcpyDeviceToHost));
-        size_t bad = 0; for (size_t i = 0; i < n * 12; i++) bad += h0[i] != h1[i];
-        printf("permutation with pow7_asm vs pow7_lazy: %zu of %zu words differ\n", bad, n * 12);
-        hipLaunchKernelGGL(k_perm<2>, dim3(blocks), dim3(256), 0, 0, out, 3, 77ull, 1); CHECK(hipMemcpy(h1, out, 8 * n * 12, hipMemcpyDeviceToHost));
-        bad = 0; for (size_t i = 0; i < n * 12; i++) bad += h0[i] != h1[i];
-        printf("permutation with pow7x3_asm vs pow7_lazy: %zu of %zu words differ\n", bad, n * 12);
+        hipLaunchKernelGGL(k_perm<4>, dim3(blocks), dim3(256), 0, 0, out, 3, 77ull, 1); CHECK(hipMemcpy(h1, out, 8 * n * 12, hipMemcpyDeviceToHost));
+        { size_t b4 = 0; for (size_t i = 0; i < n * 12; i++) b4 += h0[i] != h1[i]; printf("permutation with pow7_b (check per S-box): %zu words differ\n", b4); }
+        hipLaunchKernelGGL(k_perm<5>, dim3(blocks), dim3(256), 0, 0, out, 3, 77ull, 1); CHECK(hipMemcpy(h1, out, 8 * n * 12, hipMemcpyDeviceToHost));
+        { size_t b5 = 0; for (size_t i = 0; i < n * 12; i++) b5 += h0[i] != h1[i]; printf("permutation with pow7_b (check per layer): %zu words differ\n", b5); }
         const int it = 20;
-        float t0 = timeit([&] { hipLaunchKernelGGL(k_perm<0>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
-        float t1 = timeit([&] { hipLaunchKernelGGL(k_perm<1>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
-        float t2 = timeit([&] { hipLaunchKernelGGL(k_perm<2>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
         double np = (double)n * it;
-        printf("permutation, hipcc S-box      %8.3f ms  %6.3f G perm/s\n", t0, np / t0 / 1e6);
-        printf("permutation, pow7_asm         %8.3f ms  %6.3f G perm/s\n", t1, np / t1 / 1e6);
-        printf("permutation, pow7x3_asm       %8.3f ms  %6.3f G perm/s\n", t2, np / t2 / 1e6);
+        float t0 = timeit([&] { hipLaunchKernelGGL(k_perm<0>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
+        float t4 = timeit([&] { hipLaunchKernelGGL(k_perm<4>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
+        float t5 = timeit([&] { hipLaunchKernelGGL(k_perm<5>, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
+        printf("permutation, pow7_lazy        %8.3f ms  %6.3f G perm/s\n", t0, np / t0 / 1e6);
+        printf("permutation, pow7_b / S-box   %8.3f ms  %6.3f G perm/s\n", t4, np / t4 / 1e6);
+        printf("permutation, pow7_b / layer   %8.3f ms  %6.3f G perm/s\n", t5, np / t5 / 1e6);
     }
     {
         const int it = 20; double np = (double)n * it;
         hipLaunchKernelGGL(k_prod3, dim3(blocks), dim3(256), 0, 0, out, 3, 77ull, 1); CHECK(hipMemcpy(h1, out, 8 * n * 12, hipMemcpyDeviceToHost));
         size_t bad = 0; for (size_t i = 0; i < n * 12; i++) bad += h0[i] != h1[i];
-        printf("production poseidon_perm vs pow7_lazy build: %zu of %zu words differ\n", bad, n * 12);
+        printf("production poseidon_perm vs the pow7_lazy permutation: %zu of %zu words differ\n", bad, n * 12);
         float t2 = timeit([&] { hipLaunchKernelGGL(k_prod2, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
         float t3 = timeit([&] { hipLaunchKernelGGL(k_prod3, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
         float t4 = timeit([&] { hipLaunchKernelGGL(k_prod4, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });

@@ -180,3 +180,50 @@ const EDGE = [0n, 1n, 2n, F.p - 1n, F.p - 2n, 0xFFFFFFFFn, 0x100000000n, 0xFFFFF
     }
     write("zerofiers.json", hx(out));
 }
+
+// ---------------------------------------------------------------- stage-2 hints: calculateZ / calculateS / calculateH1H2 (polutils.js:105-164), run as they are
+async function hints() {
+    const { calculateZ, calculateS, calculateH1H2 } = require(path.join(ref, "src/helpers/polutils.js"));
+    const col = (n, dim) => { const a = []; for (let i = 0; i < n; i++) a.push(dim === 1 ? (rndF() || 1n) : rnd3()); return a; };
+    const z = [], s = [], h = [];
+    for (const [n, dn, dd] of [[1, 1, 1], [2, 1, 1], [16, 1, 1], [37, 3, 1], [64, 1, 3], [50, 3, 3], [300, 3, 3]]) {
+        const num = col(n, dn), den = col(n, dd);
+        z.push({ n, dimNum: dn, dimDen: dd, num, den, gprod: await calculateZ(F, num, den) });
+        const one = dn === 1 ? rndF() : rnd3();            // calculateS takes ONE numerator (polutils.js:153)
+        s.push({ n, dimNum: dn, dimDen: dd, num: one, den, gsum: await calculateS(F, one, den) });
+    }
+    // a grand product that closes: numerators = the denominators rotated by one row (a permutation argument)
+    { const den = col(33, 3), num = den.slice(1).concat([den[0]]); z.push({ n: 33, dimNum: 3, dimDen: 3, num, den, gprod: await calculateZ(F, num, den) }); }
+    for (const [n, dim, distinct] of [[1, 1, 1], [8, 1, 3], [64, 1, 64], [200, 3, 17], [128, 3, 128], [100, 1, 1]]) {
+        const vals = col(distinct, dim);
+        const t = []; for (let i = 0; i < n; i++) t.push(distinct < n ? vals[Number(rnd64() % BigInt(distinct))] : vals[i]);
+        const f = []; for (let i = 0; i < n; i++) f.push(t[Number(rnd64() % BigInt(n))]);
+        if (n >= 8) for (let i = 0; i < n / 4; i++) f[i] = t[0];                       // one heavily used entry
+        const [h1, h2] = calculateH1H2(F, f, t);
+        h.push({ n, dim, f, t, h1, h2 });
+    }
+    write("hints.json", hx({ gprod: z, gsum: s, h1h2: h }));
+}
+
+// ---------------------------------------------------------------- proof2zkin (src/proof2zkin.js:1-75) on synthetic proof objects of every shape it distinguishes
+function zkin() {
+    const { proof2zkin } = require(path.join(ref, "src/proof2zkin.js"));
+    const dig = () => [rndF(), rndF(), rndF(), rndF()];
+    const list = (n, g) => { const a = []; for (let i = 0; i < n; i++) a.push(g()); return a; };
+    const out = [];
+    for (const [nStages, widths, nSub, steps, nQueries] of [[1, { cm1: 2, cm2: 3 }, 0, [5, 3, 1], 2], [2, { cm1: 3, cm2: 4, cm3: 6 }, 0, [6, 2], 3],
+        [3, { cm1: 2, cm2: 0, cm3: 5, cm4: 3 }, 2, [7, 4, 2], 2], [2, { cm1: 1, cm2: 2, cm3: 3 }, 1, [4], 1]]) {
+        const qStage = nStages + 1;
+        const starkInfo = { starkStruct: { nQueries, steps: steps.map((b) => ({ nBits: b })) }, nStages, nSubproofValues: nSub, mapSectionsN: widths };
+        const p = { evals: list(5, rnd3), subproofValues: list(nSub, rnd3), fri: [] };
+        for (let s = 1; s <= qStage; s++) p["root" + s] = dig();
+        const opening = (w, levels) => [list(w, rndF), list(levels, dig)];
+        p.fri.push({ polQueries: list(nQueries, () => { const q = []; for (let s = 1; s <= qStage; s++) q.push(opening(widths["cm" + s], steps[0])); q.push(opening(2, steps[0])); return q; }) });
+        for (let i = 1; i < steps.length; i++) p.fri.push({ root: dig(), polQueries: list(nQueries, () => opening(3 << (steps[i - 1] - steps[i]), steps[i])) });
+        p.fri.push(list(1 << steps[steps.length - 1], rnd3));
+        out.push({ starkInfo, proof: p, zkin: proof2zkin(p, starkInfo) });
+    }
+    write("proof2zkin.json", hx(out));
+}
+
+hints().then(zkin);

@@ -63,9 +63,11 @@ def proof2zkin(p, starkInfo):
         z["s%d_vals" % i] = [p["fri"][i]["polQueries"][q][0] for q in range(nQueries)]
         z["s%d_siblings" % i] = [p["fri"][i]["polQueries"][q][1] for q in range(nQueries)]
     stages = [1] + [s for s in range(2, nStages + 1) if starkInfo["mapSectionsN"].get("cm%d" % s, 0) > 0]
-    z["s0_valsC"], z["s0_siblingsC"] = [], []
-    for s in stages + [qStage]:
-        z["s0_vals%d" % s], z["s0_siblings%d" % s] = [], []
+    # the reference creates the fields in this order (proof2zkin.js:31-47) and JSON.stringify keeps it in the zkin file
+    for kind in ("vals", "siblings"):
+        z["s0_%sC" % kind] = []
+        for s in stages + [qStage]:
+            z["s0_%s%d" % (kind, s)] = []
     for i in range(nQueries):
         query = p["fri"][0]["polQueries"][i]
         for s in stages:

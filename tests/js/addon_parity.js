@@ -205,6 +205,23 @@ class ChunkedBuffer {
             for (let i = 0; i < ff.length; i++) { assert.strictEqual(h1[i], sArr[2 * i][0]); assert.strictEqual(h2[i], sArr[2 * i + 1][0]); }
         }
         assert.throws(() => PU.calculateH1H2(null, [4n], [5n]), /Number not included/);
+        {   // the same three drop-ins against vectors the reference's own functions wrote (tests/golden/hints.json, oracle/gen_golden.js)
+            const hints = G("hints.json");
+            const norm = (v, dim) => v.map((r) => { const x = H(r); return dim === 1 ? x : (Array.isArray(x) ? x : [x, 0n, 0n]); });   // F.one in row 0 of an extension column
+            for (const c of hints.gprod) {
+                const dim = Math.max(c.dimNum, c.dimDen);
+                assert.deepStrictEqual(await PU.calculateZ(null, norm(c.num, c.dimNum), norm(c.den, c.dimDen)), norm(c.gprod, dim), "calculateZ golden n=" + c.n);
+            }
+            for (const c of hints.gsum) {
+                const dim = Math.max(c.dimNum, c.dimDen);
+                assert.deepStrictEqual(await PU.calculateS(null, norm([c.num], c.dimNum)[0], norm(c.den, c.dimDen)), norm(c.gsum, dim), "calculateS golden n=" + c.n);
+            }
+            for (const c of hints.h1h2) {
+                const [g1, g2] = PU.calculateH1H2(null, norm(c.f, c.dim), norm(c.t, c.dim));
+                assert.deepStrictEqual(g1, norm(c.h1, c.dim), "calculateH1H2 h1 golden n=" + c.n);
+                assert.deepStrictEqual(g2, norm(c.h2, c.dim), "calculateH1H2 h2 golden n=" + c.n);
+            }
+        }
         // the three stages on a small context
         const MHs = await buildMH(false);
         const ctx = {

@@ -711,6 +711,36 @@ def test_h1h2_columns(gl, oracle, n, dim, distinct):
                 gl.calculateH1H2(torch.from_numpy(bad.reshape(-1).copy().view(np.int64)).cuda(), dt, dim)
 
 
+def test_hints_against_reference_vectors(gl):
+    """the device hint kernels against vectors written by the reference's own calculateZ / calculateS / calculateH1H2
+    (polutils.js:105-164, run by oracle/gen_golden.js)"""
+    import torch
+    g = golden("hints.json")
+
+    def rows(v, dim):
+        out = []
+        for r in v:
+            r = H(r)
+            out.append(list(r) if isinstance(r, list) else [r] + [0] * (dim - 1))       # F.one in row 0 of an extension column
+        return out
+
+    def dev(v, dim):
+        return torch.from_numpy(np.array(rows(v, dim), dtype=np.uint64).reshape(-1).view(np.int64)).cuda()
+    for c in g["gprod"]:
+        dn, dd = c["dimNum"], c["dimDen"]; dim = max(dn, dd)
+        z = gl.calculateZ(dev(c["num"], dn), dev(c["den"], dd), dn, dd).cpu().numpy().view(np.uint64).reshape(-1, dim)
+        assert z.tolist() == rows(c["gprod"], dim), (c["n"], dn, dd)
+    for c in g["gsum"]:
+        dn, dd = c["dimNum"], c["dimDen"]; dim = max(dn, dd)
+        sres = gl.calculateS(dev([c["num"]], dn), dev(c["den"], dd), dn, dd).cpu().numpy().view(np.uint64).reshape(-1, dim)
+        assert sres.tolist() == rows(c["gsum"], dim), (c["n"], dn, dd)
+    for c in g["h1h2"]:
+        d = c["dim"]
+        h1, h2 = gl.calculateH1H2(dev(c["f"], d), dev(c["t"], d), d)
+        assert h1.cpu().numpy().view(np.uint64).reshape(-1, d).tolist() == rows(c["h1"], d), (c["n"], d)
+        assert h2.cpu().numpy().view(np.uint64).reshape(-1, d).tolist() == rows(c["h2"], d), (c["n"], d)
+
+
 # ------------------------------------------------------------------ extension-weighted sums (csrc/dot.hip)
 def test_rows_and_cols_dot_ext(gl, oracle):
     import ctypes as C

@@ -167,3 +167,41 @@ def test_hint_columns_against_python_integers(oracle):
     den3 = np.zeros((n, 3), np.uint64); den3[:, 0] = den
     z3 = oracle.gprod(num3, den3, 3, 3).reshape(n, 3)
     assert [int(x) for x in z3[:, 0]] == z and not z3[:, 1:].any()
+
+
+# ---- stage-2 hints and the zkin mapping against the reference's own functions (oracle/gen_golden.js runs
+#      polutils.js calculateZ / calculateS / calculateH1H2 and src/proof2zkin.js as they are)
+def _rows(v, dim):
+    """reference values -> n x dim ints: an extension column may hold the scalar F.one in row 0 (polutils.js:135)"""
+    out = []
+    for r in v:
+        r = H(r)
+        out.append(list(r) if isinstance(r, list) else [r] + [0] * (dim - 1))
+    return out
+
+
+def test_hints_against_reference_vectors(oracle):
+    g = golden("hints.json")
+    for c in g["gprod"]:
+        dn, dd = c["dimNum"], c["dimDen"]
+        dim = max(dn, dd)
+        num = np.array(_rows(c["num"], dn), dtype=np.uint64).reshape(-1); den = np.array(_rows(c["den"], dd), dtype=np.uint64).reshape(-1)
+        assert oracle.gprod(num, den, dn, dd).reshape(-1, dim).tolist() == _rows(c["gprod"], dim), (c["n"], dn, dd)
+    for c in g["gsum"]:
+        dn, dd = c["dimNum"], c["dimDen"]
+        dim = max(dn, dd)
+        num = np.array(_rows([c["num"]], dn), dtype=np.uint64).reshape(-1); den = np.array(_rows(c["den"], dd), dtype=np.uint64).reshape(-1)
+        assert oracle.gsum(num, den, dn, dd).reshape(-1, dim).tolist() == _rows(c["gsum"], dim), (c["n"], dn, dd)
+    for c in g["h1h2"]:
+        key = (lambda r: H(r)) if c["dim"] == 1 else (lambda r: tuple(H(r)))
+        h1, h2 = oracle.h1h2([key(r) for r in c["f"]], [key(r) for r in c["t"]])
+        assert h1 == [key(r) for r in c["h1"]] and h2 == [key(r) for r in c["h2"]], (c["n"], c["dim"])
+
+
+def test_proof2zkin_against_reference_vectors():
+    from pil2gl import io
+    for c in golden("proof2zkin.json"):
+        z = io.proof2zkin(H(c["proof"]), c["starkInfo"])
+        want = H(c["zkin"])
+        assert list(z) == list(want), "field order differs"            # JSON.stringify keeps insertion order: so does the file
+        assert z == want

@@ -24,18 +24,6 @@ def s(v):
     return v
 
 
-n_bits, pairs = 6, 2
-ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 9}, {"nBits": 5}, {"nBits": 2}]}
-info, exprs, _ = stark.fibonacci_air(pairs, ss)
-cm, consts, publics = stark.fibonacci_trace(n_bits, pairs)
-be = OracleBackend()
-setup = stark.build_const_tree(be, consts, info)
-res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
-out = {"pilInfo": info, "expressionsInfo": exprs, "cm1": [str(int(v)) for v in cm.reshape(-1)], "consts": [str(int(v)) for v in consts.reshape(-1)],
-       "publics": [str(v) for v in publics], "constRoot": [str(v) for v in setup["constRoot"]],
-       "proof": json.loads(json.dumps(res["proof"], default=int)), "challenges": res["challenges"], "queries": res["queries"]}
-
-
 def strs(v):
     if isinstance(v, dict):
         return {k: strs(x) for k, x in v.items()}
@@ -46,7 +34,24 @@ def strs(v):
     return v
 
 
-for k in ("proof", "challenges"):
-    out[k] = strs(out[k])
-json.dump(out, open(os.path.join(ROOT, "tests/golden/fib_flow.json"), "w"))
-print("ok", os.path.getsize(os.path.join(ROOT, "tests/golden/fib_flow.json")))
+def write(name, hash_commits):
+    n_bits, pairs = 6, 2
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 9}, {"nBits": 5}, {"nBits": 2}]}
+    if hash_commits:
+        ss["hashCommits"] = True                  # the transcript absorbs hashes of publics / evaluations / last polynomial
+    info, exprs, _ = stark.fibonacci_air(pairs, ss)
+    cm, consts, publics = stark.fibonacci_trace(n_bits, pairs)
+    be = OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    out = {"pilInfo": info, "expressionsInfo": exprs, "cm1": [str(int(v)) for v in cm.reshape(-1)], "consts": [str(int(v)) for v in consts.reshape(-1)],
+           "publics": [str(v) for v in publics], "constRoot": [str(v) for v in setup["constRoot"]],
+           "proof": json.loads(json.dumps(res["proof"], default=int)), "challenges": res["challenges"], "queries": res["queries"]}
+    for k in ("proof", "challenges"):
+        out[k] = strs(out[k])
+    json.dump(out, open(os.path.join(ROOT, "tests/golden", name), "w"))
+    print("ok", name, os.path.getsize(os.path.join(ROOT, "tests/golden", name)))
+
+
+write("fib_flow.json", False)
+write("fib_flow_hashcommits.json", True)

@@ -3,6 +3,7 @@
 //   computeQStark(ctx, options)                                                       stark_gen_helpers.js:168-208
 //   computeEvalsStark(ctx, options)                                                   stark_gen_helpers.js:210-273
 //   computeFRIStark(ctx, options)                                                     stark_gen_helpers.js:275-335
+//   calculateHashStark(ctx, inputs)   (starkStruct.hashCommits)                       stark_gen_helpers.js:442-461
 // ctx is the reference's prover context (ctx.q_ext, ctx.cm<k>_ext, ctx.const_ext, ctx.x_ext, ctx.xDivXSubXi_ext, ctx.f_ext
 // are BigBuffers / BigUint64Arrays; ctx.MH, ctx.trees, ctx.challenges, ctx.pilInfo, ctx.expressionsInfo as the reference
 // builds them).  Each stage uploads what it reads, runs on the device and stores what the reference stores.
@@ -97,8 +98,22 @@ module.exports.computeEvalsStark = async function computeEvalsStark(ctx, options
         ctx.evals = [];
         for (let i = 0; i < nEv; i++) ctx.evals[i] = [out[3 * i], out[3 * i + 1], out[3 * i + 2]];
     } finally { for (const d of ptrs) addon.devFree(d); }
-    if (ctx.pilInfo.starkStruct.hashCommits) throw new Error("hashCommits: hash ctx.evals with the reference's calculateHashStark");
+    if (ctx.pilInfo.starkStruct.hashCommits) return [await module.exports.calculateHashStark(ctx, ctx.evals)];      // :267-272
     return ctx.evals;
+};
+
+// stark_gen_helpers.js:442-461: the hash of a list of values = the state of a fresh transcript that absorbed them
+// (used for the publics, the evaluations and the last FRI polynomial when starkStruct.hashCommits is set)
+module.exports.calculateHashStark = async function calculateHashStark(ctx, inputs) {
+    const ss = ctx.pilInfo.starkStruct;
+    let transcript;
+    if (ss.verificationHashType === "GL") {
+        transcript = new (require("./transcript.js"))(require("./poseidon.js")());
+    } else if (ss.verificationHashType === "BN128") {
+        transcript = new (require("./transcript_bn128.js"))(ss.merkleTreeCustom ? ss.merkleTreeArity : 16);
+    } else throw new Error("Invalid Hash Type: " + ss.verificationHashType);
+    for (let i = 0; i < inputs.length; i++) transcript.put(inputs[i]);
+    return transcript.getState();
 };
 
 module.exports.computeFRIStark = async function computeFRIStark(ctx, options) {

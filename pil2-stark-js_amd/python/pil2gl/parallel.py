@@ -381,7 +381,8 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     ctx = {"pilInfo": info, "publics": list(publics), "challenges": [[] for _ in range(nStages + 3)], "evals": []}
     constTree = setup["constTree"]
     transcript = be.new_transcript()
-    transcript.put(setup["constRoot"]); transcript.put(publics)
+    hash_commits = bool(ss.get("hashCommits", False))
+    transcript.put(setup["constRoot"]); S.put_commit(be, transcript, list(publics), hash_commits)
 
     sl = lambda full, w: coset_slice(be, full, nb, eb, cb, cc, w)
     loc = {"const_ext": sl(constTree["elements"], nC), "x_ext": sl(be.build_x(nbe, S.SHIFT), 1),
@@ -486,7 +487,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         del levs
     ev_t = comm.all_reduce_sum(ev_t)                                      # every entry is non-zero on one rank only
     ctx["evals"] = [[int(v) for v in r] for r in ev_t.numpy().view(np.uint64).reshape(n_ev, 3)]
-    transcript.put(ctx["evals"])
+    S.put_commit(be, transcript, ctx["evals"], hash_commits)
 
     lap("evals")
     # FRI polynomial on the local rows, then one all-gather

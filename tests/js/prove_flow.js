@@ -57,7 +57,8 @@ async function prove(g, resident) {
     require(J("native.js")).addon.sync();
     const tStart = process.hrtime.bigint();
     const transcript = new Transcript(poseidon);
-    transcript.put(MH.root(ctx.constTree)); transcript.put(ctx.publics);                        // prover.js:148-189
+    transcript.put(MH.root(ctx.constTree));                                                     // prover.js:148-189
+    transcript.put(ss.hashCommits ? await SGH.calculateHashStark(ctx, ctx.publics) : ctx.publics);
     // stage 1: extendAndMerkelize (stark_gen_helpers.js:388-412)
     await interpolate(ctx.cm1_n, pilInfo.mapSectionsN.cm1, nBits, ctx.cm1_ext, nBitsExt);
     ctx.trees[1] = await MH.merkelize(ctx.cm1_ext, pilInfo.mapSectionsN.cm1, extN);
@@ -78,6 +79,7 @@ async function prove(g, resident) {
         const sp = await ctx.fri.fold(step, ctx.friPol[step], challenge);
         ctx.friPol[step + 1] = sp.pol; ctx.friProof[step + 1] = sp.proof;
         if (step < ss.steps.length - 1) { ctx.friTrees[step + 1] = sp.tree; transcript.put(sp.proof.root); }
+        else if (ss.hashCommits) transcript.put(await SGH.calculateHashStark(ctx, sp.proof));   // stark_gen_helpers.js:349-351
         else for (const e of sp.proof) transcript.put(e);
     }
     const tq = new Transcript(poseidon); tq.put(transcript.getField());
@@ -101,8 +103,10 @@ async function prove(g, resident) {
 module.exports = { prove };
 
 if (require.main === module) (async () => {
-    const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden/fib_flow.json")));
-    await prove(g, false);
-    await prove(g, true);
+    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json"]) {
+        const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden", name)));
+        await prove(g, false);
+        await prove(g, true);
+    }
     console.log("prove flow OK");
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -88,7 +88,19 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
     # transcript replay, calculateTranscriptVerify.js:7-103
     nStages = info["nStages"]; qStage = nStages + 1
     t = be.new_transcript()
-    t.put(constRoot); t.put(publics)
+    hc = bool(ss.get("hashCommits", False))
+
+    def commit_hash(values):                                 # calculateHashStark, stark_gen_helpers.js:442-461
+        h = be.new_transcript()
+        for v in values:
+            h.put(v)
+        return h.getState()
+    t.put(constRoot)
+    if not hc:                                               # calculateTranscriptVerify.js:30-37
+        for v in publics:
+            t.put(v)
+    else:
+        t.put(commit_hash(publics))
     challenges = {}
     got_ch = [[] for _ in range(nStages + 3)]
     for st in range(1, qStage + 1):
@@ -97,8 +109,11 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
             got_ch[st - 1] = [t.getField() for _ in range(n_ch)]
         t.put(proof["root%d" % st])
     xi = t.getField(); got_ch[qStage] = [xi]
-    for ev in proof["evals"]:
-        t.put(ev)
+    if not hc:                                               # :61-68
+        for ev in proof["evals"]:
+            t.put(ev)
+    else:
+        t.put(commit_hash(proof["evals"]))
     vf1 = t.getField(); vf2 = t.getField(); got_ch[qStage + 1] = [vf1, vf2]
     for st, lst in enumerate(got_ch):
         for k, c in enumerate(lst):
@@ -108,9 +123,11 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
         chF.append(t.getField())
         if step < len(steps) - 1:
             t.put(proof["fri"][step + 1]["root"])
-        else:
+        elif not hc:                                         # :87-94
             for e in proof["fri"][-1]:
                 t.put(e)
+        else:
+            t.put(commit_hash(proof["fri"][-1]))
     chF.append(t.getField())
     if check_transcript and not (got_ch == res["challenges"] and chF == res["challengesFRISteps"]):
         return False, "transcript does not reproduce the challenges"

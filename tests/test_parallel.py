@@ -72,6 +72,11 @@ def test_sharded_proof_gpu_ranks(oracle, world, nbits, pairs, steps):
     _launch(world, "--backend", "gpu", "--nbits", str(nbits), "--pairs", str(pairs), "--steps", steps, worker=PROVE_WORKER)
 
 
+def test_sharded_hash_commits_proof_cpu(oracle):
+    """starkStruct.hashCommits in the sharded prove loop (publics, evaluations and last polynomial absorbed as hashes)"""
+    _launch(2, "--backend", "oracle", "--hashcommits", "1", worker=PROVE_WORKER)
+
+
 def test_sharded_two_stage_proof_cpu(oracle):
     """two witness stages (stage 2 = challenge + grand-product hint): stage 2 is committed by cosets like stage 1"""
     _launch(2, "--backend", "oracle", "--air", "perm", worker=PROVE_WORKER)

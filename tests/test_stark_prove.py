@@ -278,3 +278,52 @@ def test_gpu_two_stage_proof_is_identical_to_oracle_proof(oracle, n_bits, steps)
     ok, why = stark.stark_verify(gpu, r_gpu["proof"], publics, s_gpu["constRoot"], info, exprs, vinfo)   # stage-2 challenges, three opening points
     assert ok, why
     assert not stark.stark_verify(gpu, _tampered(r_gpu, "eval"), publics, s_gpu["constRoot"], info, exprs, vinfo)[0]
+
+
+# ---- starkStruct.hashCommits (the recursion starkStructs set it): the transcript absorbs the HASH of the publics, of the
+#      evaluations and of the last FRI polynomial instead of the values (prover.js:152-173, stark_gen_helpers.js:267-272,349-354)
+def _hc_case(hash_type="GL", n_bits=6, pairs=2, steps=(9, 5, 2)):
+    from pil2gl import stark
+    ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": hash_type, "hashCommits": True,
+          "steps": [{"nBits": b} for b in steps]}
+    info, exprs, vinfo = stark.fibonacci_air(pairs, ss)
+    cm, consts, publics = stark.fibonacci_trace(n_bits, pairs)
+    return stark, info, exprs, vinfo, cm, consts, publics
+
+
+@pytest.mark.parametrize("hash_type,arity", [("GL", 16), ("BN128", 16)])
+def test_hash_commits_proof_on_oracle_backend(oracle, hash_type, arity):
+    import copy
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _hc_case(hash_type, 5 if hash_type == "BN128" else 6, 1 if hash_type == "BN128" else 2, (8, 4, 2) if hash_type == "BN128" else (9, 5, 2))
+    be = stark_ref.OracleBackend(False, hash_type, arity, False)
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    kw = {"hash_type": hash_type, "arity": arity} if hash_type == "BN128" else {}
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo, **kw)
+    assert ok, why
+    # the challenges differ from the plain transcript's from the first one drawn after the publics
+    info2 = copy.deepcopy(info); info2["starkStruct"]["hashCommits"] = False
+    plain = stark.stark_gen(be, be.from_host(cm), setup, info2, exprs, publics)
+    assert plain["challenges"] != res["challenges"] and plain["proof"]["root1"] == res["proof"]["root1"]
+    # and a verifier that replays the plain transcript rejects the proof
+    assert not stark_ref.stark_verify(res, setup["constRoot"], info2, vinfo, **kw)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("hash_type,n_bits,pairs,steps", [("GL", 10, 3, (13, 9, 4)), ("BN128", 5, 1, (8, 4, 2))])
+def test_gpu_hash_commits_proof_is_identical_to_oracle_proof(oracle, hash_type, n_bits, pairs, steps):
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _hc_case(hash_type, n_bits, pairs, steps)
+    gpu = stark.GpuBackend(0, False, hash_type, 16, False)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    cpu = stark_ref.OracleBackend(False, hash_type, 16, False)
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, publics)
+    assert r_gpu["challenges"] == r_cpu["challenges"] and r_gpu["queries"] == r_cpu["queries"] and r_gpu["proof"] == r_cpu["proof"]
+    kw = {"hash_type": hash_type, "arity": 16} if hash_type == "BN128" else {}
+    ok, why = stark_ref.stark_verify(r_gpu, s_gpu["constRoot"], info, vinfo, **kw)
+    assert ok, why
+    ok, why = stark.stark_verify(gpu, r_gpu["proof"], publics, s_gpu["constRoot"], info, exprs, vinfo)
+    assert ok, why

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=2)
     ap.add_argument("--steps", default="9,5,2")
     ap.add_argument("--air", default="fib", help="fib: one witness stage; perm: two (stage 2 = grand-product hint)")
+    ap.add_argument("--hashcommits", type=int, default=0, help="starkStruct.hashCommits")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     rank = dist.get_rank()
@@ -30,6 +31,8 @@ def main():
     from pil2gl import stark, parallel
     steps = [int(x) for x in a.steps.split(",")]
     ss = {"nBits": a.nbits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
+    if a.hashcommits:
+        ss["hashCommits"] = True
     if a.air == "perm":
         info, exprs, _ = stark.permutation_air(ss)
         cm, consts, publics = stark.permutation_trace(a.nbits)

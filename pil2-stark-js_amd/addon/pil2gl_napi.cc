@@ -146,6 +146,16 @@ FN(GroupProofDev) {  // (devElems, devNodes, width, height, idx, vals BigUint64A
     napi_value v; napi_create_uint32(env, nl, &v); return v;
 }
 
+FN(GroupProofsDev) { // (devElems, devNodes, width, height, idxs BigUint64Array(n), out BigUint64Array(n*(width+4*levels))) -> nLevels: every query of a tree in one gather
+    Args a(env, info); uint64_t el = a.u64(0), nodes = a.u64(1), w = a.u64(2), h = a.u64(3);
+    uint64_t n = 0; uint64_t *idxs = a.arr(4, 1, &n); uint64_t *out = a.arr(5, n * w); if (!a.ok) return nullptr;
+    uint32_t nl = 0;
+    for (uint64_t m = h * 4; m > 4; m = ((m - 1) / 8 + 1) * 4) nl++;
+    uint64_t outLen = 0; a.arr(5, n * (w + 4ull * nl), &outLen); if (!a.ok) return nullptr;
+    P2(env, pil2gl_group_proofs_dev((const uint64_t *)(uintptr_t)el, (const uint64_t *)(uintptr_t)nodes, w, h, idxs, (uint32_t)n, out, &nl));
+    napi_value v; napi_create_uint32(env, nl, &v); return v;
+}
+
 FN(SpongeAbsorb) {  // (blocks BigUint64Array(8*n), n, cap BigUint64Array(4), out BigUint64Array(12))  transcript.js:49-66 for a list
     Args a(env, info); uint64_t n = a.u64(1);
     uint64_t *blocks = a.arr(0, 8 * n), *cap = a.arr(2, 4), *out = a.arr(3, 12); if (!a.ok) return nullptr;
@@ -195,6 +205,28 @@ FN(ComputeEvalsDev) {  // (descs BigUint64Array(5*nEvals) = [dBuf,width,offset,d
     std::vector<const uint64_t *> lp(nLev);
     for (uint64_t i = 0; i < nLev; i++) lp[i] = (const uint64_t *)(uintptr_t)levs[i];
     P2(env, pil2gl_compute_evals_dev(descs.data(), (uint32_t)nEv, nb, eb, lp.data(), (uint32_t)nLev, out, nullptr)); return mk_undefined(env);
+}
+// the two stages that are matrix-vector products (csrc/dot.hip): FRI polynomial as row sums, evaluations as column sums
+FN(RowsDotExtDev) {    // (dBuf, width, nRows, coef BigUint64Array(nOut*width*3), nOut, dAcc, accumulate)
+    Args a(env, info); uint64_t *buf = DP(0); uint64_t width = a.u64(1), nRows = a.u64(2); uint32_t nOut = (uint32_t)a.u64(4);
+    uint64_t *coef = a.arr(3, (uint64_t)nOut * width * 3); uint64_t *acc = DP(5); int accumulate = (int)a.u64(6); if (!a.ok) return nullptr;
+    P2(env, pil2gl_rows_dot_ext_dev(buf, width, nRows, coef, nOut, acc, accumulate, nullptr)); return mk_undefined(env);
+}
+FN(FriCombineDev) {    // (dAcc, K BigUint64Array(nOpen*3), vf1 BigUint64Array(3), dXDivXSubXi, nOpen, nRows, dF)
+    Args a(env, info); uint64_t *acc = DP(0); uint32_t nOpen = (uint32_t)a.u64(4); uint64_t *K = a.arr(1, 3ull * nOpen), *vf1 = a.arr(2, 3);
+    uint64_t *x = DP(3); uint64_t nRows = a.u64(5); uint64_t *f = DP(6); if (!a.ok) return nullptr;
+    P2(env, pil2gl_fri_combine_dev(acc, K, vf1, x, nOpen, nRows, f, nullptr)); return mk_undefined(env);
+}
+FN(ColsDotExtDev) {    // (dBuf, width, nRows, rowStep, levs BigUint64Array(nLev) device ptrs, out BigUint64Array(nLev*width*3))
+    Args a(env, info); uint64_t *buf = DP(0); uint64_t width = a.u64(1), nRows = a.u64(2), rowStep = a.u64(3);
+    uint64_t nLev = 0; uint64_t *levs = a.arr(4, 1, &nLev); uint64_t *out = a.arr(5, nLev * width * 3); if (!a.ok) return nullptr;
+    std::vector<const uint64_t *> lp(nLev);
+    for (uint64_t i = 0; i < nLev; i++) lp[i] = (const uint64_t *)(uintptr_t)levs[i];
+    P2(env, pil2gl_cols_dot_ext_dev(buf, width, nRows, rowStep, lp.data(), (uint32_t)nLev, out, nullptr)); return mk_undefined(env);
+}
+FN(SynthFibonacciDev) { // (nBits, nPairs, init BigUint64Array(2*nPairs), dCm): synthetic witness for benchmarks (pil2gl.h)
+    Args a(env, info); uint32_t nb = (uint32_t)a.u64(0), np = (uint32_t)a.u64(1); uint64_t *init = a.arr(2, 2ull * np); uint64_t *cm = DP(3); if (!a.ok) return nullptr;
+    P2(env, pil2gl_synth_fibonacci_dev(nb, np, init, cm, nullptr)); return mk_undefined(env);
 }
 FN(GprodDev) {         // (dNum, dimNum, dDen, dimDen, n, dOut)  polutils.js:128-143
     Args a(env, info); uint64_t *num = DP(0); uint32_t dn = (uint32_t)a.u64(1); uint64_t *den = DP(2); uint32_t dd = (uint32_t)a.u64(3); uint64_t n = a.u64(4); uint64_t *o = DP(5); if (!a.ok) return nullptr;
@@ -293,13 +325,14 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "interpolate", Interpolate }, { "fft", Fft }, { "ifft", Ifft },
         { "interpolateDev", InterpolateDev }, { "fftDev", FftDev }, { "ifftDev", IfftDev },
         { "poseidon", Poseidon }, { "linearHashRows", LinearHashRows }, { "merkelizeLevel", MerkelizeLevel },
-        { "merkleNumNodes", MerkleNumNodes }, { "merkelize", Merkelize }, { "merkelizeDev", MerkelizeDev }, { "groupProofDev", GroupProofDev },
+        { "merkleNumNodes", MerkleNumNodes }, { "merkelize", Merkelize }, { "merkelizeDev", MerkelizeDev }, { "groupProofDev", GroupProofDev }, { "groupProofsDev", GroupProofsDev },
         { "rootsFromGroupProofs", RootsFromGroupProofs }, { "spongeAbsorb", SpongeAbsorb },
         { "bn128Poseidon", Bn128Poseidon }, { "bn128SpongeAbsorb", Bn128SpongeAbsorb }, { "bn128LinearHashRows", Bn128LinearHashRows }, { "bn128MerkleNumNodes", Bn128MerkleNumNodes },
         { "bn128Merkelize", Bn128Merkelize }, { "bn128MerkelizeDev", Bn128MerkelizeDev }, { "bn128Convert", Bn128Convert },
         { "buildXDev", BuildXDev }, { "buildZhInvDev", BuildZhInvDev }, { "buildOneRowZerofierInvDev", BuildOneRowZerofierInvDev },
         { "buildFrameZerofierDev", BuildFrameZerofierDev }, { "computeQSplitDev", ComputeQSplitDev }, { "xDivXSubXiDev", XDivXSubXiDev },
         { "buildLevDev", BuildLevDev }, { "computeEvalsDev", ComputeEvalsDev }, { "gprodDev", GprodDev }, { "gsumDev", GsumDev }, { "h1h2Dev", H1H2Dev },
+        { "rowsDotExtDev", RowsDotExtDev }, { "friCombineDev", FriCombineDev }, { "colsDotExtDev", ColsDotExtDev }, { "synthFibonacciDev", SynthFibonacciDev },
         { "friFoldDev", FriFoldDev }, { "friTransposeDev", FriTransposeDev },
         { "friFold", FriFold }, { "friVerifyFold", FriVerifyFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
     };

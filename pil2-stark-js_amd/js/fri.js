@@ -128,17 +128,16 @@ class FRI {
     }
 
     proofQueries(proof, trees, friQueries) {                                  // fri.js:83-105
+        // all queries of a tree in one call where the MerkleHash offers it (same values as a getGroupProof per query)
+        const open = (tree, idxs) => (this.MH.getGroupProofs ? this.MH.getGroupProofs(tree, idxs) : idxs.map((i) => this.MH.getGroupProof(tree, i)));
         for (let step = 0; step < this.steps.length; step++) {
             proof[step].polQueries = [];
             if (step === 0) {
-                for (let i = 0; i < friQueries.length; i++) {
-                    const polQuery = [];
-                    for (let j = 0; j < trees[step].length; ++j) polQuery.push(this.MH.getGroupProof(trees[step][j], friQueries[i]));
-                    proof[step].polQueries.push(polQuery);
-                }
+                const perTree = trees[step].map((t) => open(t, friQueries));
+                for (let i = 0; i < friQueries.length; i++) proof[step].polQueries.push(perTree.map((p) => p[i]));
             } else {
                 for (let i = 0; i < friQueries.length; i++) friQueries[i] = friQueries[i] % (1 << this.steps[step].nBits);
-                for (let i = 0; i < friQueries.length; i++) proof[step].polQueries.push(this.MH.getGroupProof(trees[step], friQueries[i]));
+                proof[step].polQueries = open(trees[step], friQueries);
             }
         }
     }

@@ -64,6 +64,21 @@ class MerkleHash {
         return isFlat(e) ? e[tree.width * idx + subIdx] : e.getElement(tree.width * idx + subIdx);     // DevBuffer answers getElement too
     }
 
+    // getGroupProof for every query of a tree (fri.js:83-105 opens each tree at all query rows): for a device-resident
+    // tree one gather kernel and one copy back instead of a copy per row and per level
+    getGroupProofs(tree, idxs) {
+        if (!(isDev(tree.elements) && isDev(tree.nodes)) || idxs.length === 0) return idxs.map((i) => this.getGroupProof(tree, i));
+        for (const idx of idxs) if ((idx < 0) || (idx >= tree.height)) throw new Error("Out of range");
+        let nl = 0; for (let n = tree.height * 4; n > 4; n = (Math.floor((n - 1) / 8) + 1) * 4) nl++;
+        const w = tree.width, stride = w + 4 * nl, out = new BigUint64Array(idxs.length * stride);
+        addon.groupProofsDev(tree.elements.ptr, tree.nodes.ptr, w, tree.height, BigUint64Array.from(idxs, BigInt), out);
+        return idxs.map((_, q) => {
+            const o = q * stride, mp = [];
+            for (let l = 0; l < nl; l++) mp.push([out[o + w + 4 * l], out[o + w + 4 * l + 1], out[o + w + 4 * l + 2], out[o + w + 4 * l + 3]]);
+            return [Array.from(out.subarray(o, o + w)), mp];
+        });
+    }
+
     getGroupProof(tree, idx) {          // merklehash_p.js:142-168
         if ((idx < 0) || (idx >= tree.height)) throw new Error("Out of range");
         if (isDev(tree.elements) && isDev(tree.nodes)) {        // only the opened row and its siblings cross PCIe

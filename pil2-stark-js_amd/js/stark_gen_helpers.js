@@ -83,20 +83,43 @@ module.exports.computeEvalsStark = async function computeEvalsStark(ctx, options
             if (!uploaded.has(name)) { const d = devTmp(words); ptrs.push(d); upload(d, buf, words); uploaded.set(name, d); }
             return uploaded.get(name);
         };
-        const nEv = ctx.pilInfo.evMap.length, descs = new BigUint64Array(5 * nEv);
-        for (let i = 0; i < nEv; i++) {                                                      // :233-247
-            const ev = ctx.pilInfo.evMap[i];
-            let name, size, offset, dim;
-            if (ev.type == "const") { name = "const_ext"; size = ctx.pilInfo.nConstants; offset = ev.id; dim = 1; }
-            else if (ev.type == "cm") { const p = ctx.pilInfo.cmPolsMap[ev.id]; name = "cm" + p.stage + "_ext"; size = ctx.pilInfo.mapSectionsN["cm" + p.stage]; offset = p.stagePos; dim = p.dim; }
-            else throw new Error("Invalid ev type: " + ev.type);
-            const d = devOf(name, ctx[name], size * ctx.extN);
-            descs.set([d, BigInt(size), BigInt(offset), BigInt(dim), BigInt(ctx.pilInfo.openingPoints.findIndex((p) => p === ev.prime))], 5 * i);
-        }
-        const out = new BigUint64Array(3 * nEv);
-        addon.computeEvalsDev(descs, nEv, ctx.nBits, ctx.extendBits, levs, out);             // :248-264
+        const nEv = ctx.pilInfo.evMap.length;
+        const place = (ev) => {                                                              // :233-247
+            if (ev.type == "const") return { name: "const_ext", size: ctx.pilInfo.nConstants, offset: ev.id, dim: 1 };
+            if (ev.type == "cm") { const p = ctx.pilInfo.cmPolsMap[ev.id]; return { name: "cm" + p.stage + "_ext", size: ctx.pilInfo.mapSectionsN["cm" + p.stage], offset: p.stagePos, dim: p.dim }; }
+            throw new Error("Invalid ev type: " + ev.type);
+        };
+        const openIdx = (ev) => ctx.pilInfo.openingPoints.findIndex((p) => p === ev.prime);
         ctx.evals = [];
-        for (let i = 0; i < nEv; i++) ctx.evals[i] = [out[3 * i], out[3 * i + 1], out[3 * i + 2]];
+        if (nOpen <= 4) {
+            // eval_e = sum_k v_e[k << b] LEv[k] (:250-264) for EVERY column of a section and every opening in one sweep of
+            // the section (pil2gl_cols_dot_ext_dev); a dim-3 polynomial q0 + q1 x + q2 x^2 is assembled from its base columns
+            const sums = new Map();
+            for (const ev of ctx.pilInfo.evMap) {
+                const pl = place(ev);
+                if (sums.has(pl.name)) continue;
+                const out = new BigUint64Array(nOpen * pl.size * 3);
+                addon.colsDotExtDev(devOf(pl.name, ctx[pl.name], pl.size * ctx.extN), pl.size, N, 1 << ctx.extendBits, levs, out);
+                sums.set(pl.name, out);
+            }
+            const mulX = (a) => [a[2], (a[0] + a[2]) % P, a[1]];                             // times x in F[x]/(x^3 - x - 1), f3g.js:94-102
+            for (let i = 0; i < nEv; i++) {
+                const ev = ctx.pilInfo.evMap[i], pl = place(ev), out = sums.get(pl.name), li = openIdx(ev);
+                const col = (c) => { const o = 3 * (li * pl.size + c); return [out[o], out[o + 1], out[o + 2]]; };
+                let acc = col(pl.offset);
+                for (let t = 1; t < pl.dim; t++) { let term = col(pl.offset + t); for (let k = 0; k < t; k++) term = mulX(term); acc = acc.map((v, j) => (v + term[j]) % P); }
+                ctx.evals[i] = acc;
+            }
+        } else {
+            const descs = new BigUint64Array(5 * nEv);
+            for (let i = 0; i < nEv; i++) {
+                const ev = ctx.pilInfo.evMap[i], pl = place(ev);
+                descs.set([devOf(pl.name, ctx[pl.name], pl.size * ctx.extN), BigInt(pl.size), BigInt(pl.offset), BigInt(pl.dim), BigInt(openIdx(ev))], 5 * i);
+            }
+            const out = new BigUint64Array(3 * nEv);
+            addon.computeEvalsDev(descs, nEv, ctx.nBits, ctx.extendBits, levs, out);         // :248-264
+            for (let i = 0; i < nEv; i++) ctx.evals[i] = [out[3 * i], out[3 * i + 1], out[3 * i + 2]];
+        }
     } finally { for (const d of ptrs) addon.devFree(d); }
     if (ctx.pilInfo.starkStruct.hashCommits) return [await module.exports.calculateHashStark(ctx, ctx.evals)];      // :267-272
     return ctx.evals;
@@ -116,6 +139,47 @@ module.exports.calculateHashStark = async function calculateHashStark(ctx, input
     return transcript.getState();
 };
 
+// The FRI polynomial the friExp op-list computes (friPolinomial.js:26-50) is, per opening o (ascending) and evMap order
+// j = 1..n_o,  F_o = sum_j (p_j - ev_j) vf2^(n_o-j)  and  f = Horner in vf1 over o of F_o xDivXSubXi_o: per section one
+// extension weight per base column (pil2gl_rows_dot_ext_dev), then one combine kernel.  Same field elements as the
+// op-list, about a tenth of its multiplications.  Only for device-resident sections and the layout the formula covers
+// (the openings of evMap are exactly openingPoints, at most four); otherwise the op-list runs.
+function friPolynomialAsRowSums(ctx) {
+    const info = ctx.pilInfo, nOpen = info.openingPoints.length, extN = ctx.extN;
+    const openings = Array.from(new Set(info.evMap.map((ev) => ev.prime))).sort((a, b) => a - b);
+    if (nOpen > 4 || openings.length !== nOpen || openings.some((o, i) => o !== info.openingPoints[i])) return false;
+    if (!isDev(ctx.f_ext) || !isDev(ctx.xDivXSubXi_ext)) return false;
+    const vf1 = asE3(ctx.challenges[info.nStages + 2][0]), vf2 = asE3(ctx.challenges[info.nStages + 2][1]);
+    const mulX = (a) => [a[2], (a[0] + a[2]) % P, a[1]];
+    const coefs = new Map(), K = new BigUint64Array(3 * nOpen);
+    for (let oi = 0; oi < nOpen; oi++) {
+        const terms = []; info.evMap.forEach((ev, i) => { if (ev.prime === openings[oi]) terms.push(i); });
+        const ws = []; let w = [1n, 0n, 0n];
+        for (let k = 0; k < terms.length; k++) { ws.push(w); w = e3mul(w, vf2); }
+        let kacc = [0n, 0n, 0n];
+        terms.forEach((i, j) => {
+            const ev = info.evMap[i], W = ws[terms.length - 1 - j];
+            const t = e3mul(asE3(ctx.evals[i]), W); kacc = kacc.map((v, c) => (v + t[c]) % P);
+            let name, width, col, dim;
+            if (ev.type == "const") { name = "const_ext"; width = info.nConstants; col = ev.id; dim = 1; }
+            else { const p = info.cmPolsMap[ev.id]; name = "cm" + p.stage + "_ext"; width = info.mapSectionsN["cm" + p.stage]; col = p.stagePos; dim = p.dim; }
+            if (!coefs.has(name)) coefs.set(name, { width, c: new BigUint64Array(nOpen * width * 3) });
+            const c = coefs.get(name).c;
+            let Wt = W;
+            for (let t2 = 0; t2 < dim; t2++) { const o = 3 * (oi * width + col + t2); for (let q = 0; q < 3; q++) c[o + q] = (c[o + q] + Wt[q]) % P; Wt = mulX(Wt); }
+        });
+        K.set(kacc, 3 * oi);
+    }
+    for (const name of coefs.keys()) if (!isDev(ctx[name])) return false;
+    const acc = devTmp(3 * nOpen * extN);
+    try {
+        let first = true;
+        for (const [name, { width, c }] of coefs) { addon.rowsDotExtDev(ctx[name].ptr, width, extN, c, nOpen, acc, first ? 0 : 1); first = false; }
+        addon.friCombineDev(acc, K, BigUint64Array.from(vf1), ctx.xDivXSubXi_ext.ptr, nOpen, extN, ctx.f_ext.ptr);
+    } finally { addon.devFree(acc); }
+    return true;
+}
+
 module.exports.computeFRIStark = async function computeFRIStark(ctx, options) {
     const stage = ctx.pilInfo.nStages + 2, nOpen = ctx.pilInfo.openingPoints.length, extN = ctx.extN;
     ctx.friPol = []; ctx.friProof = []; ctx.friTrees = [];
@@ -131,8 +195,9 @@ module.exports.computeFRIStark = async function computeFRIStark(ctx, options) {
             addon.xDivXSubXiDev(ctx.nBitsExt, BigUint64Array.from(openingXi(ctx, ctx.pilInfo.openingPoints[i], false)), nOpen, i, dX);
         if (!xRes) download(ctx.xDivXSubXi_ext, dX, 3 * extN * nOpen);
     } finally { if (!xRes) addon.devFree(dX); }
-    await callCalculateExps(stage, ctx.expressionsInfo.expressionsCode.find((e) => e.expId === ctx.pilInfo.friExpId).code, "ext", ctx,
-                            options.parallelExec, options.useThreads, false);               // :324
+    if (!friPolynomialAsRowSums(ctx))
+        await callCalculateExps(stage, ctx.expressionsInfo.expressionsCode.find((e) => e.expId === ctx.pilInfo.friExpId).code, "ext", ctx,
+                                options.parallelExec, options.useThreads, false);           // :324
     if (isDev(ctx.f_ext)) { ctx.friPol[0] = ctx.f_ext; return; }     // resident: FRI.fold takes the device polynomial as it is
     ctx.friPol[0] = new Array(extN);
     for (let i = 0; i < extN; i++) {

@@ -38,12 +38,13 @@ async function prove(g, resident) {
     const ctx = { prover: "stark", pilInfo, expressionsInfo: g.expressionsInfo, nBits, nBitsExt, extendBits: nBitsExt - nBits, N, extN, MH,
         publics: g.publics.map(BigInt), challenges: [[], [], [], []], evals: [], subproofValues: [], trees: [] };
     // setup (stark_buildConstTree.js:6-43) and initProverStark (stark_gen_helpers.js:104-160)
-    ctx.const_n = fromHost(g.consts instanceof BigUint64Array ? g.consts : BigUint64Array.from(g.consts, BigInt));
+    const asBuf = (v) => (v instanceof DevBuffer ? v : fromHost(v instanceof BigUint64Array ? v : BigUint64Array.from(v, BigInt)));
+    ctx.const_n = asBuf(g.consts);
     ctx.const_ext = alloc(pilInfo.nConstants * extN);
     await interpolate(ctx.const_n, pilInfo.nConstants, nBits, ctx.const_ext, nBitsExt);
     ctx.constTree = await MH.merkelize(ctx.const_ext, pilInfo.nConstants, extN);
     assert.deepStrictEqual(MH.root(ctx.constTree), g.constRoot.map(BigInt), "constant tree root");
-    ctx.cm1_n = fromHost(g.cm1 instanceof BigUint64Array ? g.cm1 : BigUint64Array.from(g.cm1, BigInt));
+    ctx.cm1_n = asBuf(g.cm1);
     ctx.cm1_ext = alloc(pilInfo.mapSectionsN.cm1 * extN);
     ctx.cm2_ext = alloc(pilInfo.mapSectionsN.cm2 * extN);
     ctx.q_ext = alloc(pilInfo.qDim * extN);
@@ -70,7 +71,7 @@ async function prove(g, resident) {
     // evaluations
     ctx.challenges[2] = [transcript.getField()];
     const evals = await SGH.computeEvalsStark(ctx, {});
-    for (const ev of evals) transcript.put(ev);
+    transcript.put(evals);          // prover.js absorbs them one by one (addTranscriptStark); as one list the drop-in transcript chains the permutations in one device call -- same state
     ctx.challenges[3] = [transcript.getField(), transcript.getField()];
     await SGH.computeFRIStark(ctx, { parallelExec: false, useThreads: false });
     // FRI folding (computeFRIFolding :337-356) and queries (:474-493, fri.js:83-105)
@@ -80,7 +81,7 @@ async function prove(g, resident) {
         ctx.friPol[step + 1] = sp.pol; ctx.friProof[step + 1] = sp.proof;
         if (step < ss.steps.length - 1) { ctx.friTrees[step + 1] = sp.tree; transcript.put(sp.proof.root); }
         else if (ss.hashCommits) transcript.put(await SGH.calculateHashStark(ctx, sp.proof));   // stark_gen_helpers.js:349-351
-        else for (const e of sp.proof) transcript.put(e);
+        else transcript.put(sp.proof);
     }
     const tq = new Transcript(poseidon); tq.put(transcript.getField());
     const friQueries = tq.getPermutations(ss.nQueries, ss.steps[0].nBits);
@@ -100,7 +101,18 @@ async function prove(g, resident) {
     if (resident) assert(ctx.trees[1].nodes instanceof DevBuffer && ctx.friTrees[1].nodes instanceof DevBuffer && ctx.friPol[1] instanceof DevBuffer);
     return { proof, ctx, seconds };
 }
-module.exports = { prove };
+// DevBuffers have no finalizer: release what a resident prove() allocated (everything reachable from ctx except the
+// caller's own inputs), so that a config-3 proof (107 GB extension) can be repeated in one process
+function freeCtx(ctx, keep = []) {
+    const seen = new Set(keep);
+    (function walk(v, depth) {
+        if (!v || typeof v !== "object" || depth > 4) return;
+        if (v instanceof DevBuffer) { if (!seen.has(v)) { seen.add(v); v.free(); } return; }
+        if (ArrayBuffer.isView(v)) return;
+        for (const x of (Array.isArray(v) ? v : Object.values(v))) walk(x, depth + 1);
+    })(ctx, 0);
+}
+module.exports = { prove, freeCtx };
 
 if (require.main === module) (async () => {
     for (const name of ["fib_flow.json", "fib_flow_hashcommits.json"]) {

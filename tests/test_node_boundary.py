@@ -47,3 +47,69 @@ def test_config2_proof_from_node_device_resident():
     """config 2's shape proved from Node with HBM-resident buffers: digest of the proof equals the CPU checker's"""
     out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "prove_c2.js")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0 and "prove c2 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def _canon(v):          # canonical text of a proof: decimal strings, no whitespace, keys in insertion order (= tests/js/prove_c3.js)
+    if isinstance(v, dict):
+        return "{" + ",".join('"%s":%s' % (k, _canon(x)) for k, x in v.items()) + "}"
+    if isinstance(v, (list, tuple)):
+        return "[" + ",".join(_canon(x) for x in v) + "]"
+    return '"%d"' % int(v)
+
+
+def _node_vs_python_proof(tmp_path, n_bits, n_cols, steps, n_queries):
+    """the same witness proved twice on the device -- stage loop in Python (pil2gl.stark.stark_gen) and stage loop in Node
+    (tests/js/prove_flow.js over the JS drop-ins, device-resident) -> (python seconds, node seconds, digests equal)"""
+    import hashlib
+    import json
+    import time
+    import numpy as np
+    import torch
+    import bench
+    from pil2gl import stark
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": n_queries, "verificationHashType": "GL", "splitLinearHash": False,
+          "steps": [{"nBits": b} for b in steps]}
+    info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
+    gpu = stark.GpuBackend(0, False)
+    dev = torch.device("cuda", 0)
+    cm, consts, publics = bench.fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
+    start = [int(v) for v in cm[:n_cols].cpu().numpy().view(np.uint64)]
+    setup = stark.build_const_tree(gpu, consts, info)
+    best, res = 1e9, None
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        res = stark.stark_gen(gpu, cm, setup, info, exprs, publics)
+        torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+    digest = hashlib.sha256(_canon(res["proof"]).encode()).hexdigest()
+    job = {"pilInfo": info, "expressionsInfo": exprs, "start": [str(v) for v in start], "publics": [str(v) for v in publics],
+           "constRoot": [str(v) for v in setup["constRoot"]], "queries": res["queries"]}
+    f = tmp_path / "job.json"
+    f.write_text(json.dumps(job))
+    del cm, setup, res
+    torch.cuda.empty_cache()
+    out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "prove_c3.js"), str(f), "3"], capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0 and "prove c3 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    return best, line["proof_seconds"], line["proofSha256"] == digest
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_node_driven_proof_equals_python_driven_proof_2e18(tmp_path):
+    """2^18 x 20: same digest (the reference's JS orchestration and the Python mirror sequence the same C-ABI calls)"""
+    _, _, same = _node_vs_python_proof(tmp_path, 18, 20, (21, 16, 11, 6), 32)
+    assert same
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_config3_proof_driven_from_node(tmp_path):
+    """BASELINE config 3 (2^24 x 100, FRI 27/22/17/12/7, 64 queries) with Node driving: the north_star boundary at the size
+    that matters.  Same proof as the Python-driven one; the wall time is reported, and must stay within 10 % of it"""
+    import torch
+    if torch.cuda.mem_get_info()[0] < 230e9:
+        pytest.skip("needs ~200 GB of free device memory")
+    t_py, t_node, same = _node_vs_python_proof(tmp_path, 24, 100, (27, 22, 17, 12, 7), 64)
+    print("config 3 proof: python-driven %.3f s, node-driven %.3f s" % (t_py, t_node))
+    assert same
+    assert t_node < 1.10 * t_py, (t_py, t_node)

@@ -574,6 +574,49 @@ def test_expression_evaluator(gl, oracle, n_ops, prime_shift):
         assert (d.cpu().numpy().view(np.uint64).reshape(r.shape) == r).all()
 
 
+@pytest.mark.parametrize("jit", ["0", "1"])
+def test_expression_evaluator_minimal_programs_of_the_first_kernels_miscompile(gl, oracle, jit, monkeypatch):
+    """The first evaluator kernel (commit 8435cfa) returned components 0 and 1 of ext values wrong whenever a program
+    contained a COPY: hipcc -O1..-O3 dropped r[0] = a[0], r[1] = a[1] of the `default:` arm of its switch over the op code
+    (reproduced and bisected with the old source in round 2).  These are the smallest programs that
+    showed it -- a lone copy of an ext scalar, and sub -> tmp -> copy -- plus every op with every operand-dimension pair,
+    through the interpreter and the run-time compiled kernel."""
+    import torch
+    import ctypes as C
+    from pil2gl import _lib
+    from gl_oracle import TMP, SEC, SCALAR
+    monkeypatch.setenv("PIL2GL_EXPR_JIT", jit)
+    rng = np.random.default_rng(4)
+    n_bits, widths = 4, [5, 9, 1, 3]
+    dest = (SEC, 3, 3, 0, 0)
+    programs = [
+        [("copy", dest, (SCALAR, 3, 0, 0, 18), None)],
+        [("sub", (TMP, 3, 0, 0, 0), (SCALAR, 1, 0, 0, 6), (SCALAR, 3, 0, 0, 18)), ("copy", dest, (TMP, 3, 0, 0, 0), None)],
+        [("sub", (TMP, 3, 0, 0, 0), (SCALAR, 1, 0, 0, 6), (SCALAR, 3, 0, 0, 18)), ("add", (TMP, 3, 0, 0, 1), (TMP, 3, 0, 0, 0), (TMP, 3, 0, 0, 0)),
+         ("add", (TMP, 1, 0, 0, 2), (SEC, 1, 1, -1, 4), (SEC, 1, 2, -2, 0)), ("copy", dest, (TMP, 3, 0, 0, 1), None)],
+        [("copy", (TMP, 3, 0, 0, 0), (SEC, 3, 1, 1, 2), None), ("copy", (TMP, 3, 0, 0, 1), (TMP, 3, 0, 0, 0), None), ("copy", dest, (TMP, 3, 0, 0, 1), None)],
+    ]
+    for op in ("add", "sub", "mul"):
+        for da in (1, 3):
+            for db in (1, 3):
+                programs.append([(op, (TMP, max(da, db), 0, 0, 0), (SCALAR, da, 0, 0, 3), (SEC, db, 1, 0, 1)), ("copy", (SEC, max(da, db), 3, 0, 0), (TMP, max(da, db), 0, 0, 0), None)])
+    for ops in programs:
+        secs = [rand_field(rng, (1 << n_bits, w)) for w in widths]; secs[-1][:] = 0
+        scalars = rand_field(rng, 40)
+        n_tmp = 1 + max([o[1][4] for o in ops if o[1][0] == TMP] + [0])
+        ref = [s_.copy() for s_ in secs]
+        oracle.eval_program(ops, n_tmp, ref, scalars, n_bits, 0)
+        dsecs = [torch.from_numpy(s_.view(np.int64)).cuda() for s_ in secs]
+        prog = oracle.make_program(ops, n_tmp, struct_op=_lib.GlxOp, struct_prog=_lib.GlxProgram)
+        csecs = (_lib.GlxSection * 4)()
+        for i, t in enumerate(dsecs):
+            csecs[i].ptr = t.data_ptr(); csecs[i].width = widths[i]
+        ctx = _lib.GlxCtx(n_bits, 0, 4, scalars.size, csecs, scalars.ctypes.data_as(_lib.u64p))
+        _lib.call("pil2gl_eval_program_dev", C.byref(prog), C.byref(ctx), None)
+        torch.cuda.synchronize()
+        assert (dsecs[3].cpu().numpy().view(np.uint64).reshape(ref[3].shape) == ref[3]).all(), ops
+
+
 def test_expression_evaluator_many_live_tmps(gl, oracle):
     """more live temporaries than fit LDS: exercises the global-memory spill path of the evaluator"""
     import torch

@@ -58,16 +58,24 @@ __device__ __forceinline__ void mds_layer(u64 st[12]) {
     }
 }
 
+#ifndef POSEIDON_SBOX_GROUP
+#define POSEIDON_SBOX_GROUP 6       // S-boxes per fallback check: the inputs of a group stay live until its check (12: 24 VGPRs spilled in the leaf kernel and 41 GB of scratch traffic per config-3 launch; 6 and 4: none; same rate)
+#endif
 // S-box layers of the matrix-core form, on the 13-instruction products (pow7_b): a full layer is checked once, and a
 // wave in which some lane hit the rare borrow recomputes the layer with pow7_lazy (the branch is wave-uniform: every
 // lane recomputes, same values)
+template <int GROUP = POSEIDON_SBOX_GROUP>
 __device__ __forceinline__ void sbox_full(u64 st[12], const u64 *__restrict__ rc) {
-    u64 bad = 0, in[12];
+    static_assert(12 % GROUP == 0, "group must divide the state");
 #pragma unroll
-    for (int i = 0; i < 12; i++) { in[i] = add_lazy_canon(st[i], rc[i]); st[i] = pow7_b(in[i], bad); }
-    if (__builtin_expect(bad != 0, 0)) {
+    for (int g = 0; g < 12; g += GROUP) {
+        u64 bad = 0, in[GROUP];
 #pragma unroll
-        for (int i = 0; i < 12; i++) st[i] = pow7_lazy(in[i]);
+        for (int i = 0; i < GROUP; i++) { in[i] = add_lazy_canon(st[g + i], rc[g + i]); st[g + i] = pow7_b(in[i], bad); }
+        if (__builtin_expect(bad != 0, 0)) {
+#pragma unroll
+            for (int i = 0; i < GROUP; i++) st[g + i] = pow7_lazy(in[i]);
+        }
     }
 }
 __device__ __forceinline__ u64 sbox_one(u64 x) {

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))                 # pil2-stark-js_amd/
-LIB_PATH = os.path.join(PKG_ROOT, "lib", "libpil2gl.so")
+LIB_PATH = os.environ.get("PIL2GL_LIB") or os.path.join(PKG_ROOT, "lib", "libpil2gl.so")      # PIL2GL_LIB: another build of the same ABI (A/B measurements)
 
 u64p = C.POINTER(C.c_uint64)
 vp = C.c_void_p

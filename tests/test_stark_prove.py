@@ -113,6 +113,46 @@ def test_device_verifier_agrees_with_restated_verifier(oracle, n_bits, n_pairs, 
     assert not stark.stark_verify(gpu, res["proof"], wrong_publics, setup["constRoot"], info, exprs, vinfo)[0]
 
 
+def _query_verifier_of(info, exprs):
+    """verifierInfo.queryVerifier as generateCode.js:239-249 builds it: the FRI expression's op-list with every witness
+    operand turned into {type: "tree<stage>", treePos, dim} (codegen.js:249-255) and the value left in the last temporary"""
+    import copy
+    code = copy.deepcopy(exprs["expressionsCode"][info["friExpId"]]["code"]["code"])
+    n_tmp = 1 + max([r["id"] for c in code for r in [c["dest"]] + c["src"] if r["type"] == "tmp"], default=-1)
+    for c in code:
+        for r in [c["dest"]] + c["src"]:
+            if r["type"] == "cm":
+                p = info["cmPolsMap"][r["id"]]
+                r.update(type="tree%d" % p["stage"], treePos=p["stagePos"], dim=p["dim"], stageId=0)
+                r.pop("id"); r.pop("prime", None)
+            elif r["type"] == "const":
+                r.pop("prime", None)
+    assert code[-1]["dest"]["type"] == "f"
+    code[-1]["dest"] = {"type": "tmp", "id": n_tmp, "dim": 3}
+    return {"code": code}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("two_stage", [False, True])
+def test_device_verifier_runs_the_references_query_program_shape(oracle, two_stage):
+    """the reference's verifier does not re-run the prover's FRI op-list: it runs verifierInfo.queryVerifier, whose witness
+    operands are tree<stage> records and whose result is its last temporary (stark_verify.js:185-238, 245-246)"""
+    if two_stage:
+        stark, info, exprs, vinfo, cm, consts, publics = _perm_case(9, (12, 8, 4))
+    else:
+        stark, info, exprs, vinfo, cm, consts, publics = _setup(9, 3, [12, 8, 4], n_queries=9)
+    gpu = stark.GpuBackend(0, False)
+    setup = stark.build_const_tree(gpu, consts, info)
+    res = stark.stark_gen(gpu, gpu.from_host(cm), setup, info, exprs, publics)
+    qv = _query_verifier_of(info, exprs)
+    assert any(r["type"].startswith("tree") for c in qv["code"] for r in c["src"])
+    vq = {**vinfo, "queryVerifier": qv}
+    ok, why = stark.stark_verify(gpu, res["proof"], publics, setup["constRoot"], info, None, vq)   # no prover expressions needed
+    assert ok, why
+    for what in ("opened value", "eval", "fri layer value"):
+        assert not stark.stark_verify(gpu, _tampered(res, what), publics, setup["constRoot"], info, None, vq)[0], what
+
+
 @pytest.mark.gpu
 def test_fri_verify_fold_batch(oracle):
     """pil2gl_fri_verify_fold: per query evalPol(ifft(group), challenge * sinv) (fri.js:121-127) against the oracle's fold of

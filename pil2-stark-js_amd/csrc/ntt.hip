@@ -88,9 +88,8 @@ __device__ __forceinline__ void dit_step(u64 *tile, const u64 *TW, u32 k, u32 lp
             const u32 rho = bitrev32(blk & ((1u << cn) - 1), cn), sh = k - lm - cn;
 #pragma unroll
             for (u32 q = 0; q < R; q++) {
-                u64 o = fermat::to_gl_lazy(v[q]);
-                if (rho) o = mul_lazy(o, TW[(rho * (np + (q << lp))) << sh]);
-                col[q * st] = o;
+                // rho = 0 multiplies by TW[0] = 1: cheaper than a lane-dependent branch around every product
+                col[q * st] = mul_lazy(fermat::to_gl_lazy(v[q]), TW[(rho * (np + (q << lp))) << sh]);
             }
         } else {
 #pragma unroll
@@ -148,10 +147,12 @@ struct PassParams {
     u32 n, scatter;                 // scatter: store row bitrev_n(g*2^k + t) (lo = 0 pass of a natural-order transform)
 };
 
-template <bool INV, bool DIT>
+// KC = 0: any geometry; KC = 8: the geometry of the wide matrices (8 stages, 16 column slots x 16 sub-transform lanes, one
+// slot group), with every stride, LDS offset and twiddle index a compile-time constant
+template <bool INV, bool DIT, int KC>
 __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     extern __shared__ u64 lds[];
-    const u32 k = P.k, K = 1u << k, S = blockDim.x, by = blockDim.y;
+    const u32 k = KC ? KC : P.k, K = 1u << k, S = KC ? 16 : blockDim.x, by = KC ? 16 : blockDim.y;
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
     u64 *tile = lds, *TW = tile + ((size_t)S << k), *TWO = TW + K;
 
@@ -159,7 +160,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     const u32 cc = bid % P.nColChunks; bid /= P.nColChunks;
     const u32 gt = bid % P.nGroupTiles;
     const u32 hi = bid / P.nGroupTiles;
-    const u32 gi = x / P.Wc, ci = x - gi * P.Wc;
+    const u32 gi = KC ? 0 : x / P.Wc, ci = x - gi * P.Wc;
     const u64 c = (u64)cc * P.Wc + ci;
     const bool valid = c < P.C;
     // slot groups: adjacent blocks; in the scattering pass blocks nGroupTiles apart, whose bit-reversed rows are adjacent
@@ -174,8 +175,8 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     for (u32 i = 0; i < LOADB; i++) { const u32 t = y + i * by; vin[i] = (valid && t < K) ? P.src[base + (u64)t * P.tStride] : 0; }
     for (u32 j = tid; j < K; j += nth) TW[j] = P.twK[j << (10 - k)];
     if (P.hasTw) {
-        for (u32 idx = tid; idx < P.nbT * K; idx += nth) {
-            u32 b = gt * P.nbT + (idx >> k);
+        for (u32 idx = tid; idx < (KC ? 1 : P.nbT) * K; idx += nth) {
+            u32 b = gt * (KC ? 1 : P.nbT) + (idx >> k);
             u64 v = root_pow(P.tw, P.logM, b * bitrev32(idx & (K - 1), k));
             if (P.scale) v = mul(v, P.scale);
             TWO[idx] = v;
@@ -198,7 +199,12 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
         for (u32 i = 0; i < LOADB; i++) { const u32 t = t0 + i * by; vin[i] = (valid && t < K) ? P.src[base + (u64)t * P.tStride] : 0; }
     }
     __syncthreads();
-    if (DIT) dit_stages<INV>(tile, TW, k, S, x, y, by); else dif_stages<INV>(tile, TW, k, S, x, y, by);
+    if constexpr (KC == 8) {
+        if (DIT) { dit_step<4, INV>(tile, TW, 8, 0, 4, 16, x, y, 16); dit_step<4, INV>(tile, TW, 8, 4, 0, 16, x, y, 16); }
+        else { dif_step<4, INV>(tile, TW, 8, 8, 16, x, y, 16); dif_step<4, INV>(tile, TW, 8, 4, 16, x, y, 16); }
+    } else {
+        if (DIT) dit_stages<INV>(tile, TW, k, S, x, y, by); else dif_stages<INV>(tile, TW, k, S, x, y, by);
+    }
     if (!valid) return;
     for (u32 t = y; t < K; t += by) {
         u64 v = tile[t * S + x];
@@ -220,20 +226,22 @@ struct LdeParams {
 };
 
 // Finishes the iNTT on bits [0,k), scales by the coset factors and starts the forward NTT (see header).
-template <int EPT>
+// SC = 0: any geometry; SC > 0: 8 stages, SC column slots x 16 sub-transform lanes, one slot group (EPT = 16) -- the geometry
+// of the wide matrices, with compile-time strides
+template <int EPT, int SC>
 __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
     extern __shared__ u64 lds[];
-    const u32 k = P.k, K = 1u << k, S = blockDim.x, by = blockDim.y;
+    const u32 k = SC ? 8 : P.k, K = 1u << k, S = SC ? SC : blockDim.x, by = SC ? 16 : blockDim.y;
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
     u64 *tile = lds, *TWi = tile + ((size_t)S << k), *TWf = TWi + K, *Sc = TWf + K, *Uc = Sc + (size_t)P.G * K;
 
     u32 bid = xcd_local_block();
     const u32 cc = bid % P.nColChunks;
     const u32 gt = bid / P.nColChunks;
-    const u32 gi = x / P.Wc, ci = x - gi * P.Wc;
+    const u32 gi = SC ? 0 : x / P.Wc, ci = x - gi * P.Wc;
     const u64 c = (u64)cc * P.Wc + ci;
     const bool valid = c < P.C;
-    const u64 g = (u64)gt * P.G + gi;               // index of this slot's 2^k-row block
+    const u64 g = (u64)gt * (SC ? 1 : P.G) + gi;    // index of this slot's 2^k-row block
     const u64 base = g * K * P.C + c;
 
     u64 coef[EPT];                                  // EPT >= K / by rows per lane: all loads in flight while the tables are built
@@ -251,7 +259,8 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
 #pragma unroll
     for (int i = 0; i < EPT; i++) { const u32 t = y + i * by; if (t < K) tile[t * S + x] = coef[i]; }
     __syncthreads();
-    dif_stages<true>(tile, TWi, k, S, x, y, by);
+    if constexpr (SC != 0) { dif_step<4, true>(tile, TWi, 8, 8, SC, x, y, 16); dif_step<4, true>(tile, TWi, 8, 4, SC, x, y, 16); }
+    else dif_stages<true>(tile, TWi, k, S, x, y, by);
 #pragma unroll
     for (int i = 0; i < EPT; i++) { u32 t = y + i * by; coef[i] = t < K ? tile[t * S + x] : 0; }
     __syncthreads();
@@ -266,7 +275,8 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
 #pragma unroll
         for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[tileOff + i * by * S] = mul_lazy(coef[i], Sc[scOff + i * by]); }
         __syncthreads();
-        dit_stages<false>(tile, TWf, k, S, x, y, by);
+        if constexpr (SC != 0) { dit_step<4, false>(tile, TWf, 8, 0, 4, SC, x, y, 16); dit_step<4, false>(tile, TWf, 8, 4, 0, SC, x, y, 16); }
+        else dit_stages<false>(tile, TWf, k, S, x, y, by);
         asm volatile("" : "+v"(dstOff), "+v"(tileOff));
         if (valid) {
 #pragma unroll
@@ -348,8 +358,12 @@ int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit,
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
     if (dit && inverse) return fail(PIL2GL_EINVAL, "no inverse decimation-in-time pass");
 #define PASS_CASE(INV_, DIT_)                                                                                     \
-    { P2_TRY(set_lds((const void *)ntt_pass_kernel<INV_, DIT_>, ldsBytes));                                          \
-      hipLaunchKernelGGL((ntt_pass_kernel<INV_, DIT_>), dim3((unsigned)blocks), dim3(g.S, g.by), ldsBytes, st, P); }
+    { if (k == 8 && g.S == 16 && g.by == 16 && g.nbT == 1 && g.Wc == 16 && !env_u32("PIL2GL_NTT_GENERIC", 0)) {      \
+          P2_TRY(set_lds((const void *)ntt_pass_kernel<INV_, DIT_, 8>, ldsBytes));                                   \
+          hipLaunchKernelGGL((ntt_pass_kernel<INV_, DIT_, 8>), dim3((unsigned)blocks), dim3(16, 16), ldsBytes, st, P); \
+      } else {                                                                                                     \
+          P2_TRY(set_lds((const void *)ntt_pass_kernel<INV_, DIT_, 0>, ldsBytes));                                   \
+          hipLaunchKernelGGL((ntt_pass_kernel<INV_, DIT_, 0>), dim3((unsigned)blocks), dim3(g.S, g.by), ldsBytes, st, P); } }
     if (dit) PASS_CASE(false, true) else if (inverse) PASS_CASE(true, false) else PASS_CASE(false, false)
 #undef PASS_CASE
     KERNEL_CHECK();
@@ -446,12 +460,19 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
         dim3 grid((unsigned)blocks), block(g.S, g.by);
 #define LDE_CASE(E_)                                                                              \
         if (need <= E_) {                                                                         \
-            P2_TRY(set_lds((const void *)lde_mid_kernel<E_>, ldsBytes));                           \
-            hipLaunchKernelGGL(lde_mid_kernel<E_>, grid, block, ldsBytes, st, P);                  \
+            P2_TRY(set_lds((const void *)lde_mid_kernel<E_, 0>, ldsBytes));                        \
+            hipLaunchKernelGGL((lde_mid_kernel<E_, 0>), grid, block, ldsBytes, st, P);             \
         } else
+#define LDE_FIXED(S_)                                                                             \
+        if (kf == 8 && g.S == S_ && g.by == 16 && g.nbT == 1 && !env_u32("PIL2GL_NTT_GENERIC", 0)) { \
+            P2_TRY(set_lds((const void *)lde_mid_kernel<16, S_>, ldsBytes));                       \
+            hipLaunchKernelGGL((lde_mid_kernel<16, S_>), grid, block, ldsBytes, st, P);            \
+        } else
+        LDE_FIXED(15) LDE_FIXED(16)
         LDE_CASE(1) LDE_CASE(2) LDE_CASE(4) LDE_CASE(8) LDE_CASE(16) LDE_CASE(32) LDE_CASE(64)
         { return fail(PIL2GL_EINVAL, "lde tile too tall for the thread block (need %u rows per thread)", need); }
 #undef LDE_CASE
+#undef LDE_FIXED
         KERNEL_CHECK();
     }
     // 3. remaining forward stages, decimation in time, bits [kf, n) from the bottom up, in place on
@@ -533,16 +554,21 @@ static int host_wrap(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64
     P2_TRY(check_ntt_args(src, dst, nBits, nBitsOut));
     uint64_t nIn = (nPols << nBits), nOut = (nPols << nBitsOut);
     if (nIn == 0) return PIL2GL_OK;
+    // device copies: up to 1 GiB each they live in persistent slots (a caller looping over BigBuffers of one size -- the
+    // reference's extendAndMerkelize does -- pays the allocations once); larger ones are allocated and freed per call
+    const uint64_t keepWords = 1ull << 27;
+    const bool keepIn = nIn <= keepWords, keepOut = nOut <= keepWords;
     uint64_t *dIn = nullptr, *dOut = nullptr;
-    HIP_TRY(hipMalloc((void **)&dIn, nIn * 8));
-    hipError_t e = hipMalloc((void **)&dOut, nOut * 8);
-    if (e != hipSuccess) { (void)hipFree(dIn); return hip_fail(e, "hipMalloc(dst)"); }
+    if (keepIn) P2_TRY(scratch(12, nIn, &dIn)); else HIP_TRY(hipMalloc((void **)&dIn, nIn * 8));
     int rc = PIL2GL_OK;
-    e = hipMemcpy(dIn, src, nIn * 8, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D");
+    if (keepOut) rc = scratch(13, nOut, &dOut);
+    else { hipError_t e = hipMalloc((void **)&dOut, nOut * 8); if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(dst)"); }
+    hipError_t e = hipSuccess;
+    if (rc == PIL2GL_OK) { e = hipMemcpy(dIn, src, nIn * 8, hipMemcpyHostToDevice); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy H2D"); }
     if (rc == PIL2GL_OK) rc = mode == 0 ? lde_launch(dIn, nPols, nBits, dOut, nBitsOut, 0, 0, 0, nullptr, false) : ntt_launch(dIn, nPols, nBits, dOut, mode == 2, 0);
     if (rc == PIL2GL_OK) { e = hipMemcpy(dst, dOut, nOut * 8, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy D2H"); }
-    (void)hipFree(dIn); (void)hipFree(dOut);
+    if (!keepIn) (void)hipFree(dIn);
+    if (!keepOut && dOut) (void)hipFree(dOut);
     return rc;
 }
 int pil2gl_interpolate(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt) { return host_wrap(src, nPols, nBits, dst, nBitsExt, 0); }

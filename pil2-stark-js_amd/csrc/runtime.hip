@@ -13,7 +13,7 @@ static bool g_ready = false;
 static int g_device = -1;
 static Tables g_tables = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
 static u64 *g_tables_mem = nullptr;
-static const u32 N_SCRATCH = 12;
+static const u32 N_SCRATCH = 14;      // 12, 13: device copies of the host-pointer NTT entry points (ntt.hip host_wrap)
 static u64 *g_scratch[N_SCRATCH] = { nullptr };
 static u64 g_scratch_words[N_SCRATCH] = { 0 };
 

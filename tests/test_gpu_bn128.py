@@ -204,7 +204,9 @@ def test_transcript_chain_kernel(bn, orc):
 
 def test_config4_shape_tree_opens(bn):
     """BASELINE config 4's shape (100 columns, BN128 linear hash, arity 16; 2^24 extended rows here, 2^27 in the config):
-    every opened path of the device-built tree recomputes the root through the host-side verification rule"""
+    every opened path of the device-built tree recomputes the root through the ORACLE's rule (bn128_oracle.root_from_group_proof:
+    the leaf's linear hash and six arity-16 levels in Python integers) and through the library's own verifier"""
+    import bn128_oracle as orc
     import torch
     h, w = 1 << 24, 100
     g = torch.Generator(device="cuda"); g.manual_seed(4)
@@ -217,5 +219,6 @@ def test_config4_shape_tree_opens(bn):
         assert len(mp) == 6 and all(len(l) == 16 for l in mp)
         assert v == [int(x) for x in buf[idx * w:(idx + 1) * w].cpu().numpy().view(np.uint64)]
         assert MH.verifyGroupProof(root, mp, idx, v)
+        assert orc.root_from_group_proof([[int(x) for x in l] for l in mp], idx, v, 16, False) == int(root)
     v[3] ^= 1
     assert not MH.verifyGroupProof(root, mp, idx, v)

@@ -67,6 +67,28 @@ def test_interpolate(gl, oracle, nBits, nPols, extBits):
         assert (out == oracle.interpolate(a, nBits, nBits + extBits)).all()
 
 
+@pytest.mark.parametrize("nBits,nPols,extBits", [(16, 30, 3), (16, 32, 1), (17, 100, 1)])
+def test_ntt_fixed_geometry_kernels(gl, oracle, nBits, nPols, extBits, monkeypatch):
+    """wide matrices with 8-stage passes run kernel instances whose strides are compile-time constants (ntt_pass_kernel<.., 8>,
+    lde_mid_kernel<16, 15|16>): the oracle's result, and bit-for-bit what the any-geometry instances give"""
+    rng = np.random.default_rng(nBits * 100 + nPols)
+    a = rand_field(rng, ((1 << nBits), nPols))
+    want = oracle.interpolate(a, nBits, nBits + extBits)
+    for generic in ("0", "1"):
+        monkeypatch.setenv("PIL2GL_NTT_GENERIC", generic)
+        out = np.zeros(((1 << (nBits + extBits)), nPols), np.uint64)
+        gl.interpolate(a, nPols, nBits, out, nBits + extBits)
+        assert np.array_equal(out, want), generic
+        f = np.zeros_like(a); gl.fft(a, nPols, nBits, f)
+        g = np.zeros_like(a); gl.ifft(f, nPols, nBits, g)
+        assert np.array_equal(g, a), generic
+        if generic == "0":
+            f0 = f
+        else:
+            assert np.array_equal(f, f0)
+    assert np.array_equal(f0[:, :3], oracle.fft_cols(np.ascontiguousarray(a[:, :3]), nBits))
+
+
 def test_interpolate_golden_kat(gl):
     # SURVEY 8(c)(2) / tests/golden/ntt.json "index3" ext 1
     c = [x for x in golden("ntt.json")["cases"] if x["name"] == "index3"][0]

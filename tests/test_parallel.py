@@ -85,3 +85,66 @@ def test_sharded_two_stage_proof_cpu(oracle):
 @pytest.mark.gpu
 def test_sharded_two_stage_proof_gpu_ranks(oracle):
     _launch(4, "--backend", "gpu", "--air", "perm", "--nbits", "10", "--steps", "13,9,4", worker=PROVE_WORKER)
+
+
+@pytest.mark.gpu
+def test_config5_rank_share_on_one_gpu(oracle):
+    """BASELINE config 5 (2^26 rows x 200 columns -> 2^29 extended rows: 859 GB, fits only sharded over 8 GPUs): rank 0's share
+    (coset 0 of 8: the 107 GB trace doubling as the LDE's workspace, a 107 GB slice, its leaves, its block of the tree)
+    run alone on one GPU, the other ranks' digests stood in.  Column c of the trace is the x table rotated by s_c rows, i.e.
+    the polynomial w^(s_c) X, so every extended value has a closed form: slice row pos of coset 0 is 7 w^(s_c + pos).
+    Checked against it: sampled rows up to the last one (word offsets beyond 2^33); against the oracle: the leaf digests of
+    those rows and the sibling paths of rows in this rank's leaf block up to the root."""
+    import numpy as np
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
+    import pil2gl
+    from pil2gl import stark, parallel
+    import gl_oracle as orc
+    pil2gl.init(0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 245e9:
+        pytest.skip("needs 245 GB of free device memory (%.0f GB free)" % (free / 1e9))
+    P = 0xFFFFFFFF00000001
+    nb, C, eb, world = 26, 200, 3, 8
+    N = 1 << nb
+    be = stark.GpuBackend(0, False)
+    x = be.build_x(nb, 1)                                           # w^i
+    trace = be.empty(N * C)
+    shifts = [(c * 7919 + 1 + (c % 3) * (N // 3)) % N for c in range(C)]
+    tv = trace.view(N, C)
+    for c in range(C):
+        tv[:, c] = torch.roll(x, -shifts[c])
+    del x
+    comm = parallel.Comm(rehearse_world=world)
+    cb, cc = parallel.coset_range(0, world, eb)
+    assert (cb, cc) == (0, 1)
+    local = be.empty(N * cc * C)
+    be.interpolate_cosets(trace, C, nb, local, nb + eb, cb, cc, trace)    # the trace is the workspace: nothing else fits
+    del trace, tv
+    digests = be.linear_hash_rows(local, C, N * cc)
+    w = int(orc.root(nb))
+    rows = [0, 1, 5, (N >> 3) - 1, (N >> 3), N // 2 + 12345, N - 2, N - 1]
+    lv = local.view(N, C)
+    dg = be.as_torch(digests).view(N, 4)
+    for pos in rows:
+        want = [7 * pow(w, shifts[c] + pos, P) % P for c in range(C)]
+        got = [int(v) for v in lv[pos].cpu().numpy().view(np.uint64)]
+        assert got == want, pos
+        assert [int(v) for v in dg[pos].cpu().numpy().view(np.uint64)] == [int(v) for v in orc.linear_hash(np.array(want, dtype=np.uint64))], pos
+    tree = parallel.ShardedTree(be, [be.as_torch(digests).reshape(-1)] * world, N, cc, comm)
+    block = N * cc                                                  # leaves of this rank's block: positions < N/8, all cosets
+    idxs = [0, 8, 8 * 5 + 3, block - 1, block // 2 + 77]
+    sib = tree.siblings(idxs)
+    for leaf, mp in zip(idxs, sib):
+        assert len(mp) == nb + eb
+        pos = leaf >> eb                                             # every coset's stand-in digest is coset 0's
+        cur = [int(v) for v in dg[pos].cpu().numpy().view(np.uint64)]
+        i = leaf
+        for s in mp:                                                 # merklehash_p.js:169-189
+            pair = (cur + list(s)) if i % 2 == 0 else (list(s) + cur)
+            cur = [int(v) for v in orc.poseidon(np.array(pair, dtype=np.uint64), np.zeros(4, np.uint64), 4)]
+            i >>= 1
+        assert cur == [int(v) for v in tree.root], leaf
+    del local, digests, tree
+    torch.cuda.empty_cache()

@@ -47,14 +47,16 @@ __host__ __device__ constexpr u32 next_chunk(u32 rem) { return rem <= 4 ? rem : 
 __host__ __device__ constexpr u32 brev_c(u32 i, int c) { u32 r = 0; for (int b = 0; b < c; b++) r |= ((i >> b) & 1u) << (c - 1 - b); return r; }
 
 // Gentleman-Sande group on blocks of 2^lm rows: natural in -> bit-reversed out (within the group's c index bits)
-template <int C, bool INV>
+// PAD (fixed-geometry kernels: k = 8, C = 4): tile row t lives at row t + (t >> 4), one spare row per 16, so that the four
+// sub-transforms a wave reads together (rows 256 words apart otherwise: the same LDS banks) start in different banks
+template <int C, bool INV, bool PAD = false>
 __device__ __forceinline__ void dif_step(u64 *tile, const u64 *TW, u32 k, u32 lm, u32 S, u32 x, u32 y, u32 by) {
     constexpr u32 R = 1u << C;
-    const u32 ls = lm - C, nD = 1u << (k - C), st = S << ls;
+    const u32 ls = lm - C, nD = 1u << (k - C), st = PAD && ls == 4 ? (S << ls) + S : S << ls;
     const bool last = ls == 0;
     for (u32 d = y; d < nD; d += by) {
         const u32 np = d & ((1u << ls) - 1);
-        u64 *col = tile + (size_t)(((d >> ls) << lm) + np) * S + x;
+        u64 *col = tile + (size_t)(((d >> ls) << lm) + np + (PAD && ls == 0 ? d : 0)) * S + x;
         fermat::f128 v[R];
 #pragma unroll
         for (u32 r = 0; r < R; r++) v[r] = fermat::from_gl(col[r * st]);
@@ -73,13 +75,13 @@ __device__ __forceinline__ void dif_step(u64 *tile, const u64 *TW, u32 k, u32 lm
 }
 // Cooley-Tukey group joining 2^C finished blocks of 2^lp rows: bit-reversed in -> natural out.  The inputs already carry
 // this group's twiddles (applied when they were stored); the outputs get the next group's (cn = its stage count, 0: none).
-template <int C, bool INV>
+template <int C, bool INV, bool PAD = false>
 __device__ __forceinline__ void dit_step(u64 *tile, const u64 *TW, u32 k, u32 lp, u32 cn, u32 S, u32 x, u32 y, u32 by) {
     constexpr u32 R = 1u << C;
-    const u32 lm = lp + C, nD = 1u << (k - C), st = S << lp;
+    const u32 lm = lp + C, nD = 1u << (k - C), st = PAD && lp == 4 ? (S << lp) + S : S << lp;
     for (u32 d = y; d < nD; d += by) {
         const u32 np = d & ((1u << lp) - 1), blk = d >> lp;
-        u64 *col = tile + (size_t)((blk << lm) + np) * S + x;
+        u64 *col = tile + (size_t)((blk << lm) + np + (PAD && lp == 0 ? blk : 0)) * S + x;
         fermat::f128 v[R];
 #pragma unroll
         for (u32 r = 0; r < R; r++) v[r] = fermat::from_gl(col[r * st]);
@@ -154,7 +156,10 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     extern __shared__ u64 lds[];
     const u32 k = KC ? KC : P.k, K = 1u << k, S = KC ? 16 : blockDim.x, by = KC ? 16 : blockDim.y;
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
-    u64 *tile = lds, *TW = tile + ((size_t)S << k), *TWO = TW + K;
+    constexpr bool PAD = KC != 0;                   // one spare tile row per 16 (see dif_step)
+    const u32 tileRows = PAD ? K + (K >> 4) : K;
+    u64 *tile = lds, *TW = tile + (size_t)S * tileRows, *TWO = TW + K;
+#define TROW(t_) (PAD ? (t_) + ((t_) >> 4) : (t_))
 
     u32 bid = xcd_local_block();
     const u32 cc = bid % P.nColChunks; bid /= P.nColChunks;
@@ -190,7 +195,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
             if (t < K) {
                 u64 v = vin[i];
                 if (DIT && P.hasTw) v = mul_lazy(v, TWO[gi * K + t]);
-                tile[t * S + x] = v;
+                tile[TROW(t) * S + x] = v;
             }
         }
         t0 += LOADB * by;
@@ -200,19 +205,20 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     }
     __syncthreads();
     if constexpr (KC == 8) {
-        if (DIT) { dit_step<4, INV>(tile, TW, 8, 0, 4, 16, x, y, 16); dit_step<4, INV>(tile, TW, 8, 4, 0, 16, x, y, 16); }
-        else { dif_step<4, INV>(tile, TW, 8, 8, 16, x, y, 16); dif_step<4, INV>(tile, TW, 8, 4, 16, x, y, 16); }
+        if (DIT) { dit_step<4, INV, true>(tile, TW, 8, 0, 4, 16, x, y, 16); dit_step<4, INV, true>(tile, TW, 8, 4, 0, 16, x, y, 16); }
+        else { dif_step<4, INV, true>(tile, TW, 8, 8, 16, x, y, 16); dif_step<4, INV, true>(tile, TW, 8, 4, 16, x, y, 16); }
     } else {
         if (DIT) dit_stages<INV>(tile, TW, k, S, x, y, by); else dif_stages<INV>(tile, TW, k, S, x, y, by);
     }
     if (!valid) return;
     for (u32 t = y; t < K; t += by) {
-        u64 v = tile[t * S + x];
+        u64 v = tile[TROW(t) * S + x];
         if (P.hasTw) { if (!DIT) v = mul(v, TWO[gi * K + t]); }
         else if (P.scale) v = mul(v, P.scale);
         u64 addr = P.scatter ? (u64)bitrev32((u32)(g * K + t), P.n) * P.C + c : base + (u64)t * P.tStride;
         P.dst[addr] = v;
     }
+#undef TROW
 }
 
 struct LdeParams {
@@ -233,7 +239,9 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
     extern __shared__ u64 lds[];
     const u32 k = SC ? 8 : P.k, K = 1u << k, S = SC ? SC : blockDim.x, by = SC ? 16 : blockDim.y;
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
-    u64 *tile = lds, *TWi = tile + ((size_t)S << k), *TWf = TWi + K, *Sc = TWf + K, *Uc = Sc + (size_t)P.G * K;
+    constexpr bool PAD = SC != 0;                   // one spare tile row per 16 (see dif_step)
+    const u32 tileRows = PAD ? K + (K >> 4) : K, rowStep = PAD ? by + 1 : by;      // rows y + i*by -> y + i*(by+1) when padded (by = 16)
+    u64 *tile = lds, *TWi = tile + (size_t)S * tileRows, *TWf = TWi + K, *Sc = TWf + K, *Uc = Sc + (size_t)P.G * K;
 
     u32 bid = xcd_local_block();
     const u32 cc = bid % P.nColChunks;
@@ -257,12 +265,12 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
         Sc[idx] = s0;
     }
 #pragma unroll
-    for (int i = 0; i < EPT; i++) { const u32 t = y + i * by; if (t < K) tile[t * S + x] = coef[i]; }
+    for (int i = 0; i < EPT; i++) { const u32 t = y + i * by; if (t < K) tile[(y + i * rowStep) * S + x] = coef[i]; }
     __syncthreads();
-    if constexpr (SC != 0) { dif_step<4, true>(tile, TWi, 8, 8, SC, x, y, 16); dif_step<4, true>(tile, TWi, 8, 4, SC, x, y, 16); }
+    if constexpr (SC != 0) { dif_step<4, true, true>(tile, TWi, 8, 8, SC, x, y, 16); dif_step<4, true, true>(tile, TWi, 8, 4, SC, x, y, 16); }
     else dif_stages<true>(tile, TWi, k, S, x, y, by);
 #pragma unroll
-    for (int i = 0; i < EPT; i++) { u32 t = y + i * by; coef[i] = t < K ? tile[t * S + x] : 0; }
+    for (int i = 0; i < EPT; i++) { u32 t = y + i * by; coef[i] = t < K ? tile[(y + i * rowStep) * S + x] : 0; }
     __syncthreads();
     const u32 nCosets = P.cosetCount;
     for (u32 j = 0; j < nCosets; j++) {
@@ -273,16 +281,16 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
         asm volatile("" : "+v"(dstOff), "+v"(tileOff), "+v"(scOff));
         const u64 dstStep = (u64)by * P.cosetCount * P.C;
 #pragma unroll
-        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[tileOff + i * by * S] = mul_lazy(coef[i], Sc[scOff + i * by]); }
+        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[tileOff + i * rowStep * S] = mul_lazy(coef[i], Sc[scOff + i * by]); }
         __syncthreads();
-        if constexpr (SC != 0) { dit_step<4, false>(tile, TWf, 8, 0, 4, SC, x, y, 16); dit_step<4, false>(tile, TWf, 8, 4, 0, SC, x, y, 16); }
+        if constexpr (SC != 0) { dit_step<4, false, true>(tile, TWf, 8, 0, 4, SC, x, y, 16); dit_step<4, false, true>(tile, TWf, 8, 4, 0, SC, x, y, 16); }
         else dit_stages<false>(tile, TWf, k, S, x, y, by);
         asm volatile("" : "+v"(dstOff), "+v"(tileOff));
         if (valid) {
 #pragma unroll
             for (int i = 0; i < EPT; i++) {
                 u32 t = y + i * by;
-                if (t < K) P.dst[dstOff + i * dstStep] = tile[tileOff + i * by * S];
+                if (t < K) P.dst[dstOff + i * dstStep] = tile[tileOff + i * rowStep * S];
             }
         }
         for (u32 idx = tid; idx < P.G * K; idx += nth) Sc[idx] = mul(Sc[idx], Uc[idx]);
@@ -353,12 +361,13 @@ int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit,
     Geom g = make_geom(k, C, totalGroups, env_u32("PIL2GL_NTT_TILE", 4096), 256);
     P.Wc = g.Wc; P.nbT = g.nbT; P.nColChunks = g.nColChunks; P.nGroupTiles = (u32)(totalGroups / g.nbT);
     u64 K = 1ull << k;
-    size_t ldsBytes = 8 * ((size_t)g.S * K + K + (P.hasTw ? (size_t)g.nbT * K : 0));
+    const bool fixedGeom = k == 8 && g.S == 16 && g.by == 16 && g.nbT == 1 && g.Wc == 16 && !env_u32("PIL2GL_NTT_GENERIC", 0);
+    size_t ldsBytes = 8 * ((size_t)g.S * (fixedGeom ? K + K / 16 : K) + K + (P.hasTw ? (size_t)g.nbT * K : 0));
     u64 blocks = (u64)nHi * P.nGroupTiles * P.nColChunks;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
     if (dit && inverse) return fail(PIL2GL_EINVAL, "no inverse decimation-in-time pass");
 #define PASS_CASE(INV_, DIT_)                                                                                     \
-    { if (k == 8 && g.S == 16 && g.by == 16 && g.nbT == 1 && g.Wc == 16 && !env_u32("PIL2GL_NTT_GENERIC", 0)) {      \
+    { if (fixedGeom) {                                                                                            \
           P2_TRY(set_lds((const void *)ntt_pass_kernel<INV_, DIT_, 8>, ldsBytes));                                   \
           hipLaunchKernelGGL((ntt_pass_kernel<INV_, DIT_, 8>), dim3((unsigned)blocks), dim3(16, 16), ldsBytes, st, P); \
       } else {                                                                                                     \
@@ -454,6 +463,8 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
             ldsBytes = 8 * ((size_t)g.S * K + 2 * K + 2 * (size_t)g.nbT * K);
         }
         P.Wc = g.Wc; P.G = g.nbT; P.nColChunks = g.nColChunks;
+        const bool fixedGeom = kf == 8 && (g.S == 15 || g.S == 16) && g.by == 16 && g.nbT == 1 && !env_u32("PIL2GL_NTT_GENERIC", 0);
+        if (fixedGeom) ldsBytes += 8 * (size_t)g.S * (K / 16);
         u32 need = (u32)((K + g.by - 1) / g.by);
         u64 blocks = (totalGroups / g.nbT) * g.nColChunks;
         if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
@@ -464,7 +475,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
             hipLaunchKernelGGL((lde_mid_kernel<E_, 0>), grid, block, ldsBytes, st, P);             \
         } else
 #define LDE_FIXED(S_)                                                                             \
-        if (kf == 8 && g.S == S_ && g.by == 16 && g.nbT == 1 && !env_u32("PIL2GL_NTT_GENERIC", 0)) { \
+        if (fixedGeom && g.S == S_) {                                                             \
             P2_TRY(set_lds((const void *)lde_mid_kernel<16, S_>, ldsBytes));                       \
             hipLaunchKernelGGL((lde_mid_kernel<16, S_>), grid, block, ldsBytes, st, P);            \
         } else

@@ -349,8 +349,8 @@ def all_gather_rows(be, local, n_bits, cc, width, comm):
 def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None, timings=None, comm=None):
     """pil2gl.stark.stark_gen with every witness stage, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
-    single-process one.  Replicated: the iNTT of q (3 columns) and the FRI folding; the trees above the leaves are split
-    by leaf blocks (ShardedTree).
+    single-process one.  Replicated: the iNTT of q (3 columns) and the FRI steps after the first fold (the first FRI tree's
+    leaves and the first fold are computed by cosets); the stage trees above the leaves are split by leaf blocks (ShardedTree).
     rehearse_world=K: rank 0's share of a K-rank proof run alone (own slices stand in for the gathered ones, so the
     result is not a valid proof): per-GPU time and memory on one GPU.  timings: dict that receives seconds per stage."""
     from . import stark as S
@@ -365,8 +365,8 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     rehearse_world = world if comm.mode == "rehearse" else None
     ss = info["starkStruct"]
     if ss["nBitsExt"] > 27 and comm.mode != "rehearse":
-        # the replicated steps (iNTT of q, first FRI fold) run on the whole extended domain; the library's transforms stop at 2^27 rows
-        raise ValueError("a sharded PROOF needs nBitsExt <= 27 (got %d): the quotient's iNTT and the first FRI fold are replicated; "
+        # the replicated iNTT of q runs on the whole extended domain; the library's transforms stop at 2^27 rows
+        raise ValueError("a sharded PROOF needs nBitsExt <= 27 (got %d): the quotient's iNTT is replicated; "
                          "the sharded COMMIT (extend_and_merkelize_sharded) has no such limit" % ss["nBitsExt"])
     nb, nbe = ss["nBits"], ss["nBitsExt"]
     eb, N, E = nbe - nb, 1 << ss["nBits"], 1 << ss["nBitsExt"]
@@ -497,24 +497,45 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     loc["f_ext"] = be.empty(3 << nloc)
     if not (hasattr(be, "fri_polynomial_fast") and be.fri_polynomial_fast(info, loc, widths, ctx["evals"], vfs[0], vfs[1], nloc, loc["f_ext"])):
         run_local(exprs["expressionsCode"][info["friExpId"]]["code"])
-    f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, comm)
-
     lap("fri_expr")
-    # folding and its trees, replicated; openings: the rows of the committed stages from their owners, everything else is local
-    # the first FRI tree (2^steps[1].nBits leaves of 3 * 2^(bits0 - bits1) words: as many leaf permutations as a 12-column stage)
-    # is split by contiguous leaf blocks: every rank holds the whole transposed polynomial, hashes its block of leaves and
-    # builds the subtree over them; only the subtree roots are exchanged.  The later trees are 32x smaller and replicated.
-    fri_sharded = {}
-
-    def fri_tree(step, tb, w, h):
-        blk = h // world
-        if step != 1 or h % world or blk < 2:
-            return None
-        lo = rank * blk * w
-        dig = be.linear_hash_rows(tb[lo:lo + blk * w], w, blk)
-        fri_sharded[step] = (tb, w, ShardedTree(be, None, blk, 1, comm, block_digests=dig))
-        return fri_sharded[step][2]
-    friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, f_ext, transcript, tree_builder=fri_tree)
+    # Folding.  The first FRI tree commits the UNFOLDED polynomial in groups {i 2^b1 + g : i < 2^(b0-b1)} (fri.js:62-74 at
+    # step 0, where nothing is folded), and the first fold combines exactly those groups (fri.js:45-60 at step 1).  A group
+    # lies in ONE coset (g mod 2^eb; b1 >= eb), and coset j's rows are the same matrix one size down: group g = 2^eb g' + j
+    # is rows {i 2^(b1-eb) + g'} of the rank's slice, with sinv_g = shift^-1 w^-g = (shift^-1 w^-j) (w^(2^eb))^-g'.  So a rank
+    # transposes, hashes and folds its own cosets with the ordinary kernels, and what travels is the 2^b1 leaf digests and the
+    # 2^b1 folded values (0.23 GB at config 3) instead of the polynomial (3.2 GB); the tree above the leaves and every
+    # later step (2^(b0-b1) times smaller) are replicated.
+    steps = ss["steps"]
+    fri_first = None
+    if len(steps) >= 2 and steps[1]["nBits"] >= eb:
+        b0, b1 = steps[0]["nBits"], steps[1]["nBits"]
+        nX, gl_ = 1 << (b0 - b1), 1 << (b1 - eb)                         # group size; groups (= tree-1 leaves) per coset
+        ch0 = transcript.getField()
+        ft = be.as_torch(loc["f_ext"]).reshape(N, cc, 3)
+        f_cos = [be.from_torch(ft[:, jl, :].contiguous().reshape(-1)) if cc > 1 else loc["f_ext"] for jl in range(cc)]
+        tbs = [be.fri_transpose(fj, nb, b1 - eb) for fj in f_cos]          # [gl_][nX*3]: row g' = the values of group 2^eb g' + j
+        dig = torch.stack([be.as_torch(be.linear_hash_rows(tb, 3 * nX, gl_)).reshape(gl_, 4) for tb in tbs], dim=1)   # [gl_][cc][4]
+        parts = comm.all_gather(dig.reshape(-1).contiguous())
+        leaves = torch.stack([p_.reshape(gl_, cc * 4) for p_ in parts], dim=1).reshape(-1)      # leaf g = g' 2^eb + rank cc + jl
+        nodes1 = be.merkelize_digests(be.from_torch(leaves), 1 << b1)
+        root1 = be.root({"nodes": nodes1})
+        transcript.put(root1)
+        ch1 = transcript.getField()
+        w_inv = S._inv(S.root_of_unity(b0))
+        sinv = S._inv(S.SHIFT)
+        fold = torch.stack([be.as_torch(be.fri_fold(fj, nb, b1 - eb, sinv * pow(w_inv, cb + jl, S.P) % S.P, ch1)).reshape(gl_, 3)
+                            for jl, fj in enumerate(f_cos)], dim=1)          # [gl_][cc][3]
+        del f_cos, ft
+        parts = comm.all_gather(fold.reshape(-1).contiguous())
+        friPol = be.from_torch(torch.stack([p_.reshape(gl_, cc * 3) for p_ in parts], dim=1).reshape(-1))
+        friTrees, friProof = [None] * len(steps), [{} for _ in range(len(steps) + 1)]
+        friTrees[1] = {"nodes": nodes1, "sharded_leaves": True}
+        friProof[1] = {"root": list(root1)}
+        fri_first = (tbs, 3 * nX, nodes1, 1 << b1)
+        friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, None, transcript, resume=(1, friPol, friTrees, friProof, [ch0, ch1]))
+    else:
+        f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, comm)
+        friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, f_ext, transcript)
     lap("fri_fold")
     chq = transcript.getField(); challengesFRI.append(chq)
     tq = be.new_transcript(); tq.put(chq)
@@ -527,8 +548,16 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         w = shards[s_]["width"]
         pieces.append(open_rows_local(be, shards[s_], queries, rank, world).cpu().reshape(-1) if not rehearse_world else torch.zeros(len(queries) * w, dtype=torch.int64))
         pieces.append(strees[s_].siblings_local(queries).reshape(-1))
-    if 1 in fri_sharded:
-        pieces.append(fri_sharded[1][2].siblings_local(q1).reshape(-1))
+    if fri_first is not None:                                          # the opened groups of the first FRI tree, from the cosets' owners
+        tbs, w1, nodes1, h1 = fri_first
+        g1 = torch.zeros((len(q1), w1), dtype=torch.int64)
+        own = [(k, (g >> eb), (g & ((1 << eb) - 1)) - cb) for k, g in enumerate(q1) if cb <= (g & ((1 << eb) - 1)) < cb + cc]
+        for jl in range(cc):
+            sel = [(k, gp) for k, gp, j_ in own if j_ == jl]
+            if sel:
+                tt = be.as_torch(tbs[jl]).reshape(-1, w1)
+                g1[torch.tensor([k for k, _ in sel])] = tt[torch.tensor([gp for _, gp in sel], device=tt.device)].cpu()
+        pieces.append(g1.reshape(-1))
     summed = comm.all_reduce_sum(torch.cat(pieces))
     parts, o = [], 0
     for p_ in pieces:
@@ -542,11 +571,9 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     q = list(queries)
     for step in range(1, len(ss["steps"])):
         q = [qi % (1 << ss["steps"][step]["nBits"]) for qi in q]
-        if step in fri_sharded:
-            tb, w, stree = fri_sharded[step]
-            sib = stree.siblings_finish(q, parts[-1])
-            tt = be.as_torch(tb).reshape(-1, w)
-            vals = tt[torch.tensor(q, device=tt.device)].cpu().numpy().view(np.uint64).reshape(len(q), w)      # one gather for all queries
+        if step == 1 and fri_first is not None:
+            sib = be.merkle_siblings(nodes1, h1, q)
+            vals = parts[-1].numpy().view(np.uint64).reshape(len(q), w1)
             friProof[step]["polQueries"] = [[[int(v) for v in vals[i]], sib[i]] for i in range(len(q))]
         else:
             friProof[step]["polQueries"] = [list(p_) for p_ in be.group_proofs(friTrees[step], q)]

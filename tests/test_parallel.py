@@ -72,6 +72,13 @@ def test_sharded_proof_gpu_ranks(oracle, world, nbits, pairs, steps):
     _launch(world, "--backend", "gpu", "--nbits", str(nbits), "--pairs", str(pairs), "--steps", steps, worker=PROVE_WORKER)
 
 
+@pytest.mark.parametrize("steps", ["9,2", "9"])
+def test_sharded_proof_with_fri_groups_across_cosets_cpu(oracle, steps):
+    """the first FRI tree's groups stay inside one coset only while steps[1].nBits >= the extension bits; below that (or
+    with a single FRI step, whose polynomial is absorbed whole) the FRI polynomial is all-gathered and folded everywhere"""
+    _launch(2, "--backend", "oracle", "--steps", steps, worker=PROVE_WORKER)
+
+
 def test_sharded_hash_commits_proof_cpu(oracle):
     """starkStruct.hashCommits in the sharded prove loop (publics, evaluations and last polynomial absorbed as hashes)"""
     _launch(2, "--backend", "oracle", "--hashcommits", "1", worker=PROVE_WORKER)

@@ -14,6 +14,8 @@
 #include "common.h"
 #include "gl_field.cuh"
 #include <vector>
+#include <stdint.h>
+#include <stdlib.h>
 #include <algorithm>
 
 using namespace gl;
@@ -121,6 +123,199 @@ __global__ void __launch_bounds__(256) rows_dot_kernel(RowsDotParams P) {
         }
 }
 
+// The same sums for matrices whose rows are long (the 100-column stage matrix): a workgroup takes 64 CONSECUTIVE rows -- one
+// contiguous piece of memory, 51 KB at 100 columns -- and streams it into LDS with all 256 threads (consecutive lanes read
+// consecutive words, whole cache lines, every DRAM page once), instead of each wave collecting 64 separate 128-byte row
+// pieces per column tile (which left the kernel at 2.3 TB/s with 1.7x the bytes fetched).  Lanes <-> rows as before, so the
+// weights stay wave-uniform; the four waves split the COLUMNS of the tile, their unreduced sums (< 2^64 by the same 1024-term
+// bound) are added in LDS (ds_add_u64), and the 3*NOUT folds are dealt over the waves.  Rows wider than CW_MAX columns are taken
+// in column chunks of whole-chunk row segments.
+constexpr u32 STREAM_CW_MAX = 128;
+template <int NOUT>
+__global__ void __launch_bounds__(256) rows_dot_stream_kernel(RowsDotParams P, u32 cw, u32 LD) {
+    extern __shared__ u64 sm[];                 // tile [64][LD], then the summed partial sums [NOUT*18][64]
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u64 row0 = (u64)blockIdx.x * 64;
+    u64 S[NOUT][3][6];
+#pragma unroll
+    for (int o = 0; o < NOUT; o++)
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+#pragma unroll
+            for (int i = 0; i < 6; i++) S[o][k][i] = 0;
+    constexpr u32 NB = 13;                      // loads of a thread in flight together (two batches cover 64 x 100)
+    for (u64 c0 = 0; c0 < P.width; c0 += cw) {
+        const u32 w = (u32)min((u64)cw, P.width - c0);
+        const u32 total = 64 * w, dq = 256 / w, dr = 256 - dq * w;
+        u32 r = tid / w, c = tid - r * w;
+        for (u32 u0 = 0; u0 < total; u0 += 256 * NB) {
+            u64 v[NB]; u32 at[NB];
+#pragma unroll
+            for (u32 i = 0; i < NB; i++) {
+                const bool in = u0 + 256 * i + tid < total;
+                at[i] = in ? r * LD + c : 0xFFFFFFFFu;
+                v[i] = (in && row0 + r < P.nRows) ? P.buf[(row0 + r) * P.stride + P.col0 + c0 + c] : 0;
+                c += dr; r += dq;
+                if (c >= w) { c -= w; r++; }
+            }
+            if (u0 == 0) __syncthreads();       // the previous chunk's tile has been consumed by every wave
+#pragma unroll
+            for (u32 i = 0; i < NB; i++) if (at[i] != 0xFFFFFFFFu) sm[at[i]] = v[i];
+        }
+        __syncthreads();
+        const u32 cb = w * wave / 4, ce = w * (wave + 1) / 4;
+        for (u32 cc = cb; cc < ce; cc++) {
+            const u64 p = sm[lane * LD + cc];
+            const u32 p0 = (u32)p, p1 = (u32)(p >> 32);
+#pragma unroll
+            for (int o = 0; o < NOUT; o++) {
+                const u32 *L = P.coefLimbs + (((u64)o * P.stride + P.col0 + c0 + cc) * 9);   // wave-uniform -> scalar loads
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const u32 w0 = L[3 * k], w1 = L[3 * k + 1], w2 = L[3 * k + 2];
+                    S[o][k][0] += (u64)p0 * w0; S[o][k][1] += (u64)p0 * w1; S[o][k][2] += (u64)p0 * w2;
+                    S[o][k][3] += (u64)p1 * w0; S[o][k][4] += (u64)p1 * w1; S[o][k][5] += (u64)p1 * w2;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int o = 0; o < NOUT; o++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int i = 0; i < 6; i++) sm[((o * 3 + k) * 6 + i) * 64 + lane] = S[o][k][i];
+    }
+    __syncthreads();
+    if (wave != 0) {
+#pragma unroll
+        for (int o = 0; o < NOUT; o++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int i = 0; i < 6; i++)
+                    __hip_atomic_fetch_add(&sm[((o * 3 + k) * 6 + i) * 64 + lane], S[o][k][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __syncthreads();
+    const u64 myRow = row0 + lane;
+    if (myRow >= P.nRows) return;
+    u64 *out = P.acc + myRow * (3ull * P.nOut);
+    for (u32 pi = wave; pi < 3 * NOUT; pi += 4) {
+        u64 T6[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) T6[i] = sm[(pi * 6 + i) * 64 + lane];
+        u64 v = fold6(T6);
+        if (P.accumulate) v = add(v, out[pi]);
+        out[pi] = v;
+    }
+}
+
+
+// ---------------------------------------------------------------- the same sums on the matrix cores
+// out[r][o] = sum_c M[r][c] * W[c][o] is a matrix product, and a row of M is already the right operand: 8*width bytes, byte i of
+// column c having weight 2^(8i).  With every weight written in SIGNED base-256 digits (d_0..d_8 in [-128,127]: nine of them),
+//     out[r][o] = sum_p 2^(8p) G[r][o][p],     G[r][o][p] = sum_c sum_i byte_i(M[r][c]) * d_(p-i)(W[c][o])       (p < 16)
+// is an i8 x i8 -> i32 product with K = 8*width and 16 planes per output: v_mfma_i32_32x32x32_i8 with the 32 trace rows of a
+// row group as the N dimension (operand B: lane (n, g) feeds 16 consecutive bytes of ITS row, straight from the staged
+// tile), and the (output, plane) pairs as the M dimension, ordered so that the 16 result registers of lane (n, h) are the 16
+// planes of output 2*tile + h for row n (result rows 8q + 4h + r, see poseidon_mds_mfma.cuh).  Bytes are fed as (b ^ 0x80) = b - 128;
+// the missing 128 * sum_i 2^(8i) * sum_c W[c][o] is a constant per output and is added with the plane offset at the end.
+// One persistent workgroup of 8 waves per CU walks over tiles of 64 consecutive rows (one contiguous piece of memory, streamed
+// into LDS by all 512 threads; the NEXT tile's loads are in flight while this one is multiplied).  The digit matrix (1 KB per
+// K-step and M tile: 75 KB at 100 columns) sits in LDS beside the tile for the whole kernel; wave (g, t) -- row group g, M
+// tile t -- runs the K-steps of ITS 32 rows x 2 outputs as one accumulator chain and recombines the planes from its own
+// registers: no sums cross waves.  Per row 1.2 MFMAs instead of 3600 v_mad_u64_u32: what is left is the streaming read
+// (profiles/r02_rows_dot_*.txt).
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr u32 MF_WAVES = 8, MF_ROWS = 64, MF_MAXW = 112;
+constexpr int MF_PLANE_OFFSET = 1 << 24;        // every plane sum is > -2^24: the accumulators start at 2^24
+
+struct RowsDotMfmaParams {
+    const u64 *buf; u64 nRows, stride, col0; u32 width, nOut;
+    const v4i *atab;            // [kSteps][NT][64 lanes]: 16 digit bytes per lane
+    const u64 *bias;            // [3*nOut] canonical
+    u64 *acc; u32 accumulate;
+    u64 nTiles;
+    u32 kSteps;
+};
+
+template <int NT>
+__global__ void __launch_bounds__(512, 1) rows_dot_mfma_kernel(RowsDotMfmaParams P) {
+    extern __shared__ u64 sm[];
+    constexpr u32 NTH = 64 * MF_WAVES, NG = MF_ROWS / 32;
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    const u32 wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const u32 rowBytes = P.width * 8, LDB = rowBytes + 16;          // 16-byte aligned rows, 4-dword skew between rows
+    unsigned char *tile = (unsigned char *)sm;
+    v4i *Alds = (v4i *)(tile + MF_ROWS * LDB);                       // [kSteps][NT][64]
+    const u32 upr = P.width / 2;                                     // 16-byte units per row
+    for (u32 i = tid; i < P.kSteps * NT * 64; i += NTH) Alds[i] = P.atab[i];
+    const u32 n = lane & 31, gk = lane >> 5;
+    const u32 total = MF_ROWS * upr, dq = NTH / upr, dr = NTH - dq * upr;
+    // a thread's share of a tile: up to NL 16-byte units, unit tid + 512 i = (row r_i, unit c_i of the row), the same for
+    // every tile and stepped through as a recurrence
+    constexpr u32 NL = (MF_ROWS * (MF_MAXW / 2) + NTH - 1) / NTH;    // 7
+    const u32 r00 = tid / upr, c00 = tid - r00 * upr;
+    v4i nxt[NL];
+    auto fetch = [&](u64 tileIdx) {
+        const u64 row0 = tileIdx * MF_ROWS;
+        const u64 *base = P.buf + row0 * P.stride + P.col0;
+        u32 r = r00, c = c00;
+#pragma unroll
+        for (u32 i = 0; i < NL; i++) {
+            const v4i z = { 0, 0, 0, 0 };
+            nxt[i] = (NTH * i + tid < total && row0 + r < P.nRows) ? *(const v4i *)(base + (u64)r * P.stride + 2 * c) : z;
+            c += dr; r += dq;
+            if (c >= upr) { c -= upr; r++; }
+        }
+    };
+    if (blockIdx.x < P.nTiles) fetch(blockIdx.x);
+    const u32 g = wave / NT, t = wave - g * NT;                      // this wave's rows 32 g + n and outputs 2 t + h (waves >= NG*NT only load)
+    const unsigned char *brow = tile + (32 * g + n) * LDB + 16 * gk;
+    const v4i *arow = Alds + t * 64 + lane;
+    for (u64 tileIdx = blockIdx.x; tileIdx < P.nTiles; tileIdx += gridDim.x) {
+        const u64 row0 = tileIdx * MF_ROWS;
+        __syncthreads();                        // the previous tile has been consumed by every wave (first pass: the digits are in place)
+        {
+            u32 r = r00, c = c00;
+#pragma unroll
+            for (u32 i = 0; i < NL; i++) {
+                if (NTH * i + tid < total) *(v4i *)(tile + r * LDB + 16 * c) = nxt[i] ^ (int)0x80808080;
+                c += dr; r += dq;
+                if (c >= upr) { c -= upr; r++; }
+            }
+        }
+        // the next tile's rows travel while this one is multiplied and folded
+        if (tileIdx + gridDim.x < P.nTiles) fetch(tileIdx + gridDim.x);
+        __syncthreads();
+        if (wave < NG * NT) {
+            v16i acc;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = MF_PLANE_OFFSET;
+            for (u32 s_ = 0; s_ < P.kSteps; s_++)
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(arow[s_ * NT * 64], *(const v4i *)(brow + 32 * s_), acc, 0, 0, 0);
+            const u32 o = 2 * t + gk;
+            const u64 row = row0 + 32 * g + n;
+            if (o < 3 * P.nOut && row < P.nRows) {
+                u64 w[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    w[j] = (u64)(u32)acc[4 * j] + ((u64)(u32)acc[4 * j + 1] << 8) + ((u64)(u32)acc[4 * j + 2] << 16) + ((u64)(u32)acc[4 * j + 3] << 24);   // < 2^50
+                // w0 + w1 2^32 + w2 2^64 + w3 2^96 = w0 + w1 2^32 + w2 (2^32 - 1) - w3   (mod p)
+                u64 v = add(add(w[0], mul(w[1], 1ull << 32)), mul(w[2], EPS));
+                v = add(sub(v, w[3]), P.bias[o]);
+                u64 *out = P.acc + row * (3ull * P.nOut) + o;
+                if (P.accumulate) v = add(v, *out);
+                *out = v;
+            }
+        }
+    }
+}
+
 // f[r] = Horner over openings (vf1) of (acc[r][o] - K_o) * X[r][o]    (friPolinomial.js:38-50)
 __global__ void fri_combine_kernel(const u64 *__restrict__ acc, const u64 *__restrict__ K, E3 vf1, const u64 *__restrict__ xdiv,
                                    u32 nOpen, u64 nRows, u64 *__restrict__ f) {
@@ -213,6 +408,76 @@ inline unsigned nblk(u64 n, u32 t = 256) { return (unsigned)((n + t - 1) / t); }
 
 using namespace pil2gl;
 
+// host side of rows_dot_mfma_kernel: signed base-256 digits of the weights laid out as the MFMA's A operand, the constant per output
+static int launch_rows_dot_mfma(const u64 *buf, u64 winWidth, u64 nRows, u64 stride, u64 col0, const uint64_t *hostCoef /* [nOut][stride][3] */,
+                                u32 nOut, u64 *acc, bool accumulate, hipStream_t st) {
+    const u64 Pm = 0xFFFFFFFF00000001ull;
+    const int NT = nOut == 1 ? 2 : 3;
+    const u32 nO = 3 * nOut;
+    std::vector<signed char> dig((size_t)winWidth * nO * 9);
+    std::vector<u64> bias(nO);
+    unsigned __int128 k128 = 0, offs = 0;
+    for (int i = 0; i < 8; i++) k128 += (unsigned __int128)128 << (8 * i);
+    {   // sum_p 2^24 * 2^(8p) mod p, the power kept reduced (2^24 * 2^120 does not fit 128 bits)
+        unsigned __int128 pw = 1;
+        for (int p_ = 0; p_ < 16; p_++) { offs = (offs + (pw * (u64)MF_PLANE_OFFSET) % Pm) % Pm; pw = (pw * 256) % Pm; }
+    }
+    for (u32 o = 0; o < nO; o++) {
+        unsigned __int128 sumw = 0;
+        for (u64 c = 0; c < winWidth; c++) {
+            u64 w = hostCoef[((u64)(o / 3) * stride + col0 + c) * 3 + (o % 3)] % Pm;
+            sumw = (sumw + w) % Pm;
+            int carry = 0;
+            for (int j = 0; j < 9; j++) {
+                int b = (j < 8 ? (int)((w >> (8 * j)) & 255) : 0) + carry;
+                carry = 0;
+                if (b >= 128) { b -= 256; carry = 1; }
+                dig[((size_t)c * nO + o) * 9 + j] = (signed char)b;
+            }
+        }
+        unsigned __int128 b = ((k128 % Pm) * sumw) % Pm;
+        bias[o] = (u64)((b + Pm - offs) % Pm);
+    }
+    const u32 kSteps = (u32)((winWidth * 8 + 31) / 32);
+    std::vector<signed char> atab((size_t)kSteps * NT * 64 * 16, 0);
+    for (u32 s_ = 0; s_ < kSteps; s_++)
+        for (int t = 0; t < NT; t++)
+            for (u32 lane = 0; lane < 64; lane++) {
+                const u32 m = lane & 31, gk = lane >> 5;
+                const u32 h = (m >> 2) & 1, pl = 4 * (m >> 3) + (m & 3), o = 2 * t + h;
+                if (o >= nO) continue;
+                signed char *dst = &atab[(((size_t)s_ * NT + t) * 64 + lane) * 16];
+                for (u32 kk = 0; kk < 16; kk++) {
+                    const u64 byteOff = 32ull * s_ + 16 * gk + kk;
+                    if (byteOff >= winWidth * 8) continue;              // past the row: zero digits (the lane reads the row's padding)
+                    const u64 c = byteOff >> 3; const u32 i = (u32)(byteOff & 7);
+                    const int j = (int)pl - (int)i;
+                    dst[kk] = (j >= 0 && j <= 8) ? dig[((size_t)c * nO + o) * 9 + j] : 0;
+                }
+            }
+    u64 *d;
+    const size_t atWords = (atab.size() + 7) / 8;
+    P2_TRY(scratch(7, atWords + nO + 2, &d));
+    HIP_TRY(hipMemcpyAsync(d, atab.data(), atab.size(), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d + atWords, bias.data(), nO * 8, hipMemcpyHostToDevice, st));
+    RowsDotMfmaParams P = { buf, nRows, stride, col0, (u32)winWidth, nOut, (const v4i *)d, d + atWords, acc, (u32)accumulate, (nRows + MF_ROWS - 1) / MF_ROWS, kSteps };
+    const size_t lds = (size_t)MF_ROWS * (winWidth * 8 + 16) + atab.size();
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const unsigned grid = (unsigned)std::min<u64>(P.nTiles, (u64)cus);
+    if (NT == 2) {
+        HIP_TRY(hipFuncSetAttribute((const void *)rows_dot_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((rows_dot_mfma_kernel<2>), dim3(grid), dim3(64 * MF_WAVES), lds, st, P);
+    } else {
+        HIP_TRY(hipFuncSetAttribute((const void *)rows_dot_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((rows_dot_mfma_kernel<3>), dim3(grid), dim3(64 * MF_WAVES), lds, st, P);
+    }
+    KERNEL_CHECK();
+    HIP_TRY(hipStreamSynchronize(st));          // the tables are host temporaries in a shared scratch slot
+    return PIL2GL_OK;
+}
+
 extern "C" {
 
 int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, const uint64_t *hostCoef, uint32_t nOut,
@@ -222,6 +487,11 @@ int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
     if (nOut < 1 || nOut > 4) return fail(PIL2GL_EINVAL, "nOut must be 1..4");
     if (width == 0 || nRows == 0) return PIL2GL_OK;
     hipStream_t st = as_stream(stream);
+    {   // long even rows, one or two outputs: the matrix cores (any window of a wider matrix that fits goes the same way)
+        const char *sw = getenv("PIL2GL_ROWS_DOT_MFMA");
+        if (!(sw && sw[0] == '0') && nOut <= 2 && width >= 32 && width <= MF_MAXW && width % 2 == 0 && ((uintptr_t)buf & 15) == 0)
+            return launch_rows_dot_mfma(buf, width, nRows, width, 0, hostCoef, nOut, acc, accumulate != 0, st);
+    }
     const u64 nC = (u64)nOut * width * 3;
     std::vector<u32> limbs(nC * 3);
     for (u64 i = 0; i < nC; i++) {
@@ -234,8 +504,26 @@ int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
     const unsigned blocks = (unsigned)((nRows + 255) / 256);
     // a lane's six partial sums take one term below 2^54 per column and are folded once per launch: windows of at most
     // 1024 columns, the later ones accumulating onto the first one's result
+    const char *sw = getenv("PIL2GL_ROWS_DOT_STREAM");
+    const bool stream_ok = !(sw && sw[0] == '0');
     for (u64 col0 = 0; col0 < width; col0 += 1024) {
         RowsDotParams P = { buf, std::min<u64>(1024, width - col0), nRows, width, col0, (const u32 *)d, nOut, acc, (u32)(accumulate != 0 || col0 != 0) };
+        if (stream_ok && P.width >= 32) {               // long rows: whole-row streaming tiles
+            const u32 nch = (u32)((P.width + STREAM_CW_MAX - 1) / STREAM_CW_MAX), cw = (u32)((P.width + nch - 1) / nch), LD = cw | 1;
+            const size_t lds = 8 * std::max<size_t>((size_t)64 * LD, (size_t)nOut * 18 * 64);
+            const unsigned sb = (unsigned)((nRows + 63) / 64);
+#define STREAM_CASE(N_) { if (lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)rows_dot_stream_kernel<N_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                          hipLaunchKernelGGL((rows_dot_stream_kernel<N_>), dim3(sb), dim3(256), lds, st, P, cw, LD); }
+            switch (nOut) {
+            case 1: STREAM_CASE(1) break;
+            case 2: STREAM_CASE(2) break;
+            case 3: STREAM_CASE(3) break;
+            default: STREAM_CASE(4) break;
+            }
+#undef STREAM_CASE
+            KERNEL_CHECK();
+            continue;
+        }
         switch (nOut) {
         case 1: rows_dot_kernel<1><<<blocks, 256, 0, st>>>(P); break;
         case 2: rows_dot_kernel<2><<<blocks, 256, 0, st>>>(P); break;

@@ -807,15 +807,48 @@ def test_hints_against_reference_vectors(gl):
 
 
 # ------------------------------------------------------------------ extension-weighted sums (csrc/dot.hip)
-def test_rows_and_cols_dot_ext(gl, oracle):
+def test_rows_dot_kernels_agree_on_many_tiles(gl, monkeypatch):
+    """more row tiles than the persistent grid of the matrix-core kernel has workgroups (2 per CU), and extreme byte patterns
+    (all bytes 0x00 / 0x7f / 0x80 / 0xff in values and weights): the three kernels give the same sums"""
+    import torch
+    from pil2gl import _lib
+    rng = np.random.default_rng(77)
+    n_rows, width, n_out = 100003, 100, 2
+    m = rand_field(rng, (n_rows, width))
+    pats = np.array([0, 0x7F7F7F7F7F7F7F7F, 0x8080808080808080, 0xFFFFFFFF00000000, P - 1, 0x00FF00FF00FF00FF], dtype=np.uint64)
+    m[::7] = pats[rng.integers(0, len(pats), m[::7].shape)]
+    coef = rand_field(rng, (n_out, width, 3)); coef[:, ::5] = pats[rng.integers(0, len(pats), coef[:, ::5].shape)] % np.uint64(P)
+    dm = torch.from_numpy(m.view(np.int64).reshape(-1)).cuda()
+    res = {}
+    for mode in ("mfma", "stream", "tile"):
+        monkeypatch.setenv("PIL2GL_ROWS_DOT_MFMA", "1" if mode == "mfma" else "0")
+        monkeypatch.setenv("PIL2GL_ROWS_DOT_STREAM", "0" if mode == "tile" else "1")
+        acc = torch.zeros(n_rows * n_out * 3, dtype=torch.int64, device="cuda")
+        _lib.call("pil2gl_rows_dot_ext_dev", gl._ptr(dm), width, n_rows, gl._ptr(coef), n_out, gl._ptr(acc), 0, None)
+        res[mode] = acc.cpu().numpy().view(np.uint64)
+    assert np.array_equal(res["mfma"], res["tile"]) and np.array_equal(res["stream"], res["tile"])
+    rows = [0, 1, 63, 64, 7 * 1000, n_rows - 1]
+    want = (m[rows].astype(object) @ coef.astype(object).transpose(1, 0, 2).reshape(width, n_out * 3)) % P
+    assert (res["mfma"].reshape(n_rows, n_out * 3)[rows].astype(object) == want).all()
+
+
+@pytest.mark.parametrize("mode", ["mfma", "stream", "tile"])
+def test_rows_and_cols_dot_ext(gl, oracle, monkeypatch, mode):
+    """the three kernels behind pil2gl_rows_dot_ext_dev.  mfma (default): even rows of 32..112 columns with one or two outputs go
+    to the matrix cores (rows_dot_mfma_kernel); stream: rows of 32 columns and more through the whole-row streaming kernel on
+    the vector ALU (what the other shapes take anyway); tile: every shape through the column-tile kernel"""
     import ctypes as C
+    monkeypatch.setenv("PIL2GL_ROWS_DOT_MFMA", "1" if mode == "mfma" else "0")
+    monkeypatch.setenv("PIL2GL_ROWS_DOT_STREAM", "0" if mode == "tile" else "1")
     import torch
     from pil2gl import _lib
     rng = np.random.default_rng(31)
     # every row is checked; widths around the 16-column tile, row counts around the 256-row block, and a buffer that does not
     # start on a 128-byte line
     for n_rows, width, n_out, skew in [(1000, 37, 2, 0), (64, 1, 1, 0), (4097, 100, 3, 0), (300, 16, 4, 0), (515, 12, 1, 0), (1030, 20, 4, 0),
-                                       (256, 4, 2, 0), (777, 36, 2, 0), (3, 100, 1, 0), (700, 100, 2, 1), (259, 44, 3, 0)]:
+                                       (256, 4, 2, 0), (777, 36, 2, 0), (3, 100, 1, 0), (700, 100, 2, 1), (259, 44, 3, 0),
+                                       (200, 128, 2, 0), (65, 129, 1, 0), (1000, 255, 4, 1), (63, 33, 3, 0), (129, 32, 2, 0),
+                                       (4097, 100, 2, 0), (64, 112, 2, 0), (200, 110, 1, 0), (1, 34, 2, 0)]:
         m = rand_field(rng, (n_rows, width)); m[0, 0] = P - 1; m[-1, -1] = 0
         coef = rand_field(rng, (n_out, width, 3)); coef[0, 0] = [P - 1, P - 1, P - 1]
         store = torch.zeros(n_rows * width + skew, dtype=torch.int64, device="cuda")

@@ -173,6 +173,11 @@ int pil2gl_compute_evals_dev(const pil2gl_eval_desc *descs, uint32_t nEvals, uin
  * (friPolinomial.js:26-36) for every opening at once. */
 int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, const uint64_t *hostCoef, uint32_t nOut,
                             uint64_t *acc, int accumulate, void *stream);
+/* the same over nBufs matrices with the same rows -- the stage matrices and the constants the FRI polynomial walks
+ * (friPolinomial.js:26-50): acc[r][o] (+)= sum_k sum_c bufs[k][r][c] * hostCoefs[k][o][c], in one pass over all of them when
+ * their columns fit the matrix-core kernel side by side (<= 112 columns in all, even widths, nOut <= 2). */
+int pil2gl_rows_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows,
+                                  const uint64_t *const *hostCoefs, uint32_t nOut, uint64_t *acc, int accumulate, void *stream);
 /* f[r] = Horner in vf1 over the openings of (acc[r][o] - K_o) * xDivXSubXi[r][o]   (friPolinomial.js:38-50);
  * hostK: nOpen x 3 (K_o = sum_j ev_j vf2^(n_o - j)). */
 int pil2gl_fri_combine_dev(const uint64_t *acc, const uint64_t *hostK, const uint64_t vf1[3], const uint64_t *xDivXSubXi,

@@ -212,6 +212,20 @@ FN(RowsDotExtDev) {    // (dBuf, width, nRows, coef BigUint64Array(nOut*width*3)
     uint64_t *coef = a.arr(3, (uint64_t)nOut * width * 3); uint64_t *acc = DP(5); int accumulate = (int)a.u64(6); if (!a.ok) return nullptr;
     P2(env, pil2gl_rows_dot_ext_dev(buf, width, nRows, coef, nOut, acc, accumulate, nullptr)); return mk_undefined(env);
 }
+FN(RowsDotExtMultiDev) {   // (dBufs BigUint64Array(n) device ptrs, widths BigUint64Array(n), nRows, coefs Array(n) of BigUint64Array(nOut*width*3), nOut, dAcc, accumulate)
+    Args a(env, info); uint64_t n = 0; uint64_t *ptrs = a.arr(0, 1, &n); uint64_t *widths = a.arr(1, n); uint64_t nRows = a.u64(2);
+    uint32_t nOut = (uint32_t)a.u64(4); uint64_t *acc = DP(5); int accumulate = (int)a.u64(6); if (!a.ok || n == 0 || n > 16) return nullptr;
+    std::vector<const uint64_t *> bp(n), cp(n);
+    for (uint64_t k = 0; k < n; k++) {
+        bp[k] = (const uint64_t *)(uintptr_t)ptrs[k];
+        napi_value el; if (napi_get_element(env, a.argv[3], (uint32_t)k, &el) != napi_ok) { napi_throw_error(env, nullptr, "coefs must be an array of BigUint64Array"); return nullptr; }
+        napi_typedarray_type ty; size_t len; void *data; napi_value ab; size_t off;
+        if (napi_get_typedarray_info(env, el, &ty, &len, &data, &ab, &off) != napi_ok || ty != napi_biguint64_array || len < (size_t)nOut * widths[k] * 3) {
+            napi_throw_error(env, nullptr, "coefs[k] must be a BigUint64Array of nOut*width*3 words"); return nullptr; }
+        cp[k] = (const uint64_t *)data;
+    }
+    P2(env, pil2gl_rows_dot_ext_multi_dev(bp.data(), widths, (uint32_t)n, nRows, cp.data(), nOut, acc, accumulate, nullptr)); return mk_undefined(env);
+}
 FN(FriCombineDev) {    // (dAcc, K BigUint64Array(nOpen*3), vf1 BigUint64Array(3), dXDivXSubXi, nOpen, nRows, dF)
     Args a(env, info); uint64_t *acc = DP(0); uint32_t nOpen = (uint32_t)a.u64(4); uint64_t *K = a.arr(1, 3ull * nOpen), *vf1 = a.arr(2, 3);
     uint64_t *x = DP(3); uint64_t nRows = a.u64(5); uint64_t *f = DP(6); if (!a.ok) return nullptr;
@@ -332,7 +346,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "buildXDev", BuildXDev }, { "buildZhInvDev", BuildZhInvDev }, { "buildOneRowZerofierInvDev", BuildOneRowZerofierInvDev },
         { "buildFrameZerofierDev", BuildFrameZerofierDev }, { "computeQSplitDev", ComputeQSplitDev }, { "xDivXSubXiDev", XDivXSubXiDev },
         { "buildLevDev", BuildLevDev }, { "computeEvalsDev", ComputeEvalsDev }, { "gprodDev", GprodDev }, { "gsumDev", GsumDev }, { "h1h2Dev", H1H2Dev },
-        { "rowsDotExtDev", RowsDotExtDev }, { "friCombineDev", FriCombineDev }, { "colsDotExtDev", ColsDotExtDev }, { "synthFibonacciDev", SynthFibonacciDev },
+        { "rowsDotExtDev", RowsDotExtDev }, { "rowsDotExtMultiDev", RowsDotExtMultiDev }, { "friCombineDev", FriCombineDev }, { "colsDotExtDev", ColsDotExtDev }, { "synthFibonacciDev", SynthFibonacciDev },
         { "friFoldDev", FriFoldDev }, { "friTransposeDev", FriTransposeDev },
         { "friFold", FriFold }, { "friVerifyFold", FriVerifyFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
     };

@@ -234,8 +234,12 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 constexpr u32 MF_WAVES = 8, MF_ROWS = 64, MF_MAXW = 112;
 constexpr int MF_PLANE_OFFSET = 1 << 24;        // every plane sum is > -2^24: the accumulators start at 2^24
 
+constexpr u32 MF_MAXSEG = 4;
 struct RowsDotMfmaParams {
-    const u64 *buf; u64 nRows, stride, col0; u32 width, nOut;
+    // the K dimension is the concatenation of up to MF_MAXSEG matrices with the same rows (a stage's matrices side by side):
+    // segment k holds segW[k] (even) columns and starts at 16-byte unit segU0[k] of the staged row
+    const u64 *segBuf[MF_MAXSEG]; u32 segW[MF_MAXSEG], segU0[MF_MAXSEG], nSeg;
+    u64 nRows; u32 width, nOut;         // width: all segments together
     const v4i *atab;            // [kSteps][NT][64 lanes]: 16 digit bytes per lane
     const u64 *bias;            // [3*nOut] canonical
     u64 *acc; u32 accumulate;
@@ -263,12 +267,14 @@ __global__ void __launch_bounds__(512, 1) rows_dot_mfma_kernel(RowsDotMfmaParams
     v4i nxt[NL];
     auto fetch = [&](u64 tileIdx) {
         const u64 row0 = tileIdx * MF_ROWS;
-        const u64 *base = P.buf + row0 * P.stride + P.col0;
         u32 r = r00, c = c00;
 #pragma unroll
         for (u32 i = 0; i < NL; i++) {
             const v4i z = { 0, 0, 0, 0 };
-            nxt[i] = (NTH * i + tid < total && row0 + r < P.nRows) ? *(const v4i *)(base + (u64)r * P.stride + 2 * c) : z;
+            const u64 *sb = P.segBuf[0]; u32 sw = P.segW[0], su = 0;
+#pragma unroll
+            for (u32 k = 1; k < MF_MAXSEG; k++) if (k < P.nSeg && c >= P.segU0[k]) { sb = P.segBuf[k]; sw = P.segW[k]; su = P.segU0[k]; }
+            nxt[i] = (NTH * i + tid < total && row0 + r < P.nRows) ? *(const v4i *)(sb + (row0 + r) * sw + 2 * (c - su)) : z;
             c += dr; r += dq;
             if (c >= upr) { c -= upr; r++; }
         }
@@ -408,12 +414,25 @@ inline unsigned nblk(u64 n, u32 t = 256) { return (unsigned)((n + t - 1) / t); }
 
 using namespace pil2gl;
 
-// host side of rows_dot_mfma_kernel: signed base-256 digits of the weights laid out as the MFMA's A operand, the constant per output
-static int launch_rows_dot_mfma(const u64 *buf, u64 winWidth, u64 nRows, u64 stride, u64 col0, const uint64_t *hostCoef /* [nOut][stride][3] */,
+// host side of rows_dot_mfma_kernel: signed base-256 digits of the weights laid out as the MFMA's A operand, the constant per output.
+// Segment k: nRows x widths[k] matrix bufs[k] with weights hostCoefs[k] ([nOut][widths[k]][3]); out = sum over all segments' columns.
+static bool rows_dot_mfma_fits(const uint64_t *const *bufs, const uint64_t *widths, u32 nBufs, u32 nOut) {
+    const char *sw = getenv("PIL2GL_ROWS_DOT_MFMA");
+    if ((sw && sw[0] == '0') || nOut < 1 || nOut > 2 || nBufs < 1 || nBufs > MF_MAXSEG) return false;
+    u64 total = 0;
+    for (u32 k = 0; k < nBufs; k++) {
+        if (widths[k] == 0 || widths[k] % 2 || ((uintptr_t)bufs[k] & 15)) return false;
+        total += widths[k];
+    }
+    return total >= 32 && total <= MF_MAXW;
+}
+static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *widths, u32 nBufs, u64 nRows, const uint64_t *const *hostCoefs,
                                 u32 nOut, u64 *acc, bool accumulate, hipStream_t st) {
     const u64 Pm = 0xFFFFFFFF00000001ull;
     const int NT = nOut == 1 ? 2 : 3;
     const u32 nO = 3 * nOut;
+    u64 winWidth = 0;
+    for (u32 k = 0; k < nBufs; k++) winWidth += widths[k];
     std::vector<signed char> dig((size_t)winWidth * nO * 9);
     std::vector<u64> bias(nO);
     unsigned __int128 k128 = 0, offs = 0;
@@ -424,17 +443,19 @@ static int launch_rows_dot_mfma(const u64 *buf, u64 winWidth, u64 nRows, u64 str
     }
     for (u32 o = 0; o < nO; o++) {
         unsigned __int128 sumw = 0;
-        for (u64 c = 0; c < winWidth; c++) {
-            u64 w = hostCoef[((u64)(o / 3) * stride + col0 + c) * 3 + (o % 3)] % Pm;
-            sumw = (sumw + w) % Pm;
-            int carry = 0;
-            for (int j = 0; j < 9; j++) {
-                int b = (j < 8 ? (int)((w >> (8 * j)) & 255) : 0) + carry;
-                carry = 0;
-                if (b >= 128) { b -= 256; carry = 1; }
-                dig[((size_t)c * nO + o) * 9 + j] = (signed char)b;
+        u64 c = 0;
+        for (u32 k = 0; k < nBufs; k++)
+            for (u64 cl = 0; cl < widths[k]; cl++, c++) {
+                u64 w = hostCoefs[k][((u64)(o / 3) * widths[k] + cl) * 3 + (o % 3)] % Pm;
+                sumw = (sumw + w) % Pm;
+                int carry = 0;
+                for (int j = 0; j < 9; j++) {
+                    int b = (j < 8 ? (int)((w >> (8 * j)) & 255) : 0) + carry;
+                    carry = 0;
+                    if (b >= 128) { b -= 256; carry = 1; }
+                    dig[((size_t)c * nO + o) * 9 + j] = (signed char)b;
+                }
             }
-        }
         unsigned __int128 b = ((k128 % Pm) * sumw) % Pm;
         bias[o] = (u64)((b + Pm - offs) % Pm);
     }
@@ -460,7 +481,14 @@ static int launch_rows_dot_mfma(const u64 *buf, u64 winWidth, u64 nRows, u64 str
     P2_TRY(scratch(7, atWords + nO + 2, &d));
     HIP_TRY(hipMemcpyAsync(d, atab.data(), atab.size(), hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d + atWords, bias.data(), nO * 8, hipMemcpyHostToDevice, st));
-    RowsDotMfmaParams P = { buf, nRows, stride, col0, (u32)winWidth, nOut, (const v4i *)d, d + atWords, acc, (u32)accumulate, (nRows + MF_ROWS - 1) / MF_ROWS, kSteps };
+    RowsDotMfmaParams P;
+    u32 u0 = 0;
+    for (u32 k = 0; k < MF_MAXSEG; k++) {
+        P.segBuf[k] = k < nBufs ? bufs[k] : nullptr; P.segW[k] = k < nBufs ? (u32)widths[k] : 0; P.segU0[k] = u0;
+        if (k < nBufs) u0 += (u32)(widths[k] / 2);
+    }
+    P.nSeg = nBufs; P.nRows = nRows; P.width = (u32)winWidth; P.nOut = nOut; P.atab = (const v4i *)d; P.bias = d + atWords;
+    P.acc = acc; P.accumulate = (u32)accumulate; P.nTiles = (nRows + MF_ROWS - 1) / MF_ROWS; P.kSteps = kSteps;
     const size_t lds = (size_t)MF_ROWS * (winWidth * 8 + 16) + atab.size();
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -487,11 +515,8 @@ int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
     if (nOut < 1 || nOut > 4) return fail(PIL2GL_EINVAL, "nOut must be 1..4");
     if (width == 0 || nRows == 0) return PIL2GL_OK;
     hipStream_t st = as_stream(stream);
-    {   // long even rows, one or two outputs: the matrix cores (any window of a wider matrix that fits goes the same way)
-        const char *sw = getenv("PIL2GL_ROWS_DOT_MFMA");
-        if (!(sw && sw[0] == '0') && nOut <= 2 && width >= 32 && width <= MF_MAXW && width % 2 == 0 && ((uintptr_t)buf & 15) == 0)
-            return launch_rows_dot_mfma(buf, width, nRows, width, 0, hostCoef, nOut, acc, accumulate != 0, st);
-    }
+    if (rows_dot_mfma_fits(&buf, &width, 1, nOut))    // long even rows, one or two outputs: the matrix cores
+        return launch_rows_dot_mfma(&buf, &width, 1, nRows, &hostCoef, nOut, acc, accumulate != 0, st);
     const u64 nC = (u64)nOut * width * 3;
     std::vector<u32> limbs(nC * 3);
     for (u64 i = 0; i < nC; i++) {
@@ -533,6 +558,23 @@ int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
         KERNEL_CHECK();
     }
     HIP_TRY(hipStreamSynchronize(st));      // `limbs` is a host temporary and the scratch slot is reused by the next call
+    return PIL2GL_OK;
+}
+
+// the same sums over several matrices with the same rows (the stage matrices the FRI polynomial reads: friPolinomial.js:26-50
+// walks cm1..cmQ and the constants): out[r][o] = sum_k sum_c bufs[k][r][c] * hostCoefs[k][o][c].  One pass over all of them
+// when they fit the matrix-core kernel side by side, else one call per matrix accumulating into acc.
+int pil2gl_rows_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows,
+                                  const uint64_t *const *hostCoefs, uint32_t nOut, uint64_t *acc, int accumulate, void *stream) {
+    P2_TRY(ensure_init());
+    if (!bufs || !widths || !hostCoefs || !acc || nBufs == 0) return fail(PIL2GL_EINVAL, "null buffer");
+    for (uint32_t k = 0; k < nBufs; k++) if (!bufs[k] || !hostCoefs[k]) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nOut < 1 || nOut > 4) return fail(PIL2GL_EINVAL, "nOut must be 1..4");
+    if (nRows == 0) return PIL2GL_OK;
+    if (rows_dot_mfma_fits(bufs, widths, nBufs, nOut))
+        return launch_rows_dot_mfma(bufs, widths, nBufs, nRows, hostCoefs, nOut, acc, accumulate != 0, as_stream(stream));
+    for (uint32_t k = 0; k < nBufs; k++)
+        P2_TRY(pil2gl_rows_dot_ext_dev(bufs[k], widths[k], nRows, hostCoefs[k], nOut, acc, (accumulate != 0 || k > 0) ? 1 : 0, stream));
     return PIL2GL_OK;
 }
 

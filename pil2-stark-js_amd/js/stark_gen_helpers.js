@@ -173,8 +173,10 @@ function friPolynomialAsRowSums(ctx) {
     for (const name of coefs.keys()) if (!isDev(ctx[name])) return false;
     const acc = devTmp(3 * nOpen * extN);
     try {
-        let first = true;
-        for (const [name, { width, c }] of coefs) { addon.rowsDotExtDev(ctx[name].ptr, width, extN, c, nOpen, acc, first ? 0 : 1); first = false; }
+        // all the matrices the polynomial reads in ONE pass when they fit the matrix-core kernel side by side (pil2gl.h)
+        const names = [...coefs.keys()];
+        addon.rowsDotExtMultiDev(BigUint64Array.from(names.map((nm) => BigInt(ctx[nm].ptr))), BigUint64Array.from(names.map((nm) => BigInt(coefs.get(nm).width))),
+            extN, names.map((nm) => coefs.get(nm).c), nOpen, acc, 0);
         addon.friCombineDev(acc, K, BigUint64Array.from(vf1), ctx.xDivXSubXi_ext.ptr, nOpen, extN, ctx.f_ext.ptr);
     } finally { addon.devFree(acc); }
     return true;

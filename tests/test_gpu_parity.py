@@ -832,6 +832,30 @@ def test_rows_dot_kernels_agree_on_many_tiles(gl, monkeypatch):
     assert (res["mfma"].reshape(n_rows, n_out * 3)[rows].astype(object) == want).all()
 
 
+@pytest.mark.parametrize("widths,n_out,n_rows", [((100, 6, 2), 2, 1000), ((100, 7, 2), 2, 333), ((40, 40, 30), 1, 129), ((34,), 2, 64),
+                                                 ((2, 6, 100), 2, 4099), ((100, 6, 2, 2, 2), 2, 70), ((60, 60), 2, 200), ((100, 6, 2), 3, 100)])
+def test_rows_dot_over_several_matrices(gl, widths, n_out, n_rows):
+    """pil2gl_rows_dot_ext_multi_dev: the stage matrices of the FRI polynomial side by side in one pass of the matrix-core kernel
+    (even widths, <= 112 columns together, <= 4 matrices, <= 2 outputs), anything else matrix by matrix: sum over all columns"""
+    import ctypes as C
+    import torch
+    from pil2gl import _lib
+    rng = np.random.default_rng(sum(widths) + n_rows)
+    ms = [rand_field(rng, (n_rows, w)) for w in widths]
+    cs = [rand_field(rng, (n_out, w, 3)) for w in widths]
+    ms[0][0, 0] = P - 1; cs[0][0, 0] = [P - 1, P - 1, P - 1]
+    dms = [torch.from_numpy(m.view(np.int64).reshape(-1)).cuda() for m in ms]
+    ptrs = (C.c_void_p * len(widths))(*[t.data_ptr() for t in dms])
+    ws = np.array(widths, dtype=np.uint64)
+    cps = (C.c_void_p * len(widths))(*[c.ctypes.data for c in cs])
+    acc = torch.zeros(n_rows * n_out * 3, dtype=torch.int64, device="cuda")
+    for accumulate in (0, 1):
+        _lib.call("pil2gl_rows_dot_ext_multi_dev", ptrs, C.c_void_p(ws.ctypes.data), len(widths), n_rows, cps, n_out, gl._ptr(acc), accumulate, None)
+    want = sum(m.astype(object) @ c.astype(object).transpose(1, 0, 2).reshape(w, n_out * 3) for m, c, w in zip(ms, cs, widths))
+    got = acc.cpu().numpy().view(np.uint64).reshape(n_rows, n_out * 3)
+    assert (got.astype(object) == (2 * want) % P).all()
+
+
 @pytest.mark.parametrize("mode", ["mfma", "stream", "tile"])
 def test_rows_and_cols_dot_ext(gl, oracle, monkeypatch, mode):
     """the three kernels behind pil2gl_rows_dot_ext_dev.  mfma (default): even rows of 32..112 columns with one or two outputs go

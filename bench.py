@@ -46,6 +46,7 @@ EXT_BITS = 3
 # measured issue cost of the instructions the integer floor is priced in (tools/microbench.hip, tools/mfma_mds.hip, MI355X)
 CYC_MAD_U64_U32 = 4.5
 CYC_MFMA_ISSUE = 8.0
+CYC_CARRY_OP = 4.4           # v_addc_co_u32 / v_subb_co_u32 (measured, twice a plain 32-bit operation's share)
 
 
 def parse():
@@ -257,6 +258,22 @@ def poseidon_int_roofline(perms, ms):
             "frac": floor / achieved, "clock_GHz_assumed": CLOCK_HZ / 1e9,
             "floor_terms": {"v_mad_u64_u32": 472 * 5, "cycles_each": CYC_MAD_U64_U32, "v_mfma_i32_32x32x32_i8": 30 * 18, "issue_cycles_each": CYC_MFMA_ISSUE},
             "note": "reductions, carries, byte-plane recombination and round constants are overhead by this definition"}
+
+
+def lde_int_roofline(n_bits, n_cols, cosets, ms):
+    """integer-issue roofline of the LDE (iNTT of 2^n rows, then n forward stages on each of `cosets` cosets).
+    achieved = SIMD issue cycles per wave-wide element-stage (64 elements through one butterfly stage); floor = what a radix-2
+    butterfly costs per element if nothing but its irreducible instructions were issued: half a modular multiplication
+    (5 v_mad_u64_u32: four partial products + the fold of the high half) and one 64-bit add or sub (2 carry-chain
+    instructions).  Twiddle generation, reductions' carry handling, LDS traffic and addressing are overhead by this
+    definition; so is the 9th transform a row-major LDE cannot avoid (the inverse)."""
+    stages = n_cols * (1 << n_bits) * n_bits * (1 + cosets)
+    achieved = N_SIMD * CLOCK_HZ * (ms * 1e-3) / (stages / 64.0)
+    floor = 2.5 * CYC_MAD_U64_U32 + 2 * CYC_CARRY_OP
+    return {"bound": "int-issue", "kernel": "interpolate (ntt_pass_kernel x / lde_mid_kernel)", "achieved": achieved, "floor": floor,
+            "unit": "SIMD issue cycles per 64 element-stages", "frac": floor / achieved, "clock_GHz_assumed": CLOCK_HZ / 1e9,
+            "floor_terms": {"v_mad_u64_u32": 2.5, "cycles_each": CYC_MAD_U64_U32, "carry_chain_ops": 2, "cycles_each_carry": CYC_CARRY_OP},
+            "note": "the passes run at 94-100 % of their vector-ALU issue slots (profiles/r02_valu_utilisation.json): the distance to the floor is instruction count, not memory"}
 
 
 def bn128_mads(t):
@@ -585,11 +602,23 @@ def main():
         if args.split and n_cols > 4:
             batch = max(8, (n_cols + 3) // 4); nb = (n_cols + batch - 1) // batch
             leaf_perms = rows * (sum((min(batch, n_cols - b * batch) + 7) // 8 if min(batch, n_cols - b * batch) > 4 else 0 for b in range(nb)) + (((4 * nb) + 7) // 8 if nb > 1 else 0))
+        # the FRI polynomial's weighted row sums over the stage matrix (2 openings): the HBM-bound kernel of the proof
+        t_dot = None
+        if n_cols % 2 == 0 and 32 <= n_cols <= 112:
+            import numpy as _np
+            from pil2gl import _lib as _l
+            coef = _np.random.default_rng(5).integers(0, 2 ** 63, (2, n_cols, 3), dtype=_np.uint64) % _np.uint64(0xFFFFFFFF00000001)
+            dacc = torch.empty(rows * 6, dtype=torch.int64, device=dev)
+            t_dot = ev_time(lambda: _l.call("pil2gl_rows_dot_ext_dev", pil2gl._ptr(dst), n_cols, rows, pil2gl._ptr(coef), 2, pil2gl._ptr(dacc), 0, None), iters)
+            del dacc
         kernels = [
             {"kernel": "linear_hash_kernel", "ms": t_leaf, "alg_bytes": 8 * rows * n_cols + 32 * rows, "perms": leaf_perms},
             {"kernel": "interpolate (ntt_pass_kernel x / lde_mid_kernel)", "ms": t_lde, "alg_bytes": 8 * N * n_cols * (1 + cc)},
             {"kernel": "merkle_level_kernel (first level)", "ms": t_lvl, "alg_bytes": 32 * rows + 16 * rows, "perms": rows // 2},
         ]
+        if t_dot is not None:
+            kernels.append({"kernel": "rows_dot_mfma_kernel (FRI polynomial: weighted sums of every row, 2 openings)", "ms": t_dot, "alg_bytes": 8 * rows * n_cols + 48 * rows,
+                            "bound": "hbm"})
         if wl == "c3" and not sharded_mode:                    # the committed PMC passes were taken at config 3, one GPU
             pf = pmc_file()
             kernels[0]["traffic"] = load_pmc(pf, "linear_hash_kernel")
@@ -627,6 +656,7 @@ def main():
                        "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "GL-Poseidon-12",
                        "parallelism": ("coset-sharded x%d" % world) if sharded_mode else ("replicas x%d" % world if world > 1 else "single GPU")},
             "roofline": roofline, "roofline_int_issue": poseidon_int_roofline(kernels[0]["perms"], kernels[0]["ms"]) if kernels[0]["perms"] else None,
+            "roofline_int_issue_lde": lde_int_roofline(n_bits, n_cols, cc, kernels[1]["ms"]),
             "kernels": kernels,
         }
         if dist is not None:

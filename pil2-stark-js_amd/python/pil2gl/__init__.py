@@ -59,6 +59,11 @@ def init(device=0):
     call("pil2gl_init", int(device))
 
 
+def shutdown():
+    """pil2gl_shutdown: releases the library's device state (tables, scratch slots, compiled kernels); init() starts afresh"""
+    _lib.load().pil2gl_shutdown()
+
+
 def device_info():
     name = C.create_string_buffer(64); cus = C.c_uint32(); mem = C.c_uint64()
     call("pil2gl_device_info", name, 64, C.byref(cus), C.byref(mem))

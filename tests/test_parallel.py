@@ -108,7 +108,9 @@ def test_config5_rank_share_on_one_gpu(oracle):
     import pil2gl
     from pil2gl import stark, parallel
     import gl_oracle as orc
-    pil2gl.init(0)
+    import gc
+    pil2gl.shutdown(); pil2gl.init(0)                               # the library's scratch slots of earlier tests
+    gc.collect(); torch.cuda.empty_cache()                          # what they left in torch's allocator cache
     free, _ = torch.cuda.mem_get_info()
     if free < 245e9:
         pytest.skip("needs 245 GB of free device memory (%.0f GB free)" % (free / 1e9))

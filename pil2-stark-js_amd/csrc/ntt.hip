@@ -66,8 +66,7 @@ __device__ __forceinline__ void dif_step(u64 *tile, const u64 *TW, u32 k, u32 lm
         for (u32 i = 0; i < R; i++) {
             const u32 q = brev_c(i, C);
             u64 o = fermat::to_gl_lazy(v[i]);
-            if (last) o = canon(o);
-            else if (q) o = mul_lazy(o, TW[e1 * q]);
+            if (!last && q) o = mul_lazy(o, TW[e1 * q]);            // the tile stays lazy: whoever stores a FINAL result canonicalises it
             col[i * st] = o;
         }
     }
@@ -95,7 +94,7 @@ __device__ __forceinline__ void dit_step(u64 *tile, const u64 *TW, u32 k, u32 lp
             }
         } else {
 #pragma unroll
-            for (u32 q = 0; q < R; q++) col[q * st] = canon(fermat::to_gl_lazy(v[q]));
+            for (u32 q = 0; q < R; q++) col[q * st] = fermat::to_gl_lazy(v[q]);     // lazy, see dif_step
         }
     }
     __syncthreads();
@@ -147,6 +146,7 @@ struct PassParams {
     u32 Wc, nbT;                    // tile slots S = nbT*Wc : nbT adjacent groups x Wc columns
     u32 nColChunks, nGroupTiles;
     u32 n, scatter;                 // scatter: store row bitrev_n(g*2^k + t) (lo = 0 pass of a natural-order transform)
+    u32 canonOut;                   // 1: this pass writes a transform's result (canonical values); 0: the next pass takes any representative
 };
 
 // KC = 0: any geometry; KC = 8: the geometry of the wide matrices (8 stages, 16 column slots x 16 sub-transform lanes, one
@@ -213,8 +213,9 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     if (!valid) return;
     for (u32 t = y; t < K; t += by) {
         u64 v = tile[TROW(t) * S + x];
-        if (P.hasTw) { if (!DIT) v = mul(v, TWO[gi * K + t]); }
-        else if (P.scale) v = mul(v, P.scale);
+        if (P.hasTw && !DIT) v = P.canonOut ? mul(v, TWO[gi * K + t]) : mul_lazy(v, TWO[gi * K + t]);
+        else if (!P.hasTw && P.scale) v = mul(v, P.scale);
+        else if (P.canonOut) v = canon(v);
         u64 addr = P.scatter ? (u64)bitrev32((u32)(g * K + t), P.n) * P.C + c : base + (u64)t * P.tStride;
         P.dst[addr] = v;
     }
@@ -227,6 +228,7 @@ struct LdeParams {
     const u64 *twKi, *twKf;         // w_1024^-j, w_1024^j (tile twiddles)
     u64 C, ninv;
     u32 n, k, extBits;
+    u32 canonOut;                   // 1: no pass follows (n <= k): the stored values are the result
     u32 cosetBegin, cosetCount;     // this call produces cosets [cosetBegin, cosetBegin+cosetCount) of the 2^extBits (multi-GPU: one slice per rank)
     u32 Wc, G, nColChunks;
 };
@@ -290,7 +292,7 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
 #pragma unroll
             for (int i = 0; i < EPT; i++) {
                 u32 t = y + i * by;
-                if (t < K) P.dst[dstOff + i * dstStep] = tile[tileOff + i * rowStep * S];
+                if (t < K) { const u64 v = tile[tileOff + i * rowStep * S]; P.dst[dstOff + i * dstStep] = P.canonOut ? canon(v) : v; }
             }
         }
         for (u32 idx = tid; idx < P.G * K; idx += nth) Sc[idx] = mul(Sc[idx], Uc[idx]);
@@ -348,9 +350,9 @@ int set_lds(const void *fn, size_t bytes) {
 }
 
 // One pass over index bits [lo, lo+k) of a 2^n x C matrix.
-int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit, bool inverse, u64 scale, bool scatter, hipStream_t st) {
+int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit, bool inverse, u64 scale, bool scatter, bool canonOut, hipStream_t st) {
     PassParams P;
-    P.src = src; P.dst = dst;
+    P.src = src; P.dst = dst; P.canonOut = canonOut;
     P.tw = inverse ? tables().powWi : tables().powW;
     P.twK = inverse ? tables().tw1024i : tables().tw1024;
     P.C = C; P.scale = scale; P.k = k; P.logM = lo + k; P.hasTw = lo > 0; P.dit = dit; P.n = n; P.scatter = scatter;
@@ -402,7 +404,7 @@ int ntt_launch(const u64 *src, u64 C, u32 n, u64 *dst, bool inverse, hipStream_t
     u32 ks[32];
     int np = split_bits(n, kmax, ks);
     u64 scale = inverse ? h_inv(N % 0xFFFFFFFF00000001ull) : 0;
-    if (np == 1) return launch_pass(src, dst, C, n, 0, n, false, inverse, scale, true, st);
+    if (np == 1) return launch_pass(src, dst, C, n, 0, n, false, inverse, scale, true, true, st);
     u64 *tmp;
     P2_TRY(scratch(0, N * C, &tmp));
     u32 lo = n;
@@ -410,7 +412,7 @@ int ntt_launch(const u64 *src, u64 C, u32 n, u64 *dst, bool inverse, hipStream_t
         lo -= ks[i];
         const u64 *in = i == 0 ? src : tmp;
         u64 *out = i == np - 1 ? dst : tmp;
-        P2_TRY(launch_pass(in, out, C, n, lo, ks[i], false, inverse, i == 0 ? scale : 0, i == np - 1, st));
+        P2_TRY(launch_pass(in, out, C, n, lo, ks[i], false, inverse, i == 0 ? scale : 0, i == np - 1, i == np - 1, st));
     }
     return PIL2GL_OK;
 }
@@ -439,7 +441,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
         u32 lo = n;
         for (int i = 0; i < np; i++) {
             lo -= ks[i];
-            P2_TRY(launch_pass(i == 0 ? src : tmp, tmp, C, n, lo, ks[i], false, true, 0, false, st));
+            P2_TRY(launch_pass(i == 0 ? src : tmp, tmp, C, n, lo, ks[i], false, true, 0, false, false, st));
         }
         coef = tmp;
     }
@@ -448,7 +450,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
         LdeParams P;
         P.src = coef; P.dst = dst; P.twi = tables().powWi; P.twf = tables().powW; P.twKi = tables().tw1024i; P.twKf = tables().tw1024; P.pow7 = unitShift ? nullptr : tables().pow7;
         P.C = C; P.ninv = h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb;
-        P.cosetBegin = cosetBegin; P.cosetCount = cosetCount;
+        P.cosetBegin = cosetBegin; P.cosetCount = cosetCount; P.canonOut = n > kf ? 0 : 1;
         u64 totalGroups = 1ull << (n - kf);
         u32 nThreads = env_u32("PIL2GL_LDE_THREADS", 512);
         // LDS = tile (S*K) + two local twiddle tables (K) + coset scale tables (2*G*K); narrow matrices
@@ -493,7 +495,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
         int np = split_bits(n - kf, kmax, ks);
         u32 lo = kf;
         for (int i = 0; i < np; i++) {
-            P2_TRY(launch_pass(dst, dst, C * cosetCount, n, lo, ks[i], true, false, 0, false, st));
+            P2_TRY(launch_pass(dst, dst, C * cosetCount, n, lo, ks[i], true, false, 0, false, i == np - 1, st));
             lo += ks[i];
         }
     }

@@ -355,5 +355,29 @@ class ChunkedBuffer {
             assert(MH4.verifyGroupProof(BigInt(p.s2_root), p.s2_siblings[q], ys[q] % (1 << 11), p.s2_vals[q].map(BigInt)), "final proof s2 q" + q);
         }
     }
+    // --- weighted row sums of the FRI polynomial (pil2gl.h: rows_dot_ext / rows_dot_ext_multi): one matrix, and three matrices
+    //     side by side in one pass of the matrix-core kernel, against BigInt arithmetic
+    {
+        const native = require(path.join(root, "pil2-stark-js_amd/js/native.js"));
+        const { addon, DevBuffer } = native;
+        const Pm = 0xFFFFFFFF00000001n;
+        let seed = 12345n; const rnd = () => { seed = (seed * 6364136223846793005n + 1442695040888963407n) & 0xFFFFFFFFFFFFFFFFn; return seed % Pm; };
+        const nRows = 131, widths = [34, 6, 2], nOut = 2;
+        const mats = widths.map((w) => BigUint64Array.from({ length: nRows * w }, rnd));
+        const coefs = widths.map((w) => BigUint64Array.from({ length: nOut * w * 3 }, rnd));
+        mats[0][0] = Pm - 1n; coefs[0][0] = Pm - 1n;
+        const dm = mats.map((m) => DevBuffer.from(m));
+        const want = (ks) => { const r = new BigUint64Array(nRows * nOut * 3);
+            for (let i = 0; i < nRows; i++) for (let o = 0; o < nOut; o++) for (let q = 0; q < 3; q++) { let a = 0n;
+                for (const k of ks) for (let c = 0; c < widths[k]; c++) a += mats[k][i * widths[k] + c] * coefs[k][(o * widths[k] + c) * 3 + q];
+                r[(i * nOut + o) * 3 + q] = a % Pm; }
+            return r; };
+        const acc = new DevBuffer(nRows * nOut * 3);
+        addon.rowsDotExtDev(dm[0].ptr, widths[0], nRows, coefs[0], nOut, acc.ptr, 0);
+        assert.deepStrictEqual(acc.slice(0, acc.length), want([0]), "rowsDotExtDev");
+        addon.rowsDotExtMultiDev(BigUint64Array.from(dm.map((d) => BigInt(d.ptr))), BigUint64Array.from(widths.map(BigInt)), nRows, coefs, nOut, acc.ptr, 0);
+        assert.deepStrictEqual(acc.slice(0, acc.length), want([0, 1, 2]), "rowsDotExtMultiDev");
+        dm.forEach((d) => d.free()); acc.free();
+    }
     console.log("addon parity OK");
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -89,6 +89,46 @@ def test_ntt_fixed_geometry_kernels(gl, oracle, nBits, nPols, extBits, monkeypat
     assert np.array_equal(f0[:, :3], oracle.fft_cols(np.ascontiguousarray(a[:, :3]), nBits))
 
 
+def test_ntt_at_the_largest_domain(gl, oracle):
+    """2^27 rows, the largest domain the transforms take (config 3's extended domain; the quotient's iNTT / NTT run there):
+    fft then ifft returns the input bit for bit; the transform of the coefficient vector (0, c, 0, ...) is c w^i (closed form,
+    rows sampled up to the last one); the transform is linear on sampled rows; one row more is refused"""
+    import torch
+    from pil2gl import _lib
+    nb, C = 27, 3
+    n = 1 << nb
+    g = torch.Generator(device="cuda"); g.manual_seed(27)
+    a = torch.randint(0, 1 << 62, (n * C,), dtype=torch.int64, device="cuda", generator=g)
+    cvals = [5, P - 2, 0x123456789ABCDEF]
+    av = a.view(n, C)
+    f = torch.empty_like(a); back = torch.empty_like(a)
+    gl.fft(a, C, nb, f)
+    gl.ifft(f, C, nb, back)
+    assert torch.equal(back, a)
+    e = torch.zeros(n * C, dtype=torch.int64, device="cuda")
+    ev = e.view(n, C)
+    for c_, v in enumerate(cvals):
+        ev[1, c_] = np.array([v], dtype=np.uint64).view(np.int64)[0]
+    fe = torch.empty_like(e)
+    gl.fft(e, C, nb, fe)
+    w = int(oracle.root(nb))
+    rows = [0, 1, 2, 12345, n // 2, n - 2, n - 1]
+    got = fe.view(n, C)[rows].cpu().numpy().view(np.uint64)
+    for k, i in enumerate(rows):
+        assert [int(x) for x in got[k]] == [v * pow(w, i, P) % P for v in cvals], i
+    # linearity on the same rows: fft(a + e) = fft(a) + fft(e)   (a + e differs from a in row 1 only)
+    s_ = a.clone(); sv = s_.view(n, C)
+    row1 = [(int(x) + v) % P for x, v in zip(av[1].cpu().numpy().view(np.uint64), cvals)]
+    sv[1] = torch.from_numpy(np.array(row1, dtype=np.uint64).view(np.int64)).cuda()
+    fs = torch.empty_like(a)
+    gl.fft(s_, C, nb, fs)
+    fa = f.view(n, C)[rows].cpu().numpy().view(np.uint64); fsv = fs.view(n, C)[rows].cpu().numpy().view(np.uint64)
+    for k in range(len(rows)):
+        assert [int(x) for x in fsv[k]] == [(int(x) + int(y)) % P for x, y in zip(fa[k], got[k])]
+    with pytest.raises(Exception):
+        gl.fft(a, 1, 28, f)
+
+
 def test_interpolate_golden_kat(gl):
     # SURVEY 8(c)(2) / tests/golden/ntt.json "index3" ext 1
     c = [x for x in golden("ntt.json")["cases"] if x["name"] == "index3"][0]

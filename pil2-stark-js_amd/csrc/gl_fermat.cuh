@@ -69,16 +69,6 @@ __device__ __forceinline__ f128 shl(const f128 &v) {
 
 // any representative with |v| < 2^101 -> lazy field element:  (w1:w0) + w2 (2^32-1) - w3, with w3 biased by 32 to
 // keep it unsigned and the bias (32 * 2^96 = -32) returned through the multiply-add's addend
-#ifdef PIL2GL_FAST_REDUCE_EXPERIMENT
-// MEASUREMENT ONLY (not exact: ignores a borrow of probability 2^-91): upper bound of what a cheaper reduction could give
-__device__ __forceinline__ u64 to_gl_lazy(const f128 &v) {
-    const u64 lo = ((u64)v.w1 << 32) | v.w0;
-    const u64 A = (u64)v.w2 * EPS + (u64)(32u - v.w3);
-    u64 s;
-    const bool c = __builtin_uaddl_overflow(lo, A, &s);
-    return s + (c ? (u64)(EPS - 32) : (u64)-32ll);
-}
-#else
 __device__ __forceinline__ u64 to_gl_lazy(const f128 &v) {
     const u64 lo = ((u64)v.w1 << 32) | v.w0;
     const u32 hh = v.w3 + 32u;
@@ -88,7 +78,6 @@ __device__ __forceinline__ u64 to_gl_lazy(const f128 &v) {
     const bool c = __builtin_uaddl_overflow(t0, t1, &t2);
     return t2 + ((c ? EPS : 0) - (br ? EPS : 0));
 }
-#endif
 
 template <int C, bool INV, int H, int BASE, int I>
 struct DifStage {

@@ -186,6 +186,10 @@ int pil2gl_fri_combine_dev(const uint64_t *acc, const uint64_t *hostK, const uin
  * and every opening at once; hostOut: nLev x width x 3, levs[l]: device nRows x 3). */
 int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, uint64_t rowStep, const uint64_t *const *levs,
                             uint32_t nLev, uint64_t *hostOut, void *stream);
+/* the same over nBufs (<= 8) matrices with the same rows in one sweep of the weights (computeEvalsStark walks every committed
+ * stage and the constants, stark_gen_helpers.js:233-264): hostOuts[k] receives nLev x widths[k] x 3. */
+int pil2gl_cols_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows, uint64_t rowStep,
+                                  const uint64_t *const *levs, uint32_t nLev, uint64_t *const *hostOuts, void *stream);
 
 /* ---- expression evaluator: src/prover/prover_helpers.js:23-259 ------------- */
 /* callCalculateExps / calculateExps: run the op-list on every row of the domain.  Section pointers in

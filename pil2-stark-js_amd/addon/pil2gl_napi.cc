@@ -238,6 +238,20 @@ FN(ColsDotExtDev) {    // (dBuf, width, nRows, rowStep, levs BigUint64Array(nLev
     for (uint64_t i = 0; i < nLev; i++) lp[i] = (const uint64_t *)(uintptr_t)levs[i];
     P2(env, pil2gl_cols_dot_ext_dev(buf, width, nRows, rowStep, lp.data(), (uint32_t)nLev, out, nullptr)); return mk_undefined(env);
 }
+FN(ColsDotExtMultiDev) {   // (dBufs BigUint64Array(n) device ptrs, widths BigUint64Array(n), nRows, rowStep, levs BigUint64Array(nLev) device ptrs, outs Array(n) of BigUint64Array(nLev*width*3))
+    Args a(env, info); uint64_t n = 0; uint64_t *ptrs = a.arr(0, 1, &n); uint64_t *widths = a.arr(1, n); uint64_t nRows = a.u64(2), rowStep = a.u64(3);
+    uint64_t nLev = 0; uint64_t *levs = a.arr(4, 1, &nLev); if (!a.ok || n == 0 || n > 8) return nullptr;
+    std::vector<const uint64_t *> bp(n), lp(nLev); std::vector<uint64_t *> op(n);
+    for (uint64_t i = 0; i < nLev; i++) lp[i] = (const uint64_t *)(uintptr_t)levs[i];
+    for (uint64_t k = 0; k < n; k++) {
+        bp[k] = (const uint64_t *)(uintptr_t)ptrs[k];
+        napi_value el; napi_typedarray_type ty; size_t len; void *data; napi_value ab; size_t off;
+        if (napi_get_element(env, a.argv[5], (uint32_t)k, &el) != napi_ok || napi_get_typedarray_info(env, el, &ty, &len, &data, &ab, &off) != napi_ok ||
+            ty != napi_biguint64_array || len < (size_t)nLev * widths[k] * 3) { napi_throw_error(env, nullptr, "outs[k] must be a BigUint64Array of nLev*width*3 words"); return nullptr; }
+        op[k] = (uint64_t *)data;
+    }
+    P2(env, pil2gl_cols_dot_ext_multi_dev(bp.data(), widths, (uint32_t)n, nRows, rowStep, lp.data(), (uint32_t)nLev, op.data(), nullptr)); return mk_undefined(env);
+}
 FN(SynthFibonacciDev) { // (nBits, nPairs, init BigUint64Array(2*nPairs), dCm): synthetic witness for benchmarks (pil2gl.h)
     Args a(env, info); uint32_t nb = (uint32_t)a.u64(0), np = (uint32_t)a.u64(1); uint64_t *init = a.arr(2, 2ull * np); uint64_t *cm = DP(3); if (!a.ok) return nullptr;
     P2(env, pil2gl_synth_fibonacci_dev(nb, np, init, cm, nullptr)); return mk_undefined(env);
@@ -346,7 +360,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "buildXDev", BuildXDev }, { "buildZhInvDev", BuildZhInvDev }, { "buildOneRowZerofierInvDev", BuildOneRowZerofierInvDev },
         { "buildFrameZerofierDev", BuildFrameZerofierDev }, { "computeQSplitDev", ComputeQSplitDev }, { "xDivXSubXiDev", XDivXSubXiDev },
         { "buildLevDev", BuildLevDev }, { "computeEvalsDev", ComputeEvalsDev }, { "gprodDev", GprodDev }, { "gsumDev", GsumDev }, { "h1h2Dev", H1H2Dev },
-        { "rowsDotExtDev", RowsDotExtDev }, { "rowsDotExtMultiDev", RowsDotExtMultiDev }, { "friCombineDev", FriCombineDev }, { "colsDotExtDev", ColsDotExtDev }, { "synthFibonacciDev", SynthFibonacciDev },
+        { "rowsDotExtDev", RowsDotExtDev }, { "rowsDotExtMultiDev", RowsDotExtMultiDev }, { "friCombineDev", FriCombineDev }, { "colsDotExtDev", ColsDotExtDev }, { "colsDotExtMultiDev", ColsDotExtMultiDev }, { "synthFibonacciDev", SynthFibonacciDev },
         { "friFoldDev", FriFoldDev }, { "friTransposeDev", FriTransposeDev },
         { "friFold", FriFold }, { "friVerifyFold", FriVerifyFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
     };

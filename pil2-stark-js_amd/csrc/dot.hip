@@ -14,6 +14,7 @@
 #include "common.h"
 #include "gl_field.cuh"
 #include <vector>
+#include <string.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -338,8 +339,12 @@ __global__ void fri_combine_kernel(const u64 *__restrict__ acc, const u64 *__res
     f[3 * r] = res.v[0]; f[3 * r + 1] = res.v[1]; f[3 * r + 2] = res.v[2];
 }
 
+constexpr u32 CD_MAXSEG = 8;
 struct ColsDotParams {
-    const u64 *buf; u64 width; u64 nRows; u64 rowStep;      // rows k*rowStep, k < nRows
+    // columns of up to CD_MAXSEG matrices with the same rows, side by side: lane c of the launch belongs to the segment whose
+    // [segC0, segC0 + segW) holds it (one sweep of the weights for all of them)
+    const u64 *segBuf[CD_MAXSEG]; u32 segW[CD_MAXSEG], segC0[CD_MAXSEG], nSeg;
+    u64 width; u64 nRows; u64 rowStep;      // width: all segments together; rows k*rowStep, k < nRows
     const u32 *levLimbs;        // [nLev][nRows][3 comps][3 limbs]
     u32 nLev;
     u64 *partial;               // [nChunks][nLev][width][3]
@@ -361,11 +366,14 @@ __global__ void __launch_bounds__(256) cols_dot_kernel(ColsDotParams P) {
             for (int i = 0; i < 6; i++) S[l][k][i] = 0;
     const bool valid = c < P.width;
     constexpr int RB = 8;                            // rows whose loads are in flight together
-    const u64 stride = P.rowStep * P.width;
+    const u64 *buf = P.segBuf[0]; u64 sw = P.segW[0], cl = c;
+#pragma unroll
+    for (u32 k = 1; k < CD_MAXSEG; k++) if (k < P.nSeg && c >= P.segC0[k]) { buf = P.segBuf[k]; sw = P.segW[k]; cl = c - P.segC0[k]; }
+    const u64 stride = P.rowStep * sw;
     for (u64 kb = k0; kb < k1; kb += RB) {
         u64 pv[RB];
 #pragma unroll
-        for (int j = 0; j < RB; j++) pv[j] = (valid && kb + j < k1) ? P.buf[(kb + j) * stride + c] : 0;
+        for (int j = 0; j < RB; j++) pv[j] = (valid && kb + j < k1) ? buf[(kb + j) * stride + cl] : 0;
 #pragma unroll
         for (int j = 0; j < RB; j++) {
             const u64 k = kb + j;
@@ -594,11 +602,15 @@ int pil2gl_fri_combine_dev(const uint64_t *acc, const uint64_t *hostK, const uin
     return PIL2GL_OK;
 }
 
-int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, uint64_t rowStep, const uint64_t *const *levs,
-                            uint32_t nLev, uint64_t *hostOut, void *stream) {
+// evaluations over several matrices with the same rows in ONE sweep of the weights: hostOuts[k] receives nLev x widths[k] x 3
+int pil2gl_cols_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows, uint64_t rowStep,
+                                  const uint64_t *const *levs, uint32_t nLev, uint64_t *const *hostOuts, void *stream) {
     P2_TRY(ensure_init());
-    if (!buf || !levs || !hostOut) return fail(PIL2GL_EINVAL, "null buffer");
+    if (!bufs || !widths || !levs || !hostOuts || nBufs == 0) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nBufs > CD_MAXSEG) return fail(PIL2GL_EINVAL, "at most %u matrices per call", CD_MAXSEG);
     if (nLev < 1 || nLev > 4) return fail(PIL2GL_EINVAL, "nLev must be 1..4");
+    u64 width = 0;
+    for (uint32_t k = 0; k < nBufs; k++) { if (!bufs[k] || !hostOuts[k]) return fail(PIL2GL_EINVAL, "null buffer"); if (widths[k] >> 31) return fail(PIL2GL_EINVAL, "matrix too wide"); width += widths[k]; }
     if (width == 0 || nRows == 0) return PIL2GL_OK;
     hipStream_t st = as_stream(stream);
     const u32 rpc = 1024;
@@ -609,7 +621,10 @@ int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
     u32 *limbs = (u32 *)d;
     u64 *partial = d + ((u64)nLev * nRows * 9 * 4 + 7) / 8, *part2 = partial + nChunks * n, *res = part2 + nGroups * n;
     for (u32 l = 0; l < nLev; l++) limbs_kernel<<<nblk(nRows * 3), 256, 0, st>>>(levs[l], nRows * 3, limbs + (u64)l * nRows * 9);
-    ColsDotParams P = { buf, width, nRows, rowStep, limbs, nLev, partial, rpc };
+    ColsDotParams P;
+    u32 c0 = 0;
+    for (u32 k = 0; k < CD_MAXSEG; k++) { P.segBuf[k] = k < nBufs ? bufs[k] : nullptr; P.segW[k] = k < nBufs ? (u32)widths[k] : 0; P.segC0[k] = c0; if (k < nBufs) c0 += (u32)widths[k]; }
+    P.nSeg = nBufs; P.width = width; P.nRows = nRows; P.rowStep = rowStep; P.levLimbs = limbs; P.nLev = nLev; P.partial = partial; P.rowsPerChunk = rpc;
     const u32 threads = (u32)std::min<u64>(256, (width + 63) / 64 * 64);
     dim3 grid((unsigned)nChunks, nblk(width, threads));
     switch (nLev) {
@@ -621,9 +636,23 @@ int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
     cols_dot_final_kernel<<<dim3(nblk(n), (unsigned)nGroups), 256, 0, st>>>(partial, nChunks, per, n, part2);
     cols_dot_final_kernel<<<dim3(nblk(n), 1), 256, 0, st>>>(part2, (nChunks + per - 1) / per, nGroups, n, res);
     KERNEL_CHECK();
-    HIP_TRY(hipMemcpyAsync(hostOut, res, n * 8, hipMemcpyDeviceToHost, st));
+    std::vector<u64> host(n);
+    HIP_TRY(hipMemcpyAsync(host.data(), res, n * 8, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    // res is [nLev][all columns][3]; hostOuts[k] is [nLev][widths[k]][3]
+    u64 cbeg = 0;
+    for (uint32_t k = 0; k < nBufs; k++) {
+        for (u32 l = 0; l < nLev; l++)
+            memcpy(hostOuts[k] + ((u64)l * widths[k]) * 3, host.data() + ((u64)l * width + cbeg) * 3, widths[k] * 3 * 8);
+        cbeg += widths[k];
+    }
     return PIL2GL_OK;
+}
+
+int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, uint64_t rowStep, const uint64_t *const *levs,
+                            uint32_t nLev, uint64_t *hostOut, void *stream) {
+    if (!buf || !hostOut) { P2_TRY(ensure_init()); return fail(PIL2GL_EINVAL, "null buffer"); }
+    return pil2gl_cols_dot_ext_multi_dev(&buf, &width, 1, nRows, rowStep, levs, nLev, &hostOut, stream);
 }
 
 }  // extern "C"

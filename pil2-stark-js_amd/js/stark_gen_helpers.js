@@ -94,13 +94,16 @@ module.exports.computeEvalsStark = async function computeEvalsStark(ctx, options
         if (nOpen <= 4) {
             // eval_e = sum_k v_e[k << b] LEv[k] (:250-264) for EVERY column of a section and every opening in one sweep of
             // the section (pil2gl_cols_dot_ext_dev); a dim-3 polynomial q0 + q1 x + q2 x^2 is assembled from its base columns
-            const sums = new Map();
+            const sums = new Map(), secs = [];
             for (const ev of ctx.pilInfo.evMap) {
                 const pl = place(ev);
                 if (sums.has(pl.name)) continue;
-                const out = new BigUint64Array(nOpen * pl.size * 3);
-                addon.colsDotExtDev(devOf(pl.name, ctx[pl.name], pl.size * ctx.extN), pl.size, N, 1 << ctx.extendBits, levs, out);
-                sums.set(pl.name, out);
+                sums.set(pl.name, new BigUint64Array(nOpen * pl.size * 3)); secs.push(pl);
+            }
+            for (let g0 = 0; g0 < secs.length; g0 += 8) {              // the matrices of a group in one sweep of the weights (pil2gl.h)
+                const grp = secs.slice(g0, g0 + 8);
+                addon.colsDotExtMultiDev(BigUint64Array.from(grp.map((pl) => BigInt(devOf(pl.name, ctx[pl.name], pl.size * ctx.extN)))), BigUint64Array.from(grp.map((pl) => BigInt(pl.size))),
+                    N, 1 << ctx.extendBits, levs, grp.map((pl) => sums.get(pl.name)));
             }
             const mulX = (a) => [a[2], (a[0] + a[2]) % P, a[1]];                             // times x in F[x]/(x^3 - x - 1), f3g.js:94-102
             for (let i = 0; i < nEv; i++) {

@@ -935,6 +935,26 @@ def test_rows_and_cols_dot_ext(gl, oracle, monkeypatch, mode):
         got = acc.cpu().numpy().view(np.uint64).reshape(n_rows, n_out * 3)
         want = (m.astype(object) @ coef.astype(object).transpose(1, 0, 2).reshape(width, n_out * 3)) % P
         assert (got.astype(object) == want).all(), (n_rows, width, n_out)
+    # several matrices in one sweep of the weights (pil2gl_cols_dot_ext_multi_dev) == matrix by matrix
+    nb2, eb2 = 10, 3
+    mats = [rand_field(rng, (1 << (nb2 + eb2), w)) for w in (100, 6, 2, 65)]
+    dmats = [torch.from_numpy(m.view(np.int64)).cuda() for m in mats]
+    levs2 = [rand_field(rng, (1 << nb2, 3)) for _ in range(3)]
+    dlevs2 = [torch.from_numpy(l.view(np.int64)).cuda() for l in levs2]
+    lv2 = (C.c_void_p * 3)(*[t.data_ptr() for t in dlevs2])
+    single = []
+    for m, dmat in zip(mats, dmats):
+        o = np.zeros((3, m.shape[1], 3), np.uint64)
+        _lib.call("pil2gl_cols_dot_ext_dev", gl._ptr(dmat), m.shape[1], 1 << nb2, 1 << eb2, lv2, 3, gl._ptr(o), None)
+        single.append(o)
+    multi = [np.zeros_like(o) for o in single]
+    ptrs = (C.c_void_p * len(mats))(*[t.data_ptr() for t in dmats])
+    ws = np.array([m.shape[1] for m in mats], dtype=np.uint64)
+    outs = (C.c_void_p * len(mats))(*[o.ctypes.data for o in multi])
+    _lib.call("pil2gl_cols_dot_ext_multi_dev", ptrs, C.c_void_p(ws.ctypes.data), len(mats), 1 << nb2, 1 << eb2, lv2, 3, outs, None)
+    for a_, b_ in zip(single, multi):
+        assert np.array_equal(a_, b_)
+    assert single[1][2, 5].tolist() == oracle.eval_pol_at(mats[1], 5, 1, nb2, eb2, levs2[2]).tolist()
     # column sums against the oracle's per-column evaluation (stark_gen_helpers.js:250-264)
     nb, eb, width = 11, 3, 9
     buf = rand_field(rng, (1 << (nb + eb), width)); dbuf = torch.from_numpy(buf.view(np.int64)).cuda()

@@ -72,6 +72,14 @@ def test_sharded_proof_gpu_ranks(oracle, world, nbits, pairs, steps):
     _launch(world, "--backend", "gpu", "--nbits", str(nbits), "--pairs", str(pairs), "--steps", steps, worker=PROVE_WORKER)
 
 
+@pytest.mark.gpu
+def test_sharded_proof_over_rccl_one_rank(oracle):
+    """the RCCL branch of the exchange layer (device tensors into the collectives, the digest all-gather started asynchronously
+    per chunk of hashed leaves, sums on the device): all the box's one GPU allows is a group of ONE rank, which still runs every
+    collective call of the N-rank schedule; 2^16 rows so that the chunked path is taken"""
+    _launch(1, "--backend", "gpu", "--pg", "nccl", "--nbits", "16", "--pairs", "4", "--steps", "19,14,9,4", worker=PROVE_WORKER)
+
+
 @pytest.mark.parametrize("steps", ["9,2", "9"])
 def test_sharded_proof_with_fri_groups_across_cosets_cpu(oracle, steps):
     """the first FRI tree's groups stay inside one coset only while steps[1].nBits >= the extension bits; below that (or

@@ -23,8 +23,14 @@ def main():
     ap.add_argument("--steps", default="9,5,2")
     ap.add_argument("--air", default="fib", help="fib: one witness stage; perm: two (stage 2 = grand-product hint)")
     ap.add_argument("--hashcommits", type=int, default=0, help="starkStruct.hashCommits")
+    ap.add_argument("--pg", default="gloo", help="process-group backend; nccl (= RCCL) needs one GPU per rank")
     a = ap.parse_args()
-    dist.init_process_group("gloo")
+    if a.pg == "nccl":
+        import torch
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group("gloo")
     rank = dist.get_rank()
     import gl_oracle as orc
     orc.build(); orc.set_threads(2)

@@ -160,6 +160,10 @@ int pil2gl_build_frame_zerofier_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t 
 int pil2gl_compute_q_split_dev(const uint64_t *qq1, uint32_t nBits, uint32_t nBitsExt, uint32_t qDim, uint32_t qDeg, uint64_t *qq2, void *stream);
 /* computeFRIStark xDivXSubXi  stark_gen_helpers.js:293-322: out[3*(k*nOpen+iOpen)+c] = (x_k / (x_k - xi))_c */
 int pil2gl_x_div_x_sub_xi_dev(uint32_t nBitsExt, const uint64_t xi[3], uint64_t nOpen, uint64_t iOpen, uint64_t *out, void *stream);
+/* the rows of cosets [cosetBegin, cosetBegin + cosetCount) of the 2^extBits only (one rank's slice of a coset-sharded proof), in
+ * slice order: row pos * cosetCount + jl stands for extended row (pos << extBits) + cosetBegin + jl; cosetCount a power of two. */
+int pil2gl_x_div_x_sub_xi_cosets_dev(uint32_t nBitsExt, uint32_t extBits, const uint64_t xi[3], uint64_t nOpen, uint64_t iOpen,
+                                     uint32_t cosetBegin, uint32_t cosetCount, uint64_t *out, void *stream);
 /* computeEvalsStark  stark_gen_helpers.js:216-264: lev = ifft_N(xi^k) (extension, N x 3);
  * evals[e] = sum_k v_e[k << extendBits] * lev[k] for nEvals columns described by (buffer, width, offset, dim). */
 int pil2gl_build_lev_dev(uint32_t nBits, const uint64_t xi[3], uint64_t *lev, void *stream);

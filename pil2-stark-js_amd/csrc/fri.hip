@@ -110,14 +110,18 @@ __global__ void q_split_kernel(const u64 *__restrict__ qq1, u32 nBits, u32 nBits
 // field element t.  A lane takes XD_BATCH rows k, k+T, k+2T, ... (T = threads in the grid: neighbouring lanes stay on
 // neighbouring rows) and inverts their norms with one field inversion (Montgomery's trick, the device form of the
 // reference's F.batchInverse :316); x advances by the constant w_E^T from row to row.
+// Coset slices (one rank's rows of a sharded proof): local row l = pos * cc + jl stands for extended row (pos << eb) + cb + jl; T is
+// a multiple of cc, so a lane's rows keep their coset and x still advances by one constant, w_N^(T / cc).
 constexpr int XD_BATCH = 16;
 struct XDivConst { u64 xi0, b, c, c2, bc2, m1, k0, cc, ccbb; };
-__global__ void __launch_bounds__(256) x_div_x_sub_xi_kernel(u32 nBitsExt, XDivConst K, u64 nOpen, u64 iOpen, const u64 *__restrict__ powW, u64 wStep, u64 *__restrict__ out) {
-    const u64 E = 1ull << nBitsExt, T = (u64)gridDim.x * blockDim.x;
+__global__ void __launch_bounds__(256) x_div_x_sub_xi_kernel(u32 nBitsExt, XDivConst K, u64 nOpen, u64 iOpen, const u64 *__restrict__ powW, u64 wStep, u64 *__restrict__ out,
+                                                             u64 E /* rows written */, u32 extBits, u32 cosetBegin, u32 ccLog) {
+    const u64 T = (u64)gridDim.x * blockDim.x;
     const u64 k0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (k0 >= E) return;
     u64 xs[XD_BATCH], as[XD_BATCH], ts[XD_BATCH], pre[XD_BATCH];
-    u64 x = mul(7, root_pow(powW, nBitsExt, (u32)k0));
+    const u64 g0 = ((k0 >> ccLog) << extBits) + cosetBegin + (k0 & ((1ull << ccLog) - 1));      // extended row of local row k0
+    u64 x = mul(7, root_pow(powW, nBitsExt, (u32)g0));
     int n = 0;
 #pragma unroll
     for (int i = 0; i < XD_BATCH; i++) {
@@ -367,8 +371,17 @@ int pil2gl_compute_q_split_dev(const uint64_t *qq1, uint32_t nBits, uint32_t nBi
     return PIL2GL_OK;
 }
 int pil2gl_x_div_x_sub_xi_dev(uint32_t nBitsExt, const uint64_t xi[3], uint64_t nOpen, uint64_t iOpen, uint64_t *out, void *stream) {
+    return pil2gl_x_div_x_sub_xi_cosets_dev(nBitsExt, 0, xi, nOpen, iOpen, 0, 1, out, stream);
+}
+// rows of cosets [cosetBegin, cosetBegin + cosetCount) of the 2^extBits only, in slice order (row pos * cosetCount + jl); cosetCount a
+// power of two; extBits = 0: the whole table
+int pil2gl_x_div_x_sub_xi_cosets_dev(uint32_t nBitsExt, uint32_t extBits, const uint64_t xi[3], uint64_t nOpen, uint64_t iOpen,
+                                     uint32_t cosetBegin, uint32_t cosetCount, uint64_t *out, void *stream) {
     P2_TRY(ensure_init());
-    if (!xi || !out || iOpen >= nOpen || nBitsExt > 31) return fail(PIL2GL_EINVAL, "bad xDivXSubXi arguments");
+    if (!xi || !out || iOpen >= nOpen || nBitsExt > 31 || extBits > nBitsExt) return fail(PIL2GL_EINVAL, "bad xDivXSubXi arguments");
+    if (cosetCount == 0 || (cosetCount & (cosetCount - 1)) || (uint64_t)cosetBegin + cosetCount > (1ull << extBits))
+        return fail(PIL2GL_EINVAL, "coset range [%u,%u) outside 2^%u (the count must be a power of two)", cosetBegin, cosetBegin + cosetCount, extBits);
+    u32 ccLog = 0; while ((1u << ccLog) < cosetCount) ccLog++;
     const u64 GP = 0xFFFFFFFF00000001ull;
     const u64 xi0 = xi[0] % GP, b = h_sub(0, xi[1] % GP), c = h_sub(0, xi[2] % GP);
     const u64 bb = h_mul(b, b), cc = h_mul(c, c), bc = h_mul(b, c);
@@ -377,11 +390,11 @@ int pil2gl_x_div_x_sub_xi_dev(uint32_t nBitsExt, const uint64_t xi[3], uint64_t 
     K.m1 = h_sub(h_add(bc, bb), cc);
     K.k0 = h_sub(h_sub(h_mul(b, cc), h_mul(bb, b)), h_mul(cc, c));
     K.cc = cc; K.ccbb = h_sub(cc, bb);
-    const u64 E = 1ull << nBitsExt;
+    const u64 E = (1ull << (nBitsExt - extBits)) << ccLog;                          // rows of the slice
     const unsigned blocks = nblk((E + XD_BATCH - 1) / XD_BATCH);
-    const u64 T = (u64)blocks * 256;
-    const u64 wStep = h_pow(h_root(nBitsExt), T);                                   // w_E^T
-    x_div_x_sub_xi_kernel<<<blocks, 256, 0, as_stream(stream)>>>(nBitsExt, K, nOpen, iOpen, tables().powW, wStep, out);
+    const u64 T = (u64)blocks * 256;                                                // a multiple of cosetCount (<= 256)
+    const u64 wStep = h_pow(h_root(nBitsExt), (T >> ccLog) << extBits);             // w_E^(extended rows between a lane's rows)
+    x_div_x_sub_xi_kernel<<<blocks, 256, 0, as_stream(stream)>>>(nBitsExt, K, nOpen, iOpen, tables().powW, wStep, out, E, extBits, cosetBegin, ccLog);
     KERNEL_CHECK();
     return PIL2GL_OK;
 }

@@ -95,6 +95,7 @@ SIGNATURES = {
     "pil2gl_build_frame_zerofier_dev": (_I, [_U32, _U32, _U64, _U64, vp, vp]),
     "pil2gl_compute_q_split_dev": (_I, [vp, _U32, _U32, _U32, _U32, vp, vp]),
     "pil2gl_x_div_x_sub_xi_dev": (_I, [_U32, vp, _U64, _U64, vp, vp]),
+    "pil2gl_x_div_x_sub_xi_cosets_dev": (_I, [_U32, _U32, vp, _U64, _U64, _U32, _U32, vp, vp]),
     "pil2gl_build_lev_dev": (_I, [_U32, vp, vp, vp]),
     "pil2gl_compute_evals_dev": (_I, [C.POINTER(EvalDesc), _U32, _U32, _U32, C.POINTER(vp), _U32, vp, vp]),
     "pil2gl_rows_dot_ext_dev": (_I, [vp, _U64, _U64, vp, _U32, vp, _I, vp]),

@@ -493,7 +493,10 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     # FRI polynomial on the local rows, then one all-gather
     vfs = [transcript.getField(), transcript.getField()]
     ctx["challenges"][qStage + 1] = vfs
-    loc["xDivXSubXi_ext"] = sl(be.x_div_x_sub_xi(nbe, xis), widths["xDivXSubXi_ext"])
+    if hasattr(be, "x_div_x_sub_xi_cosets") and cc & (cc - 1) == 0:    # only this rank's rows of the table
+        loc["xDivXSubXi_ext"] = be.x_div_x_sub_xi_cosets(nbe, eb, xis, cb, cc)
+    else:
+        loc["xDivXSubXi_ext"] = sl(be.x_div_x_sub_xi(nbe, xis), widths["xDivXSubXi_ext"])
     loc["f_ext"] = be.empty(3 << nloc)
     if not (hasattr(be, "fri_polynomial_fast") and be.fri_polynomial_fast(info, loc, widths, ctx["evals"], vfs[0], vfs[1], nloc, loc["f_ext"])):
         run_local(exprs["expressionsCode"][info["friExpId"]]["code"])

@@ -565,7 +565,20 @@ def test_step_helpers(gl, oracle):
     for i in range(2):
         xi = np.ascontiguousarray(xis[i])
         _lib.call("pil2gl_x_div_x_sub_xi_dev", nbe, gl._ptr(xi), 2, i, gl._ptr(d), st)
-    assert (_host(d).reshape(1 << nbe, 6) == oracle.x_div_x_sub_xi(nbe, xis)).all()
+    full = oracle.x_div_x_sub_xi(nbe, xis)
+    assert (_host(d).reshape(1 << nbe, 6) == full).all()
+    # the same table for a coset slice only (a rank of a sharded proof): row pos * cc + jl = extended row (pos << eb) + cb + jl
+    eb_ = nbe - nb
+    last = (1 << eb_) - 1
+    for cb, cc in {(0, 1), (last, 1), (0, 1 << eb_), (2 if last >= 3 else 0, 2 if last >= 3 else 1)}:
+        ds = _dev(gl, ((1 << nb) * cc) * 6)
+        for i in range(2):
+            xi = np.ascontiguousarray(xis[i])
+            _lib.call("pil2gl_x_div_x_sub_xi_cosets_dev", nbe, eb_, gl._ptr(xi), 2, i, cb, cc, gl._ptr(ds), st)
+        want = full.reshape(1 << nb, 1 << eb_, 6)[:, cb:cb + cc].reshape(-1, 6)
+        assert (_host(ds).reshape(-1, 6) == want).all(), (cb, cc)
+    with pytest.raises(Exception):
+        _lib.call("pil2gl_x_div_x_sub_xi_cosets_dev", nbe, eb_, gl._ptr(xi), 2, 0, 0, 3, gl._ptr(d), st)
     # LEv + evals (stark_gen_helpers.js:216-264)
     xi = rand_field(rng, 3)
     lev = _dev(gl, (1 << nb) * 3)

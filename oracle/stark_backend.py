@@ -73,10 +73,11 @@ class OracleBackend:
     def merkle_siblings(self, nodes, height, idxs):
         return [[[int(x) for x in s] for s in orc.group_proof(nodes, height, i)] for i in idxs]
 
-    def merkelize_digest_block(self, parts, N, cc, r):
+    def merkelize_digest_block(self, parts, N, cc, r, sliced=False):
         world = len(parts)
         nb_ = N // world
-        leaves = np.stack([p.cpu().numpy().view(np.uint64).reshape(N, cc * 4)[r * nb_:(r + 1) * nb_] for p in parts], axis=1).reshape(-1)
+        leaves = np.stack([p.cpu().numpy().view(np.uint64).reshape(nb_, cc * 4) if sliced else p.cpu().numpy().view(np.uint64).reshape(N, cc * 4)[r * nb_:(r + 1) * nb_]
+                           for p in parts], axis=1).reshape(-1)
         return self.merkelize_digests(leaves, nb_ * cc * world)
 
     def as_torch(self, t):

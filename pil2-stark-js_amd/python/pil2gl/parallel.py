@@ -383,11 +383,64 @@ def all_gather_rows(be, local, n_bits, cc, width, comm):
     return be.from_torch(full)
 
 
+def quotient_coefficients_sharded(be, q_loc, nb, eb, cb, cc, qDim, qDeg, comm):
+    """computeQStark's first half (stark_gen_helpers.js:168-190: qq1 = ifft over the extended domain of q, then the split into qDeg
+    chunks of N coefficients scaled by shift^(-N p)) WITHOUT gathering q: -> [N][qDeg*qDim] on every rank, the first N rows of
+    pil2gl_compute_q_split_dev's result.  With r = 2^eb pos + j the size-E inverse transform factors by cosets,
+        c'_(pN+i) = 2^-eb  sum_j  w_2^eb^(-pj)  w_E^(-ij)  C_j[i],       C_j = ifft_N(q on coset j),
+    so a rank transforms ITS cosets (N rows each), multiplies by w_E^(-ij), and the sum over the cosets is taken where row i
+    lives: rows are dealt over the ranks in blocks (an all-to-all of 1/w of everybody's rows), the qDeg chunks that are
+    kept are combined there, and the blocks are all-gathered.  Exchanged per rank at config 3 on 8 ranks: 0.35 + 0.7 GB
+    instead of the 2.8 GB of q, and no rank runs the size-E transform."""
+    from . import stark as S
+    N, E, w = 1 << nb, 1 << (nb + eb), comm.world
+    nblk = N // w
+    qt = be.as_torch(q_loc).reshape(N, cc, qDim)
+    x_e = be.as_torch(be.build_x(nb + eb, 1))                           # w_E^i
+    ar = torch.arange(N, dtype=torch.int64, device=x_e.device)
+    tws = []
+    T = []
+    for jl in range(cc):
+        j = cb + jl
+        qj = be.from_torch(qt[:, jl, :].contiguous().reshape(-1))
+        Cj = be.empty(qDim << nb)
+        be.ifft(qj, qDim, nb, Cj)
+        tw = be.from_torch(x_e[((E - j) * ar) % E].contiguous())           # w_E^(-i j)
+        Tj = be.empty(qDim << nb)
+        ops = [(S.OPC["mul"], (S.SEC, 1, 2, 0, k), (S.SEC, 1, 0, 0, k), (S.SEC, 1, 1, 0, 0)) for k in range(qDim)]
+        be.eval_program(ops, 1, [(Cj, qDim), (tw, 1), (Tj, qDim)], np.zeros(1, np.uint64), nb, 0)
+        T.append(be.as_torch(Tj).reshape(w, nblk, qDim))
+        tws.append(tw)
+    del x_e, ar, tws
+    mine = torch.stack(T, dim=1).reshape(-1).contiguous()               # [w][cc][nblk][qDim]: chunk s = my cosets' rows of block s
+    parts = comm.all_to_all(mine)                                       # parts[s] = [cc][nblk][qDim] of rank s's cosets
+    G = torch.stack([p_.reshape(cc, nblk, qDim) for p_ in parts], dim=0).reshape(w * cc, nblk, qDim).permute(1, 0, 2).contiguous()   # [nblk][2^eb][qDim]
+    nco = w * cc
+    inv_n = S._inv(nco)
+    w_c = pow(S.root_of_unity(nb + eb), E // nco, S.P)                   # w_(2^eb)
+    s_in = pow(S._inv(S.SHIFT), N, S.P)
+    scal = np.array([inv_n * pow(s_in, p_, S.P) % S.P * pow(w_c, (-p_ * j) % nco, S.P) % S.P for p_ in range(qDeg) for j in range(nco)], dtype=np.uint64)
+    ops = []
+    for p_ in range(qDeg):
+        for k in range(qDim):
+            ops.append((S.OPC["mul"], (S.TMP, 1, 0, 0, 0), (S.SEC, 1, 0, 0, k), (S.SCALAR, 1, 0, 0, p_ * nco)))
+            for j in range(1, nco):
+                ops.append((S.OPC["mul"], (S.TMP, 1, 0, 0, 1), (S.SEC, 1, 0, 0, j * qDim + k), (S.SCALAR, 1, 0, 0, p_ * nco + j)))
+                dest = (S.SEC, 1, 1, 0, p_ * qDim + k) if j == nco - 1 else (S.TMP, 1, 0, 0, 0)
+                ops.append((S.OPC["add"], dest, (S.TMP, 1, 0, 0, 0), (S.TMP, 1, 0, 0, 1)))
+            if nco == 1:
+                ops.append((S.OPC["copy"], (S.SEC, 1, 1, 0, p_ * qDim + k), (S.TMP, 1, 0, 0, 0), None))
+    blk = be.empty(nblk * qDeg * qDim)
+    be.eval_program(ops, 2, [(be.from_torch(G.reshape(-1)), nco * qDim), (blk, qDeg * qDim)], scal, _log2(nblk), 0)
+    return be.from_torch(torch.cat([p_.reshape(-1) for p_ in comm.all_gather(be.as_torch(blk).reshape(-1))]))
+
+
 def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None, timings=None, comm=None):
     """pil2gl.stark.stark_gen with every witness stage, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
-    single-process one.  Replicated: the iNTT of q (3 columns) and the FRI steps after the first fold (the first FRI tree's
-    leaves and the first fold are computed by cosets); the stage trees above the leaves are split by leaf blocks (ShardedTree).
+    single-process one.  Replicated: the N-row transform of the split quotient and the FRI steps after the first fold (the
+    quotient's coefficients come from per-coset transforms combined by row blocks, the first FRI tree's leaves and the first
+    fold are computed by cosets); the stage trees above the leaves are split by leaf blocks (ShardedTree).
     rehearse_world=K: rank 0's share of a K-rank proof run alone (own slices stand in for the gathered ones, so the
     result is not a valid proof): per-GPU time and memory on one GPU.  timings: dict that receives seconds per stage."""
     from . import stark as S
@@ -465,15 +518,21 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     loc["q_ext"] = be.empty(qDim << nloc)
     run_local(exprs["expressionsCode"][info["cExpId"]]["code"])
     lap("q_expr")
-    q_ext = all_gather_rows(be, loc["q_ext"], nb, cc, qDim, comm)
+    import os
+    split_q = os.environ.get("PIL2GL_Q_GATHER", "0") != "1" and N % world == 0 and (N // world) >= 2 and cc & (cc - 1) == 0
+    q_ext = None if split_q else all_gather_rows(be, loc["q_ext"], nb, cc, qDim, comm)
+    # computeQStark (stark_gen_helpers.js:168-208): the coefficients of q by cosets and row blocks (quotient_coefficients_sharded;
+    # PIL2GL_Q_GATHER=1: all-gather q and transform it everywhere); the split quotient has degree < N per column, so its
+    # extension is again "one coset per rank": evaluations on the subgroup, then the unshifted coset extension of the own
+    # cosets, own leaves, exchanged digests
+    if split_q:                                                # the coefficients without gathering q (by cosets, then by row blocks)
+        qq2 = quotient_coefficients_sharded(be, loc["q_ext"], nb, eb, cb, cc, qDim, qDeg, comm)
+    else:
+        qq1 = be.empty(qDim << nbe)
+        be.ifft(q_ext, qDim, nbe, qq1)
+        qq2 = be.q_split(qq1, nb, nbe, qDim, qDeg)
+        del qq1, q_ext
     del loc["q_ext"]
-    # computeQStark (stark_gen_helpers.js:168-208): the iNTT of q needs all of q and is replicated (3 columns); the split
-    # quotient has degree < N per column, so its extension is again "one coset per rank": evaluations on the subgroup, then
-    # the unshifted coset extension of the own cosets, own leaves, gathered digests
-    qq1 = be.empty(qDim << nbe)
-    be.ifft(q_ext, qDim, nbe, qq1)
-    qq2 = be.q_split(qq1, nb, nbe, qDim, qDeg)
-    del qq1, q_ext
     q_sub = be.empty(nQ << nb)
     be.fft(qq2[:nQ << nb], nQ, nb, q_sub)                    # rows >= N of qq2 are zero: these are all its coefficients
     del qq2

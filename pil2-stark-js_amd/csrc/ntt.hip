@@ -149,12 +149,13 @@ struct PassParams {
     u32 canonOut;                   // 1: this pass writes a transform's result (canonical values); 0: the next pass takes any representative
 };
 
-// KC = 0: any geometry; KC = 8: the geometry of the wide matrices (8 stages, 16 column slots x 16 sub-transform lanes, one
-// slot group), with every stride, LDS offset and twiddle index a compile-time constant
-template <bool INV, bool DIT, int KC>
+// KC = 0: any geometry; KC = 8: the geometry of the wide matrices (8 stages, SC = 15 or 16 column slots x 16 sub-transform lanes,
+// one slot group: 16 slots for rows of 128 bytes and more in 16-column chunks, 15 for the 100-column matrices whose seven
+// chunks are 15 wide), with every stride, LDS offset and twiddle index a compile-time constant
+template <bool INV, bool DIT, int KC, int SC = 16>
 __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     extern __shared__ u64 lds[];
-    const u32 k = KC ? KC : P.k, K = 1u << k, S = KC ? 16 : blockDim.x, by = KC ? 16 : blockDim.y;
+    const u32 k = KC ? KC : P.k, K = 1u << k, S = KC ? SC : blockDim.x, by = KC ? 16 : blockDim.y;
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
     constexpr bool PAD = KC != 0;                   // one spare tile row per 16 (see dif_step)
     const u32 tileRows = PAD ? K + (K >> 4) : K;
@@ -205,8 +206,8 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     }
     __syncthreads();
     if constexpr (KC == 8) {
-        if (DIT) { dit_step<4, INV, true>(tile, TW, 8, 0, 4, 16, x, y, 16); dit_step<4, INV, true>(tile, TW, 8, 4, 0, 16, x, y, 16); }
-        else { dif_step<4, INV, true>(tile, TW, 8, 8, 16, x, y, 16); dif_step<4, INV, true>(tile, TW, 8, 4, 16, x, y, 16); }
+        if (DIT) { dit_step<4, INV, true>(tile, TW, 8, 0, 4, SC, x, y, 16); dit_step<4, INV, true>(tile, TW, 8, 4, 0, SC, x, y, 16); }
+        else { dif_step<4, INV, true>(tile, TW, 8, 8, SC, x, y, 16); dif_step<4, INV, true>(tile, TW, 8, 4, SC, x, y, 16); }
     } else {
         if (DIT) dit_stages<INV>(tile, TW, k, S, x, y, by); else dif_stages<INV>(tile, TW, k, S, x, y, by);
     }
@@ -363,15 +364,18 @@ int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit,
     Geom g = make_geom(k, C, totalGroups, env_u32("PIL2GL_NTT_TILE", 4096), 256);
     P.Wc = g.Wc; P.nbT = g.nbT; P.nColChunks = g.nColChunks; P.nGroupTiles = (u32)(totalGroups / g.nbT);
     u64 K = 1ull << k;
-    const bool fixedGeom = k == 8 && g.S == 16 && g.by == 16 && g.nbT == 1 && g.Wc == 16 && !env_u32("PIL2GL_NTT_GENERIC", 0);
+    const bool fixedGeom = k == 8 && (g.S == 16 || g.S == 15) && g.by == 16 && g.nbT == 1 && g.Wc == g.S && !env_u32("PIL2GL_NTT_GENERIC", 0);
     size_t ldsBytes = 8 * ((size_t)g.S * (fixedGeom ? K + K / 16 : K) + K + (P.hasTw ? (size_t)g.nbT * K : 0));
     u64 blocks = (u64)nHi * P.nGroupTiles * P.nColChunks;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
     if (dit && inverse) return fail(PIL2GL_EINVAL, "no inverse decimation-in-time pass");
 #define PASS_CASE(INV_, DIT_)                                                                                     \
-    { if (fixedGeom) {                                                                                            \
-          P2_TRY(set_lds((const void *)ntt_pass_kernel<INV_, DIT_, 8>, ldsBytes));                                   \
-          hipLaunchKernelGGL((ntt_pass_kernel<INV_, DIT_, 8>), dim3((unsigned)blocks), dim3(16, 16), ldsBytes, st, P); \
+    { if (fixedGeom && g.S == 16) {                                                                               \
+          P2_TRY(set_lds((const void *)ntt_pass_kernel<INV_, DIT_, 8, 16>, ldsBytes));                               \
+          hipLaunchKernelGGL((ntt_pass_kernel<INV_, DIT_, 8, 16>), dim3((unsigned)blocks), dim3(16, 16), ldsBytes, st, P); \
+      } else if (fixedGeom) {                                                                                      \
+          P2_TRY(set_lds((const void *)ntt_pass_kernel<INV_, DIT_, 8, 15>, ldsBytes));                               \
+          hipLaunchKernelGGL((ntt_pass_kernel<INV_, DIT_, 8, 15>), dim3((unsigned)blocks), dim3(15, 16), ldsBytes, st, P); \
       } else {                                                                                                     \
           P2_TRY(set_lds((const void *)ntt_pass_kernel<INV_, DIT_, 0>, ldsBytes));                                   \
           hipLaunchKernelGGL((ntt_pass_kernel<INV_, DIT_, 0>), dim3((unsigned)blocks), dim3(g.S, g.by), ldsBytes, st, P); } }

@@ -88,6 +88,9 @@ __device__ __forceinline__ u64 sbox_one(u64 x) {
 // in-place permutation; st[] canonical or lazy in, canonical out.
 // Matrix-core form (poseidon_mds_mfma.cuh): the whole wave must reach every call (no lane may have left the kernel or
 // sit in another branch, because the MDS operands of all 64 lanes feed one MFMA); `m` comes from mds_mfma_init().
+// NCANON: how many leading outputs are made canonical (12: all; a sponge between two of its permutations needs none -- the
+// next permutation takes any representative --, a digest needs its 4)
+template <int NCANON = 12>
 __device__ inline void poseidon_perm(u64 st[12], const MdsMfma &m) {
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
@@ -105,7 +108,7 @@ __device__ inline void poseidon_perm(u64 st[12], const MdsMfma &m) {
         mds_layer_mfma(st, m);
     }
 #pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = canon(st[i]);
+    for (int i = 0; i < NCANON; i++) st[i] = canon(st[i]);
 }
 
 // vector-ALU form (any subset of lanes): in-place permutation; st[] canonical or lazy in, canonical out.

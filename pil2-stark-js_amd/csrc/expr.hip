@@ -424,6 +424,14 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
          " _Pragma(\"unroll\") for (int k = 0; k < 3; k++) { const u32 w0 = L[3*k], w1 = L[3*k+1], w2 = L[3*k+2];\n"
          "  S[k][0] += (u64)p0 * w0; S[k][1] += (u64)p0 * w1; S[k][2] += (u64)p0 * w2; S[k][3] += (u64)p1 * w0; S[k][4] += (u64)p1 * w1; S[k][5] += (u64)p1 * w2; } }\n";
     o << "__device__ __noinline__ E3 e3_mul_call(E3 a, E3 b) { return e3_mul(a, b); }\n";
+    // Long programs call their modular multiplications instead of inlining them: the straight-line kernel of the 666-op
+    // constraint program of the bench AIR is 65 KB of code with inlined products, more than the 64 KB instruction cache two CUs
+    // share, and every wave walks through all of it once; with calls it is 34 KB and the kernel 14 % faster (48.8 -> 42.1 ms
+    // at config 3).  Short programs keep the inlined form.  PIL2GL_EXPR_MULCALL=0|1 overrides.
+    const char *mcEnv = getenv("PIL2GL_EXPR_MULCALL");
+    const bool mulCall = mcEnv ? mcEnv[0] == '1' : ops.size() >= 200;
+    const std::string MUL = mulCall ? "mul_call(" : "mul(";
+    if (mulCall) o << "__device__ __noinline__ u64 mul_call(u64 a, u64 b) { return mul(a, b); }\n";
     o << "extern \"C\" __global__ void __launch_bounds__(256) jit_eval(JitArgs A) {\n";
     o << " const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (row >= (1ull << A.nBits)) return;\n";
     o << " const u64 mask = (1ull << A.nBits) - 1; const u64 *__restrict__ SC = A.scalars; const u32 *__restrict__ LM = A.limbs;\n";
@@ -468,8 +476,8 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
             if (da == 3 && db == 3) {
                 o << " { E3 x_ = { { " << rd(a, 0) << ", " << rd(a, 1) << ", " << rd(a, 2) << " } }, y_ = { { " << rd(b, 0) << ", " << rd(b, 1) << ", " << rd(b, 2) << " } }; E3 z_ = e3_mul_call(x_, y_);";
                 r[0] = "z_.v[0]"; r[1] = "z_.v[1]"; r[2] = "z_.v[2]";
-            } else if (da == 3) { for (int c = 0; c < 3; c++) r[c] = "mul(" + rd(a, c) + ", " + rd(b, 0) + ")"; }
-            else { for (int c = 0; c < 3; c++) r[c] = c < (int)db || c == 0 ? "mul(" + rd(a, 0) + ", " + rd(b, c) + ")" : "0ull"; }
+            } else if (da == 3) { for (int c = 0; c < 3; c++) r[c] = MUL + rd(a, c) + ", " + rd(b, 0) + ")"; }
+            else { for (int c = 0; c < 3; c++) r[c] = c < (int)db || c == 0 ? MUL + rd(a, 0) + ", " + rd(b, c) + ")" : "0ull"; }
             break;
         default: for (int c = 0; c < 3; c++) r[c] = rd(a, c); break;     // copy
         }
@@ -585,6 +593,12 @@ extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *c
                 static bool warned = false;
                 if (!warned) { fprintf(stderr, "pil2gl: run-time compilation unavailable (%s); using the interpreter kernel\n", pil2gl_last_error()); warned = true; }
                 goto interpreter;
+            }
+            if (getenv("PIL2GL_JIT_INFO")) {
+                int regs = 0, lds = 0, loc = 0, maxt = 0;
+                (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn); (void)hipFuncGetAttribute(&lds, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn);
+                (void)hipFuncGetAttribute(&loc, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn); (void)hipFuncGetAttribute(&maxt, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, fn);
+                fprintf(stderr, "pil2gl jit_eval: %zu ops, regs %d, lds %d, scratch %d, max threads %d\n", ops.size(), regs, lds, loc, maxt);
             }
             JitArgs A; memset(&A, 0, sizeof A);
             A.scalars = c.scalars; A.limbs = c.limbs; A.nBits = ctx->nBits;

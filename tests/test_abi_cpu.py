@@ -115,3 +115,12 @@ def test_constraint_program_compiles_with_hiprtc_and_fuses_horner():
     assert nbytes.value > 1000
     assert fused.value == 2 * 10 + 3          # every constraint became one lazy multiply-accumulate term
     assert time.time() - t0 < 120
+    # the form long programs take (modular multiplications called, not inlined: the kernel must fit the instruction cache)
+    inlined = nbytes.value
+    os.environ["PIL2GL_EXPR_MULCALL"] = "1"
+    try:
+        rc = lib.pil2gl_debug_jit_compile(C.byref(prog), C.byref(c), C.byref(nbytes), C.byref(fused))
+    finally:
+        del os.environ["PIL2GL_EXPR_MULCALL"]
+    assert rc == 0, lib.pil2gl_last_error()
+    assert 1000 < nbytes.value < inlined

@@ -260,6 +260,11 @@ int pil2gl_debug_jit_compile(const glx_program *prog, const glx_ctx *ctx, uint64
 /* `layers` consecutive Poseidon MDS layers (glwasm.js:428-440 matrix) applied to n 12-element states (host pointers,
  * any u64 representatives in, canonical out): mfma = 1 the matrix-core layer the hash kernels use, 0 the vector-ALU one */
 int pil2gl_selftest_mds(const uint64_t *states, uint64_t n, uint32_t layers, int mfma, uint64_t *out);
+/* the Poseidon-12 permutation (glwasm.js:216-426) of n 12-element states (host pointers, any u64 representatives in, canonical
+ * out) in each of the library's statements of it: what = 0 the hash kernels' form (matrix-core MDS, rounds 4..25 four to a
+ * linear layer), 1 matrix-core MDS with one layer per round, 2 vector ALU only; 3 / 4 = rounds 4..25 ALONE (folded-constant
+ * form: lane 0 + c, x^7, MDS) in the forms of 0 / 1 -- arbitrary states reach the partial rounds' recombination that way */
+int pil2gl_selftest_poseidon(const uint64_t *states, uint64_t n, int what, uint64_t *out);
 /* extension a*b and 1/a on the device (n triples) */
 int pil2gl_selftest_ext(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *inv);
 

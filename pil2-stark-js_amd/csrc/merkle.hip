@@ -49,7 +49,7 @@ __global__ void __launch_bounds__(256, 3) linear_hash_kernel(const u64 *__restri
     const u64 row = live ? row0 : height - 1;       // width, split are uniform: every lane takes the same path
     const u64 *v = in + row * width;
     MdsMfma m;
-    mds_mfma_init(m);
+    poseidon_init(m);
     u64 d[4];
     if (!split || width <= 4) {
         linear_hash_plain(v, (u32)width, d, m);
@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(256, 3) merkle_level_kernel(const u64 *__restr
     const bool live = i0 < nOps;
     const u64 i = live ? i0 : nOps - 1;
     MdsMfma m;
-    mds_mfma_init(m);
+    poseidon_init(m);
     u64 st[12];
 #pragma unroll
     for (int j = 0; j < 8; j++) st[j] = in[8 * i + j];
@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(256, 2) merkle_path_roots_kernel(const u64 *__
     const bool live = i0 < count;
     const u64 i = live ? i0 : count - 1;
     MdsMfma m;
-    mds_mfma_init(m);
+    poseidon_init(m);
     u64 cur[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) cur[j] = canon(leaf[4 * i + j]);
@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(256, 4) poseidon_batch_kernel(const u64 *__res
     const bool live = i0 < count;
     const u64 i = live ? i0 : count - 1;
     MdsMfma m;
-    mds_mfma_init(m);
+    poseidon_init(m);
     u64 st[12];
 #pragma unroll
     for (int j = 0; j < 8; j++) st[j] = canon(in[8 * i + j]);          // F.e(): poseidon.js:65-67
@@ -185,6 +185,33 @@ __global__ void __launch_bounds__(256, 2) mds_selftest_kernel(const u64 *__restr
 #pragma unroll
     for (int j = 0; j < 12; j++) st[j] = in[12 * i + j];
     for (u32 l = 0; l < layers; l++) { if (mfma) mds_layer_mfma(st, m); else mds_layer(st); }
+    if (!live) return;
+#pragma unroll
+    for (int j = 0; j < 12; j++) out[12 * i + j] = canon(st[j]);
+}
+
+// diagnostics: the permutation in its three statements, and rounds 4..25 alone in their two (the blocked form leaves the
+// state offset by a constant that round 26's table absorbs: POSEIDON_BLK_RC26 - POSEIDON_GL_RC26F is added back here so
+// that both forms return the same field elements)
+__global__ void __launch_bounds__(256, 2) poseidon_selftest_kernel(const u64 *__restrict__ in, u64 n, int what, u64 *__restrict__ out) {
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i0 < n;
+    const u64 i = live ? i0 : n - 1;
+    MdsMfma m;
+    poseidon_init(m);
+    u64 st[12];
+#pragma unroll
+    for (int j = 0; j < 12; j++) st[j] = in[12 * i + j];
+    if (what == 0) poseidon_perm(st, m);
+    else if (what == 1) poseidon_perm_single(st, m);
+    else if (what == 2) poseidon_perm(st);
+    else {
+        poseidon_partial_rounds(st, m, what == 3 ? 0 : 1);
+        if (what == 3) {
+#pragma unroll
+            for (int j = 0; j < 12; j++) st[j] = sub(add(canon(st[j]), POSEIDON_BLK_RC26[j]), POSEIDON_GL_RC26F[j]);
+        }
+    }
     if (!live) return;
 #pragma unroll
     for (int j = 0; j < 12; j++) out[12 * i + j] = canon(st[j]);
@@ -414,6 +441,18 @@ int pil2gl_selftest_mds(const uint64_t *states, uint64_t n, uint32_t layers, int
                     [](const u64 *i, const u64 *, u64 *o, void *p) {
                         MdsArgs *a = (MdsArgs *)p;
                         mds_selftest_kernel<<<(unsigned)((a->n + 255) / 256), 256>>>(i, a->n, a->layers, a->mfma, o);
+                        KERNEL_CHECK();
+                        return (int)PIL2GL_OK;
+                    }, &a);
+}
+int pil2gl_selftest_poseidon(const uint64_t *states, uint64_t n, int what, uint64_t *out) {
+    if (n == 0) return PIL2GL_OK;
+    if (what < 0 || what > 4) return fail(PIL2GL_EINVAL, "what must be 0..4");
+    MdsArgs a = { n, 0, what };
+    return with_dev(states, n * 12, nullptr, 0, out, n * 12,
+                    [](const u64 *i, const u64 *, u64 *o, void *p) {
+                        MdsArgs *a = (MdsArgs *)p;
+                        poseidon_selftest_kernel<<<(unsigned)((a->n + 255) / 256), 256>>>(i, a->n, a->mfma, o);
                         KERNEL_CHECK();
                         return (int)PIL2GL_OK;
                     }, &a);

@@ -85,13 +85,43 @@ __device__ __forceinline__ u64 sbox_one(u64 x) {
     return y;
 }
 
+}  // namespace gl
+#include "poseidon_blocks.cuh"
+namespace gl {
+
 // in-place permutation; st[] canonical or lazy in, canonical out.
 // Matrix-core form (poseidon_mds_mfma.cuh): the whole wave must reach every call (no lane may have left the kernel or
 // sit in another branch, because the MDS operands of all 64 lanes feed one MFMA); `m` comes from mds_mfma_init().
 // NCANON: how many leading outputs are made canonical (12: all; a sponge between two of its permutations needs none -- the
 // next permutation takes any representative --, a digest needs its 4)
+// Rounds 4..25 run four to a linear layer (poseidon_blocks.cuh); `m` comes from poseidon_init().
 template <int NCANON = 12>
 __device__ inline void poseidon_perm(u64 st[12], const MdsMfma &m) {
+    const v4i *__restrict__ A = m.blkA;
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) {
+        sbox_full(st, &POSEIDON_GL_RC[r * 12]);
+        mds_layer_mfma(st, m);
+    }
+#pragma unroll 1
+    for (int b = 0; b < POSEIDON_BLK_N; b++) poseidon_partial_block(st, &POSEIDON_BLK_C0[POSEIDON_BLK_K * b], A, m);
+#pragma unroll 1
+    for (int r = POSEIDON_BLK_N * POSEIDON_BLK_K; r < 22; r++) {
+        st[0] = sbox_one(add_lazy_canon(st[0], POSEIDON_BLK_C0[r]));
+        mds_layer_mfma(st, m);
+    }
+#pragma unroll 1
+    for (int r = 26; r < 30; r++) {
+        sbox_full(st, r == 26 ? POSEIDON_BLK_RC26 : &POSEIDON_GL_RC[r * 12]);
+        mds_layer_mfma(st, m);
+    }
+#pragma unroll
+    for (int i = 0; i < NCANON; i++) st[i] = canon(st[i]);
+}
+// the same with every partial round a layer of its own (round 2's form; kept for tools/sbox_bench.hip's A/B and as a second
+// statement of the permutation the parity tests compare with: pil2gl_selftest_perm)
+template <int NCANON = 12>
+__device__ inline void poseidon_perm_single(u64 st[12], const MdsMfma &m) {
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
         sbox_full(st, &POSEIDON_GL_RC[r * 12]);
@@ -109,6 +139,33 @@ __device__ inline void poseidon_perm(u64 st[12], const MdsMfma &m) {
     }
 #pragma unroll
     for (int i = 0; i < NCANON; i++) st[i] = canon(st[i]);
+}
+
+// rounds 4..25 alone, for the parity tests (which = 0 blocked, 1 one layer per round): arbitrary states in, any representatives out
+__device__ inline void poseidon_partial_rounds(u64 st[12], const MdsMfma &m, int which) {
+    if (which == 0) {
+#pragma unroll 1
+        for (int b = 0; b < POSEIDON_BLK_N; b++) poseidon_partial_block(st, &POSEIDON_BLK_C0[POSEIDON_BLK_K * b], m.blkA, m);
+#pragma unroll 1
+        for (int r = POSEIDON_BLK_N * POSEIDON_BLK_K; r < 22; r++) {
+            st[0] = sbox_one(add_lazy_canon(st[0], POSEIDON_BLK_C0[r]));
+            mds_layer_mfma(st, m);
+        }
+    } else {
+#pragma unroll 1
+        for (int r = 0; r < 22; r++) {
+            st[0] = sbox_one(add_lazy_canon(st[0], POSEIDON_GL_PARTIAL_C0[r]));
+            mds_layer_mfma(st, m);
+        }
+    }
+}
+
+// every thread of the workgroup, once, before the first permutation: the MDS operands of this lane and the workgroup's copy
+// of the blocked rounds' operand table (27 KB of LDS)
+__device__ __forceinline__ void poseidon_init(MdsMfma &m) {
+    __shared__ v4i poseidon_blk_table[POSEIDON_BLK_OPERANDS * 64];
+    mds_mfma_init(m);
+    m.blkA = poseidon_blk_load(poseidon_blk_table);
 }
 
 // vector-ALU form (any subset of lanes): in-place permutation; st[] canonical or lazy in, canonical out.

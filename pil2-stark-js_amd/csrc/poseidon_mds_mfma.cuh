@@ -32,6 +32,7 @@ struct MdsMfma {
     v4i A00;        // s = 0, t = 0
     v16i C;         // 128 * 256 in every row
     u32 sh16;       // 65536, kept opaque so that x*65536 + y stays ONE v_mad_u64_u32 (not shift + zero-extend + add)
+    const v4i *blkA; // this lane's column of the blocked partial rounds' operand table in LDS (poseidon_blocks.cuh)
 };
 
 __device__ inline void mds_mfma_init(MdsMfma &m) {

@@ -202,6 +202,78 @@ def test_poseidon_sbox_borrow_path(gl, oracle):
     assert (gl.merkelizeLevel(rows).reshape(-1, 4) == np.array([oracle.poseidon(r, None, 4) for r in rows])).all()
 
 
+def _poseidon_tables():
+    import os, re
+    from conftest import ROOT
+    txt = open(os.path.join(ROOT, "pil2-stark-js_amd", "csrc", "poseidon_gl_constants.inc")).read()
+    out = {}
+    for name in ("POSEIDON_GL_RC", "POSEIDON_GL_PARTIAL_C0", "POSEIDON_GL_RC26F"):
+        m = re.search(name + r"\[\d+\] = \{(.*?)\};", txt, re.S)
+        out[name] = [int(v, 16) for v in re.findall(r"0x([0-9a-f]{16})ull", m.group(1))]
+    return out
+
+
+def test_poseidon_statements_agree(gl, oracle):
+    """the permutation in the library's three statements of it -- matrix-core MDS with rounds 4..25 four to a linear layer (what
+    the hash kernels run), matrix-core MDS with a layer per round, vector ALU only -- on random, non-canonical and structured
+    states; the first against the oracle as well"""
+    from pil2gl import _lib
+    rng = np.random.default_rng(2024)
+    states = [[0] * 12, [(1 << 64) - 1] * 12, [P - 1] * 12, [P] * 12, [1] * 12, list(range(12)), [0x8080808080808080] * 12,
+              [0x7F7F7F7F7F7F7F7F] * 12, [0xFF00FF00FF00FF00] * 12, [0x00FF00FF00FF00FF] * 12, [1 << 63] * 12]
+    states += [[int(x) for x in rng.integers(0, 1 << 64, 12, dtype=np.uint64)] for _ in range(5000)]
+    a = np.array(states, dtype=np.uint64)
+    outs = []
+    for what in (0, 1, 2):
+        o = np.zeros_like(a)
+        _lib.call("pil2gl_selftest_poseidon", gl._ptr(a), a.shape[0], what, gl._ptr(o))
+        outs.append(o)
+    assert (outs[0] == outs[1]).all() and (outs[0] == outs[2]).all()
+    for k in list(range(11)) + list(range(11, 5011, 97)):
+        s = [v % P for v in states[k]]
+        assert [int(v) for v in outs[0][k]] == [int(v) for v in oracle.poseidon(s[:8], s[8:], 12)], k
+
+
+def test_partial_rounds_blocked_recombination(gl):
+    """rounds 4..25 alone, four to a linear layer (poseidon_blocks.cuh) against one layer per round and against plain integers,
+    on arbitrary states: the blocks' recombination works on biased planes of four signed coefficient digits and ends in an
+    addition that wraps with probability ~2^-15 per element (patched in a rarely taken branch) -- 2^18 random states put a few
+    hundred elements through that branch; the structured states reach the extremes of every plane"""
+    from pil2gl import _lib
+    t = _poseidon_tables()
+    PC0 = t["POSEIDON_GL_PARTIAL_C0"]
+    MC = [17, 15, 41, 16, 2, 28, 13, 13, 39, 18, 34, 20]
+    M = [[MC[(j - i) % 12] + (8 if i == 0 and j == 0 else 0) for j in range(12)] for i in range(12)]
+
+    def partial(st):
+        st = [v % P for v in st]
+        for r in range(22):
+            st[0] = pow((st[0] + PC0[r]) % P, 7, P)
+            st = [sum(M[i][j] * st[j] for j in range(12)) % P for i in range(12)]
+        return st
+    rng = np.random.default_rng(31)
+    states = [[0] * 12, [(1 << 64) - 1] * 12, [P - 1] * 12, [P] * 12, [1] * 12, [0x8080808080808080] * 12, [0x7F7F7F7F7F7F7F7F] * 12,
+              [0xFF00FF00FF00FF00] * 12, [0x00FF00FF00FF00FF] * 12, [0x0101010101010101 * k for k in range(12)]]
+    for j in range(12):
+        for v in (1, 0xFF, 1 << 63, (1 << 64) - 1, 0x80, 0xFFFFFFFF, 0xFFFFFFFF00000000):
+            s = [0] * 12; s[j] = v; states.append(s)
+            s = [(1 << 64) - 1] * 12; s[j] = v; states.append(s)
+    for _ in range(400):                     # sparse bytes: planes far from their mean
+        s = []
+        for j in range(12):
+            b = rng.integers(0, 256, 8) * (rng.random(8) < 0.3)
+            s.append(int(sum(int(x) << (8 * k) for k, x in enumerate(b))))
+        states.append(s)
+    nstruct = len(states)
+    a = np.concatenate([np.array(states, dtype=np.uint64), rng.integers(0, 1 << 64, ((1 << 18), 12), dtype=np.uint64)])
+    blk = np.zeros_like(a); one = np.zeros_like(a)
+    _lib.call("pil2gl_selftest_poseidon", gl._ptr(a), a.shape[0], 3, gl._ptr(blk))
+    _lib.call("pil2gl_selftest_poseidon", gl._ptr(a), a.shape[0], 4, gl._ptr(one))
+    assert (blk == one).all()
+    for k in list(range(nstruct)) + list(range(nstruct, a.shape[0], 4001)):
+        assert [int(v) for v in blk[k]] == partial([int(v) for v in a[k]]), k
+
+
 @pytest.mark.parametrize("mfma", [1, 0])
 def test_mds_layer_structured_inputs(gl, mfma):
     """the MDS layer alone (matrix-core and vector-ALU forms) on inputs the hash never produces by chance: zero and

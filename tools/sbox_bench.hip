@@ -4,6 +4,12 @@
 #include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
+#ifdef PBLK_NO_MFMA
+typedef int v4i_ __attribute__((ext_vector_type(4)));
+typedef int v16i_ __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ v16i_ fake_mfma(v4i_ a, v4i_ b, v16i_ c) { c[0] += a[0] ^ b[1]; c[5] += a[2] ^ b[3]; c[9] ^= a[1] + b[0]; c[14] ^= a[3] + b[2]; return c; }
+#define PBLK_MFMA(a, b, c) fake_mfma(a, b, c)
+#endif
 #include "poseidon_gl.cuh"
 using namespace gl;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
@@ -192,6 +198,28 @@ KPROD(k_prod2, 2)
 KPROD(k_prod3, 3)
 KPROD(k_prod4, 4)
 
+// the blocked partial rounds (poseidon_blocks.cuh)
+#define KBLK(NAME, W) __global__ void __launch_bounds__(256, W) NAME(u64 *out, int iters, u64 seed, int dump) { \
+    __shared__ v4i tab[POSEIDON_BLK_OPERANDS * 64]; \
+    const v4i *A = poseidon_blk_load(tab); \
+    const u64 id = (u64)blockIdx.x * blockDim.x + threadIdx.x; u64 st[12]; \
+    for (int i = 0; i < 12; i++) st[i] = mix(seed + id * 12 + i); \
+    if (dump == 2) for (int i = 0; i < 12; i++) st[i] = (i & 1) ? ~0ull - id * i : (u64)(id * i) << (i * 5); \
+    MdsMfma m; mds_mfma_init(m); \
+    for (int i = 0; i < iters; i++) poseidon_perm_blk(st, m, A); \
+    if (dump) { for (int i = 0; i < 12; i++) out[id * 12 + i] = st[i]; return; } \
+    u64 s = 0; for (int i = 0; i < 12; i++) s += st[i] * (i + 1); out[id] = s; }
+KBLK(k_blk2, 2)
+KBLK(k_blk3, 3)
+KBLK(k_blk4, 4)
+__global__ void __launch_bounds__(256, 3) k_prod_edge(u64 *out, int iters) {
+    const u64 id = (u64)blockIdx.x * blockDim.x + threadIdx.x; u64 st[12];
+    for (int i = 0; i < 12; i++) st[i] = (i & 1) ? ~0ull - id * i : (u64)(id * i) << (i * 5);
+    MdsMfma m; mds_mfma_init(m);
+    for (int i = 0; i < iters; i++) poseidon_perm(st, m);
+    for (int i = 0; i < 12; i++) out[id * 12 + i] = st[i];
+}
+
 template <typename F>
 float timeit(F f) {
     hipEvent_t s, e; hipEventCreate(&s); hipEventCreate(&e);
@@ -276,6 +304,23 @@ int main() {
         float t3 = timeit([&] { hipLaunchKernelGGL(k_prod3, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
         float t4 = timeit([&] { hipLaunchKernelGGL(k_prod4, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
         printf("production poseidon_perm, launch bounds 2 / 3 / 4 waves per SIMD: %.3f / %.3f / %.3f G perm/s\n", np / t2 / 1e6, np / t3 / 1e6, np / t4 / 1e6);
+    }
+    {
+        const int it = 100; double np = (double)n * it;
+        hipLaunchKernelGGL(k_prod3, dim3(blocks), dim3(256), 0, 0, out, 3, 77ull, 1); CHECK(hipMemcpy(h0, out, 8 * n * 12, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k_blk3, dim3(blocks), dim3(256), 0, 0, out, 3, 77ull, 1); CHECK(hipMemcpy(h1, out, 8 * n * 12, hipMemcpyDeviceToHost));
+        size_t bad = 0; for (size_t i = 0; i < n * 12; i++) bad += h0[i] != h1[i];
+        printf("blocked partial rounds vs production poseidon_perm (random states, 3 chained): %zu of %zu words differ\n", bad, n * 12);
+        hipLaunchKernelGGL(k_prod_edge, dim3(blocks), dim3(256), 0, 0, out, 2); CHECK(hipMemcpy(h0, out, 8 * n * 12, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k_blk3, dim3(blocks), dim3(256), 0, 0, out, 2, 77ull, 2); CHECK(hipMemcpy(h1, out, 8 * n * 12, hipMemcpyDeviceToHost));
+        bad = 0; for (size_t i = 0; i < n * 12; i++) bad += h0[i] != h1[i];
+        printf("blocked partial rounds vs production poseidon_perm (edge states, 2 chained): %zu of %zu words differ\n", bad, n * 12);
+        float t2 = timeit([&] { hipLaunchKernelGGL(k_blk2, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
+        float t3 = timeit([&] { hipLaunchKernelGGL(k_blk3, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
+        float t4 = timeit([&] { hipLaunchKernelGGL(k_blk4, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
+        printf("blocked partial rounds, launch bounds 2 / 3 / 4 waves per SIMD: %.3f / %.3f / %.3f G perm/s\n", np / t2 / 1e6, np / t3 / 1e6, np / t4 / 1e6);
+        float p3 = timeit([&] { hipLaunchKernelGGL(k_prod3, dim3(blocks), dim3(256), 0, 0, out, it, 1ull, 0); });
+        printf("production again (3 waves): %.3f G perm/s\n", np / p3 / 1e6);
     }
     return 0;
 }

@@ -285,6 +285,49 @@ def bn128_mads(t):
     return full + partial
 
 
+def start_watchdog(Progress, rank):
+    """A rank that has made no progress (stage boundary or collective, pil2gl.parallel.Progress) for PIL2GL_STALL_S seconds
+XX
+    is a C thread that needs no interpreter lock: a main thread stuck inside a driver call (where round 2's 2-rank run on one
+    GPU sat, silently, until it was killed) cannot keep it from firing.  torch.distributed.run tears the other ranks down."""
+    import faulthandler
+    limit = float(os.environ.get("PIL2GL_STALL_S", "240"))
+    if limit <= 0:
+        return
+
+    def rearm(what, now):
+        faulthandler.cancel_dump_traceback_later()
+        sys.stderr.write(""); sys.stderr.flush()
+        faulthandler.dump_traceback_later(limit, exit=True)
+    Progress.on_mark = rearm
+    rearm(None, 0)
+
+
+def sharded_memory_estimate(mode, n_bits, n_cols, world, rank0_extra=True):
+    """device bytes one rank of a coset-sharded run holds at its peak (8-byte words), so that a configuration that cannot fit is
+    refused with a message instead of found out by the allocator half-way (or, with ranks sharing a GPU, by a peer's collective
+    timing out).  Counted: the replicated trace, the coefficient scratch of the LDE, the rank's slice of the extension, its share
+    of the node arrays, the quotient stage (slice + coefficients), FRI buffers, exchange windows, library scratch."""
+    N = 1 << n_bits
+    cc = (1 << EXT_BITS) // world
+    w = 8
+    trace = w * N * n_cols
+    slice_ = trace * cc
+    scratch = trace                                            # coefficient matrix of the LDE
+    nodes = 2 * w * 4 * N * cc * 2                             # leaf digests + subtree, two committed stages
+    exchange = 2 * w * 4 * N * cc * 2                          # digests sent + received (all-to-all), windows when ranks share a GPU
+    if mode == "prove-sharded":
+        q = w * 3 * N * cc * 4 + w * 6 * N * cc * 2            # q slice, its coefficients and blocks; split quotient slice (qDim*qDeg = 6)
+        fri = w * 3 * N * cc * 4 + w * 6 * N * cc              # xDivXSubXi (2 openings), f, accumulators, transposed copy
+        const_ = w * 2 * N * (1 + cc) + w * 8 * N * cc
+    else:
+        q = fri = const_ = 0
+    total = trace + slice_ + scratch + nodes + exchange + q + fri + const_ + (2 << 30)
+    # (rank 0's per-kernel timing pass after the timed steps takes one more slice, but from the blocks the proof has released
+    # to torch's caching allocator: not additive)
+    return int(total * 1.08)                                   # allocator granularity / fragmentation
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher: start the N ranks as children (never exec after touching the GPU) and
     relay their output; rank 0 prints the JSON line"""
@@ -469,12 +512,22 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = os.environ.get("PIL2GL_BENCH_BACKEND", "gloo" if shared_gpu else "nccl")   # RCCL wants one device per rank
+        # a collective that has waited this long has lost its peer: fail (non-zero exit of every rank) instead of sitting out
+        # the default ten minutes and leaving an empty record
+        import datetime
+        coll_timeout = datetime.timedelta(seconds=float(os.environ.get("PIL2GL_DIST_TIMEOUT", "120")))
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=coll_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=coll_timeout)
     import pil2gl
     pil2gl.init(local_rank)
+    from pil2gl.parallel import Progress
+    if dist is not None:
+        start_watchdog(Progress, rank)
+    if dist is not None:
+        Progress.mark("process group up: %d ranks, backend %s%s; a rank without progress for %s s dumps its stacks and exits" % (
+            world, backend, ", ranks share GPUs" if shared_gpu else "", os.environ.get("PIL2GL_STALL_S", "240")), rank, key=True)
 
     wl = args.workload
     if wl == "auto":
@@ -496,6 +549,16 @@ def main():
         raise SystemExit("a sharded mode needs a world size dividing the %d cosets" % (1 << EXT_BITS))
     if mode == "prove-sharded" and n_bits + EXT_BITS > 27:
         raise SystemExit("--mode prove-sharded needs nBitsExt <= 27 (the quotient's iNTT and the first fold are replicated); use --mode commit-sharded for %s" % wl)
+    if sharded_mode:
+        free, total_mem = torch.cuda.mem_get_info()
+        sharers = (world + n_dev - 1) // n_dev if shared_gpu else 1
+        need = sharded_memory_estimate(mode, n_bits, n_cols, world, rank0_extra=(rank == 0))
+        need_all = need if sharers == 1 else sum(sharded_memory_estimate(mode, n_bits, n_cols, world, rank0_extra=(r == 0)) for r in range(sharers))
+        Progress.mark("set-up: %s %s, this rank needs about %.0f GB at its peak%s; device has %.0f GB" % (
+            mode, wl, need / 1e9, (" (%.0f GB for the %d ranks sharing it)" % (need_all / 1e9, sharers)) if sharers > 1 else "", total_mem / 1e9), rank, key=True)
+        if need_all > 0.97 * total_mem and os.environ.get("PIL2GL_SKIP_MEMCHECK", "0") in ("", "0"):
+            raise SystemExit("bench.py: %s at %s needs about %.0f GB of device memory (%d rank%s on this GPU, %.0f GB each at the peak) but the device has %.0f GB: "
+                             "refused (use --workload c2, or one GPU per rank)" % (mode, wl, need_all / 1e9, sharers, "s" if sharers > 1 else "", need / 1e9, total_mem / 1e9))
 
     from pil2gl import stark, parallel
     comm = parallel.Comm() if dist is not None else None
@@ -543,10 +606,13 @@ def main():
     # set-up, not a timed or counted step: on a box that has just been handed out the first pass after process start has
     # been seen ~180 ms (13 %) slower than the following ones (clock ramp, first touch of 150 GB); one untimed pass ahead of the
     # W warm-up steps keeps that out of a short run's mean.  PIL2GL_BENCH_PREWARM=0 skips it.
+    def mark(what):
+        if dist is not None:
+            Progress.mark(what, rank, key=(rank == 0))
     if os.environ.get("PIL2GL_BENCH_PREWARM", "1") != "0":
-        step()
-    for _ in range(args.warmup):
-        step()
+        mark("pre-warm pass"); step()
+    for i in range(args.warmup):
+        mark("warm-up step %d" % i); step()
     # the interpreter's cycle collector stays out of the timed region (round 1's line showed one step in eight or nine 43 ms
     # slower than its neighbours: a generation-2 collection walking the proof objects); collected once here instead
     gc.collect(); gc.disable()
@@ -555,10 +621,12 @@ def main():
     barrier()
     t0 = time.perf_counter()
     step_marks = []
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        mark("timed step %d" % i)
         step()
         step_marks.append(time.perf_counter())               # host clock only: no extra synchronisation inside the timed region
     barrier()
+    mark("timed region done")
     dt = time.perf_counter() - t0
     gc.enable()
     step_ms = [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)]
@@ -677,6 +745,7 @@ def main():
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:
+        mark("closing")
         dist.barrier()
         dist.destroy_process_group()
 

@@ -186,6 +186,12 @@ int pil2gl_rows_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *w
  * hostK: nOpen x 3 (K_o = sum_j ev_j vf2^(n_o - j)). */
 int pil2gl_fri_combine_dev(const uint64_t *acc, const uint64_t *hostK, const uint64_t vf1[3], const uint64_t *xDivXSubXi,
                            uint32_t nOpen, uint64_t nRows, uint64_t *f, void *stream);
+/* the same with the Horner order given: the k-th term is opening order[k] (host, a permutation of 0..nOpen-1; acc, hostK and
+ * xDivXSubXi stay indexed by the opening's position in openingPoints).  The reference generates the terms in the order of
+ * Object.keys(friExps) (friPolinomial.js:42-50): non-negative openings ascending, then negative ones as they first appear in
+ * evMap -- with a previous-row opening ([-1, 0, 1]) that is 0, 1, -1, not the order of openingPoints. */
+int pil2gl_fri_combine_order_dev(const uint64_t *acc, const uint64_t *hostK, const uint64_t vf1[3], const uint64_t *xDivXSubXi,
+                                 uint32_t nOpen, const uint32_t *order, uint64_t nRows, uint64_t *f, void *stream);
 /* hostOut[l][c] = sum_k buf[k*rowStep][c] * levs[l][k]   (stark_gen_helpers.js:250-264 for every column of a buffer
  * and every opening at once; hostOut: nLev x width x 3, levs[l]: device nRows x 3). */
 int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, uint64_t rowStep, const uint64_t *const *levs,

@@ -34,12 +34,12 @@ def strs(v):
     return v
 
 
-def write(name, hash_commits):
+def write(name, hash_commits, prev_row=False):
     n_bits, pairs = 6, 2
     ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 9}, {"nBits": 5}, {"nBits": 2}]}
     if hash_commits:
         ss["hashCommits"] = True                  # the transcript absorbs hashes of publics / evaluations / last polynomial
-    info, exprs, _ = stark.fibonacci_air(pairs, ss)
+    info, exprs, _ = stark.fibonacci_air(pairs, ss, prev_row)
     cm, consts, publics = stark.fibonacci_trace(n_bits, pairs)
     be = OracleBackend()
     setup = stark.build_const_tree(be, consts, info)
@@ -55,3 +55,5 @@ def write(name, hash_commits):
 
 write("fib_flow.json", False)
 write("fib_flow_hashcommits.json", True)
+# an AIR that also reads the PREVIOUS row: openings [-1, 0, 1], FRI polynomial terms in the reference's key order 0, 1, -1
+write("fib_flow_prevrow.json", False, True)

@@ -226,10 +226,13 @@ FN(RowsDotExtMultiDev) {   // (dBufs BigUint64Array(n) device ptrs, widths BigUi
     }
     P2(env, pil2gl_rows_dot_ext_multi_dev(bp.data(), widths, (uint32_t)n, nRows, cp.data(), nOut, acc, accumulate, nullptr)); return mk_undefined(env);
 }
-FN(FriCombineDev) {    // (dAcc, K BigUint64Array(nOpen*3), vf1 BigUint64Array(3), dXDivXSubXi, nOpen, nRows, dF)
+FN(FriCombineDev) {    // (dAcc, K BigUint64Array(nOpen*3), vf1 BigUint64Array(3), dXDivXSubXi, nOpen, nRows, dF[, order BigUint64Array(nOpen)])
     Args a(env, info); uint64_t *acc = DP(0); uint32_t nOpen = (uint32_t)a.u64(4); uint64_t *K = a.arr(1, 3ull * nOpen), *vf1 = a.arr(2, 3);
-    uint64_t *x = DP(3); uint64_t nRows = a.u64(5); uint64_t *f = DP(6); if (!a.ok) return nullptr;
-    P2(env, pil2gl_fri_combine_dev(acc, K, vf1, x, nOpen, nRows, f, nullptr)); return mk_undefined(env);
+    uint64_t *x = DP(3); uint64_t nRows = a.u64(5); uint64_t *f = DP(6);
+    uint32_t order[4] = { 0, 1, 2, 3 };
+    if (!a.is_nullish(7)) { uint64_t *o = a.arr(7, nOpen); if (a.ok && nOpen <= 4) for (uint32_t k = 0; k < nOpen; k++) order[k] = (uint32_t)o[k]; }
+    if (!a.ok) return nullptr;
+    P2(env, pil2gl_fri_combine_order_dev(acc, K, vf1, x, nOpen, order, nRows, f, nullptr)); return mk_undefined(env);
 }
 FN(ColsDotExtDev) {    // (dBuf, width, nRows, rowStep, levs BigUint64Array(nLev) device ptrs, out BigUint64Array(nLev*width*3))
     Args a(env, info); uint64_t *buf = DP(0); uint64_t width = a.u64(1), nRows = a.u64(2), rowStep = a.u64(3);

@@ -323,18 +323,20 @@ __global__ void __launch_bounds__(512, 1) rows_dot_mfma_kernel(RowsDotMfmaParams
     }
 }
 
-// f[r] = Horner over openings (vf1) of (acc[r][o] - K_o) * X[r][o]    (friPolinomial.js:38-50)
+// f[r] = Horner over openings (vf1) of (acc[r][o] - K_o) * X[r][o]    (friPolinomial.js:38-50); the k-th Horner term is
+// opening o = byte k of `order` (the reference walks Object.keys(friExps): not always the order of openingPoints)
 __global__ void fri_combine_kernel(const u64 *__restrict__ acc, const u64 *__restrict__ K, E3 vf1, const u64 *__restrict__ xdiv,
-                                   u32 nOpen, u64 nRows, u64 *__restrict__ f) {
+                                   u32 nOpen, u32 order, u64 nRows, u64 *__restrict__ f) {
     const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nRows) return;
     E3 res = { { 0, 0, 0 } };
-    for (u32 o = 0; o < nOpen; o++) {
+    for (u32 k = 0; k < nOpen; k++) {
+        const u32 o = (order >> (8 * k)) & 255;
         const u64 *a = acc + (r * nOpen + o) * 3, *x = xdiv + (r * nOpen + o) * 3;
         E3 F = { { sub(a[0], K[3 * o]), sub(a[1], K[3 * o + 1]), sub(a[2], K[3 * o + 2]) } };
         E3 X = { { x[0], x[1], x[2] } };
         E3 t = e3_mul(F, X);
-        res = o == 0 ? t : e3_add(e3_mul(vf1, res), t);
+        res = k == 0 ? t : e3_add(e3_mul(vf1, res), t);
     }
     f[3 * r] = res.v[0]; f[3 * r + 1] = res.v[1]; f[3 * r + 2] = res.v[2];
 }
@@ -432,7 +434,19 @@ static bool rows_dot_mfma_fits(const uint64_t *const *bufs, const uint64_t *widt
         if (widths[k] == 0 || widths[k] % 2 || ((uintptr_t)bufs[k] & 15)) return false;
         total += widths[k];
     }
-    return total >= 32 && total <= MF_MAXW;
+    if (total < 32 || total > MF_MAXW) return false;
+    // the kernel keeps a 64-row tile and the digit planes in up to ~144 KB of LDS: only where a workgroup may have that much
+    // (gfx950: 160 KB); elsewhere the streaming kernel takes the call
+    static int ldsMax = -1;
+    if (ldsMax < 0) {
+        int dev = 0, v = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) v = 0;
+        ldsMax = v;
+    }
+    const u32 kSteps = (u32)((total * 8 + 31) / 32), NT = nOut == 1 ? 2 : 3;
+    const size_t need = (size_t)MF_ROWS * (total * 8 + 16) + (size_t)kSteps * NT * 1024;
+    return (size_t)ldsMax >= need;
 }
 static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *widths, u32 nBufs, u64 nRows, const uint64_t *const *hostCoefs,
                                 u32 nOut, u64 *acc, bool accumulate, hipStream_t st) {
@@ -588,15 +602,25 @@ int pil2gl_rows_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *w
 
 int pil2gl_fri_combine_dev(const uint64_t *acc, const uint64_t *hostK, const uint64_t vf1[3], const uint64_t *xDivXSubXi,
                            uint32_t nOpen, uint64_t nRows, uint64_t *f, void *stream) {
+    const uint32_t ident[4] = { 0, 1, 2, 3 };
+    return pil2gl_fri_combine_order_dev(acc, hostK, vf1, xDivXSubXi, nOpen, ident, nRows, f, stream);
+}
+int pil2gl_fri_combine_order_dev(const uint64_t *acc, const uint64_t *hostK, const uint64_t vf1[3], const uint64_t *xDivXSubXi,
+                                 uint32_t nOpen, const uint32_t *order, uint64_t nRows, uint64_t *f, void *stream) {
     P2_TRY(ensure_init());
-    if (!acc || !hostK || !vf1 || !xDivXSubXi || !f || nOpen < 1 || nOpen > 4) return fail(PIL2GL_EINVAL, "bad FRI combine arguments");
+    if (!acc || !hostK || !vf1 || !xDivXSubXi || !f || !order || nOpen < 1 || nOpen > 4) return fail(PIL2GL_EINVAL, "bad FRI combine arguments");
+    u32 ord = 0, seen = 0;
+    for (u32 k = 0; k < nOpen; k++) {
+        if (order[k] >= nOpen || (seen >> order[k] & 1)) return fail(PIL2GL_EINVAL, "order must be a permutation of the openings");
+        seen |= 1u << order[k]; ord |= order[k] << (8 * k);
+    }
     hipStream_t st = as_stream(stream);
     std::vector<u64> k(hostK, hostK + 3ull * nOpen);
     u64 *d;
     P2_TRY(scratch(7, 16, &d));
     HIP_TRY(hipMemcpyAsync(d, k.data(), k.size() * 8, hipMemcpyHostToDevice, st));
     E3 v = { { vf1[0], vf1[1], vf1[2] } };
-    fri_combine_kernel<<<nblk(nRows), 256, 0, st>>>(acc, d, v, xDivXSubXi, nOpen, nRows, f);
+    fri_combine_kernel<<<nblk(nRows), 256, 0, st>>>(acc, d, v, xDivXSubXi, nOpen, ord, nRows, f);
     KERNEL_CHECK();
     HIP_TRY(hipStreamSynchronize(st));
     return PIL2GL_OK;

@@ -381,6 +381,8 @@ int pil2gl_x_div_x_sub_xi_cosets_dev(uint32_t nBitsExt, uint32_t extBits, const 
     if (!xi || !out || iOpen >= nOpen || nBitsExt > 31 || extBits > nBitsExt) return fail(PIL2GL_EINVAL, "bad xDivXSubXi arguments");
     if (cosetCount == 0 || (cosetCount & (cosetCount - 1)) || (uint64_t)cosetBegin + cosetCount > (1ull << extBits))
         return fail(PIL2GL_EINVAL, "coset range [%u,%u) outside 2^%u (the count must be a power of two)", cosetBegin, cosetBegin + cosetCount, extBits);
+    // a lane's rows are T = 256*blocks apart and must stay in one coset for its constant step: T a multiple of cosetCount
+    if (cosetCount > 256) return fail(PIL2GL_EINVAL, "at most 256 cosets per call (%u asked)", cosetCount);
     u32 ccLog = 0; while ((1u << ccLog) < cosetCount) ccLog++;
     const u64 GP = 0xFFFFFFFF00000001ull;
     const u64 xi0 = xi[0] % GP, b = h_sub(0, xi[1] % GP), c = h_sub(0, xi[2] % GP);

@@ -142,15 +142,25 @@ module.exports.calculateHashStark = async function calculateHashStark(ctx, input
     return transcript.getState();
 };
 
-// The FRI polynomial the friExp op-list computes (friPolinomial.js:26-50) is, per opening o (ascending) and evMap order
-// j = 1..n_o,  F_o = sum_j (p_j - ev_j) vf2^(n_o-j)  and  f = Horner in vf1 over o of F_o xDivXSubXi_o: per section one
-// extension weight per base column (pil2gl_rows_dot_ext_dev), then one combine kernel.  Same field elements as the
-// op-list, about a tenth of its multiplications.  Only for device-resident sections and the layout the formula covers
-// (the openings of evMap are exactly openingPoints, at most four); otherwise the op-list runs.
+// The FRI polynomial the friExp op-list computes (friPolinomial.js:26-50) is, per opening o and evMap order
+// j = 1..n_o,  F_o = sum_j (p_j - ev_j) vf2^(n_o-j)  and  f = Horner in vf1 over the openings of F_o xDivXSubXi_o: per section
+// one extension weight per base column (pil2gl_rows_dot_ext_dev), then one combine kernel.  Same field elements as the
+// op-list, about a tenth of its multiplications.  The Horner order is the reference's: friPolinomial.js:42 walks
+// Object.keys(friExps) -- an object's integer-like keys come first, ascending, then the others ("-1") as they were
+// inserted, i.e. as the opening first appears in evMap -- which with a previous-row opening ([-1, 0, 1]) is 0, 1, -1
+// and NOT the order of openingPoints; everything here is indexed by the position in openingPoints, `order` lists the
+// terms.  Only for device-resident sections and the layout the formula covers (the openings of evMap are exactly
+// openingPoints, at most four); otherwise the op-list runs.
+function friOpeningOrder(info) {
+    const keys = {};
+    for (const ev of info.evMap) if (!(ev.prime in keys)) keys[ev.prime] = true;       // the same object, so the same key order
+    return Object.keys(keys).map(Number);
+}
+module.exports.friOpeningOrder = friOpeningOrder;
 function friPolynomialAsRowSums(ctx) {
     const info = ctx.pilInfo, nOpen = info.openingPoints.length, extN = ctx.extN;
-    const openings = Array.from(new Set(info.evMap.map((ev) => ev.prime))).sort((a, b) => a - b);
-    if (nOpen > 4 || openings.length !== nOpen || openings.some((o, i) => o !== info.openingPoints[i])) return false;
+    const openings = info.openingPoints, hornerOrder = friOpeningOrder(info);
+    if (nOpen > 4 || hornerOrder.length !== nOpen || hornerOrder.some((o) => openings.indexOf(o) < 0)) return false;
     if (!isDev(ctx.f_ext) || !isDev(ctx.xDivXSubXi_ext)) return false;
     const vf1 = asE3(ctx.challenges[info.nStages + 2][0]), vf2 = asE3(ctx.challenges[info.nStages + 2][1]);
     const mulX = (a) => [a[2], (a[0] + a[2]) % P, a[1]];
@@ -180,7 +190,8 @@ function friPolynomialAsRowSums(ctx) {
         const names = [...coefs.keys()];
         addon.rowsDotExtMultiDev(BigUint64Array.from(names.map((nm) => BigInt(ctx[nm].ptr))), BigUint64Array.from(names.map((nm) => BigInt(coefs.get(nm).width))),
             extN, names.map((nm) => coefs.get(nm).c), nOpen, acc, 0);
-        addon.friCombineDev(acc, K, BigUint64Array.from(vf1), ctx.xDivXSubXi_ext.ptr, nOpen, extN, ctx.f_ext.ptr);
+        addon.friCombineDev(acc, K, BigUint64Array.from(vf1), ctx.xDivXSubXi_ext.ptr, nOpen, extN, ctx.f_ext.ptr,
+            BigUint64Array.from(hornerOrder.map((o) => BigInt(openings.indexOf(o)))));
     } finally { addon.devFree(acc); }
     return true;
 }

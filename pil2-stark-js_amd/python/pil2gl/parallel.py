@@ -46,6 +46,38 @@ class _Pending:
         return self.parts
 
 
+class Progress:
+    """Where a sharded run is, for whoever has to explain a run that stopped: every stage boundary and every collective
+    calls mark().  PIL2GL_TRACE=1 prints one flushed stderr line per mark (rank, seconds since start, free device memory),
+    PIL2GL_TRACE=0 none, unset only the marks a caller flags as key (bench.py: set-up and one per step); on_mark lets the
+    caller re-arm a stall timer at every mark."""
+    t0 = None
+    last = ("start", 0.0)
+    count = 0
+    on_mark = None              # bench.py re-arms its stall timer here
+
+    @classmethod
+    def mark(cls, what, rank=None, key=False):
+        import os, sys, time as _t
+        if cls.t0 is None:
+            cls.t0 = _t.perf_counter()
+        now = _t.perf_counter() - cls.t0
+        cls.last = (what, now)
+        cls.count += 1
+        if cls.on_mark is not None:
+            cls.on_mark(what, now)
+        if os.environ.get("PIL2GL_TRACE", "1" if key else "0") not in ("", "0"):       # unset: only the caller's key marks
+            mem = ""
+            try:
+                if torch.cuda.is_available() and torch.cuda.is_initialized():
+                    free, total = torch.cuda.mem_get_info()
+                    mem = " free %.1f/%.1f GB" % (free / 1e9, total / 1e9)
+            except Exception:
+                pass
+            r = rank if rank is not None else os.environ.get("RANK", "0")
+            sys.stderr.write("[pil2gl r%s %8.3fs]%s %s\n" % (r, now, mem, what)); sys.stderr.flush()
+
+
 class Comm:
     """Exchange layer of the sharded prover: the few collectives SURVEY.md 8e names (all-gather of leaf digests, of q and of
     the FRI polynomial; sums of a few opened rows / evaluations), with the bytes they move counted.
@@ -80,6 +112,7 @@ class Comm:
         if self.mode == "ipc" and self.world == 1:
             self.mode = "gloo"
         self._win, self._peer, self._turn = [None, None], [None, None], 0
+        self.IPC_WINDOW_WORDS = max(1 << 16, int(os.environ.get("PIL2GL_IPC_WINDOW_WORDS", Comm.IPC_WINDOW_WORDS)))   # (small in the tests: pieces)
 
     # ---- helpers
     def _count(self, sent, received):
@@ -94,28 +127,52 @@ class Comm:
 
     def barrier(self):
         if self.mode != "rehearse":
+            Progress.mark("barrier", self.rank)
             dist.barrier(group=self.group)
 
+    IPC_WINDOW_WORDS = 1 << 27      # 1 GiB: hipIpcOpenMemHandle on a 2 GiB allocation never returned on this driver (dmabuf IPC);
+                                    # larger exchanges go through the windows in pieces
+
     def _windows(self, n, device):
-        """both windows hold at least n words on every rank (n is the same on every rank)"""
+        """both windows hold min(n, IPC_WINDOW_WORDS) words on every rank (n is the same on every rank)"""
+        n = min(n, self.IPC_WINDOW_WORDS)
         if self._win[0] is not None and self._win[0].numel() >= n:
             return
         from torch.multiprocessing.reductions import reduce_tensor
+        cap = max(n, 1 << 16)
+        Progress.mark("IPC windows: 2 x %.2f GB" % (8 * cap / 1e9), self.rank)
         torch.cuda.synchronize()
         dist.barrier(group=self.group)                          # nobody still reads the old windows
         self._peer = [None, None]
-        cap = max(n, 1 << 16)
         self._win = [torch.empty(cap, dtype=torch.int64, device=device) for _ in range(2)]
         mine = [reduce_tensor(w) for w in self._win]
         everyone = [None] * self.world
         dist.all_gather_object(everyone, mine, group=self.group)
         self._peer = [[(self._win[k] if r == self.rank else everyone[r][k][0](*everyone[r][k][1])) for r in range(self.world)] for k in range(2)]
+        Progress.mark("IPC windows mapped", self.rank)
+
+    def _ipc_pieces(self, mine, take):
+        """ranks sharing a GPU: `mine` (1-D, same length everywhere) goes through the windows in pieces of at most
+        IPC_WINDOW_WORDS; after a piece [c0, c1) of every rank stands in its window, take(r, view, c0, c1) copies what this
+        rank wants of rank r's piece (view = that piece, the own tensor's slice for r = rank)"""
+        n = mine.numel()
+        self._windows(n, mine.device)
+        step = self._win[0].numel()
+        for c0 in range(0, n, step):
+            c1 = min(n, c0 + step)
+            k = self._turn; self._turn ^= 1
+            self._win[k][:c1 - c0].copy_(mine[c0:c1])
+            torch.cuda.synchronize()
+            dist.barrier(group=self.group)                      # every rank's piece is in place (and the other window is free again)
+            for r in range(self.world):
+                take(r, mine[c0:c1] if r == self.rank else self._peer[k][r][:c1 - c0], c0, c1)
 
     # ---- collectives
     def all_gather_start(self, mine, outs=None):
         """mine: 1-D int64 tensor (same length on every rank).  -> handle whose wait() returns the list of every rank's
         tensor (rank order), written into `outs` when given (a list of `world` contiguous tensors)"""
         n = mine.numel()
+        Progress.mark("all_gather of %d words per rank (%s)" % (n, self.mode), self.rank)
         if self.mode == "rehearse":
             self._count(8 * n, 8 * n * (self.world - 1))
             if outs is not None:
@@ -127,15 +184,9 @@ class Comm:
         if self.mode == "gloo" and self._auto_ipc and mine.is_cuda:
             self.mode = "ipc"                                    # every rank takes this branch at the same exchange
         if self.mode == "ipc" and mine.is_cuda:
-            self._windows(n, mine.device)
-            k = self._turn; self._turn ^= 1
-            self._win[k][:n].copy_(mine)
-            torch.cuda.synchronize()
-            dist.barrier(group=self.group)
             if outs is None:
                 outs = [torch.empty_like(mine) for _ in range(self.world)]
-            for r in range(self.world):
-                outs[r].copy_(mine if r == self.rank else self._peer[k][r][:n])
+            self._ipc_pieces(mine, lambda r, view, c0, c1: outs[r][c0:c1].copy_(view))
             return _Done(outs)
         x = mine
         if self.mode != "nccl" and x.is_cuda:                  # gloo with device data: through the host (slow; tests only)
@@ -165,18 +216,22 @@ class Comm:
         if n % self.world:
             raise ValueError("all_to_all needs %d equal chunks" % self.world)
         ch = n // self.world
+        Progress.mark("all_to_all of %d words per rank (%s)" % (n, self.mode), self.rank)
         self._count(8 * (n - ch), 8 * (n - ch))
         if self.mode == "rehearse":
             return [mine[:ch]] * self.world
         if self.mode == "gloo" and self._auto_ipc and mine.is_cuda:
             self.mode = "ipc"
         if self.mode == "ipc" and mine.is_cuda:
-            self._windows(n, mine.device)
-            k = self._turn; self._turn ^= 1
-            self._win[k][:n].copy_(mine)
-            torch.cuda.synchronize()
-            dist.barrier(group=self.group)
-            return [(mine if r == self.rank else self._peer[k][r])[self.rank * ch:(self.rank + 1) * ch].clone() for r in range(self.world)]
+            got = [torch.empty(ch, dtype=mine.dtype, device=mine.device) for _ in range(self.world)]
+            lo, hi = self.rank * ch, (self.rank + 1) * ch        # the chunk of every rank's tensor meant for this rank
+
+            def take(r, view, c0, c1):
+                a, b = max(lo, c0), min(hi, c1)
+                if a < b:
+                    got[r][a - lo:b - lo].copy_(view[a - c0:b - c0])
+            self._ipc_pieces(mine, take)
+            return got
         x = mine
         if self.mode != "nccl" and x.is_cuda:
             x = x.cpu()
@@ -191,6 +246,7 @@ class Comm:
         returns a host tensor"""
         if self.mode == "rehearse":
             return t.cpu()
+        Progress.mark("all_reduce of %d words (%s)" % (t.numel(), self.mode), self.rank)
         self._count(8 * t.numel(), 8 * t.numel())
         if self.mode == "nccl":
             x = t if t.is_cuda else t.cuda()
@@ -448,6 +504,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     t_last = [time.perf_counter()]
 
     def lap(name):
+        Progress.mark("stage done: " + name, comm.rank)
         if timings is not None:
             be.sync(); now = time.perf_counter(); timings[name] = timings.get(name, 0.0) + now - t_last[0]; t_last[0] = now
     comm = _comm_of(comm, group, rehearse_world)

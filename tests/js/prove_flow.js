@@ -115,7 +115,7 @@ function freeCtx(ctx, keep = []) {
 module.exports = { prove, freeCtx };
 
 if (require.main === module) (async () => {
-    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json"]) {
+    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json"]) {
         const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden", name)));
         await prove(g, false);
         await prove(g, true);

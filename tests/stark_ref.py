@@ -168,6 +168,8 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
         xdiv = []
         for opening in info["openingPoints"]:
             w = pow(wN, abs(opening), P)
+            if opening < 0:                                   # stark_verify.js:206-208
+                w = pow(w, P - 2, P)
             den = _sub(x, [c * w % P for c in xi])
             xdiv.append(_mul([int(v) for v in orc.inv3(den)], x))
 

@@ -7,11 +7,11 @@ import pytest
 from conftest import P
 
 
-def _setup(n_bits, n_pairs, steps, n_queries=8):
+def _setup(n_bits, n_pairs, steps, n_queries=8, prev_row=False):
     from pil2gl import stark
     ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": n_queries, "verificationHashType": "GL",
           "steps": [{"nBits": b} for b in steps]}
-    info, exprs, vinfo = stark.fibonacci_air(n_pairs, ss)
+    info, exprs, vinfo = stark.fibonacci_air(n_pairs, ss, prev_row)
     cm, consts, publics = stark.fibonacci_trace(n_bits, n_pairs)
     return stark, info, exprs, vinfo, cm, consts, publics
 
@@ -49,6 +49,59 @@ def test_prove_and_verify_on_oracle_backend(oracle, n_bits, n_pairs, steps):
     res2 = stark.stark_gen(be, be.from_host(cm2), setup, info, exprs, publics)
     ok2, why2 = stark_ref.stark_verify(res2, setup["constRoot"], info, vinfo)
     assert not ok2
+
+
+def test_fri_opening_order_is_the_references_key_order():
+    """friPolinomial.js:42-50 folds the openings in the order of Object.keys(friExps): node itself is asked for that order"""
+    import json, shutil, subprocess
+    from pil2gl import stark
+    cases = [[0, 1], [0, 1, -1], [-1, 0, 1], [1, -1, 0, -2], [2, 0, -1, 10, 1], [-2, -1, 0]]
+    for primes in cases:
+        assert sorted(stark.fri_opening_order({"evMap": [{"prime": p} for p in primes + primes[::-1]]})) == sorted(primes)
+    assert stark.fri_opening_order({"evMap": [{"prime": p} for p in [0, 1, -1, 0, 1]]}) == [0, 1, -1]
+    assert stark.fri_opening_order({"evMap": [{"prime": p} for p in [-1, 1, 0]]}) == [0, 1, -1]
+    assert stark.fri_opening_order({"evMap": [{"prime": p} for p in [-1, 10, -2, 2, 0]]}) == [0, 2, 10, -1, -2]
+    node = shutil.which("node")
+    if node:
+        js = "const r=[];for(const c of %s){const o={};for(const p of c)if(!(p in o))o[p]=1;r.push(Object.keys(o).map(Number));}console.log(JSON.stringify(r))" % json.dumps(cases)
+        got = json.loads(subprocess.run([node, "-e", js], capture_output=True, text=True, timeout=60).stdout)
+        assert got == [stark.fri_opening_order({"evMap": [{"prime": p} for p in c]}) for c in cases]
+
+
+def test_previous_row_opening_proof_on_oracle_backend(oracle):
+    """an AIR that reads the previous row: openings [-1, 0, 1]; the proof verifies, and the weighted-sum plan of the FRI polynomial
+    (what the GPU backend runs instead of the op-list) lists its terms in the op-list's order 0, 1, -1"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _setup(6, 2, [9, 5, 2], prev_row=True)
+    assert info["openingPoints"] == [-1, 0, 1] and stark.fri_opening_order(info) == [0, 1, -1]
+    be = stark_ref.OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    plan = stark.fri_polynomial_plan(info, res["proof"]["evals"], res["challenges"][3][1])
+    assert plan is not None and plan[3] == [1, 2, 0]
+    cm2 = cm.copy(); cm2[9, 1] ^= 1                       # breaks only the previous-row identity's neighbourhood
+    res2 = stark.stark_gen(be, be.from_host(cm2), setup, info, exprs, publics)
+    assert not stark_ref.stark_verify(res2, setup["constRoot"], info, vinfo)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bits,n_pairs,steps", [(6, 2, [9, 5, 2]), (12, 5, [15, 10, 5])])
+def test_gpu_previous_row_opening_proof_is_identical_to_oracle_proof(oracle, n_bits, n_pairs, steps):
+    """the GPU backend computes the FRI polynomial as weighted row sums + one combine kernel, the oracle backend runs the op-list:
+    with openings [-1, 0, 1] the two agree only if the combine takes its terms in the reference's order (0, 1, -1)"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _setup(n_bits, n_pairs, steps, prev_row=True)
+    gpu = stark.GpuBackend(0)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    cpu = stark_ref.OracleBackend()
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, publics)
+    assert r_gpu["proof"] == r_cpu["proof"]
+    ok, why = stark_ref.stark_verify(r_gpu, s_gpu["constRoot"], info, vinfo)
+    assert ok, why
 
 
 @pytest.mark.gpu

@@ -18,6 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
 
 import torch
 import torch.distributed as dist
+import datetime
+TIMEOUT = datetime.timedelta(seconds=120)      # a lost peer fails the test within two minutes instead of ten
 
 
 def main():
@@ -28,7 +30,7 @@ def main():
     ap.add_argument("--npols", type=int, default=5)
     ap.add_argument("--split", type=int, default=0)
     a = ap.parse_args()
-    dist.init_process_group("gloo")
+    dist.init_process_group("gloo", timeout=TIMEOUT)
     rank, world = dist.get_rank(), dist.get_world_size()
     import gl_oracle as orc
     from conftest import rand_field

@@ -13,6 +13,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
 
 import torch.distributed as dist
+import datetime
+TIMEOUT = datetime.timedelta(seconds=120)      # a lost peer fails the test within two minutes instead of ten
 
 
 def main():
@@ -28,9 +30,9 @@ def main():
     if a.pg == "nccl":
         import torch
         torch.cuda.set_device(0)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+        dist.init_process_group("nccl", device_id=torch.device("cuda", 0), timeout=TIMEOUT)
     else:
-        dist.init_process_group("gloo")
+        dist.init_process_group("gloo", timeout=TIMEOUT)
     rank = dist.get_rank()
     import gl_oracle as orc
     orc.build(); orc.set_threads(2)

@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(256, 2) k_perm(u64 *out, int iters, u64 seed, 
     const u64 id = (u64)blockIdx.x * blockDim.x + threadIdx.x; u64 st[12]; \
     for (int i = 0; i < 12; i++) st[i] = mix(seed + id * 12 + i); \
     MdsMfma m; mds_mfma_init(m); \
-    for (int i = 0; i < iters; i++) poseidon_perm(st, m); \
+    for (int i = 0; i < iters; i++) poseidon_perm_single(st, m); \
     if (dump) { for (int i = 0; i < 12; i++) out[id * 12 + i] = st[i]; return; } \
     u64 s = 0; for (int i = 0; i < 12; i++) s += st[i] * (i + 1); out[id] = s; }
 KPROD(k_prod2, 2)
@@ -200,13 +200,11 @@ KPROD(k_prod4, 4)
 
 // the blocked partial rounds (poseidon_blocks.cuh)
 #define KBLK(NAME, W) __global__ void __launch_bounds__(256, W) NAME(u64 *out, int iters, u64 seed, int dump) { \
-    __shared__ v4i tab[POSEIDON_BLK_OPERANDS * 64]; \
-    const v4i *A = poseidon_blk_load(tab); \
     const u64 id = (u64)blockIdx.x * blockDim.x + threadIdx.x; u64 st[12]; \
     for (int i = 0; i < 12; i++) st[i] = mix(seed + id * 12 + i); \
     if (dump == 2) for (int i = 0; i < 12; i++) st[i] = (i & 1) ? ~0ull - id * i : (u64)(id * i) << (i * 5); \
-    MdsMfma m; mds_mfma_init(m); \
-    for (int i = 0; i < iters; i++) poseidon_perm_blk(st, m, A); \
+    MdsMfma m; poseidon_init(m); \
+    for (int i = 0; i < iters; i++) poseidon_perm(st, m); \
     if (dump) { for (int i = 0; i < 12; i++) out[id * 12 + i] = st[i]; return; } \
     u64 s = 0; for (int i = 0; i < 12; i++) s += st[i] * (i + 1); out[id] = s; }
 KBLK(k_blk2, 2)
@@ -216,7 +214,7 @@ __global__ void __launch_bounds__(256, 3) k_prod_edge(u64 *out, int iters) {
     const u64 id = (u64)blockIdx.x * blockDim.x + threadIdx.x; u64 st[12];
     for (int i = 0; i < 12; i++) st[i] = (i & 1) ? ~0ull - id * i : (u64)(id * i) << (i * 5);
     MdsMfma m; mds_mfma_init(m);
-    for (int i = 0; i < iters; i++) poseidon_perm(st, m);
+    for (int i = 0; i < iters; i++) poseidon_perm_single(st, m);
     for (int i = 0; i < 12; i++) out[id * 12 + i] = st[i];
 }
 

@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--replicas", action="store_true", help="N > 1: independent proofs per rank (weak scaling) instead of ONE sharded proof")
     ap.add_argument("--split", action="store_true", help="splitLinearHash leaves (linearhash_gpu.js)")
     ap.add_argument("--full-tree", action="store_true", help="commit-sharded: every rank builds the whole tree above the gathered leaves (default: the tree is split by leaf blocks, pil2gl.parallel.ShardedTree)")
+    ap.add_argument("--air", default="fib", choices=["fib", "perm"], help="prove modes: fib = C/2 Fibonacci machines, one witness stage (the headline line); "
+                    "perm = C/11 permutation checks, TWO witness stages with grand-product hints (2 + 9 base columns each: polutils.js:105-164, hints_helpers.js:81-123)")
     ap.add_argument("--shard-of", type=int, default=0, help="a sharded mode on ONE GPU: run rank 0's share of a K-GPU job (per-GPU time/memory rehearsal, e.g. --workload c5 --shard-of 8)")
     return ap.parse_args()
 
@@ -95,6 +97,20 @@ def fibonacci_trace_gpu(dev, n_bits, n_pairs, rank):
     first = cm[:2].cpu().numpy().view(np.uint64); last = cm[(N - 1) * 2 * n_pairs:(N - 1) * 2 * n_pairs + 1].cpu().numpy().view(np.uint64)
     publics = [int(first[1]), int(first[0]), int(last[0])]
     return cm, consts, publics
+
+
+def permutation_trace_gpu(dev, n_bits, copies, seed=0x5EED0000):
+    """stage-1 witness of `copies` permutation checks on the device: a_k uniform, b_k[i] = a_k[(s_k i + o_k) mod N] (s_k odd),
+    row-major N x 2K like pil2gl.stark.permutation_trace; plus the constants L1 / LLAST"""
+    N = 1 << n_bits
+    cm = torch.empty((N, 2 * copies), dtype=torch.int64, device=dev)
+    i = torch.arange(N, dtype=torch.int64, device=dev)
+    for k in range(copies):
+        a = make_trace(N, 1, seed + k, dev)
+        cm[:, 2 * k] = a
+        cm[:, 2 * k + 1] = a[(i * (5 + 2 * k) + 3 + k) & (N - 1)]
+    consts = np.zeros((N, 2), dtype=np.uint64); consts[0, 0] = 1; consts[N - 1, 1] = 1
+    return cm.reshape(-1), consts, []
 
 
 def ev_time(fn, iters):
@@ -135,7 +151,7 @@ def fri_steps_for(n_bits_ext):
     return steps
 
 
-def cpu_baseline_prove(n_cols, split):
+def cpu_baseline_prove(n_cols, split, air="fib"):
     """the same full proof by the prove loop over the CPU oracle backend (C/OpenMP port) on a bounded sample"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gl_oracle
@@ -148,8 +164,12 @@ def cpu_baseline_prove(n_cols, split):
 
     def run(nb):
         ss = {"nBits": nb, "nBitsExt": nb + EXT_BITS, "nQueries": 64, "verificationHashType": "GL", "steps": [{"nBits": b} for b in fri_steps_for(nb + EXT_BITS)]}
-        info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
-        cm, consts, publics = stark.fibonacci_trace(nb, n_cols // 2)
+        if air == "perm":
+            info, exprs, _ = stark.permutation_air(ss, max(1, n_cols // 11))
+            cm, consts, publics = stark.permutation_trace(nb, copies=max(1, n_cols // 11))
+        else:
+            info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
+            cm, consts, publics = stark.fibonacci_trace(nb, n_cols // 2)
         be = OracleBackend(split)
         setup = stark.build_const_tree(be, consts, info)
         t0 = time.perf_counter()
@@ -161,7 +181,8 @@ def cpu_baseline_prove(n_cols, split):
         t = run(n_bits)
     cells = (1 << n_bits) * n_cols
     return {"value": cells / t, "unit": "trace-cells/s", "cores": cores, "kind": "port",
-            "sample": "full proof of 2^%d x %d Fibonacci AIR, blow-up 8, prove loop over the OpenMP C oracle backend, %.1f s" % (n_bits, n_cols, t),
+            "sample": "full proof of 2^%d x %d %s AIR, blow-up 8, prove loop over the OpenMP C oracle backend, %.1f s" % (
+                n_bits, n_cols, "two-stage permutation-check" if air == "perm" else "Fibonacci", t),
             "port_vs_reference_js": port_calibration()}
 
 
@@ -568,8 +589,14 @@ def main():
         n_cols -= n_cols & 1                                   # pairs of columns
         ss = {"nBits": n_bits, "nBitsExt": n_bits + EXT_BITS, "nQueries": 64, "verificationHashType": "GL",
               "splitLinearHash": bool(args.split), "steps": [{"nBits": b} for b in fri_steps_for(n_bits + EXT_BITS)]}
-        info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
-        src, consts, publics = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0 if mode == "prove-sharded" else rank)   # sharded: ONE trace
+        if args.air == "perm":
+            copies = max(1, n_cols // 11)
+            n_cols = 11 * copies                               # cells of both witness stages together: 2 + 9 base columns per check
+            info, exprs, _ = stark.permutation_air(ss, copies)
+            src, consts, publics = permutation_trace_gpu(dev, n_bits, copies)
+        else:
+            info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
+            src, consts, publics = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0 if mode == "prove-sharded" else rank)   # sharded: ONE trace
         setup = stark.build_const_tree(be, consts, info)
         prove_ctx = (setup, info, exprs, publics)
     elif mode == "commit-sharded":                             # ONE trace, replicated; the cosets of its extension are split
@@ -657,11 +684,13 @@ def main():
             dst = torch.empty(rows * n_cols, dtype=torch.int64, device=dev)
         iters = max(1, min(3, args.steps))
         digests = torch.empty(rows * 4, dtype=torch.int64, device=dev)
+        # (--air perm: the witness is two stages of 2K and 9K columns; the per-kernel figures are taken on one N x 11K matrix)
+        ksrc = make_trace(N, n_cols, 77, dev) if (prove_ctx is not None and args.air == "perm") else src
         if sharded_mode:
             ws = src if wl == "c5" else None
-            lde = lambda: be.interpolate_cosets(src, n_cols, n_bits, dst, n_bits + EXT_BITS, 0, cc, ws)
+            lde = lambda: be.interpolate_cosets(ksrc, n_cols, n_bits, dst, n_bits + EXT_BITS, 0, cc, ws)
         else:
-            lde = lambda: pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
+            lde = lambda: pil2gl.interpolate(ksrc, n_cols, n_bits, dst, n_bits + EXT_BITS)
         t_lde = ev_time(lde, iters)
         t_leaf = ev_time(lambda: pil2gl.linearHash(dst, n_cols, args.split, digests), iters)
         lvl = torch.empty(rows * 2, dtype=torch.int64, device=dev)
@@ -704,7 +733,8 @@ def main():
         out = {}
         if prove_ctx is not None:
             info = prove_ctx[1]
-            metric = "STARK prove time (ms_per_step) and trace-cells/s, synthetic Fibonacci AIR, GL Poseidon Merkle + FRI, blow-up 8"
+            air_name = "two-stage permutation-check AIR (%d checks: 2 + 9 base columns each, grand-product hints)" % (n_cols // 11) if args.air == "perm" else "Fibonacci AIR"
+            metric = "STARK prove time (ms_per_step) and trace-cells/s, synthetic %s, GL Poseidon Merkle + FRI, blow-up 8" % air_name
             workload = "full proof (commit, Q, evals, FRI %s, %d queries) of 2^%d rows x %d cols -> 2^%d rows, %s linear hash, %s" % (
                 "/".join(str(x["nBits"]) for x in info["starkStruct"]["steps"]), info["starkStruct"]["nQueries"], n_bits, n_cols, n_bits + EXT_BITS, "split" if args.split else "plain",
                 "ONE proof split by cosets over the GPUs (leaf digests, q, evaluations, FRI polynomial exchanged)" if mode == "prove-sharded" else "per GPU")
@@ -718,7 +748,7 @@ def main():
         out = {
             "metric": metric,
             "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if sharded_mode else "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": ("strong" if sharded_mode else "weak") if world > 1 else None, "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": workload, "mode": mode, "config": wl,
                        "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "GL-Poseidon-12",
@@ -736,12 +766,14 @@ def main():
             cexp = prove_ctx[2]["expressionsCode"][prove_ctx[1]["cExpId"]]["code"]["code"]
             fexp = prove_ctx[2]["expressionsCode"][prove_ctx[1]["friExpId"]]["code"]["code"]
             out["prove"] = {"seconds": ms_per_step / 1e3, "stages_s": {k: round(v, 4) for k, v in stage_times.items()}, "host_ms_of_each_step": step_ms,
-                            "air": {"machines": n_cols // 2, "constraint_ops_per_extended_row": len(cexp), "fri_ops_per_extended_row": len(fexp),
+                            "air": {"name": args.air, "machines": (n_cols // 11) if args.air == "perm" else n_cols // 2, "witness_stages": prove_ctx[1]["nStages"],
+                                    "stage_widths": {k: v for k, v in prove_ctx[1]["mapSectionsN"].items()}, "hints": len(prove_ctx[1].get("hints", [])),
+                                    "constraint_ops_per_extended_row": len(cexp), "fri_ops_per_extended_row": len(fexp),
                                     "openings": len(prove_ctx[1]["openingPoints"]), "evaluations": len(prove_ctx[1]["evMap"])}}
         if world == 1:
             out["witness_upload"] = h2d_sample(dev, 8 * N * n_cols)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline_prove(n_cols, args.split) if prove_ctx is not None else cpu_baseline_commit(n_cols, args.split)
+            out["cpu_baseline"] = cpu_baseline_prove(n_cols, args.split, args.air) if prove_ctx is not None else cpu_baseline_commit(n_cols, args.split)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -80,6 +80,41 @@ def proof2zkin(p, starkInfo):
     return z
 
 
+def zkin2proof(z, starkInfo):
+    """the inverse of proof2zkin (src/proof2zkin.js:1-75): a zkin object (e.g. a *.proof.zkin.json the reference prover wrote,
+    decimal strings or integers) -> the proof object starkVerify takes (stark_verify.js:8: proof.root1.., proof.evals,
+    proof.fri[0].polQueries[q] = [[vals, siblings] per committed stage, quotient stage, constant tree], proof.fri[k] =
+    {root, polQueries[q] = [vals, siblings]}, proof.fri[last] = the final polynomial)"""
+    def ints(v):
+        if isinstance(v, (list, tuple)):
+            return [ints(x) for x in v]
+        return int(v)
+    friSteps = starkInfo["starkStruct"]["steps"]
+    nQueries = starkInfo["starkStruct"]["nQueries"]
+    nStages = starkInfo["nStages"]
+    qStage = nStages + 1
+    p = {"evals": ints(z["evals"])}
+    for stage in range(1, qStage + 1):
+        p["root%d" % stage] = ints(z["root%d" % stage])
+    stages = [1] + [s for s in range(2, nStages + 1) if starkInfo["mapSectionsN"].get("cm%d" % s, 0) > 0]
+    q0 = []
+    for i in range(nQueries):
+        query = [[[], []] for _ in range(nStages + 2)]
+        for s in stages:
+            query[s - 1] = [ints(z["s0_vals%d" % s][i]), ints(z["s0_siblings%d" % s][i])]
+        query[nStages] = [ints(z["s0_vals%d" % qStage][i]), ints(z["s0_siblings%d" % qStage][i])]
+        query[nStages + 1] = [ints(z["s0_valsC"][i]), ints(z["s0_siblingsC"][i])]
+        q0.append(query)
+    p["fri"] = [{"polQueries": q0}]
+    for k in range(1, len(friSteps)):
+        p["fri"].append({"root": ints(z["s%d_root" % k]),
+                         "polQueries": [[ints(z["s%d_vals" % k][q]), ints(z["s%d_siblings" % k][q])] for q in range(nQueries)]})
+    p["fri"].append(ints(z["finalPol"]))
+    if "subproofValues" in z:
+        p["subproofValues"] = ints(z["subproofValues"])
+    return p
+
+
 def _strings(v):
     if isinstance(v, dict):
         return {k: _strings(x) for k, x in v.items()}

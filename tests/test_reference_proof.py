@@ -85,3 +85,130 @@ def test_reference_proof_paths_and_folds(oracle):
             else:
                 assert z["finalPol"][idx] == folded, (s, q)
         pol_bits = out_bits
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The whole verification of that proof, with the two programs its verifier circuit evaluates: the constraint identity at the
+# evaluation point and the FRI polynomial at the query points, transliterated op by op from the circuit the reference
+# generated for it (test/compressor/verifier.circom:277-679 -> tests/golden/ref_compressor_verifier_programs.json by
+# oracle/gen_compressor_verifier_programs.py).  Order of checks: stark_verify.js:8-218.
+def _programs():
+    g = golden("ref_compressor_verifier_programs.json")
+    return g["starkInfo"], g["verifierInfo"], [int(v) for v in g["constRoot"]]
+
+
+def _challenges(ch, info):
+    """the challenges by stage as stark_verify.js keeps them (stage s at index s-1)"""
+    n = info["nStages"]
+    out = [[] for _ in range(n + 3)]
+    for st in range(2, n + 1):
+        out[st - 1] = [list(c) for c in ch[st]]
+    out[n] = [list(ch["q"])]; out[n + 1] = [list(ch["xi"])]; out[n + 2] = [list(c) for c in ch["fri"]]
+    return out
+
+
+def test_reference_proof_programs_match_the_proof(oracle):
+    """the evaluation identity holds for the reference's proof, and the FRI polynomial computed at each query point from the
+    opened rows is the value the first FRI layer opens there (stark_verify.js:95-152, :180-215; fri.js:118-136) -- on host
+    big integers through the restated interpreter, and through the oracle's evaluator"""
+    from pil2gl import stark
+    info, vinfo, root_c = _programs()
+    assert root_c == ROOT_C and [s["nBits"] for s in info["starkStruct"]["steps"]] == STEPS
+    z = _ints(golden("ref_compressor_verifier.proof.zkin.json"))
+
+    def replay3():                                          # stage 3 draws three challenges (verifier.circom:104-106)
+        t = oracle.Transcript()
+        t.put(ROOT_C); t.put(z["publics"])
+        t.put(z["root1"])
+        c2 = [t.get_field(), t.get_field()]; t.put(z["root2"])
+        c3 = [t.get_field(), t.get_field(), t.get_field()]; t.put(z["root3"])
+        return c2, c3
+    ch, fri_steps, queries = _replay(oracle, z)
+    c2, c3 = replay3()
+    assert [list(c) for c in c2] == [list(c) for c in ch[2]] and [list(c) for c in c3[:2]] == [list(c) for c in ch[3]]
+    ch[3] = c3
+    challenges = _challenges(ch, info)
+    nb, nbe = info["starkStruct"]["nBits"], info["starkStruct"]["nBitsExt"]
+    xi = [int(v) for v in ch["xi"]]
+    xN = stark.ext_pow(xi, 1 << nb)
+    Z = stark.ext_inv([(xN[0] - 1) % P, xN[1], xN[2]])
+    evals = [[int(v) for v in e] for e in z["evals"]]
+
+    def resolve(r, row=None):
+        ty = r["type"]
+        if ty == "eval": return evals[r["id"]]
+        if ty == "challenge": return [int(v) for v in challenges[r["stage"] - 1][r["stageId"]]]
+        if ty == "public": return int(z["publics"][r["id"]])
+        if ty == "number": return int(r["value"]) % P
+        if ty == "Zi": return list(Z)
+        if ty == "const": return int(row["C"][r["id"]])
+        if ty == "xDivXSubXi": return row["x"][r["id"]]
+        if ty.startswith("tree"):
+            v = row[int(ty[4:])]
+            return int(v[r["treePos"]]) if r["dim"] == 1 else [int(x) for x in v[r["treePos"]:r["treePos"] + 3]]
+        raise ValueError(ty)
+    lhs = stark.execute_code(vinfo["qVerifier"]["code"], resolve)
+    q_ev = [k for k, e in enumerate(info["evMap"]) if e["type"] == "cm" and info["cmPolsMap"][e["id"]]["stage"] == info["nStages"] + 1]
+    q, xAcc = [0, 0, 0], [1, 0, 0]
+    for k in q_ev:
+        q = [(a + b) % P for a, b in zip(q, stark.ext_mul(xAcc, evals[k]))]; xAcc = stark.ext_mul(xAcc, xN)
+    assert lhs == q, "Invalid evaluations"
+    keep = evals
+    evals = [list(e) for e in keep]; evals[12][1] = (evals[12][1] + 1) % P          # a witness column's evaluation
+    assert stark.execute_code(vinfo["qVerifier"]["code"], resolve) != q
+    evals = keep
+    # the FRI polynomial at the query points
+    wN, wE = int(oracle.root(nb)), int(oracle.root(nbe))
+    for qi, idx in enumerate(queries):
+        x = 7 * pow(wE, idx, P) % P
+        xd = []
+        for o in info["openingPoints"]:
+            w = pow(wN, o, P)
+            den = [(x - xi[0] * w) % P, (-xi[1] * w) % P, (-xi[2] * w) % P]
+            xd.append([v * x % P for v in stark.ext_inv(den)])
+        row = {1: z["s0_vals1"][qi], 2: z["s0_vals2"][qi], 3: z["s0_vals3"][qi], 4: z["s0_vals4"][qi], "C": z["s0_valsC"][qi], "x": xd}
+        val = stark.execute_code(vinfo["queryVerifier"]["code"], lambda r: resolve(r, row))
+        grp = np.array(z["s1_vals"][qi], dtype=np.uint64).reshape(-1, 3)
+        assert [int(v) for v in grp[idx >> STEPS[1]]] == val, qi
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_reference_proof_full_device_verification(oracle):
+    """pil2gl.stark.stark_verify -- device transcript, evaluation identity, one batched opening check per tree, the query-point
+    program on the device evaluator, FRI.verify -- accepts the proof the reference prover wrote, and rejects it once altered"""
+    import copy
+    from pil2gl import stark, io
+    info, vinfo, root_c = _programs()
+    z = golden("ref_compressor_verifier.proof.zkin.json")
+    proof = io.zkin2proof(z, info)
+    publics = [int(v) for v in z["publics"]]
+    assert io.proof2zkin(proof, info) == {k: v for k, v in _ints(z).items() if k != "publics"}
+    be = stark.GpuBackend(0)
+    ok, why = stark.stark_verify(be, proof, publics, root_c, info, None, vinfo)
+    assert ok, why
+
+    def tampered(what):
+        bad = copy.deepcopy(proof)
+        if what == "eval":
+            bad["evals"][12][0] = (bad["evals"][12][0] + 1) % P
+        elif what == "opened value":
+            bad["fri"][0]["polQueries"][3][0][0][2] = (bad["fri"][0]["polQueries"][3][0][0][2] + 1) % P
+        elif what == "sibling":
+            bad["fri"][0]["polQueries"][2][2][1][4][0] = (bad["fri"][0]["polQueries"][2][2][1][4][0] + 1) % P
+        elif what == "fri layer value":
+            bad["fri"][1]["polQueries"][5][0][4] = (bad["fri"][1]["polQueries"][5][0][4] + 1) % P
+        elif what == "fri layer sibling":
+            bad["fri"][2]["polQueries"][0][1][0][0] = (bad["fri"][2]["polQueries"][0][1][0][0] + 1) % P
+        elif what == "last polynomial":
+            bad["fri"][-1][1][2] = (bad["fri"][-1][1][2] + 1) % P
+        elif what == "root":
+            bad["root2"][0] = (bad["root2"][0] + 1) % P
+        return bad
+    for what in ("eval", "opened value", "sibling", "fri layer value", "fri layer sibling", "last polynomial", "root"):
+        ok, why = stark.stark_verify(be, tampered(what), publics, root_c, info, None, vinfo)
+        assert not ok, what
+    ok, _ = stark.stark_verify(be, proof, [publics[0], (publics[1] + 1) % P, publics[2]], root_c, info, None, vinfo)
+    assert not ok

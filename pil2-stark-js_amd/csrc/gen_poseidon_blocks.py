@@ -178,6 +178,57 @@ def table_index():
     return idx
 
 
+# Single layers (the eight full rounds and the partial rounds left over by the blocks) on the same biased accumulators:
+# row set s = outputs 4s..4s+3, logical row v = 4*ii + b (plane b of output 4s+ii), K group t = elements 4t..4t+3; the
+# circulant makes the operand depend on (t - s) mod 3 only, except M[0][0]'s +8 (s = t = 0): operands L0, L1, L2, L00.
+def layer_row(s, t, v):
+    ii, b = v >> 2, v & 3
+    out = [0] * 16
+    for e in range(4):
+        out[4 * e + b] = M[4 * s + ii][4 * t + e]
+    return out
+
+
+def layer_operand(d, special, lane):
+    """operand A of a single layer for (t - s) mod 3 = d (special: s = t = 0, with the +8), lane's 4 dwords"""
+    i, g = lane & 31, lane >> 5
+    if ((i >> 2) & 1) != g:
+        return [0, 0, 0, 0]
+    v = 4 * (i >> 3) + (i & 3)
+    row = layer_row(0, d, v)                  # s = 0, t = d: coefficients MC[(4d + e - ii) mod 12] (+8 at [0][0])
+    if not special and d == 0 and v < 4:      # the plain (t - s) = 0 operand has no +8
+        row = [c - (8 if (k >> 2) == 0 and (k & 3) == (v & 3) and (v >> 2) == 0 else 0) for k, c in enumerate(row)]
+    return [sum((row[4 * e + b] & 255) << (8 * b) for b in range(4)) for e in range(4)]
+
+
+def layer_device(x):
+    """one MDS layer on device representatives (any u64), biased accumulators: device words out"""
+    lo, hi = [v & 0xFFFFFFFF for v in x], [v >> 32 for v in x]
+    out = [0] * 12
+    for s in range(3):
+        accs = []
+        for words in (lo, hi):
+            acc = [ACC_BIAS] * 16
+            for t in range(3):
+                data = []
+                for e in range(4):
+                    data += sbytes(words[4 * t + e])
+                for v in range(16):
+                    row = layer_row(s, t, v)
+                    acc[v] += sum(row[k] * data[k] for k in range(16))
+            accs.append([a & 0xFFFFFFFF for a in acc])
+        for ii in range(4):
+            xs, ys = recombine_xy(accs[0][4 * ii:4 * ii + 4], accs[1][4 * ii:4 * ii + 4], 4)
+            out[4 * s + ii] = finish(xs, ys)
+    return out
+
+
+def layer_error():
+    """what a biased single layer adds to every true output (a constant per output)"""
+    z = layer_device([0] * 12)
+    return [v % P for v in z]
+
+
 # ---- integer model of the device arithmetic ----------------------------------------------------------------------------
 def sbytes(word):
     return [((word >> (8 * b)) & 255) - 128 for b in range(4)]
@@ -299,10 +350,18 @@ def derive_affine():
 
 
 def fold_constants():
-    """S-box addends of the 22 partial rounds and round 26's constants for the device schedule: NBLK blocks of K rounds, then
-    single layers.  err = device representative - true value of the state, a known vector at every point."""
+    """Round constants for the device schedule.  err = device representative - true value of the state, a known vector at every
+    point: every biased layer adds layer_error(), every block its own constants; the S-box addends absorb it.
+    Schedule: full rounds 0..3 (biased layers), NBLK blocks of K partial rounds, the remaining partial rounds as biased single
+    layers, full rounds 26..28 (biased layers), round 29 with the EXACT layer (its outputs leave the permutation).
+    Returns (rcf[8][12] for rounds 0-3, 26-29; chat[22])."""
     eu, ex = derive_affine()
-    err = [0] * 12
+    el = layer_error()
+    rcf = [[RC[i] for i in range(12)]]
+    err = list(el)
+    for r in range(1, 4):
+        rcf.append([(RC[12 * r + i] - err[i]) % P for i in range(12)])
+        err = list(el)                                        # all twelve lanes pass an S-box: only the layer's own constant remains
     chat = []
     r = 0
     for _ in range(NBLK):
@@ -319,51 +378,62 @@ def fold_constants():
                for o in range(12)]
         chat += ch
         r += K
-    while r < 22:                                             # single layers: exact, the error just goes through M
+    while r < 22:                                             # single biased layers: the error goes through M and gains the layer's own
         chat.append((PC0[r] - err[0]) % P)
-        err = mds([0] + err[1:])
+        err = [(a + b) % P for a, b in zip(mds([0] + err[1:]), el)]
         r += 1
-    rc26 = [(RC26F[i] - err[i]) % P for i in range(12)]
-    return chat, rc26
+    rcf.append([(RC26F[i] - err[i]) % P for i in range(12)])
+    for r in range(27, 30):
+        rcf.append([(RC[12 * r + i] - el[i]) % P for i in range(12)])
+    fold_constants.err_in, fold_constants.err_out = list(el), list(err)      # what rounds 4..25 expect on their input / leave on their output
+    return rcf, chat
 
 
-def perm_device(st, chat, rc26):
+def perm_device(st, rcf, chat):
     st = [v % P for v in st]
     for r in range(4):
-        st = mds([sbox(st[i] + RC[12 * r + i]) for i in range(12)])
+        st = layer_device([sbox(st[i] + rcf[r][i]) for i in range(12)])
     r = 0
     for _ in range(NBLK):
         st = block_device(st, chat[r:r + K])
         r += K
     while r < 22:
         st[0] = sbox(st[0] + chat[r])
-        st = mds(st)
+        st = layer_device(st)
         r += 1
-    for r in range(26, 30):
-        rc = rc26 if r == 26 else RC[12 * r:12 * r + 12]
-        st = mds([sbox(st[i] + rc[i]) for i in range(12)])
-    return st
+    for k in range(4, 7):
+        st = layer_device([sbox(st[i] + rcf[k][i]) for i in range(12)])
+    return mds([sbox(st[i] + rcf[7][i]) for i in range(12)])
 
 
-def write_inc(chat, rc26):
+def write_inc(rcf, chat):
     idx = table_index()
     words = []
     for (s, t) in idx:
         for lane in range(64):
             words += lane_operand(s, t, lane)
+    for d, special in ((0, False), (1, False), (2, False), (0, True)):       # single-layer operands: (t - s) mod 3 = 0, 1, 2, then s = t = 0
+        for lane in range(64):
+            words += layer_operand(d, special, lane)
     tco = [MP[m][0][0] for m in range(1, K - 1)]              # (M^1)[0][0], (M^2)[0][0]
     with open(os.path.join(HERE, "poseidon_gl_blocks.inc"), "w") as f:
         f.write("// GENERATED by gen_poseidon_blocks.py -- operands and folded constants of the blocked partial rounds (poseidon_blocks.cuh)\n")
-        f.write("#define POSEIDON_BLK_K %d\n#define POSEIDON_BLK_N %d\n#define POSEIDON_BLK_OPERANDS %d\n" % (K, NBLK, len(idx)))
+        f.write("#define POSEIDON_BLK_K %d\n#define POSEIDON_BLK_N %d\n#define POSEIDON_BLK_OPERANDS %d\n" % (K, NBLK, len(idx) + 4))
+        f.write("#define POSEIDON_BLK_LAYER_OPERAND %d      // single-layer operands: +0, +1, +2 by (t - s) mod 3, +3 for s = t = 0\n" % len(idx))
         f.write("// (M^m)[0][0], m = 1..%d\n" % (K - 2))
         f.write("#define POSEIDON_BLK_T1 %du\n#define POSEIDON_BLK_T2 %du\n" % (tco[0], tco[1]))
-        f.write("// operand A per (row set, K group) and lane: [operand][lane][4 dwords]; order: row sets 0..6 x state groups 0..2, then row sets 0..5 x increments\n")
+        f.write("// operand A per (row set, K group) and lane: [operand][lane][4 dwords]; order: row sets 0..6 x state groups 0..2, then row sets 0..5 x increments, then the single layer's four\n")
         f.write("POSEIDON_GL_RC_QUAL const uint32_t POSEIDON_BLK_A[%d] = {\n" % len(words))
         for i in range(0, len(words), 16):
             f.write("    " + ", ".join("0x%08xu" % w for w in words[i:i + 16]) + ",\n")
-        f.write("};\n// S-box addends of the 22 partial rounds for the blocked schedule, and round 26's constants\n")
+        f.write("};\n// S-box addends of the 22 partial rounds for the blocked schedule, and the constants of the full rounds 0..3, 26..29\n")
         f.write("POSEIDON_GL_RC_QUAL const uint64_t POSEIDON_BLK_C0[22] = {\n    " + ", ".join("0x%016xull" % v for v in chat) + ",\n};\n")
-        f.write("POSEIDON_GL_RC_QUAL const uint64_t POSEIDON_BLK_RC26[12] = {\n    " + ", ".join("0x%016xull" % v for v in rc26) + ",\n};\n")
+        for name, vec in (("POSEIDON_BLK_ERR_IN", fold_constants.err_in), ("POSEIDON_BLK_ERR_OUT", fold_constants.err_out)):
+            f.write("POSEIDON_GL_RC_QUAL const uint64_t %s[12] = {\n    " % name + ", ".join("0x%016xull" % v for v in vec) + ",\n};\n")
+        f.write("POSEIDON_GL_RC_QUAL const uint64_t POSEIDON_BLK_RCF[96] = {\n")
+        for row in rcf:
+            f.write("    " + ", ".join("0x%016xull" % v for v in row) + ",\n")
+        f.write("};\n")
 
 
 def main():
@@ -378,8 +448,8 @@ def main():
             if ROWSETS[s][v] is not None:
                 worst = max(worst, 128 * sum(abs(a) for t in range(4 if s < 6 else 3) for a in a_row(ROWSETS[s][v], t)))
     assert 257 * worst < (1 << 28), "plane bound too large for the 32-bit pair sums"
-    chat, rc26 = fold_constants()
-    write_inc(chat, rc26)
+    rcf, chat = fold_constants()
+    write_inc(rcf, chat)
     n = 0
     if "--check" in sys.argv:
         n = int(sys.argv[sys.argv.index("--check") + 1])
@@ -395,7 +465,7 @@ def main():
         for e in edge:
             cases.append(([e] * 12, None))
         for st, want in cases:
-            a, b, c = perm_plain(st), perm_textbook(st), [v % P for v in perm_device(st, chat, rc26)]
+            a, b, c = perm_plain(st), perm_textbook(st), [v % P for v in perm_device(st, rcf, chat)]
             assert a == b, "folded-constant form differs from the textbook form"
             assert want is None or a == want, "plain permutation differs from the reference vector"
             assert c == a, "blocked form differs"

@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256, 3) linear_hash_kernel(const u64 *__restri
 }
 
 // glwasm.js:1220-1254: out[i] = Poseidon(in[8i..8i+7], capacity 0)[0..3]
-__global__ void __launch_bounds__(256, 3) merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, u64 *__restrict__ out) {
+__global__ void __launch_bounds__(256, 4) merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, u64 *__restrict__ out) {
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i0 < nOps;
     const u64 i = live ? i0 : nOps - 1;
@@ -190,14 +190,13 @@ __global__ void __launch_bounds__(256, 2) mds_selftest_kernel(const u64 *__restr
     for (int j = 0; j < 12; j++) out[12 * i + j] = canon(st[j]);
 }
 
-// diagnostics: the permutation in its three statements, and rounds 4..25 alone in their two (the blocked form leaves the
-// state offset by a constant that round 26's table absorbs: POSEIDON_BLK_RC26 - POSEIDON_GL_RC26F is added back here so
-// that both forms return the same field elements)
+// diagnostics: the permutation in its three statements, and rounds 4..25 alone in their two
 __global__ void __launch_bounds__(256, 2) poseidon_selftest_kernel(const u64 *__restrict__ in, u64 n, int what, u64 *__restrict__ out) {
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i0 < n;
     const u64 i = live ? i0 : n - 1;
     MdsMfma m;
+    mds_mfma_init(m);
     poseidon_init(m);
     u64 st[12];
 #pragma unroll
@@ -205,13 +204,7 @@ __global__ void __launch_bounds__(256, 2) poseidon_selftest_kernel(const u64 *__
     if (what == 0) poseidon_perm(st, m);
     else if (what == 1) poseidon_perm_single(st, m);
     else if (what == 2) poseidon_perm(st);
-    else {
-        poseidon_partial_rounds(st, m, what == 3 ? 0 : 1);
-        if (what == 3) {
-#pragma unroll
-            for (int j = 0; j < 12; j++) st[j] = sub(add(canon(st[j]), POSEIDON_BLK_RC26[j]), POSEIDON_GL_RC26F[j]);
-        }
-    }
+    else poseidon_partial_rounds(st, m, what == 3 ? 0 : 1);
     if (!live) return;
 #pragma unroll
     for (int j = 0; j < 12; j++) out[12 * i + j] = canon(st[j]);

@@ -54,6 +54,62 @@ __device__ __forceinline__ u64 blk_combine_exact(u64 X, u64 Y) {
     return c ? r + EPS : r;
 }
 
+// A single MDS layer with its operands read from the LDS table (nothing of it stays in registers between layers).
+// EXACT = false: biased accumulators like the blocks (the constant they leave is folded into the next S-box addends by the
+// generator); EXACT = true: accumulators start at 128*rowsum, the outputs are the true field elements (the permutation's last
+// layer).  Same values as mds_layer_mfma(), which keeps its operands in registers.
+template <bool EXACT>
+__device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m) {
+    const v4i *__restrict__ A = m.blkA + POSEIDON_BLK_LAYER_OPERAND * 64;
+    v4i Bl[3], Bh[3];
+#pragma unroll
+    for (int t = 0; t < 3; t++)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            Bl[t][e] = (int)((u32)st[4 * t + e] ^ 0x80808080u);
+            Bh[t][e] = (int)((u32)(st[4 * t + e] >> 32) ^ 0x80808080u);
+        }
+    v16i init;
+#pragma unroll
+    for (int i = 0; i < 16; i++) init[i] = EXACT ? 128 * 256 : 0x40000000;
+    const v4i a0 = A[0], a1 = A[64], a2 = A[128], a00 = A[192];
+    u64 cm[12], any = 0;
+#pragma unroll
+    for (int s = 0; s < 3; s++) {
+        v16i L = init, H = init;
+#pragma unroll
+        for (int t = 0; t < 3; t++) {
+            const int d = (t - s + 3) % 3;
+            const v4i a = (s == 0 && t == 0) ? a00 : (d == 0 ? a0 : (d == 1 ? a1 : a2));
+            L = PBLK_MFMA(a, Bl[t], L);
+            H = PBLK_MFMA(a, Bh[t], H);
+        }
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            u32 xa = blk_pair(L[4 * ii], L[4 * ii + 1]), xc = blk_pair(L[4 * ii + 2], L[4 * ii + 3]);
+            u32 ya = blk_pair(H[4 * ii], H[4 * ii + 1]), yc = blk_pair(H[4 * ii + 2], H[4 * ii + 3]);
+            if (EXACT && s == 0 && ii == 0) {       // row 0's sum is 264, not 256: see mds_layer_mfma
+                xa += 1024u * 257u; xc += 1024u * 257u; ya += 1024u * 257u; yc += 1024u * 257u;
+            }
+            const u64 X = (u64)xc * m.sh16 + xa;
+            const u64 Y = (u64)yc * m.sh16 + ya;
+            const u64 tt = (u64)(u32)(Y >> 32) * EPS + X;
+            u32 th;
+            asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(th), "=s"(cm[4 * s + ii]) : "v"((u32)(tt >> 32)), "v"((u32)Y));
+            any |= cm[4 * s + ii];
+            st[4 * s + ii] = ((u64)th << 32) | (u32)tt;
+        }
+    }
+    if (__builtin_expect(any != 0, 0)) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            u32 e;
+            asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(e) : "s"(cm[i]));
+            st[i] += e;
+        }
+    }
+}
+
 // one block of four partial rounds; c = the block's four S-box addends; A = this lane's column of the LDS operand table.
 // st[] any representatives in, any representatives out.  Like mds_layer_mfma: the whole wave must arrive together.
 __device__ __forceinline__ void poseidon_partial_block(u64 st[12], const u64 *__restrict__ c, const v4i *__restrict__ A, const MdsMfma &m) {

@@ -94,27 +94,30 @@ namespace gl {
 // sit in another branch, because the MDS operands of all 64 lanes feed one MFMA); `m` comes from mds_mfma_init().
 // NCANON: how many leading outputs are made canonical (12: all; a sponge between two of its permutations needs none -- the
 // next permutation takes any representative --, a digest needs its 4)
-// Rounds 4..25 run four to a linear layer (poseidon_blocks.cuh); `m` comes from poseidon_init().
+// Rounds 4..25 run four to a linear layer (poseidon_blocks.cuh), every layer but the last on biased accumulators whose
+// constants the generator folded into POSEIDON_BLK_RCF / POSEIDON_BLK_C0; `m` comes from poseidon_init().
 template <int NCANON = 12>
 __device__ inline void poseidon_perm(u64 st[12], const MdsMfma &m) {
     const v4i *__restrict__ A = m.blkA;
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
-        sbox_full(st, &POSEIDON_GL_RC[r * 12]);
-        mds_layer_mfma(st, m);
+        sbox_full(st, &POSEIDON_BLK_RCF[r * 12]);
+        mds_layer_lds<false>(st, m);
     }
 #pragma unroll 1
     for (int b = 0; b < POSEIDON_BLK_N; b++) poseidon_partial_block(st, &POSEIDON_BLK_C0[POSEIDON_BLK_K * b], A, m);
 #pragma unroll 1
     for (int r = POSEIDON_BLK_N * POSEIDON_BLK_K; r < 22; r++) {
         st[0] = sbox_one(add_lazy_canon(st[0], POSEIDON_BLK_C0[r]));
-        mds_layer_mfma(st, m);
+        mds_layer_lds<false>(st, m);
     }
 #pragma unroll 1
-    for (int r = 26; r < 30; r++) {
-        sbox_full(st, r == 26 ? POSEIDON_BLK_RC26 : &POSEIDON_GL_RC[r * 12]);
-        mds_layer_mfma(st, m);
+    for (int r = 4; r < 7; r++) {
+        sbox_full(st, &POSEIDON_BLK_RCF[r * 12]);
+        mds_layer_lds<false>(st, m);
     }
+    sbox_full(st, &POSEIDON_BLK_RCF[7 * 12]);
+    mds_layer_lds<true>(st, m);
 #pragma unroll
     for (int i = 0; i < NCANON; i++) st[i] = canon(st[i]);
 }
@@ -141,16 +144,22 @@ __device__ inline void poseidon_perm_single(u64 st[12], const MdsMfma &m) {
     for (int i = 0; i < NCANON; i++) st[i] = canon(st[i]);
 }
 
-// rounds 4..25 alone, for the parity tests (which = 0 blocked, 1 one layer per round): arbitrary states in, any representatives out
+// rounds 4..25 alone, for the parity tests (which = 0 blocked, 1 one layer per round): arbitrary states in, any representatives
+// out.  The blocked form expects the constant a biased layer leaves on its input and leaves its own on its output
+// (POSEIDON_BLK_ERR_IN / _OUT, from the generator): taken off here so that both forms map field elements to field elements.
 __device__ inline void poseidon_partial_rounds(u64 st[12], const MdsMfma &m, int which) {
     if (which == 0) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = add_lazy_canon(st[i], POSEIDON_BLK_ERR_IN[i]);
 #pragma unroll 1
         for (int b = 0; b < POSEIDON_BLK_N; b++) poseidon_partial_block(st, &POSEIDON_BLK_C0[POSEIDON_BLK_K * b], m.blkA, m);
 #pragma unroll 1
         for (int r = POSEIDON_BLK_N * POSEIDON_BLK_K; r < 22; r++) {
             st[0] = sbox_one(add_lazy_canon(st[0], POSEIDON_BLK_C0[r]));
-            mds_layer_mfma(st, m);
+            mds_layer_lds<false>(st, m);
         }
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = sub(canon(st[i]), POSEIDON_BLK_ERR_OUT[i]);
     } else {
 #pragma unroll 1
         for (int r = 0; r < 22; r++) {
@@ -162,9 +171,11 @@ __device__ inline void poseidon_partial_rounds(u64 st[12], const MdsMfma &m, int
 
 // every thread of the workgroup, once, before the first permutation: the MDS operands of this lane and the workgroup's copy
 // of the blocked rounds' operand table (27 KB of LDS)
+// (m.A / m.C, the register operands of mds_layer_mfma(), are NOT set: a kernel that also runs that form calls mds_mfma_init first)
 __device__ __forceinline__ void poseidon_init(MdsMfma &m) {
     __shared__ v4i poseidon_blk_table[POSEIDON_BLK_OPERANDS * 64];
-    mds_mfma_init(m);
+    m.sh16 = 65536u;
+    asm volatile("" : "+s"(m.sh16));
     m.blkA = poseidon_blk_load(poseidon_blk_table);
 }
 

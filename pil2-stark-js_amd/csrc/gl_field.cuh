@@ -91,19 +91,22 @@ __device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
 // allocation and scheduling stay the compiler's.  Measured, not assumed: where independent work surrounds the products
 // (the NTT tiles) the plain form schedules better and stays; a branch per product, or folding the borrow back in place
 // (three more instructions), both lose the gain.
+#ifndef GL_SGPR_WAIT
+#define GL_SGPR_WAIT "s_nop 1\n\t"       // (tools/sbox_bench.hip builds an experiment without the wait states: what they cost)
+#endif
 __device__ __forceinline__ u64 mul_lazy_b(u64 a, u64 b, u64 &bad) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 t = (u64)a0 * b0;
     const u64 u = (u64)a0 * b1 + (t >> 32);
     u64 v, cy, z, c, br; u32 c01, c201, r0, r1;
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v), "=s"(cy) : "v"(a1), "v"(b0), "v"(u));
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c01) : "s"(cy));
+    asm(GL_SGPR_WAIT "v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c01) : "s"(cy));
     const u64 w = (u64)a1 * b1 + (((u64)c01 << 32) | (v >> 32));   // <= 2^64 - 1: the full product is < 2^128
     const u64 lo = (v << 32) | (u32)t;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)w), "v"(lo));
-    asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c201) : "s"(c));
+    asm(GL_SGPR_WAIT "v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c201) : "s"(c));
     const u64 z2 = (u64)c201 * 0xFFFFFFFFu + z;
-    asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\ts_nop 1\n\tv_subbrev_co_u32_e64 %1, %2, 0, %4, %2"
+    asm("v_sub_co_u32_e64 %0, %2, %3, %5\n\t" GL_SGPR_WAIT "v_subbrev_co_u32_e64 %1, %2, 0, %4, %2"
         : "=&v"(r0), "=&v"(r1), "=&s"(br) : "v"((u32)z2), "v"((u32)(z2 >> 32)), "v"((u32)(w >> 32)));
     bad |= br;
     return ((u64)r1 << 32) | r0;

@@ -96,8 +96,9 @@ namespace gl {
 // next permutation takes any representative --, a digest needs its 4)
 // Rounds 4..25 run four to a linear layer (poseidon_blocks.cuh), every layer but the last on biased accumulators whose
 // constants the generator folded into POSEIDON_BLK_RCF / POSEIDON_BLK_C0; `m` comes from poseidon_init().
+// (forced inline: an outlined permutation passes its state through scratch, at a fifth of the rate)
 template <int NCANON = 12>
-__device__ inline void poseidon_perm(u64 st[12], const MdsMfma &m) {
+__device__ __forceinline__ void poseidon_perm(u64 st[12], const MdsMfma &m) {
     const v4i *__restrict__ A = m.blkA;
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {

@@ -287,6 +287,40 @@ def test_config3_size_proof_verifies(oracle):
     assert len(res["proof"]["evals"]) > 0 and res["publics"] == publics
 
 
+@pytest.mark.gpu
+def test_config3_size_two_stage_proof_verifies(oracle):
+    """the two-stage workload of `bench.py --air perm` at config 3's size (2^24 rows, 9 permutation checks: 18 stage-1 and 81
+    stage-2 base columns, nine grand-product hints resolved on the device, polutils.js:105-164): the proof passes the restated
+    verifier, and stops passing when one b column is not a permutation of its a column (its running product does not close)"""
+    import gc
+    import torch
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    if not torch.cuda.is_available() or torch.cuda.mem_get_info()[0] < 200e9:
+        pytest.skip("needs ~190 GB of free device memory")
+    import stark_ref
+    import bench
+    from pil2gl import stark
+    n_bits, copies = 24, 9
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 64, "verificationHashType": "GL", "splitLinearHash": False,
+          "steps": [{"nBits": b} for b in (27, 22, 17, 12, 7)]}
+    info, exprs, vinfo = stark.permutation_air(ss, copies)
+    gpu = stark.GpuBackend(0, False)
+    cm, consts, publics = bench.permutation_trace_gpu(torch.device("cuda", 0), n_bits, copies)
+    setup = stark.build_const_tree(gpu, consts, info)
+    res = stark.stark_gen(gpu, cm, setup, info, exprs, publics)
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    del res
+    cm.view(1 << n_bits, 2 * copies)[12345, 7] += 1                     # b_3 is no longer a permutation of a_3
+    res = stark.stark_gen(gpu, cm, setup, info, exprs, publics)
+    del cm
+    torch.cuda.empty_cache()
+    ok, _ = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert not ok
+
+
 def _bn_case(n_bits=5, pairs=1):
     from pil2gl import stark
     ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 4, "verificationHashType": "BN128", "steps": [{"nBits": n_bits + 3}, {"nBits": 4}]}

@@ -213,27 +213,30 @@ def cpu_baseline_commit(n_cols, split):
 
 
 def cpu_baseline_bn128(n_cols, arity):
-    """config 4's commit on the CPU: LDE by the C port, BN128 tree by the Python-integer oracle (bn128_oracle.py; the
-    reference's arithmetic here is third-party WASM, absent from its tree) on a bounded sample"""
+    """config 4's commit on the CPU: LDE by the C port of the reference's algorithm, BN128 tree by the C port of the BN254
+    permutation (oracle/bn128_oracle.c: 4 x 64-bit Montgomery arithmetic, OpenMP over rows / nodes; checked against the
+    Python-integer oracle, which the reference's constants and its `test/final` proof pin) on all host threads, bounded sample"""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gl_oracle
     import bn128_oracle
     gl_oracle.build(); gl_oracle.set_threads(host_cores())
+    os.environ.setdefault("OMP_NUM_THREADS", str(host_cores()))
     rng = np.random.default_rng(1)
-    nb = 2
+    nb = 9
 
     def run(nb):
         a = rng.integers(0, 0xFFFFFFFF00000001, size=(1 << nb, n_cols), dtype=np.uint64)
         t0 = time.perf_counter()
         e = gl_oracle.interpolate(a, nb, nb + EXT_BITS)
-        bn128_oracle.merkelize([[int(v) for v in r] for r in e], arity, False)
+        bn128_oracle.c_merkelize_words(e, arity, False)
         return time.perf_counter() - t0
+    run(6)                                                     # builds the library, generates the constants (Grain LFSR, Python)
     t = run(nb)
-    while t < 8.0 and nb < 12:
+    while t < 8.0 and nb < 16:
         nb += 1
         t = run(nb)
-    return {"value": (1 << nb) * n_cols / t, "unit": "trace-cells/s", "cores": 1, "kind": "port",
-            "sample": "extend (C port) + BN128 arity-%d merkelize (Python-integer oracle, one thread) of 2^%d x %d, blow-up 8, %.1f s" % (arity, nb, n_cols, t)}
+    return {"value": (1 << nb) * n_cols / t, "unit": "trace-cells/s", "cores": host_cores(), "kind": "port",
+            "sample": "extend (C port) + BN128 arity-%d merkelize (C port of the BN254 permutation, OpenMP) of 2^%d x %d, blow-up 8, %.1f s" % (arity, nb, n_cols, t)}
 
 
 def load_pmc(name, kernel):
@@ -261,7 +264,7 @@ def load_pmc_lde_traffic(name):
 
 
 def pmc_file():
-    for name in ("r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
             return name
     return "pmc_traffic.json"
@@ -272,12 +275,13 @@ def poseidon_int_roofline(perms, ms):
     multiplications + 30 MDS layers per permutation).  achieved = SIMD cycles per wave of 64 permutations; floor = what the
     multiplications and the matrix-core MDS cost if nothing but their irreducible instructions were issued:
     472 x 5 v_mad_u64_u32 (four 32x32 partial products + the multiply by 2^32-1 that folds the high half; gfx950 has no
-    64-bit multiplier) + 30 x 18 v_mfma_i32_32x32x32_i8, priced at their measured issue costs."""
+    64-bit multiplier) + the 450 v_mfma_i32_32x32x32_i8 of the round-3 layer schedule, priced at their measured issue costs."""
     achieved = N_SIMD * CLOCK_HZ * (ms * 1e-3) / (perms / 64.0)
-    floor = 472 * 5 * CYC_MAD_U64_U32 + 30 * 18 * CYC_MFMA_ISSUE
+    n_mfma = 10 * 18 + 5 * 54                                # 8 full-round layers + 2 single partial layers, 5 blocks of four partial rounds (poseidon_blocks.cuh)
+    floor = 472 * 5 * CYC_MAD_U64_U32 + n_mfma * CYC_MFMA_ISSUE
     return {"bound": "int-issue", "kernel": "linear_hash_kernel", "achieved": achieved, "floor": floor, "unit": "SIMD issue cycles per wave of 64 permutations",
             "frac": floor / achieved, "clock_GHz_assumed": CLOCK_HZ / 1e9,
-            "floor_terms": {"v_mad_u64_u32": 472 * 5, "cycles_each": CYC_MAD_U64_U32, "v_mfma_i32_32x32x32_i8": 30 * 18, "issue_cycles_each": CYC_MFMA_ISSUE},
+            "floor_terms": {"v_mad_u64_u32": 472 * 5, "cycles_each": CYC_MAD_U64_U32, "v_mfma_i32_32x32x32_i8": n_mfma, "issue_cycles_each": CYC_MFMA_ISSUE},
             "note": "reductions, carries, byte-plane recombination and round constants are overhead by this definition"}
 
 
@@ -294,7 +298,7 @@ def lde_int_roofline(n_bits, n_cols, cosets, ms):
     return {"bound": "int-issue", "kernel": "interpolate (ntt_pass_kernel x / lde_mid_kernel)", "achieved": achieved, "floor": floor,
             "unit": "SIMD issue cycles per 64 element-stages", "frac": floor / achieved, "clock_GHz_assumed": CLOCK_HZ / 1e9,
             "floor_terms": {"v_mad_u64_u32": 2.5, "cycles_each": CYC_MAD_U64_U32, "carry_chain_ops": 2, "cycles_each_carry": CYC_CARRY_OP},
-            "note": "the passes run at 94-100 % of their vector-ALU issue slots (profiles/r02_valu_utilisation.json): the distance to the floor is instruction count, not memory"}
+            "note": "the passes run at 94-100 % of their vector-ALU issue slots (profiles/r03_valu_utilisation.json): the distance to the floor is instruction count, not memory"}
 
 
 def bn128_mads(t):
@@ -764,6 +768,8 @@ def main():
             kernels[0]["traffic"] = load_pmc(pf, "linear_hash_kernel")
             kernels[1]["traffic"] = load_pmc_lde_traffic(pf)
             kernels[2]["traffic"] = load_pmc(pf, "merkle_level_kernel")
+            for k in kernels[:3]:
+                k["traffic_source"] = "committed rocprofv3 PMC passes of one config-3 proof (profiles/%s: bytes by request size; not measured in this run)" % pf
         for k in kernels:
             k["GBps"] = k["alg_bytes"] / k["ms"] / 1e6
             k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS
@@ -771,7 +777,7 @@ def main():
                 k["Gperm_s"] = k["perms"] / k["ms"] / 1e6
         dom = max(kernels, key=lambda k: k["ms"])
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": dom["hbm_frac"], "traffic": dom.get("traffic"),
+                    "frac": dom["hbm_frac"], "traffic": dom.get("traffic"), "traffic_source": dom.get("traffic_source"),
                     "note": "Poseidon hashing is integer-issue bound (no 64-bit multiplier on gfx950): its HBM fraction is small by nature; roofline_int_issue prices it against its own roof, kernels[1] is the HBM-bound LDE"}
         out = {}
         if prove_ctx is not None:
@@ -816,8 +822,7 @@ def main():
         if world == 1:
             out["witness_upload"] = h2d_sample(dev, 8 * N * n_cols)
         if world == 1 and mode == "prove" and os.environ.get("PIL2GL_BENCH_FROM_HOST", "1") != "0":
-            del dst, digests, lvl
-            torch.cuda.empty_cache()
+            del dst, digests, lvl                               # (back to torch's allocator cache: the proofs below reuse the blocks)
             setup_, info_, exprs_, publics_ = prove_ctx
             out["prove_from_host"] = prove_from_host(dev, src, lambda buf: stark.stark_gen(be, buf, setup_, info_, exprs_, publics_))
         if not args.no_cpu_baseline and world == 1:

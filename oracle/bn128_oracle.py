@@ -262,3 +262,81 @@ class TranscriptBN128:
                     cur_field += 1
             res.append(a)
         return res
+
+
+# ---- the same statements in C (oracle/bn128_oracle.c): the config-4 cpu_baseline of bench.py runs on these; checked against the
+#      Python-integer functions above in tests/test_bn128_oracle.py
+_CLIB = None
+
+
+def c_lib():
+    """builds (make) and loads oracle/libbn128_oracle.so; hands it the constants of the widths it is asked for on demand"""
+    global _CLIB
+    if _CLIB is None:
+        import ctypes as C
+        import os
+        import subprocess
+        here = os.path.dirname(os.path.abspath(__file__))
+        so = os.path.join(here, "libbn128_oracle.so")
+        src = os.path.join(here, "bn128_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", here, "-s", "libbn128_oracle.so"])
+        L = C.CDLL(so)
+        L.bn_merkle_num_nodes.restype = C.c_uint64
+        L.bn_merkle_num_nodes.argtypes = [C.c_uint64, C.c_int]
+        _CLIB = L
+    return _CLIB
+
+
+def _words(vals):
+    import numpy as np
+    out = np.zeros((len(vals), 4), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        v = int(v)
+        for k in range(4):
+            out[i, k] = (v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF
+    return out
+
+
+def c_need_params(t):
+    import ctypes as C
+    L = c_lib()
+    if not L.bn_have_params(int(t)):
+        Cs, M = poseidon_constants(t)
+        cw, mw = _words(Cs), _words([M[i][j] for i in range(t) for j in range(t)])
+        assert L.bn_set_params(int(t), C.c_void_p(cw.ctypes.data), C.c_void_p(mw.ctypes.data)) == 0
+
+
+def c_poseidon(inputs, init_state=0, n_out=1):
+    import ctypes as C
+    import numpy as np
+    t = len(inputs) + 1
+    c_need_params(t)
+    iw, sw = _words([int(x) % R for x in inputs]), _words([init_state % R])
+    out = np.zeros((n_out, 4), dtype=np.uint64)
+    assert c_lib().bn_poseidon(len(inputs), C.c_void_p(iw.ctypes.data), C.c_void_p(sw.ctypes.data), n_out, C.c_void_p(out.ctypes.data)) == 0
+    return [sum(int(out[i, k]) << (64 * k) for k in range(4)) for i in range(n_out)]
+
+
+def c_merkelize_words(rows, arity, custom):
+    """rows: numpy uint64 [height][width] -> numpy uint64 [nNodes][4], MONTGOMERY words (the reference's tree.nodes)"""
+    import ctypes as C
+    import numpy as np
+    rows = np.ascontiguousarray(rows, dtype=np.uint64)
+    h, w = rows.shape
+    n_el = (w + 2) // 3
+    if w > 4:
+        for e0 in range(0, n_el, arity):
+            c_need_params((arity if custom else min(arity, n_el - e0)) + 1)
+    if h > 1:
+        c_need_params(arity + 1)
+    L = c_lib()
+    nodes = np.zeros((int(L.bn_merkle_num_nodes(h, arity)), 4), dtype=np.uint64)
+    rc = L.bn_merkelize(C.c_void_p(rows.ctypes.data), C.c_uint64(w), C.c_uint64(h), int(arity), int(bool(custom)), C.c_void_p(nodes.ctypes.data))
+    assert rc == 0
+    return nodes
+
+
+def c_merkelize(rows, arity, custom):
+    """-> list of Fr node values in normal form, like merkelize()"""
+    return [from_montgomery_words(w) for w in c_merkelize_words(rows, arity, custom)]

@@ -132,3 +132,22 @@ def test_worker_and_class_leaf_rules():
     assert bn.linear_hash_worker(v, 16, False) == bn.linear_hash_class(v, 16, False)
     assert bn.linear_hash_worker(v, 16, True) == bn.linear_hash_class(v, 16, True)
     assert bn.linear_hash_worker(v, 16, True) != bn.linear_hash_worker(v, 16, False)
+
+
+def test_c_port_equals_python_oracle():
+    """oracle/bn128_oracle.c (the config-4 cpu_baseline of bench.py) against the Python-integer statement, which the reference's
+    constants and its `test/final` proof pin: permutations of several widths, leaf rules, ragged trees, custom mode"""
+    import numpy as np
+    import bn128_oracle as b
+    rng = np.random.default_rng(11)
+    for n_in in (1, 2, 3, 4, 8, 16):
+        ins = [int(x) for x in rng.integers(0, 1 << 63, n_in)]
+        assert b.c_poseidon(ins, 7, 3 if n_in > 1 else 2) == b.poseidon(ins, 7, 3 if n_in > 1 else 2), n_in
+    big = [b.R - 1, b.R - 2, (1 << 253) + 12345]
+    assert b.c_poseidon(big, b.R - 1, 4) == b.poseidon(big, b.R - 1, 4)
+    for (h, w, ar, cu) in ((1, 9, 16, False), (5, 3, 16, False), (7, 4, 4, False), (40, 9, 16, False), (33, 100, 16, False),
+                           (20, 21, 4, True), (17, 13, 8, False), (65, 50, 16, True), (4, 1, 2, False)):
+        rows = rng.integers(0, 0xFFFFFFFF00000001, (h, w), dtype=np.uint64)
+        assert b.c_merkelize(rows, ar, cu) == b.merkelize([[int(v) for v in r] for r in rows], ar, cu), (h, w, ar, cu)
+    rows = np.full((3, 4), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)                    # width <= 4: one 256-bit integer above r
+    assert b.c_merkelize(rows, 16, False) == b.merkelize([[int(v) for v in r] for r in rows], 16, False)

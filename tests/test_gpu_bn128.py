@@ -202,21 +202,30 @@ def test_transcript_chain_kernel(bn, orc):
         assert T.getPermutations(20, 13) == O.getPermutations(20, 13) and T.getState() == O.getState()
 
 
-def test_config4_shape_tree_opens(bn):
-    """BASELINE config 4's shape (100 columns, BN128 linear hash, arity 16; 2^24 extended rows here, 2^27 in the config):
-    every opened path of the device-built tree recomputes the root through the ORACLE's rule (bn128_oracle.root_from_group_proof:
-    the leaf's linear hash and six arity-16 levels in Python integers) and through the library's own verifier"""
+@pytest.mark.parametrize("hbits", [24, 27])
+def test_config4_shape_tree_opens(bn, hbits):
+    """BASELINE config 4's shape (100 columns, BN128 linear hash, arity 16) at 2^24 rows and at the config's own 2^27 extended
+    rows (107 GB of rows, a 15 s tree: skipped when the memory is not there): every opened path of the device-built tree
+    recomputes the root through the ORACLE's rule (bn128_oracle.root_from_group_proof: the leaf's linear hash and the
+    arity-16 levels in Python integers) and through the library's own verifier"""
     import bn128_oracle as orc
     import torch
-    h, w = 1 << 24, 100
+    import gc
+    gc.collect(); torch.cuda.empty_cache()
+    h, w = 1 << hbits, 100
+    if torch.cuda.mem_get_info()[0] < 8 * h * w * 1.25 + 8e9:
+        pytest.skip("needs %.0f GB of free device memory" % ((8 * h * w * 1.25 + 8e9) / 1e9))
     g = torch.Generator(device="cuda"); g.manual_seed(4)
-    buf = torch.randint(0, 0x7FFFFFFFFFFFFFFF, (h * w,), dtype=torch.int64, device="cuda", generator=g) % 0xFFFFFFFF00000001
+    buf = torch.empty(h * w, dtype=torch.int64, device="cuda")
+    for o in range(0, h * w, 1 << 28):
+        m = min(1 << 28, h * w - o)
+        buf[o:o + m] = torch.randint(0, 0x7FFFFFFFFFFFFFFF, (m,), dtype=torch.int64, device="cuda", generator=g) % 0xFFFFFFFF00000001
     MH = bn.buildMerkleHash(16, False)
     tree = MH.merkelize(buf, w, h)
     root = MH.root(tree)
     for idx in (0, 1, h - 1, 12345678, (h // 3) | 15):
         v, mp = MH.getGroupProof(tree, idx)
-        assert len(mp) == 6 and all(len(l) == 16 for l in mp)
+        assert len(mp) == (hbits + 3) // 4 and all(len(l) == 16 for l in mp)
         assert v == [int(x) for x in buf[idx * w:(idx + 1) * w].cpu().numpy().view(np.uint64)]
         assert MH.verifyGroupProof(root, mp, idx, v)
         assert orc.root_from_group_proof([[int(x) for x in l] for l in mp], idx, v, 16, False) == int(root)

@@ -101,9 +101,10 @@ def _challenges(ch, info):
     """the challenges by stage as stark_verify.js keeps them (stage s at index s-1)"""
     n = info["nStages"]
     out = [[] for _ in range(n + 3)]
+    ints = lambda c: [int(v) for v in c]
     for st in range(2, n + 1):
-        out[st - 1] = [list(c) for c in ch[st]]
-    out[n] = [list(ch["q"])]; out[n + 1] = [list(ch["xi"])]; out[n + 2] = [list(c) for c in ch["fri"]]
+        out[st - 1] = [ints(c) for c in ch[st]]
+    out[n] = [ints(ch["q"])]; out[n + 1] = [ints(ch["xi"])]; out[n + 2] = [ints(c) for c in ch["fri"]]
     return out
 
 
@@ -170,6 +171,15 @@ def test_reference_proof_programs_match_the_proof(oracle):
         val = stark.execute_code(vinfo["queryVerifier"]["code"], lambda r: resolve(r, row))
         grp = np.array(z["s1_vals"][qi], dtype=np.uint64).reshape(-1, 3)
         assert [int(v) for v in grp[idx >> STEPS[1]]] == val, qi
+    # the same query program through the ORACLE's expression evaluator (gl_oracle.c eval_program -- the checker the device
+    # evaluator is compared with everywhere else): pinned here by values the reference prover committed to
+    import stark_ref
+    from pil2gl import io
+    proof = io.zkin2proof(z, info)
+    vals = stark.fri_values_at_queries(stark_ref.OracleBackend(), info, None, vinfo, proof, z["publics"], challenges, queries)
+    for qi, idx in enumerate(queries):
+        grp = np.array(z["s1_vals"][qi], dtype=np.uint64).reshape(-1, 3)
+        assert [int(v) for v in grp[idx >> STEPS[1]]] == [int(v) for v in vals[qi]], qi
 
 
 import pytest

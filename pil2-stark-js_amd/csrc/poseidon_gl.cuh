@@ -58,6 +58,9 @@ __device__ __forceinline__ void mds_layer(u64 st[12]) {
     }
 }
 
+#ifndef POSEIDON_POW7
+#define POSEIDON_POW7(x, bad) pow7_b(x, bad)        // (tools/sbox_bench.hip builds cost-split experiments with other bodies)
+#endif
 #ifndef POSEIDON_SBOX_GROUP
 #define POSEIDON_SBOX_GROUP 6       // S-boxes per fallback check: the inputs of a group stay live until its check (12: 24 VGPRs spilled in the leaf kernel and 41 GB of scratch traffic per config-3 launch; 6 and 4: none; same rate)
 #endif
@@ -71,7 +74,7 @@ __device__ __forceinline__ void sbox_full(u64 st[12], const u64 *__restrict__ rc
     for (int g = 0; g < 12; g += GROUP) {
         u64 bad = 0, in[GROUP];
 #pragma unroll
-        for (int i = 0; i < GROUP; i++) { in[i] = add_lazy_canon(st[g + i], rc[g + i]); st[g + i] = pow7_b(in[i], bad); }
+        for (int i = 0; i < GROUP; i++) { in[i] = add_lazy_canon(st[g + i], rc[g + i]); st[g + i] = POSEIDON_POW7(in[i], bad); }
         if (__builtin_expect(bad != 0, 0)) {
 #pragma unroll
             for (int i = 0; i < GROUP; i++) st[g + i] = pow7_lazy(in[i]);
@@ -80,7 +83,7 @@ __device__ __forceinline__ void sbox_full(u64 st[12], const u64 *__restrict__ rc
 }
 __device__ __forceinline__ u64 sbox_one(u64 x) {
     u64 bad = 0;
-    u64 y = pow7_b(x, bad);
+    u64 y = POSEIDON_POW7(x, bad);
     if (__builtin_expect(bad != 0, 0)) y = pow7_lazy(x);
     return y;
 }

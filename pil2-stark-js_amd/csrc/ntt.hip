@@ -26,6 +26,9 @@
 #include <stdlib.h>
 #include <algorithm>
 
+#ifndef NTT_MUL
+#define NTT_MUL(a, b) mul_lazy_x(a, b)   // the twiddle products of the tile kernels: the 16-instruction exact carry-out form (A/B: -DNTT_MUL=mul_lazy, 22 compiler instructions: 208.5 vs 201.5 ms per config-3 interpolate)
+#endif
 using namespace gl;
 
 namespace {
@@ -66,7 +69,7 @@ __device__ __forceinline__ void dif_step(u64 *tile, const u64 *TW, u32 k, u32 lm
         for (u32 i = 0; i < R; i++) {
             const u32 q = brev_c(i, C);
             u64 o = fermat::to_gl_lazy(v[i]);
-            if (!last && q) o = mul_lazy(o, TW[e1 * q]);            // the tile stays lazy: whoever stores a FINAL result canonicalises it
+            if (!last && q) o = NTT_MUL(o, TW[e1 * q]);            // the tile stays lazy: whoever stores a FINAL result canonicalises it
             col[i * st] = o;
         }
     }
@@ -90,7 +93,7 @@ __device__ __forceinline__ void dit_step(u64 *tile, const u64 *TW, u32 k, u32 lp
 #pragma unroll
             for (u32 q = 0; q < R; q++) {
                 // rho = 0 multiplies by TW[0] = 1: cheaper than a lane-dependent branch around every product
-                col[q * st] = mul_lazy(fermat::to_gl_lazy(v[q]), TW[(rho * (np + (q << lp))) << sh]);
+                col[q * st] = NTT_MUL(fermat::to_gl_lazy(v[q]), TW[(rho * (np + (q << lp))) << sh]);
             }
         } else {
 #pragma unroll
@@ -195,7 +198,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
             const u32 t = t0 + i * by;
             if (t < K) {
                 u64 v = vin[i];
-                if (DIT && P.hasTw) v = mul_lazy(v, TWO[gi * K + t]);
+                if (DIT && P.hasTw) v = NTT_MUL(v, TWO[gi * K + t]);
                 tile[TROW(t) * S + x] = v;
             }
         }
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
     if (!valid) return;
     for (u32 t = y; t < K; t += by) {
         u64 v = tile[TROW(t) * S + x];
-        if (P.hasTw && !DIT) v = P.canonOut ? mul(v, TWO[gi * K + t]) : mul_lazy(v, TWO[gi * K + t]);
+        if (P.hasTw && !DIT) v = P.canonOut ? mul(v, TWO[gi * K + t]) : NTT_MUL(v, TWO[gi * K + t]);
         else if (!P.hasTw && P.scale) v = mul(v, P.scale);
         else if (P.canonOut) v = canon(v);
         u64 addr = P.scatter ? (u64)bitrev32((u32)(g * K + t), P.n) * P.C + c : base + (u64)t * P.tStride;
@@ -284,7 +287,7 @@ __global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
         asm volatile("" : "+v"(dstOff), "+v"(tileOff), "+v"(scOff));
         const u64 dstStep = (u64)by * P.cosetCount * P.C;
 #pragma unroll
-        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[tileOff + i * rowStep * S] = mul_lazy(coef[i], Sc[scOff + i * by]); }
+        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; if (t < K) tile[tileOff + i * rowStep * S] = NTT_MUL(coef[i], Sc[scOff + i * by]); }
         __syncthreads();
         if constexpr (SC != 0) { dit_step<4, false, true>(tile, TWf, 8, 0, 4, SC, x, y, 16); dit_step<4, false, true>(tile, TWf, 8, 4, 0, SC, x, y, 16); }
         else dit_stages<false>(tile, TWf, k, S, x, y, by);

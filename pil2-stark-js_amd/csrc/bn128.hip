@@ -210,15 +210,36 @@ int get_params(int t, const Params **out) {
 // ------------------------------------------------------------------------------------------ device side
 struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8]; };
 
-#define S_AT(buf, j, l) S[((((buf) * tmax + (j)) * 8 + (l)) * BN_BLOCK) + lane]
+// Where the state lives.  Elements [0, BN_LDS_ELEMS) in LDS as [element][limb][lane]; the elements above -- only the states
+// wider than BN_LDS_ELEMS have any: t = 10..17 -- in the lane's own private (scratch) memory, which the hardware swizzles so
+// that a wave's access to one word is one contiguous 256-byte piece.  9 elements = 18 KB of LDS per wave: EIGHT waves per CU
+// (two per SIMD) instead of the four that a 17-element state in LDS allows; the private half is read one term ahead of its use
+// like every operand of the wide kernels, so its L1 / L2 latency hides behind a multiply-accumulate.  The element index is
+// wave-uniform: the branch costs a scalar compare.
+#ifndef BN_LDS_ELEMS
+#define BN_LDS_ELEMS 9
+#endif
+typedef u32 __attribute__((address_space(5))) *priv_u32;
+struct St { u32 *S; priv_u32 hi; int tmax, lane; };
+#define S_LDS(st, j, l) (st).S[(((j) * 8 + (l)) * BN_BLOCK) + (st).lane]
 
-__device__ __forceinline__ void lds_load(const u32 *S, int tmax, int lane, int buf, int j, u32 x[8]) {
+__device__ __forceinline__ void lds_load(const St &st, int j, u32 x[8]) {
+    if (j < BN_LDS_ELEMS) {
 #pragma unroll
-    for (int l = 0; l < 8; l++) x[l] = S_AT(buf, j, l);
+        for (int l = 0; l < 8; l++) x[l] = S_LDS(st, j, l);
+    } else {
+#pragma unroll
+        for (int l = 0; l < 8; l++) x[l] = st.hi[(j - BN_LDS_ELEMS) * 8 + l];
+    }
 }
-__device__ __forceinline__ void lds_store(u32 *S, int tmax, int lane, int buf, int j, const u32 x[8]) {
+__device__ __forceinline__ void lds_store(const St &st, int j, const u32 x[8]) {
+    if (j < BN_LDS_ELEMS) {
 #pragma unroll
-    for (int l = 0; l < 8; l++) S_AT(buf, j, l) = x[l];
+        for (int l = 0; l < 8; l++) S_LDS(st, j, l) = x[l];
+    } else {
+#pragma unroll
+        for (int l = 0; l < 8; l++) st.hi[(j - BN_LDS_ELEMS) * 8 + l] = x[l];
+    }
 }
 // wave-uniform address.  WIDE: the tables live in global memory; saying so (the pointers reach the out-of-line helpers as
 // generic ones) turns the flat loads into global loads, whose counter is separate from the LDS one and in order, so that a
@@ -243,21 +264,21 @@ __device__ __forceinline__ void pow5(u32 x[8]) {
 // x^5 on elements [0, nSbox) after adding constants C[0..t), then the dense n x n matrix A applied to elements
 // [first, first+n) of buffer cur into buffer cur^1 (elements below `first` are copied)
 template <bool WIDE>
-__device__ __noinline__ void add_sbox(u32 *S, int tmax, int lane, int cur, int t, const u32 *C, size_t cOff, int nSbox) {
+__device__ __noinline__ void add_sbox(const St &st, int cur, int t, const u32 *C, size_t cOff, int nSbox) {
     for (int j = 0; j < t; j++) {
         u32 x[8], c[8];
-        lds_load(S, tmax, lane, cur, j, x);
+        lds_load(st, j, x);
         load_const<WIDE>(C, cOff + j, c);
         bn::fr_add(x, c);
         if (j < nSbox) pow5(x);
-        lds_store(S, tmax, lane, cur, j, x);
+        lds_store(st, j, x);
     }
 }
 // In place: every row reads the whole old state, so the n new elements wait in a per-lane private array (scratch memory,
 // 17 x 32 B, a few KB of traffic per permutation against ~10^5 multiply steps) until all rows are done; one LDS buffer per
 // wave then suffices (4 waves per CU at t = 17 instead of 2).
 template <bool WIDE>
-__device__ __noinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, const u32 *A, int n, int first) {
+__device__ __noinline__ void dense_mul(const St &st, int cur, const u32 *A, int n, int first) {
     u32 nw[17 * 8];
     for (int i = 0; i < n; i++) {
         u32 acc[17];
@@ -268,12 +289,12 @@ __device__ __noinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, cons
             // load then overlap the ~600 issue cycles of a multiply-accumulate instead of stalling the wave, which at this
             // width is alone on its SIMD.  One multiply in the loop body: the permutation has to stay in the instruction cache.
             u32 y[8], m[8];
-            lds_load(S, tmax, lane, cur, first, y);
+            lds_load(st, first, y);
             load_const<true>(A, (size_t)i * n, m);
             for (int j = 0; j < n; j++) {
                 u32 yn[8], mn[8];
                 if (j + 1 < n) {
-                    lds_load(S, tmax, lane, cur, first + j + 1, yn);
+                    lds_load(st, first + j + 1, yn);
                     load_const<true>(A, (size_t)i * n + j + 1, mn);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // keep the requests ahead of the multiply (the scheduler sinks them otherwise)
@@ -284,7 +305,7 @@ __device__ __noinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, cons
         } else {
             for (int j = 0; j < n; j++) {
                 u32 y[8], m[8];
-                lds_load(S, tmax, lane, cur, first + j, y);
+                lds_load(st, first + j, y);
                 load_const<false>(A, (size_t)i * n + j, m);
                 bn::mac17(acc, y, m);
             }
@@ -294,19 +315,16 @@ __device__ __noinline__ void dense_mul(u32 *S, int tmax, int lane, int cur, cons
 #pragma unroll
         for (int l = 0; l < 8; l++) nw[i * 8 + l] = o[l];
     }
-    for (int i = 0; i < n; i++) {
-#pragma unroll
-        for (int l = 0; l < 8; l++) S_AT(cur, first + i, l) = nw[i * 8 + l];
-    }
+    for (int i = 0; i < n; i++) lds_store(st, first + i, &nw[i * 8]);
 }
 
 // partial rounds, sparse form, in place: element 0 stays in registers.  WIDE: the next term's requests are pinned ahead of
 // the current term's two products (see dense_mul)
 template <bool WIDE>
-__device__ __noinline__ void partial_rounds(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
+__device__ __noinline__ void partial_rounds(const St &st, int cur, const PermArgs &A) {
     const int t = A.t;
     u32 x0[8], m00[8];
-    lds_load(S, tmax, lane, cur, 0, x0);
+    lds_load(st, 0, x0);
 #pragma unroll
     for (int l = 0; l < 8; l++) m00[l] = A.m00[l];
     const int n = t - 1;
@@ -321,92 +339,96 @@ __device__ __noinline__ void partial_rounds(u32 *S, int tmax, int lane, int cur,
         bn::mac17(acc, x0, m00);
         if constexpr (WIDE) {
             u32 y[8], vv[8], ww[8];
-            lds_load(S, tmax, lane, cur, 1, y);
+            lds_load(st, 1, y);
             load_const<true>(A.V, (size_t)k * n, vv);
             load_const<true>(A.W, (size_t)k * n, ww);
             for (int j = 0; j < n; j++) {
                 u32 yn[8], vn[8], wn[8], p[8];
                 if (j + 1 < n) {
-                    lds_load(S, tmax, lane, cur, 2 + j, yn);
+                    lds_load(st, 2 + j, yn);
                     load_const<true>(A.V, (size_t)k * n + j + 1, vn);
                     load_const<true>(A.W, (size_t)k * n + j + 1, wn);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 bn::mac17_and_fr_mul(acc, y, vv, p, x0, ww);   // row 0: m00*x0 + sum V_kj * y_j;  column: y_j + W_kj * x0
                 bn::fr_add(y, p);
-                lds_store(S, tmax, lane, cur, 1 + j, y);
+                lds_store(st, 1 + j, y);
 #pragma unroll
                 for (int l = 0; l < 8; l++) { y[l] = yn[l]; vv[l] = vn[l]; ww[l] = wn[l]; }
             }
         } else {
             for (int j = 0; j < n; j++) {
                 u32 y[8], vv[8], ww[8], p[8];
-                lds_load(S, tmax, lane, cur, 1 + j, y);
+                lds_load(st, 1 + j, y);
                 load_const<false>(A.V, (size_t)k * n + j, vv);
                 bn::mac17(acc, y, vv);               // row 0:   m00*x0 + sum V_kj * y_j
                 load_const<false>(A.W, (size_t)k * n + j, ww);
                 bn::fr_mul(p, x0, ww);               // column:  y_j + W_kj * x0
                 bn::fr_add(y, p);
-                lds_store(S, tmax, lane, cur, 1 + j, y);
+                lds_store(st, 1 + j, y);
             }
         }
         bn::redc17(x0, acc);
     }
-    lds_store(S, tmax, lane, cur, 0, x0);
+    lds_store(st, 0, x0);
 }
 
 // permutation of the t elements in buffer `cur`; returns the buffer holding the result
 template <bool WIDE>
-__device__ __noinline__ int bn_perm(u32 *S, int tmax, int lane, int cur, const PermArgs &A) {
+__device__ __noinline__ int bn_perm(const St &st, int cur, const PermArgs &A) {
     const int t = A.t;
     if (A.dense) {                                   // poseidon.circom:22-44 as written (tests)
         for (int r = 0; r < N_ROUNDS_F + A.rp; r++) {
             const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
-            add_sbox<WIDE>(S, tmax, lane, cur, t, A.Cd, (size_t)r * t, full ? t : 1);
-            dense_mul<WIDE>(S, tmax, lane, cur, A.M, t, 0);
+            add_sbox<WIDE>(st, cur, t, A.Cd, (size_t)r * t, full ? t : 1);
+            dense_mul<WIDE>(st, cur, A.M, t, 0);
         }
         return cur;
     }
     for (int r = 0; r < 4; r++) {
-        add_sbox<WIDE>(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
-        dense_mul<WIDE>(S, tmax, lane, cur, A.M, t, 0);
+        add_sbox<WIDE>(st, cur, t, A.C8, (size_t)r * t, t);
+        dense_mul<WIDE>(st, cur, A.M, t, 0);
     }
     {
         const int n = t - 1;
-        partial_rounds<WIDE>(S, tmax, lane, cur, A);
-        dense_mul<WIDE>(S, tmax, lane, cur, A.D, n, 1);    // diag(1, Mh^RP)
+        partial_rounds<WIDE>(st, cur, A);
+        dense_mul<WIDE>(st, cur, A.D, n, 1);    // diag(1, Mh^RP)
     }
     for (int r = 4; r < 8; r++) {
-        add_sbox<WIDE>(S, tmax, lane, cur, t, A.C8, (size_t)r * t, t);
-        dense_mul<WIDE>(S, tmax, lane, cur, A.M, t, 0);
+        add_sbox<WIDE>(st, cur, t, A.C8, (size_t)r * t, t);
+        dense_mul<WIDE>(st, cur, A.M, t, 0);
     }
     return cur;
 }
 
-__device__ __forceinline__ void to_mont_store(u32 *S, int tmax, int lane, int buf, int j, const u64 w[4]) {
+__device__ __forceinline__ void to_mont_store(const St &st, int j, const u64 w[4]) {
     u32 x[8], r2[8], o[8];
 #pragma unroll
     for (int k = 0; k < 4; k++) { x[2 * k] = (u32)w[k]; x[2 * k + 1] = (u32)(w[k] >> 32); }
 #pragma unroll
     for (int l = 0; l < 8; l++) r2[l] = bn::r2_limb(l);
     bn::fr_mul(o, x, r2);                            // frm_toMontgomery: x * 2^256 mod r (x < 2^256)
-    lds_store(S, tmax, lane, buf, j, o);
+    lds_store(st, j, o);
 }
-__device__ __forceinline__ void zero_store(u32 *S, int tmax, int lane, int buf, int j) {
-#pragma unroll
-    for (int l = 0; l < 8; l++) S_AT(buf, j, l) = 0;
+__device__ __forceinline__ void zero_store(const St &st, int j) {
+    const u32 z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    lds_store(st, j, z);
 }
-__device__ __forceinline__ void digest_out(const u32 *S, int tmax, int lane, int buf, int j, u64 *o) {
+__device__ __forceinline__ void digest_out(const St &st, int j, u64 *o) {
+    u32 x[8];
+    lds_load(st, j, x);
 #pragma unroll
-    for (int k = 0; k < 4; k++) o[k] = (u64)S_AT(buf, j, 2 * k) | ((u64)S_AT(buf, j, 2 * k + 1) << 32);
+    for (int k = 0; k < 4; k++) o[k] = (u64)x[2 * k] | ((u64)x[2 * k + 1] << 32);
 }
 
 // leaf digests (merklehash_bn128_worker.js:42-98): one row per lane
 template <bool WIDE>
-__global__ void __launch_bounds__(BN_BLOCK) bn_linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int arity, int custom,
+__global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) bn_linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int arity, int custom,
                                                                     PermArgs full, PermArgs last, u64 *__restrict__ out) {
     extern __shared__ u32 S[];
     const int lane = threadIdx.x, tmax = arity + 1;
+    u32 hi_arr[(17 - BN_LDS_ELEMS) * 8];
+    const St st = { S, (priv_u32)hi_arr, tmax, lane };
     const u64 row0 = (u64)blockIdx.x * BN_BLOCK + lane;
     const bool live = row0 < height;
     const u64 *v = in + (live ? row0 : height - 1) * width;
@@ -414,9 +436,9 @@ __global__ void __launch_bounds__(BN_BLOCK) bn_linear_hash_kernel(const u64 *__r
     if (width <= 4) {                                // :45-50: up to four words taken as one 256-bit integer
         u64 w[4] = { 0, 0, 0, 0 };
         for (u64 k = 0; k < width; k++) w[k] = v[k];
-        to_mont_store(S, tmax, lane, 0, 0, w);
+        to_mont_store(st, 0, w);
     } else {
-        zero_store(S, tmax, lane, 0, 0);             // st = 0
+        zero_store(st, 0);             // st = 0
         const u64 nEl = (width + 2) / 3;             // 3 Goldilocks words per field element (:54-67)
         u64 e = 0;
         while (e < nEl) {
@@ -424,57 +446,63 @@ __global__ void __launch_bounds__(BN_BLOCK) bn_linear_hash_kernel(const u64 *__r
             for (u64 k = 0; k < n; k++) {
                 u64 w[4] = { 0, 0, 0, 0 };
                 for (int q = 0; q < 3; q++) { const u64 idx = 3 * (e + k) + q; if (idx < width) w[q] = v[idx]; }
-                to_mont_store(S, tmax, lane, cur, 1 + (int)k, w);
+                to_mont_store(st, 1 + (int)k, w);
             }
-            if (n == (u64)arity) cur = bn_perm<WIDE>(S, tmax, lane, cur, full);
+            if (n == (u64)arity) cur = bn_perm<WIDE>(st, cur, full);
             else if (custom) {                       // :87-93: zero-pad the last chunk to `arity` inputs
-                for (u64 k = n; k < (u64)arity; k++) zero_store(S, tmax, lane, cur, 1 + (int)k);
-                cur = bn_perm<WIDE>(S, tmax, lane, cur, full);
-            } else cur = bn_perm<WIDE>(S, tmax, lane, cur, last);      // :85-86: t = nLast + 1
+                for (u64 k = n; k < (u64)arity; k++) zero_store(st, 1 + (int)k);
+                cur = bn_perm<WIDE>(st, cur, full);
+            } else cur = bn_perm<WIDE>(st, cur, last);      // :85-86: t = nLast + 1
             e += n;
         }
     }
-    if (live) digest_out(S, tmax, lane, cur, 0, out + 4 * row0);
+    if (live) digest_out(st, 0, out + 4 * row0);
 }
 
 // parents (merklehash_bn128_worker.js:104-144): out[i] = Poseidon(0; in[arity*i .. arity*i+arity-1])[0]
 template <bool WIDE>
-__global__ void __launch_bounds__(BN_BLOCK) bn_merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, int arity, PermArgs full, u64 *__restrict__ out) {
+__global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) bn_merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, int arity, PermArgs full, u64 *__restrict__ out) {
     extern __shared__ u32 S[];
     const int lane = threadIdx.x, tmax = arity + 1;
+    u32 hi_arr[(17 - BN_LDS_ELEMS) * 8];
+    const St st = { S, (priv_u32)hi_arr, tmax, lane };
     const u64 i0 = (u64)blockIdx.x * BN_BLOCK + lane;
     const bool live = i0 < nOps;
     const u64 *v = in + (live ? i0 : nOps - 1) * (u64)arity * 4;
-    zero_store(S, tmax, lane, 0, 0);
+    zero_store(st, 0);
     for (int k = 0; k < arity; k++) {                // children are already in Montgomery form
+        u32 x[8];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { const u64 w = v[4 * k + q]; S_AT(0, 1 + k, 2 * q) = (u32)w; S_AT(0, 1 + k, 2 * q + 1) = (u32)(w >> 32); }
+        for (int q = 0; q < 4; q++) { const u64 w = v[4 * k + q]; x[2 * q] = (u32)w; x[2 * q + 1] = (u32)(w >> 32); }
+        lds_store(st, 1 + k, x);
     }
-    const int cur = bn_perm<WIDE>(S, tmax, lane, 0, full);
-    if (live) digest_out(S, tmax, lane, cur, 0, out + 4 * i0);
+    const int cur = bn_perm<WIDE>(st, 0, full);
+    if (live) digest_out(st, 0, out + 4 * i0);
 }
 
 // circomlibjs poseidon(inputs, initState, nOut): normal-form words in and out (transcript, verification, tests)
 template <bool WIDE>
-__global__ void __launch_bounds__(BN_BLOCK) bn_poseidon_kernel(const u64 *__restrict__ in, const u64 *__restrict__ init, u64 count, int nIn, int nOut,
+__global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) bn_poseidon_kernel(const u64 *__restrict__ in, const u64 *__restrict__ init, u64 count, int nIn, int nOut,
                                                                  PermArgs full, u64 *__restrict__ out) {
     extern __shared__ u32 S[];
     const int lane = threadIdx.x, tmax = nIn + 1;
+    u32 hi_arr[(17 - BN_LDS_ELEMS) * 8];
+    const St st = { S, (priv_u32)hi_arr, tmax, lane };
     const u64 i0 = (u64)blockIdx.x * BN_BLOCK + lane;
     const bool live = i0 < count;
     const u64 i = live ? i0 : count - 1;
     u64 w[4] = { 0, 0, 0, 0 };
     if (init) for (int q = 0; q < 4; q++) w[q] = init[4 * i + q];
-    to_mont_store(S, tmax, lane, 0, 0, w);
+    to_mont_store(st, 0, w);
     for (int k = 0; k < nIn; k++) {
         for (int q = 0; q < 4; q++) w[q] = in[(i * nIn + k) * 4 + q];
-        to_mont_store(S, tmax, lane, 0, 1 + k, w);
+        to_mont_store(st, 1 + k, w);
     }
-    const int cur = bn_perm<WIDE>(S, tmax, lane, 0, full);
+    const int cur = bn_perm<WIDE>(st, 0, full);
     if (!live) return;
     for (int k = 0; k < nOut; k++) {                 // out of Montgomery form: multiply by 1
         u32 x[8], one[8] = { 1, 0, 0, 0, 0, 0, 0, 0 }, o[8];
-        lds_load(S, tmax, lane, cur, k, x);
+        lds_load(st, k, x);
         bn::fr_mul(o, x, one);
         for (int q = 0; q < 4; q++) out[(i * nOut + k) * 4 + q] = (u64)o[2 * q] | ((u64)o[2 * q + 1] << 32);
     }
@@ -584,7 +612,7 @@ __global__ void bn_convert_kernel(const u64 *__restrict__ in, u64 n, int toMont,
     for (int q = 0; q < 4; q++) out[4 * i + q] = (u64)o[2 * q] | ((u64)o[2 * q + 1] << 32);
 }
 
-size_t lds_bytes(int tmax) { return (size_t)tmax * 8 * BN_BLOCK * 4; }
+size_t lds_bytes(int tmax) { return (size_t)(tmax < BN_LDS_ELEMS ? tmax : BN_LDS_ELEMS) * 8 * BN_BLOCK * 4; }   // the elements above live in private memory
 
 PermArgs perm_args(const Params *P) {
     PermArgs a;
@@ -601,9 +629,17 @@ int set_lds_attr(K kernel, size_t bytes) {
     return PIL2GL_OK;
 }
 
-// a state of t elements takes t * 2 KB of LDS per wave: from t = 10 on only one wave fits per SIMD, and the kernels
-// that prefetch their operands (more registers, no cost in occupancy there) are the faster ones
-bool wide_state(int t) { return t >= 10; }
+// The kernel instances that request the next term's operands before multiplying the current one (WIDE) were the faster ones
+// while a wide state (t >= 10) kept its whole state in LDS and ran ONE wave per SIMD.  With the upper elements in private memory
+// (BN_LDS_ELEMS) two waves fit, the second wave covers the operand latency, and the kernels turn out to be bound by their vector
+// instruction COUNT (5.3e10 per 2^20 x 100 arity-16 commit = 0.85 of the vector issue slots of its 110 ms): the plain instances,
+// which do not rotate prefetched operands through registers, are 12 % faster (121.1 -> 106.6 ms).  PIL2GL_BN128_WIDE=1 selects
+// the prefetching instances for an A/B run.
+bool wide_state(int t) {
+    static const int force = getenv("PIL2GL_BN128_WIDE") ? atoi(getenv("PIL2GL_BN128_WIDE")) : 0;
+    (void)t;
+    return force != 0;
+}
 
 int check_arity(uint32_t arity) {
     if (arity < 2 || arity > 16 || (arity & (arity - 1))) return fail(PIL2GL_EINVAL, "arity must be 2, 4, 8 or 16 (got %u)", arity);

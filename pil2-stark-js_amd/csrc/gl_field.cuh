@@ -91,10 +91,67 @@ __device__ __forceinline__ u64 mul_lazy(u64 a, u64 b) {
 // allocation and scheduling stay the compiler's.  Measured, not assumed: where independent work surrounds the products
 // (the NTT tiles) the plain form schedules better and stays; a branch per product, or folding the borrow back in place
 // (three more instructions), both lose the gain.
+#ifndef GL_MUL_B
+#define GL_MUL_B 12         // which form of the carry-out product: 13 (round 2), 12 (its tail on the carry flags), 11 (no moves at all: fewer instructions, slower)
+#endif
 #ifndef GL_SGPR_WAIT
 #define GL_SGPR_WAIT "s_nop 1\n\t"       // (tools/sbox_bench.hip builds an experiment without the wait states: what they cost)
 #endif
 __device__ __forceinline__ u64 mul_lazy_b(u64 a, u64 b, u64 &bad) {
+#if GL_MUL_B == 12
+    // Twelve vector instructions: round 2's product with its tail -- select, multiply-add by 2^32-1, two subtractions -- replaced by
+    // three additions / subtractions that take the multiply-add's carry c as their carry-in:
+    //   r = z + c (2^32-1) - w1   as   r0 = z0 - w1 - c (borrow b),  r1 = (z1 + c) - b
+    // (z1 + c cannot wrap: a wrapped z is below 2^64 - 2^33).  Same number of SGPR-carried carries in a row as before (three), one
+    // multiply-add fewer.  The last borrow is the rare case (probability ~2^-32) the caller recomputes.
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1 + (t >> 32);
+    u64 v, cy, z, c, bo, br, cx; u32 c01, r0, r1, r1a;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v), "=s"(cy) : "v"(a1), "v"(b0), "v"(u));
+    asm(GL_SGPR_WAIT "v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c01) : "s"(cy));
+    const u64 w = (u64)a1 * b1 + (((u64)c01 << 32) | (v >> 32));   // <= 2^64 - 1: the full product is < 2^128
+    const u64 lo = (v << 32) | (u32)t;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)w), "v"(lo));
+    asm(GL_SGPR_WAIT "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r0), "=s"(bo) : "v"((u32)z), "v"((u32)(w >> 32)), "s"(c));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cx) : "v"((u32)(z >> 32)), "s"(c));
+    asm(GL_SGPR_WAIT "v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r1), "=s"(br) : "v"(r1a), "s"(bo));
+    bad |= br;
+    return ((u64)r1 << 32) | r0;
+#elif GL_MUL_B == 11
+    // ELEVEN vector instructions: five multiply-adds and six 32-bit additions / subtractions with carry (round 3; measured 3 %
+    // SLOWER than the 13-instruction form in the permutation: five SGPR-carried carries in a row instead of three, and the moves it
+    // removes are the cheapest instructions there are -- tools/issue_cost.hip: 2.9 cycles saturated against 4.8-5.0 for a carry
+    // operation or a multiply-add.  Kept for the record; the 13-instruction form of round 2 is kept below under GL_MUL_B_13).  In a kernel that
+    // saturates the vector issue every instruction costs the same four cycles, moves included, and the 13-instruction form carried
+    // THREE moves per product: gfx950 wants 64-bit operands in even-aligned register pairs, and (t >> 32), (v >> 32) and the low
+    // word of v are each born in the wrong half of a pair.  Here every value that has to change halves does so inside an
+    // addition that is needed anyway:
+    //   t = a0 b0;  u = a0 b1;  v = a1 b0 + u            (carry cy; t's high word is NOT added in yet)
+    //   l1 = t1 + v0   (carry ca)   -> (t0, l1) is the low 64 bits of the product, in t's own pair
+    //   h0 = v1 + ca   (carry cb)   -> (h0, cy|cb) is what a1 b1 still has to take in: cy and cb exclude each other
+    //   w  = a1 b1 + h0;  w1 += cy|cb   (as the carry-in of an add: no select, no move)
+    //   z  = w0 (2^32-1) + (t0, l1) (carry c);   r = z + c (2^32-1) - w1  as  r0 = z0 - w1 - c (borrow b),  r1 = z1 + c - b
+    // (z + c 2^64 = z + c (2^32-1) mod p; z1 + c cannot wrap: a wrapped z is below 2^64 - 2^33).  The last borrow is the rare
+    // case (probability ~2^-32) the caller recomputes, as before.
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    const u64 t = (u64)a0 * b0;
+    const u64 u = (u64)a0 * b1;
+    u64 v, cy, ca, cb, z, c, bo, br; u32 l1, h0, hc, r0, r1, r1a;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v), "=s"(cy) : "v"(a1), "v"(b0), "v"(u));
+    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(l1), "=s"(ca) : "v"((u32)(t >> 32)), "v"((u32)v));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(h0), "=s"(cb) : "v"((u32)(v >> 32)), "s"(ca));
+    const u64 cc = cy | cb;
+    const u64 w = (u64)a1 * b1 + h0;                 // the bit cc belongs at 2^32 of this addend: added to w's high word below
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(hc), "=s"(cb) : "v"((u32)(w >> 32)), "s"(cc));    // cannot wrap: the product is < 2^128
+    const u64 lo = ((u64)l1 << 32) | (u32)t;
+    asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)w), "v"(lo));
+    asm(GL_SGPR_WAIT "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r0), "=s"(bo) : "v"((u32)z), "v"(hc), "s"(c));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cb) : "v"((u32)(z >> 32)), "s"(c));
+    asm(GL_SGPR_WAIT "v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r1), "=s"(br) : "v"(r1a), "s"(bo));
+    bad |= br;
+    return ((u64)r1 << 32) | r0;
+#else           // GL_MUL_B == 13: round 2's form
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 t = (u64)a0 * b0;
     const u64 u = (u64)a0 * b1 + (t >> 32);
@@ -110,6 +167,7 @@ __device__ __forceinline__ u64 mul_lazy_b(u64 a, u64 b, u64 &bad) {
         : "=&v"(r0), "=&v"(r1), "=&s"(br) : "v"((u32)z2), "v"((u32)(z2 >> 32)), "v"((u32)(w >> 32)));
     bad |= br;
     return ((u64)r1 << 32) | r0;
+#endif
 }
 // The same carry-out product with the rare borrow folded back in place: exact, no flag for the caller (16 instructions).
 __device__ __forceinline__ u64 mul_lazy_x(u64 a, u64 b) {

@@ -74,7 +74,7 @@ __device__ __forceinline__ u64 mul_s(u64 a, u64 b, u64 &bad) {
     bad |= br;
     return ((u64)r1 << 32) | r0;
 }
-__device__ __forceinline__ u64 pow7_s(u64 x, u64 &bad) { u64 x2 = mul_s(x, x, bad), x3 = mul_s(x2, x, bad), x4 = mul_s(x2, x2, bad); return mul_s(x3, x4, bad); }
+__device__ __forceinline__ u64 pow7_s(u64 x, u64 &bad) { return pow7_b(x, bad); }      // the library's product (mul_s above: round 2's 13-instruction form, kept for reference)
 // exact variant: the borrow is folded back in place (three more instructions, no fallback)
 __device__ __forceinline__ u64 mul_e(u64 a, u64 b) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);

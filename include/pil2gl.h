@@ -263,6 +263,10 @@ int pil2gl_debug_compact_program(const glx_program *prog, glx_op *outOps, uint32
 /* host-only: run the optimiser, generate the straight-line kernel source of the program and compile it with hiprtc
  * (the path long programs take at run time); reports the code object size and the number of fused Horner terms. */
 int pil2gl_debug_jit_compile(const glx_program *prog, const glx_ctx *ctx, uint64_t *codeBytes, uint32_t *fusedOps);
+/* the two hand-written Goldilocks products on n pairs of arbitrary u64 operands (host pointers): x[i] = a*b by the exact form
+ * the transform kernels use (gl_field.cuh mul_lazy_x), pb[i] = a*b by the flagged form of the S-boxes (mul_lazy_b), both canonical;
+ * flag[i] != 0 where the flagged form asks to be recomputed (its last subtraction borrowed: probability ~2^-32 on random operands) */
+int pil2gl_selftest_products(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *x, uint64_t *pb, uint64_t *flag);
 /* `layers` consecutive Poseidon MDS layers (glwasm.js:428-440 matrix) applied to n 12-element states (host pointers,
  * any u64 representatives in, canonical out): mfma = 1 the matrix-core layer the hash kernels use, 0 the vector-ALU one */
 int pil2gl_selftest_mds(const uint64_t *states, uint64_t n, uint32_t layers, int mfma, uint64_t *out);

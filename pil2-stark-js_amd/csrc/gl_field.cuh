@@ -169,24 +169,25 @@ __device__ __forceinline__ u64 mul_lazy_b(u64 a, u64 b, u64 &bad) {
     return ((u64)r1 << 32) | r0;
 #endif
 }
-// The same carry-out product with the rare borrow folded back in place: exact, no flag for the caller (16 instructions).
+// The same carry-out product with the rare borrow folded back in place: exact, no flag for the caller (15 instructions: the
+// 12-instruction form above, then a borrow b means the true value is r - 2^64 = r - (2^32 - 1) mod p = (r0 + 1, r1 - 1 + carry)).
 __device__ __forceinline__ u64 mul_lazy_x(u64 a, u64 b) {
     const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
     const u64 t = (u64)a0 * b0;
     const u64 u = (u64)a0 * b1 + (t >> 32);
-    u64 v, cy, z, c; u32 c01, c201, r0, r1, m;
+    u64 v, cy, z, c, bo, br, cx, k; u32 c01, r0, r1, r1a, m, q0, q1;
     asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(v), "=s"(cy) : "v"(a1), "v"(b0), "v"(u));
     asm(GL_SGPR_WAIT "v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c01) : "s"(cy));
     const u64 w = (u64)a1 * b1 + (((u64)c01 << 32) | (v >> 32));
     const u64 lo = (v << 32) | (u32)t;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)w), "v"(lo));
-    asm(GL_SGPR_WAIT "v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(c201) : "s"(c));
-    const u64 z2 = (u64)c201 * 0xFFFFFFFFu + z;
-    // r = z2 - w1; on a borrow the true value is r - (2^32 - 1) = (r0 + 1, r1 - 1 + carry)
-    asm("v_sub_co_u32 %0, vcc, %3, %5\n\ts_nop 1\n\tv_subbrev_co_u32 %1, vcc, 0, %4, vcc\n\ts_nop 1\n\t"
-        "v_cndmask_b32 %2, 0, -1, vcc\n\tv_addc_co_u32 %0, vcc, 0, %0, vcc\n\ts_nop 1\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc"
-        : "=&v"(r0), "=&v"(r1), "=&v"(m) : "v"((u32)z2), "v"((u32)(z2 >> 32)), "v"((u32)(w >> 32)) : "vcc");
-    return ((u64)r1 << 32) | r0;
+    asm(GL_SGPR_WAIT "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r0), "=s"(bo) : "v"((u32)z), "v"((u32)(w >> 32)), "s"(c));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cx) : "v"((u32)(z >> 32)), "s"(c));
+    asm(GL_SGPR_WAIT "v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r1), "=s"(br) : "v"(r1a), "s"(bo));
+    asm(GL_SGPR_WAIT "v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m) : "s"(br));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(q0), "=s"(k) : "v"(r0), "s"(br));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(q1), "=s"(cx) : "v"(r1), "v"(m), "s"(k));
+    return ((u64)q1 << 32) | q0;
 }
 // any x any -> canonical
 __device__ __forceinline__ u64 mul(u64 a, u64 b) { return canon(mul_lazy(a, b)); }

@@ -206,6 +206,35 @@ extern "C" int pil2gl_selftest_field(const uint64_t *a, const uint64_t *b, uint6
     HIP_TRY(hipFree(d));
     return PIL2GL_OK;
 }
+// the hand-written products on arbitrary operands (any u64 representatives): x = mul_lazy_x (exact), b = mul_lazy_b with its
+// "recompute me" flag (flag[i] != 0: the lane's last subtraction borrowed, b[i] is then not to be used)
+__global__ void selftest_products_kernel(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *x, uint64_t *pb, uint64_t *flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    if (!live) i = n - 1;
+    const uint64_t va = a[i], vb = b[i];
+    uint64_t bad = 0;
+    const uint64_t rb = gl::mul_lazy_b(va, vb, bad);          // bad: one bit per lane of the wave
+    const uint64_t rx = gl::mul_lazy_x(va, vb);
+    if (!live) return;
+    x[i] = gl::canon(rx); pb[i] = gl::canon(rb);
+    flag[i] = (bad >> (threadIdx.x & 63)) & 1;
+}
+extern "C" int pil2gl_selftest_products(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *x, uint64_t *pb, uint64_t *flag) {
+    P2_TRY(ensure_init());
+    if (!n) return PIL2GL_OK;
+    u64 *d;
+    HIP_TRY(hipMalloc((void **)&d, 5 * n * 8));
+    HIP_TRY(hipMemcpy(d, a, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d + n, b, n * 8, hipMemcpyHostToDevice));
+    selftest_products_kernel<<<(unsigned)((n + 255) / 256), 256>>>(d, d + n, n, d + 2 * n, d + 3 * n, d + 4 * n);
+    KERNEL_CHECK();
+    HIP_TRY(hipMemcpy(x, d + 2 * n, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pb, d + 3 * n, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(flag, d + 4 * n, n * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(d));
+    return PIL2GL_OK;
+}
 extern "C" int pil2gl_selftest_ext(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *inv) {
     P2_TRY(ensure_init());
     if (!n) return PIL2GL_OK;

@@ -124,6 +124,7 @@ SIGNATURES = {
     "pil2gl_bn128_convert_dev": (_I, [vp, _U64, _I, vp, vp]),
     "pil2gl_selftest_field": (_I, [vp, vp, _U64, vp, vp, vp]),
     "pil2gl_selftest_ext": (_I, [vp, vp, _U64, vp, vp]),
+    "pil2gl_selftest_products": (_I, [vp, vp, _U64, vp, vp, vp]),
     "pil2gl_selftest_mds": (_I, [vp, _U64, _U32, _I, vp]),
     "pil2gl_selftest_poseidon": (_I, [vp, _U64, _I, vp]),
 }

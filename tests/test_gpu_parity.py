@@ -32,6 +32,33 @@ def test_field_ops_device(gl, oracle):
         assert int(m[i]) == x * y % P and int(s[i]) == (x + y) % P and int(d[i]) == (x - y) % P
 
 
+def test_handwritten_products_on_edge_operands(gl):
+    """the carry-out products of the S-boxes (flagged form) and of the transform kernels (exact form) on operands chosen for their
+    carries: every combination of 32-bit halves from {0, 1, 2^31, 2^32-2, 2^32-1}, values >= p, and pairs whose reduction borrows
+    at its last step -- w1 > z with a zero low product, e.g. 2^63 squared -- where the exact form folds the borrow back and the
+    flagged form must raise its flag (and is then not used); plus random operands, on which the flag stays down"""
+    from pil2gl import _lib
+    h = [0, 1, 1 << 31, (1 << 32) - 2, (1 << 32) - 1, 0x80000001, 0x7FFFFFFF]
+    vals = [(hi << 32) | lo for hi in h for lo in h]
+    pairs = [(x, y) for x in vals for y in vals]
+    pairs += [(1 << 63, 1 << 63), ((1 << 63) + (1 << 31), 1 << 63), (0xFFFFFFFF00000000, 0xFFFFFFFF00000000), (P, P), (P - 1, P - 1), ((1 << 64) - 1, (1 << 64) - 1)]
+    rng = np.random.default_rng(17)
+    ra = rng.integers(0, 1 << 64, 1 << 16, dtype=np.uint64); rb = rng.integers(0, 1 << 64, 1 << 16, dtype=np.uint64)
+    a = np.concatenate([np.array([p_[0] for p_ in pairs], dtype=np.uint64), ra]); b = np.concatenate([np.array([p_[1] for p_ in pairs], dtype=np.uint64), rb])
+    x = np.zeros_like(a); pb = np.zeros_like(a); fl = np.zeros_like(a)
+    _lib.call("pil2gl_selftest_products", gl._ptr(a), gl._ptr(b), a.size, gl._ptr(x), gl._ptr(pb), gl._ptr(fl))
+    flagged = 0
+    for i in range(a.size):
+        want = int(a[i]) * int(b[i]) % P
+        assert int(x[i]) == want, (hex(int(a[i])), hex(int(b[i])))
+        if fl[i]:
+            flagged += 1
+        else:
+            assert int(pb[i]) == want, (hex(int(a[i])), hex(int(b[i])))
+    assert fl[len(pairs) - 6] == 1                       # 2^63 squared: low words zero, the last subtraction borrows with certainty
+    assert flagged >= 1 and fl[len(pairs):].sum() == 0   # structured operands raise it, 2^16 random pairs do not (probability 2^-16)
+
+
 def test_ext_ops_device(gl, oracle):
     from pil2gl import _lib
     rows = H(golden("field.json")["ext"])

@@ -70,6 +70,7 @@ __device__ __forceinline__ f128 shl(const f128 &v) {
 // any representative with |v| < 2^101 -> lazy field element:  (w1:w0) + w2 (2^32-1) - w3, with w3 biased by 32 to
 // keep it unsigned and the bias (32 * 2^96 = -32) returned through the multiply-add's addend
 __device__ __forceinline__ u64 to_gl_lazy(const f128 &v) {
+#ifndef GL_FERMAT_TO_GL_ASM
     const u64 lo = ((u64)v.w1 << 32) | v.w0;
     const u32 hh = v.w3 + 32u;
     u64 t0, t2;
@@ -77,6 +78,24 @@ __device__ __forceinline__ u64 to_gl_lazy(const f128 &v) {
     const u64 t1 = (u64)v.w2 * EPS + 32u;
     const bool c = __builtin_uaddl_overflow(t0, t1, &t2);
     return t2 + ((c ? EPS : 0) - (br ? EPS : 0));
+#else
+    // the same on the carry flags (ten instructions; the compiler's form above re-derives each carry with a 64-bit compare) --
+    // measured 1 % SLOWER per config-3 interpolate (200.6 vs 198.8 ms, same box): six carries in a row; not the default:
+    //   s = (w1:w0) + [w2 (2^32-1) + 32]  (carry c);   r = s + c (2^32-1) - hh   as   r0 = s0 - hh - c (borrow b), r1 = (s1 + c) - b;
+    //   a final borrow (the value was negative: it happens, w3 may be positive) adds p: (r0 + 1, r1 - 1 + carry)
+    const u32 hh = v.w3 + 32u;
+    const u64 t1 = (u64)v.w2 * EPS + 32u;
+    u64 c, bo, br, cx, k; u32 s0, s1, r0, r1a, r1, m, q0, q1;
+    asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s0), "=s"(c) : "v"(v.w0), "v"((u32)t1));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s1), "=s"(c) : "v"(v.w1), "v"((u32)(t1 >> 32)), "s"(c));
+    asm(GL_SGPR_WAIT "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r0), "=s"(bo) : "v"(s0), "v"(hh), "s"(c));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cx) : "v"(s1), "s"(c));
+    asm(GL_SGPR_WAIT "v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r1), "=s"(br) : "v"(r1a), "s"(bo));
+    asm(GL_SGPR_WAIT "v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m) : "s"(br));
+    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(q0), "=s"(k) : "v"(r0), "s"(br));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(q1), "=s"(cx) : "v"(r1), "v"(m), "s"(k));
+    return ((u64)q1 << 32) | q0;
+#endif
 }
 
 template <int C, bool INV, int H, int BASE, int I>

@@ -89,10 +89,10 @@ __device__ __forceinline__ u64 to_gl_lazy(const f128 &v) {
     asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(s0), "=s"(c) : "v"(v.w0), "v"((u32)t1));
     asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(s1), "=s"(c) : "v"(v.w1), "v"((u32)(t1 >> 32)), "s"(c));
     asm(GL_SGPR_WAIT "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r0), "=s"(bo) : "v"(s0), "v"(hh), "s"(c));
-    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cx) : "v"(s1), "s"(c));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cx) : "v"(s1), "s"(c));
     asm(GL_SGPR_WAIT "v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r1), "=s"(br) : "v"(r1a), "s"(bo));
     asm(GL_SGPR_WAIT "v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m) : "s"(br));
-    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(q0), "=s"(k) : "v"(r0), "s"(br));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(q0), "=s"(k) : "v"(r0), "s"(br));
     asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(q1), "=s"(cx) : "v"(r1), "v"(m), "s"(k));
     return ((u64)q1 << 32) | q0;
 #endif

@@ -114,7 +114,7 @@ __device__ __forceinline__ u64 mul_lazy_b(u64 a, u64 b, u64 &bad) {
     const u64 lo = (v << 32) | (u32)t;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)w), "v"(lo));
     asm(GL_SGPR_WAIT "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r0), "=s"(bo) : "v"((u32)z), "v"((u32)(w >> 32)), "s"(c));
-    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cx) : "v"((u32)(z >> 32)), "s"(c));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cx) : "v"((u32)(z >> 32)), "s"(c));
     asm(GL_SGPR_WAIT "v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r1), "=s"(br) : "v"(r1a), "s"(bo));
     bad |= br;
     return ((u64)r1 << 32) | r0;
@@ -147,7 +147,7 @@ __device__ __forceinline__ u64 mul_lazy_b(u64 a, u64 b, u64 &bad) {
     const u64 lo = ((u64)l1 << 32) | (u32)t;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)w), "v"(lo));
     asm(GL_SGPR_WAIT "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r0), "=s"(bo) : "v"((u32)z), "v"(hc), "s"(c));
-    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cb) : "v"((u32)(z >> 32)), "s"(c));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cb) : "v"((u32)(z >> 32)), "s"(c));
     asm(GL_SGPR_WAIT "v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r1), "=s"(br) : "v"(r1a), "s"(bo));
     bad |= br;
     return ((u64)r1 << 32) | r0;
@@ -182,10 +182,10 @@ __device__ __forceinline__ u64 mul_lazy_x(u64 a, u64 b) {
     const u64 lo = (v << 32) | (u32)t;
     asm("v_mad_u64_u32 %0, %1, %2, -1, %3" : "=v"(z), "=s"(c) : "v"((u32)w), "v"(lo));
     asm(GL_SGPR_WAIT "v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r0), "=s"(bo) : "v"((u32)z), "v"((u32)(w >> 32)), "s"(c));
-    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cx) : "v"((u32)(z >> 32)), "s"(c));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r1a), "=s"(cx) : "v"((u32)(z >> 32)), "s"(c));
     asm(GL_SGPR_WAIT "v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r1), "=s"(br) : "v"(r1a), "s"(bo));
     asm(GL_SGPR_WAIT "v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(m) : "s"(br));
-    asm("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(q0), "=s"(k) : "v"(r0), "s"(br));
+    asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(q0), "=s"(k) : "v"(r0), "s"(br));
     asm(GL_SGPR_WAIT "v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(q1), "=s"(cx) : "v"(r1), "v"(m), "s"(k));
     return ((u64)q1 << 32) | q0;
 }

@@ -42,8 +42,10 @@ __device__ __forceinline__ void linear_hash_plain(const u64 *__restrict__ v, u32
     sponge(v, width, digest, m);
 }
 
-// three waves per SIMD (168 VGPRs); held to four (128 VGPRs, 114 spilled) it runs at the same rate
-__global__ void __launch_bounds__(256, 3) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int split, u64 *__restrict__ out) {
+// FOUR waves per SIMD: the permutation wants ~160 registers, so at 128 the compiler spills 130 of them to scratch -- and the kernel
+// is still 3.4 % faster than at three waves without spills (516 vs 534 ms at config 3, same box): the fourth wave covers the S-box
+// chains' carry wait states, and scratch traffic is cheap for a kernel at 0.3 TB/s (round 2's kernel ran at the same rate either way)
+__global__ void __launch_bounds__(256, 4) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int split, u64 *__restrict__ out) {
     const u64 row0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = row0 < height;
     const u64 row = live ? row0 : height - 1;       // width, split are uniform: every lane takes the same path

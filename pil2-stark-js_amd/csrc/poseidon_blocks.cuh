@@ -28,9 +28,59 @@ namespace gl {
 #undef POSEIDON_GL_RC_QUAL
 
 // (tools/sbox_bench.hip builds an experiment with the matrix instructions replaced by two vector operations: how much of the block is matrix-pipe time)
-#ifndef PBLK_MFMA
+#ifdef PBLK_MFMA
+#define PBLK_ASM_CHAIN 0
+#else
 #define PBLK_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0)
 #endif
+
+// Accumulator chains with the 2^30 bias as an INLINE CONSTANT of the first matrix instruction (srcC = 2.0, whose bit pattern is
+// 0x40000000) instead of sixteen registers holding it: hipcc has no way to say that, so the whole chain pair is one asm statement,
+// which then also has to keep the hazards the compiler would: two wait states after the vector writes of B, and the 8-pass
+// result's 11 before anything reads it (the numbers hipcc emits around the builtin form).
+#ifndef PBLK_ASM_CHAIN
+#define PBLK_ASM_CHAIN 1
+#endif
+__device__ __forceinline__ void blk_chain3(v16i &L, v16i &H, v4i a0, v4i a1, v4i a2, const v4i *Bl, const v4i *Bh) {
+#if PBLK_ASM_CHAIN
+    asm("s_nop 1\n\t"
+        "v_mfma_i32_32x32x32_i8 %0, %2, %5, 2.0\n\t"
+        "v_mfma_i32_32x32x32_i8 %1, %2, %8, 2.0\n\t"
+        "v_mfma_i32_32x32x32_i8 %0, %3, %6, %0\n\t"
+        "v_mfma_i32_32x32x32_i8 %1, %3, %9, %1\n\t"
+        "v_mfma_i32_32x32x32_i8 %0, %4, %7, %0\n\t"
+        "v_mfma_i32_32x32x32_i8 %1, %4, %10, %1\n\t"
+        "s_nop 10"
+        : "=&v"(L), "=&v"(H)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(Bl[0]), "v"(Bl[1]), "v"(Bl[2]), "v"(Bh[0]), "v"(Bh[1]), "v"(Bh[2]));
+#else
+    v16i bias;
+#pragma unroll
+    for (int i = 0; i < 16; i++) bias[i] = 0x40000000;
+    L = PBLK_MFMA(a0, Bl[0], bias); H = PBLK_MFMA(a0, Bh[0], bias);
+    L = PBLK_MFMA(a1, Bl[1], L);    H = PBLK_MFMA(a1, Bh[1], H);
+    L = PBLK_MFMA(a2, Bl[2], L);    H = PBLK_MFMA(a2, Bh[2], H);
+#endif
+}
+__device__ __forceinline__ void blk_chain4(v16i &L, v16i &H, v4i a0, v4i a1, v4i a2, v4i a3, const v4i *Bl, const v4i *Bh, v4i Dl, v4i Dh) {
+#if PBLK_ASM_CHAIN
+    asm("s_nop 1\n\t"
+        "v_mfma_i32_32x32x32_i8 %0, %2, %6, 2.0\n\t"
+        "v_mfma_i32_32x32x32_i8 %1, %2, %9, 2.0\n\t"
+        "v_mfma_i32_32x32x32_i8 %0, %3, %7, %0\n\t"
+        "v_mfma_i32_32x32x32_i8 %1, %3, %10, %1\n\t"
+        "v_mfma_i32_32x32x32_i8 %0, %4, %8, %0\n\t"
+        "v_mfma_i32_32x32x32_i8 %1, %4, %11, %1\n\t"
+        "v_mfma_i32_32x32x32_i8 %0, %5, %12, %0\n\t"
+        "v_mfma_i32_32x32x32_i8 %1, %5, %13, %1\n\t"
+        "s_nop 10"
+        : "=&v"(L), "=&v"(H)
+        : "v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(Bl[0]), "v"(Bl[1]), "v"(Bl[2]), "v"(Bh[0]), "v"(Bh[1]), "v"(Bh[2]), "v"(Dl), "v"(Dh));
+#else
+    blk_chain3(L, H, a0, a1, a2, Bl, Bh);
+    L = PBLK_MFMA(a3, Dl, L); H = PBLK_MFMA(a3, Dh, H);
+#endif
+}
 
 static constexpr int BLK_A_DWORDS = POSEIDON_BLK_OPERANDS * 64 * 4;
 
@@ -69,21 +119,21 @@ __device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m) {
             Bl[t][e] = (int)((u32)st[4 * t + e] ^ 0x80808080u);
             Bh[t][e] = (int)((u32)(st[4 * t + e] >> 32) ^ 0x80808080u);
         }
-    v16i init;
-#pragma unroll
-    for (int i = 0; i < 16; i++) init[i] = EXACT ? 128 * 256 : 0x40000000;
     const v4i a0 = A[0], a1 = A[64], a2 = A[128], a00 = A[192];
     u64 cm[12], any = 0;
 #pragma unroll
     for (int s = 0; s < 3; s++) {
-        v16i L = init, H = init;
+        v16i L, H;
+        // row set s multiplies K group t by the circulant's block (t - s) mod 3; row 0's own block carries the diagonal's 8
+        const v4i r0 = s == 0 ? a00 : (s == 1 ? a2 : a1), r1 = s == 0 ? a1 : (s == 1 ? a0 : a2), r2 = s == 0 ? a2 : (s == 1 ? a1 : a0);
+        if (EXACT) {
+            v16i init;
 #pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const int d = (t - s + 3) % 3;
-            const v4i a = (s == 0 && t == 0) ? a00 : (d == 0 ? a0 : (d == 1 ? a1 : a2));
-            L = PBLK_MFMA(a, Bl[t], L);
-            H = PBLK_MFMA(a, Bh[t], H);
-        }
+            for (int i = 0; i < 16; i++) init[i] = 128 * 256;
+            L = PBLK_MFMA(r0, Bl[0], init); H = PBLK_MFMA(r0, Bh[0], init);
+            L = PBLK_MFMA(r1, Bl[1], L);    H = PBLK_MFMA(r1, Bh[1], H);
+            L = PBLK_MFMA(r2, Bl[2], L);    H = PBLK_MFMA(r2, Bh[2], H);
+        } else blk_chain3(L, H, r0, r1, r2, Bl, Bh);
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             u32 xa = blk_pair(L[4 * ii], L[4 * ii + 1]), xc = blk_pair(L[4 * ii + 2], L[4 * ii + 3]);
@@ -122,19 +172,11 @@ __device__ __forceinline__ void poseidon_partial_block(u64 st[12], const u64 *__
             Bl[t][e] = (int)((u32)st[4 * t + e] ^ 0x80808080u);
             Bh[t][e] = (int)((u32)(st[4 * t + e] >> 32) ^ 0x80808080u);
         }
-    v16i bias;
-#pragma unroll
-    for (int i = 0; i < 16; i++) bias[i] = 0x40000000;
     // ---- the three later S-box inputs: row set 6 ----
     u64 d[4];
     {
-        v16i L = bias, H = bias;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const v4i a = A[(18 + t) * 64];
-            L = PBLK_MFMA(a, Bl[t], L);
-            H = PBLK_MFMA(a, Bh[t], H);
-        }
+        v16i L, H;
+        blk_chain3(L, H, A[18 * 64], A[19 * 64], A[20 * 64], Bl, Bh);
         // t_1: planes 0..3 at rows 0..3
         u64 X = (u64)blk_pair(L[2], L[3]) * m.sh16 + blk_pair(L[0], L[1]);
         u64 Y = (u64)blk_pair(H[2], H[3]) * m.sh16 + blk_pair(H[0], H[1]);
@@ -173,16 +215,7 @@ __device__ __forceinline__ void poseidon_partial_block(u64 st[12], const u64 *__
     // already fill the matrix pipe's shadow, tools/mfma_overlap.hip)
     u64 cm[12], any = 0;
     auto rowset = [&](int s, v16i &L, v16i &H) {
-        L = bias; H = bias;
-#pragma unroll
-        for (int t = 0; t < 3; t++) {
-            const v4i a = A[(3 * s + t) * 64];
-            L = PBLK_MFMA(a, Bl[t], L);
-            H = PBLK_MFMA(a, Bh[t], H);
-        }
-        const v4i a = A[(21 + s) * 64];
-        L = PBLK_MFMA(a, Dl, L);
-        H = PBLK_MFMA(a, Dh, H);
+        blk_chain4(L, H, A[(3 * s) * 64], A[(3 * s + 1) * 64], A[(3 * s + 2) * 64], A[(21 + s) * 64], Bl, Bh, Dl, Dh);
     };
     auto recombine = [&](int s, const v16i &L, const v16i &H) {
 #pragma unroll

@@ -434,6 +434,14 @@ def write_inc(rcf, chat):
         for row in rcf:
             f.write("    " + ", ".join("0x%016xull" % v for v in row) + ",\n")
         f.write("};\n")
+        # the same addends by WHERE the kernel adds them: biased layer k (rounds 0..3, 24, 25, 26..28) adds the addends of the S-boxes that follow it
+        assert NBLK * K == 20
+        lc = [rcf[1], rcf[2], rcf[3], [chat[0]] + [0] * 11, [chat[21]] + [0] * 11, rcf[4], rcf[5], rcf[6], rcf[7], [0] * 12]
+        f.write("// what biased layer k adds to its outputs: layers of rounds 0..3, 24, 25, 26..28, then a row of zeros (the parity tests' partial-rounds-only entry)\n")
+        f.write("POSEIDON_GL_RC_QUAL const uint64_t POSEIDON_BLK_LC[%d] = {\n" % (12 * len(lc)))
+        for row in lc:
+            f.write("    " + ", ".join("0x%016xull" % v for v in row) + ",\n")
+        f.write("};\n")
 
 
 def main():

@@ -45,7 +45,9 @@ __device__ __forceinline__ void linear_hash_plain(const u64 *__restrict__ v, u32
 // FOUR waves per SIMD: the permutation wants ~160 registers, so at 128 the compiler spills 130 of them to scratch -- and the kernel
 // is still 3.4 % faster than at three waves without spills (516 vs 534 ms at config 3, same box): the fourth wave covers the S-box
 // chains' carry wait states, and scratch traffic is cheap for a kernel at 0.3 TB/s (round 2's kernel ran at the same rate either way)
-__global__ void __launch_bounds__(256, 4) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int split, u64 *__restrict__ out) {
+// (SPLIT is a template parameter so that the plain kernel does not carry the split form's sixteen intermediate digest words)
+template <bool SPLIT>
+__global__ void __launch_bounds__(256, 4) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, u64 *__restrict__ out) {
     const u64 row0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = row0 < height;
     const u64 row = live ? row0 : height - 1;       // width, split are uniform: every lane takes the same path
@@ -53,7 +55,7 @@ __global__ void __launch_bounds__(256, 4) linear_hash_kernel(const u64 *__restri
     MdsMfma m;
     poseidon_init(m);
     u64 d[4];
-    if (!split || width <= 4) {
+    if (!SPLIT || width <= 4) {
         linear_hash_plain(v, (u32)width, d, m);
     } else {                                        // linearhash_gpu.js:30-66, glwasm.js:879-1087
         u32 w = (u32)width;
@@ -256,7 +258,8 @@ int pil2gl_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64_t hei
     if (width >= (1ull << 31)) return fail(PIL2GL_EINVAL, "row width too large");
     u64 blocks = (height + 255) / 256;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
-    linear_hash_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(in, width, height, split, out);
+    if (split) linear_hash_kernel<true><<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(in, width, height, out);
+    else linear_hash_kernel<false><<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(in, width, height, out);
     KERNEL_CHECK();
     return PIL2GL_OK;
 }

@@ -108,8 +108,10 @@ __device__ __forceinline__ u64 blk_combine_exact(u64 X, u64 Y) {
 // EXACT = false: biased accumulators like the blocks (the constant they leave is folded into the next S-box addends by the
 // generator); EXACT = true: accumulators start at 128*rowsum, the outputs are the true field elements (the permutation's last
 // layer).  Same values as mds_layer_mfma(), which keeps its operands in registers.
+// lc (biased form only): the twelve addends of whatever S-boxes come next (POSEIDON_BLK_LC), added here as two 64-bit additions
+// on X and Y -- inside the S-box the same addition is an add, an add of 2^32-1, a compare and two selects.
 template <bool EXACT>
-__device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m) {
+__device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m, const u64 *__restrict__ lc = nullptr) {
     const v4i *__restrict__ A = m.blkA + POSEIDON_BLK_LAYER_OPERAND * 64;
     v4i Bl[3], Bh[3];
 #pragma unroll
@@ -141,8 +143,9 @@ __device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m) {
             if (EXACT && s == 0 && ii == 0) {       // row 0's sum is 264, not 256: see mds_layer_mfma
                 xa += 1024u * 257u; xc += 1024u * 257u; ya += 1024u * 257u; yc += 1024u * 257u;
             }
-            const u64 X = (u64)xc * m.sh16 + xa;
-            const u64 Y = (u64)yc * m.sh16 + ya;
+            u64 X = (u64)xc * m.sh16 + xa;
+            u64 Y = (u64)yc * m.sh16 + ya;
+            if (!EXACT) { const u64 c = lc[4 * s + ii]; X += (u32)c; Y += c >> 32; }          // X, Y < 2^49 + 2^32
             const u64 tt = (u64)(u32)(Y >> 32) * EPS + X;
             u32 th;
             asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(th), "=s"(cm[4 * s + ii]) : "v"((u32)(tt >> 32)), "v"((u32)Y));
@@ -160,10 +163,11 @@ __device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m) {
     }
 }
 
-// one block of four partial rounds; c = the block's four S-box addends; A = this lane's column of the LDS operand table.
-// st[] any representatives in, any representatives out.  Like mds_layer_mfma: the whole wave must arrive together.
+// one block of four partial rounds; c = the block's four S-box addends, of which c[0] is already in st[0] (whoever produced st[]
+// added it), and c[4] = the addend of the S-box that follows the block, added to output 0 here; A = this lane's column of the
+// LDS operand table.  st[] any representatives in, any representatives out.  Like mds_layer_mfma: the whole wave must arrive together.
 __device__ __forceinline__ void poseidon_partial_block(u64 st[12], const u64 *__restrict__ c, const v4i *__restrict__ A, const MdsMfma &m) {
-    st[0] = sbox_one(add_lazy_canon(st[0], c[0]));
+    st[0] = sbox_one(st[0]);
     v4i Bl[3], Bh[3];
 #pragma unroll
     for (int t = 0; t < 3; t++)
@@ -227,9 +231,10 @@ __device__ __forceinline__ void poseidon_partial_block(u64 st[12], const u64 *__
             const u32 ah0 = blk_pair(H[o], H[o + 1]), ah1 = blk_pair(H[o + 2], H[o + 3]), ah2 = blk_pair(H[o + 4], H[o + 5]);
             const u32 e2 = al2 + ah0 + ah2, e3 = (u32)L[o + 6] + ah1 + (u32)H[o + 6];
             const int d0 = (int)(al0 - ah2), d1 = (int)(al1 - (u32)H[o + 6]);
-            const u64 X = (u64)((int64_t)d1 * (int)m.sh16 + d0);
-            const u64 Y = (u64)e3 * m.sh16 + e2;
-            const u64 tt = (u64)(u32)(Y >> 32) * EPS + X;              // 0 < tt < 2^49: Y_hi (2^32-1) >= 2^46 outweighs |X| < 2^45
+            u64 X = (u64)((int64_t)d1 * (int)m.sh16 + d0);
+            u64 Y = (u64)e3 * m.sh16 + e2;
+            if (s == 0 && ii == 0) { X += (u32)c[4]; Y += c[4] >> 32; }
+            const u64 tt = (u64)(u32)(Y >> 32) * EPS + X;              // 0 < tt < 2^49: Y_hi (2^32-1) >= 2^46 outweighs |X| < 2^45 (+ 2^32 with the addend)
             u32 th;
             asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(th), "=s"(cm[2 * s + ii]) : "v"((u32)(tt >> 32)), "v"((u32)Y));
             any |= cm[2 * s + ii];

@@ -67,6 +67,7 @@ __device__ __forceinline__ void mds_layer(u64 st[12]) {
 // S-box layers of the matrix-core form, on the 13-instruction products (pow7_b): a full layer is checked once, and a
 // wave in which some lane hit the rare borrow recomputes the layer with pow7_lazy (the branch is wave-uniform: every
 // lane recomputes, same values)
+// rc = nullptr (a compile-time fact at every call): the addends are already in st[] (mds_layer_lds put them there)
 template <int GROUP = POSEIDON_SBOX_GROUP>
 __device__ __forceinline__ void sbox_full(u64 st[12], const u64 *__restrict__ rc) {
     static_assert(12 % GROUP == 0, "group must divide the state");
@@ -74,7 +75,7 @@ __device__ __forceinline__ void sbox_full(u64 st[12], const u64 *__restrict__ rc
     for (int g = 0; g < 12; g += GROUP) {
         u64 bad = 0, in[GROUP];
 #pragma unroll
-        for (int i = 0; i < GROUP; i++) { in[i] = add_lazy_canon(st[g + i], rc[g + i]); st[g + i] = POSEIDON_POW7(in[i], bad); }
+        for (int i = 0; i < GROUP; i++) { in[i] = rc ? add_lazy_canon(st[g + i], rc[g + i]) : st[g + i]; st[g + i] = POSEIDON_POW7(in[i], bad); }
         if (__builtin_expect(bad != 0, 0)) {
 #pragma unroll
             for (int i = 0; i < GROUP; i++) st[g + i] = pow7_lazy(in[i]);
@@ -103,24 +104,27 @@ namespace gl {
 template <int NCANON = 12>
 __device__ __forceinline__ void poseidon_perm(u64 st[12], const MdsMfma &m) {
     const v4i *__restrict__ A = m.blkA;
+    // every S-box's addend but round 0's is added by the layer (or block) before it: POSEIDON_BLK_LC[k] = what layer k adds
+#pragma unroll
+    for (int i = 0; i < 12; i++) st[i] = add_lazy_canon(st[i], POSEIDON_BLK_RCF[i]);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) {
-        sbox_full(st, &POSEIDON_BLK_RCF[r * 12]);
-        mds_layer_lds<false>(st, m);
+        sbox_full(st, nullptr);
+        mds_layer_lds<false>(st, m, &POSEIDON_BLK_LC[r * 12]);
     }
 #pragma unroll 1
     for (int b = 0; b < POSEIDON_BLK_N; b++) poseidon_partial_block(st, &POSEIDON_BLK_C0[POSEIDON_BLK_K * b], A, m);
 #pragma unroll 1
     for (int r = POSEIDON_BLK_N * POSEIDON_BLK_K; r < 22; r++) {
-        st[0] = sbox_one(add_lazy_canon(st[0], POSEIDON_BLK_C0[r]));
-        mds_layer_lds<false>(st, m);
+        st[0] = sbox_one(st[0]);
+        mds_layer_lds<false>(st, m, &POSEIDON_BLK_LC[(4 + r - POSEIDON_BLK_N * POSEIDON_BLK_K) * 12]);
     }
 #pragma unroll 1
     for (int r = 4; r < 7; r++) {
-        sbox_full(st, &POSEIDON_BLK_RCF[r * 12]);
-        mds_layer_lds<false>(st, m);
+        sbox_full(st, nullptr);
+        mds_layer_lds<false>(st, m, &POSEIDON_BLK_LC[(r + 2) * 12]);
     }
-    sbox_full(st, &POSEIDON_BLK_RCF[7 * 12]);
+    sbox_full(st, nullptr);
     mds_layer_lds<true>(st, m);
 #pragma unroll
     for (int i = 0; i < NCANON; i++) st[i] = canon(st[i]);
@@ -155,12 +159,13 @@ __device__ inline void poseidon_partial_rounds(u64 st[12], const MdsMfma &m, int
     if (which == 0) {
 #pragma unroll
         for (int i = 0; i < 12; i++) st[i] = add_lazy_canon(st[i], POSEIDON_BLK_ERR_IN[i]);
+        st[0] = add_lazy_canon(st[0], POSEIDON_BLK_C0[0]);
 #pragma unroll 1
         for (int b = 0; b < POSEIDON_BLK_N; b++) poseidon_partial_block(st, &POSEIDON_BLK_C0[POSEIDON_BLK_K * b], m.blkA, m);
 #pragma unroll 1
         for (int r = POSEIDON_BLK_N * POSEIDON_BLK_K; r < 22; r++) {
-            st[0] = sbox_one(add_lazy_canon(st[0], POSEIDON_BLK_C0[r]));
-            mds_layer_lds<false>(st, m);
+            st[0] = sbox_one(st[0]);
+            mds_layer_lds<false>(st, m, &POSEIDON_BLK_LC[(r == 21 ? 9 : 4 + r - POSEIDON_BLK_N * POSEIDON_BLK_K) * 12]);     // row 9: zeros
         }
 #pragma unroll
         for (int i = 0; i < 12; i++) st[i] = sub(canon(st[i]), POSEIDON_BLK_ERR_OUT[i]);

@@ -18,12 +18,19 @@
 namespace gl {
 namespace fermat {
 
+// FERMAT_TIMING (never defined in the library build): cost-split experiments of tools/lde_cost_split.sh -- bit 0 butterflies without
+// carries, bit 1 every twiddle shift a register rotation, bit 2 no final reduction.  The results are WRONG; only the run time means anything.
+#ifndef FERMAT_TIMING
+#define FERMAT_TIMING 0
+#endif
+
 struct f128 { u32 w0, w1, w2, w3; };                 // value = w0 + w1 2^32 + w2 2^64 + (int)w3 2^96
 
 __device__ __forceinline__ f128 from_gl(u64 a) { return { (u32)a, (u32)(a >> 32), 0u, 0u }; }
 
 __device__ __forceinline__ f128 add(const f128 &a, const f128 &b) {
     f128 r;
+    if constexpr (FERMAT_TIMING & 1) { r.w0 = a.w0 + b.w0; r.w1 = a.w1 + b.w1; r.w2 = a.w2 + b.w2; r.w3 = a.w3 + b.w3; return r; }
     asm("v_add_co_u32 %0, vcc, %4, %8\n\tv_addc_co_u32 %1, vcc, %5, %9, vcc\n\tv_addc_co_u32 %2, vcc, %6, %10, vcc\n\tv_addc_co_u32 %3, vcc, %7, %11, vcc"
         : "=&v"(r.w0), "=&v"(r.w1), "=&v"(r.w2), "=&v"(r.w3)
         : "v"(a.w0), "v"(a.w1), "v"(a.w2), "v"(a.w3), "v"(b.w0), "v"(b.w1), "v"(b.w2), "v"(b.w3) : "vcc");
@@ -31,6 +38,7 @@ __device__ __forceinline__ f128 add(const f128 &a, const f128 &b) {
 }
 __device__ __forceinline__ f128 sub(const f128 &a, const f128 &b) {
     f128 r;
+    if constexpr (FERMAT_TIMING & 1) { r.w0 = a.w0 - b.w0; r.w1 = a.w1 - b.w1; r.w2 = a.w2 - b.w2; r.w3 = a.w3 - b.w3; return r; }
     asm("v_sub_co_u32 %0, vcc, %4, %8\n\tv_subb_co_u32 %1, vcc, %5, %9, vcc\n\tv_subb_co_u32 %2, vcc, %6, %10, vcc\n\tv_subb_co_u32 %3, vcc, %7, %11, vcc"
         : "=&v"(r.w0), "=&v"(r.w1), "=&v"(r.w2), "=&v"(r.w3)
         : "v"(a.w0), "v"(a.w1), "v"(a.w2), "v"(a.w3), "v"(b.w0), "v"(b.w1), "v"(b.w2), "v"(b.w3) : "vcc");
@@ -41,6 +49,7 @@ __device__ __forceinline__ f128 sub(const f128 &a, const f128 &b) {
 template <int S>
 __device__ __forceinline__ f128 shl(const f128 &v) {
     static_assert(S > 0 && S < 96, "shift out of range");
+    if constexpr (FERMAT_TIMING & 2) return { v.w1, v.w2, v.w3, v.w0 };
     constexpr int q = S / 32, r = S % 32;
     // t = v << r as five words (t4 carries the sign)
     u32 t0, t1, t2, t3, t4;
@@ -70,6 +79,7 @@ __device__ __forceinline__ f128 shl(const f128 &v) {
 // any representative with |v| < 2^101 -> lazy field element:  (w1:w0) + w2 (2^32-1) - w3, with w3 biased by 32 to
 // keep it unsigned and the bias (32 * 2^96 = -32) returned through the multiply-add's addend
 __device__ __forceinline__ u64 to_gl_lazy(const f128 &v) {
+    if constexpr (FERMAT_TIMING & 4) return (((u64)v.w1 << 32) | v.w0) ^ (((u64)v.w3 << 32) | v.w2);
 #ifndef GL_FERMAT_TO_GL_ASM
     const u64 lo = ((u64)v.w1 << 32) | v.w0;
     const u32 hh = v.w3 + 32u;

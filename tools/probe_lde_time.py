@@ -1,0 +1,20 @@
+"""config-3 interpolate timed for one build of the library (PIL2GL_LIB): same-call A/B of kernel variants"""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
+import pil2gl
+pil2gl.init(0)
+nBits = int(os.environ.get("NBITS", 24)); C = int(os.environ.get("NCOLS", 100)); eb = 3
+N, E = 1 << nBits, 1 << (nBits + eb)
+src = torch.randint(0, 2**62, (N * C,), dtype=torch.int64, device="cuda")
+dst = torch.empty(E * C, dtype=torch.int64, device="cuda")
+def timeit(fn, n=3):
+    fn(); torch.cuda.synchronize()
+    s = torch.cuda.Event(enable_timing=True); e = torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+for rnd in range(2):
+    print("%s: interpolate %.2f ms" % (os.path.basename(os.environ.get("PIL2GL_LIB", "in-tree")), timeit(lambda: pil2gl.interpolate(src, C, nBits, dst, nBits + eb))), flush=True)

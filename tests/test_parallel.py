@@ -1,5 +1,5 @@
 """Multi-process extendAndMerkelize: the cosets of the extension are split across ranks and only leaf
-digests are exchanged.  CPU: world_size 2 and 4 over gloo on the checker backend.  GPU: 2 ranks driving the HIP library on
+digests are exchanged.  CPU: world_size 2, 4 and 8 (one coset per rank, the driver's largest launch) over gloo on the checker backend.  GPU: 2 ranks driving the HIP library on
 the one card of the box (gloo exchange; the nccl path differs only in where the gathered tensor lives)."""
 import os
 import socket
@@ -48,7 +48,7 @@ def test_coset_range_partition():
         parallel.coset_range(0, 3, 3)
 
 
-@pytest.mark.parametrize("world,split", [(2, 0), (4, 1)])
+@pytest.mark.parametrize("world,split", [(2, 0), (4, 1), (8, 0)])
 def test_sharded_commit_gloo_cpu(oracle, world, split):
     _launch(world, "--backend", "oracle", "--nbits", "5", "--extbits", "3", "--npols", "5", "--split", str(split))
 
@@ -59,7 +59,7 @@ def test_sharded_commit_gpu_ranks(oracle, world, nbits, npols):
     _launch(world, "--backend", "gpu", "--nbits", str(nbits), "--extbits", "3", "--npols", str(npols))
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_sharded_proof_equals_single_process_proof_cpu(oracle, world):
     """one proof over `world` ranks (commit, constraint evaluation and FRI polynomial split by cosets; q, evaluations and
     the FRI polynomial exchanged): every rank ends with the proof of the ordinary prove loop, bit for bit"""

@@ -394,6 +394,7 @@ extern "C" int pil2gl_debug_compact_program(const glx_program *prog, glx_op *out
 // program and cached.  Long programs on large domains take this path; short ones use the interpreter above.
 #include <hip/hiprtc.h>
 #include <sstream>
+#include <set>
 #include <string>
 
 static const char *kFieldSrc =
@@ -413,7 +414,7 @@ void jit_clear() {
 }
 }
 
-static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx_ctx *ctx) {
+static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx_ctx *ctx, bool allowStage = true) {
     std::ostringstream o;
     // no #include: hiprtc pre-includes its built-in device runtime header; only the fixed-width typedefs are needed
     o << "typedef unsigned long uint64_t; typedef unsigned int uint32_t; typedef long int64_t; typedef int int32_t;\n" << kFieldSrc << "\nusing namespace gl;\n";
@@ -430,11 +431,82 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
     // at config 3).  Short programs keep the inlined form.  PIL2GL_EXPR_MULCALL=0|1 overrides.
     const char *mcEnv = getenv("PIL2GL_EXPR_MULCALL");
     const bool mulCall = mcEnv ? mcEnv[0] == '1' : ops.size() >= 200;
-    const std::string MUL = mulCall ? "mul_call(" : "mul(";
-    if (mulCall) o << "__device__ __noinline__ u64 mul_call(u64 a, u64 b) { return mul(a, b); }\n";
+    // The products are the carry-out form of gl_field.cuh (mul_lazy_x: 15 instructions, any representatives in, a lazy one out).
+    // A product whose every reader is another product or a lazy multiply-accumulate stays lazy; one that is added, subtracted,
+    // copied or stored is made canonical (four more instructions).  PIL2GL_EXPR_LAZYMUL=0: every product canonical, hipcc's form.
+    const char *lzEnv = getenv("PIL2GL_EXPR_LAZYMUL");
+    const bool lazyMul = !(lzEnv && lzEnv[0] == '0');
+    const std::string MULC = mulCall ? "mul_call(" : (lazyMul ? "canon(mul_lazy_x(" : "mul("), MULC_END = (!mulCall && lazyMul) ? "))" : ")";
+    const std::string MULL = !lazyMul ? MULC : (mulCall ? "mull_call(" : "mul_lazy_x("), MULL_END = !lazyMul ? MULC_END : ")";
+    if (mulCall) {
+        o << "__device__ __noinline__ u64 mul_call(u64 a, u64 b) { return " << (lazyMul ? "canon(mul_lazy_x(a, b))" : "mul(a, b)") << "; }\n";
+        if (lazyMul) o << "__device__ __noinline__ u64 mull_call(u64 a, u64 b) { return mul_lazy_x(a, b); }\n";
+    }
+    // lazyOK[k]: op k writes a temporary that only products and multiply-accumulates read before the slot is written again
+    std::vector<bool> lazyOK(ops.size(), false);
+    for (size_t k = 0; k < ops.size(); k++) {
+        const IOp &p = ops[k];
+        if (p.op != GLX_OP_MUL || p.dest.kind != GLX_TMP || (p.src[0].dim == 3 && p.src[1].dim == 3)) continue;
+        bool ok = true, live = true;
+        for (size_t j = k + 1; j < ops.size() && ok && live; j++) {
+            const IOp &q = ops[j];
+            for (int t = 0; t < n_src(q.op); t++) {
+                if (q.src[t].kind != GLX_TMP || q.src[t].index != p.dest.index) continue;
+                const bool tolerant = q.op == GLX_LZ_MAD || (q.op == GLX_OP_MUL && !(q.src[0].dim == 3 && q.src[1].dim == 3));
+                ok &= tolerant;
+            }
+            if (has_dest(q.op) && q.dest.kind == GLX_TMP && q.dest.index == p.dest.index) live = false;
+        }
+        lazyOK[k] = ok;
+    }
+    // PIL2GL_EXPR_STAGE=1 (an experiment, NOT the default): reads of WIDE sections through LDS.  A lane owns a row, so a direct read of
+    // column c touches 64 different cache lines for 8 bytes each, and the other 15 columns of those lines are wanted only so much
+    // later that the lines have left the L2 by then (config 3: 224 GB read for a 107 GB trace).  Staged, a wave copies a block of
+    // 16 columns of its rows -- and of the rows its row offsets reach -- into its own LDS tile with full-line reads (16 lanes per
+    // row) when the program first asks for a column of that block, and the lanes then read their operands from the tile: every
+    // line is read once.  One tile per wave: a program that keeps changing blocks restages every time, so the generator counts
+    // and falls back to direct reads when that gets silly, as it does for sections the program also writes, for offsets further
+    // than STAGE_MAX_SPAN rows apart and for domains under 256 rows.  Measured at config 3 (tools/probe_expr_ab.py, one box): 48.5 ms
+    // against 40.0 with direct reads -- the seven synchronous tile fills per wave cost more than the re-reads, which the other
+    // waves hide; a second tile per wave to fill ahead does not fit beside four waves per SIMD.  Kept because it is bit-exact,
+    // tested, and the right shape for a program with fewer operations per operand.
+    constexpr int STAGE_COLS = 16, STAGE_PITCH = 17, STAGE_MAX_SPAN = 32;
+    const char *stEnv = getenv("PIL2GL_EXPR_STAGE");
+    bool staging = allowStage && stEnv && stEnv[0] == '1' && ctx->nBits >= 8;
+    std::vector<bool> stagedSec(GLX_MAX_SECTIONS, false);
+    int64_t omin = 0, omax = 0;
+    if (staging) {
+        std::vector<bool> written(GLX_MAX_SECTIONS, false);
+        for (const IOp &p : ops) if (has_dest(p.op) && p.dest.kind == GLX_SEC) written[p.dest.section] = true;
+        bool any = false;
+        for (const IOp &p : ops)
+            for (int t = 0; t < n_src(p.op); t++) {
+                const glx_ref &r = p.src[t];
+                if (r.kind != GLX_SEC || written[r.section] || ctx->sections[r.section].width < (u64)STAGE_COLS) continue;
+                const int64_t off = (int64_t)r.prime * ((int64_t)1 << ctx->primeShift);
+                if (!any) { omin = omax = off; any = true; }
+                omin = std::min(omin, off); omax = std::max(omax, off);
+                stagedSec[r.section] = true;
+            }
+        if (!any || omax - omin > STAGE_MAX_SPAN) staging = false;
+    }
+    const int64_t stageRows = (64 + (omax - omin) + 3) / 4 * 4;
+    if (staging) {
+        const int64_t trips = stageRows * STAGE_COLS / 64;                      // stageRows is a multiple of 4; constant, so the loops unroll
+        o << "__device__ __noinline__ void stage_call(u64 *W, const u64 *g, u64 row0, u64 mask, u64 width, u32 nc) {\n"
+          << " const u32 lane = threadIdx.x & 63, c = lane & 15, r0 = lane >> 4; u64 v[" << trips << "];\n"
+          << " if (c < nc) {\n"
+          << "  _Pragma(\"unroll\") for (u32 j = 0; j < " << trips << "u; j++) v[j] = g[((row0 + r0 + 4 * j) & mask) * width + c];\n"
+          << "  _Pragma(\"unroll\") for (u32 j = 0; j < " << trips << "u; j++) W[(r0 + 4 * j) * " << STAGE_PITCH << " + c] = v[j];\n"
+          << " } }\n";
+    }
     o << "extern \"C\" __global__ void __launch_bounds__(256) jit_eval(JitArgs A) {\n";
     o << " const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (row >= (1ull << A.nBits)) return;\n";
     o << " const u64 mask = (1ull << A.nBits) - 1; const u64 *__restrict__ SC = A.scalars; const u32 *__restrict__ LM = A.limbs;\n";
+    if (staging) {
+        o << " __shared__ u64 STG_[4][" << stageRows * STAGE_PITCH << "]; u64 *W_ = STG_[threadIdx.x >> 6]; const u32 lane_ = threadIdx.x & 63;\n";
+        o << " const u64 row0_ = row - lane_ + (u64)(" << omin << "ll); const u64 *WL_ = W_ + lane_ * " << STAGE_PITCH << ";\n";
+    }
     o << " u64 LZ[3][6];\n";
     for (u32 s = 0; s < nSlots; s++) o << " u64 t" << s << "_0 = 0, t" << s << "_1 = 0, t" << s << "_2 = 0;\n";
     auto addr = [&](const glx_ref &r) {
@@ -443,23 +515,51 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
         a << "A.sec[" << r.section << "] + ((row + (u64)(" << off << "ll)) & mask) * " << ctx->sections[r.section].width << "ull + " << r.index;
         return a.str();
     };
+    int curSec = -1; int64_t curBlk = -1; u32 nStages = 0;
+    std::set<std::pair<int, int64_t>> blocksSeen;
+    // the block holding every component of a staged read, or -1 (not staged / straddles two blocks: read directly)
+    auto block_of = [&](const glx_ref &r) -> int64_t {
+        if (!staging || r.kind != GLX_SEC || !stagedSec[r.section]) return -1;
+        const int64_t b0 = r.index / STAGE_COLS, b1 = (r.index + r.dim - 1) / STAGE_COLS;
+        return b0 == b1 ? b0 : -1;
+    };
+    auto stage = [&](const glx_ref &r) {            // make the tile hold r's block
+        const int64_t b = block_of(r);
+        if (b < 0 || (curSec == (int)r.section && curBlk == b)) return;
+        const u64 width = ctx->sections[r.section].width;
+        const int64_t nc = std::min<int64_t>(STAGE_COLS, (int64_t)width - b * STAGE_COLS);
+        // a CALL: the tile's reads in flight (18 values for 72 rows) then live in the callee, not across the caller's other calls, and
+        // the call orders the caller's tile reads against the callee's writes for the compiler; the LDS unit keeps one wave's
+        // instructions in order, which is all the ordering lanes of one wave need
+        o << " stage_call(W_, A.sec[" << r.section << "] + " << b * STAGE_COLS << ", row0_, mask, " << width << "ull, " << nc << "u);\n";
+        curSec = (int)r.section; curBlk = b; nStages++; blocksSeen.insert({ curSec, b });
+    };
     auto rd = [&](const glx_ref &r, int c) {        // component c of an operand (0 beyond its dim)
         std::ostringstream a;
         if (c >= (int)r.dim) { a << "0ull"; return a.str(); }
         if (r.kind == GLX_TMP) a << "t" << r.index << "_" << c;
         else if (r.kind == GLX_SCALAR) a << "SC[" << (r.index + c) << "]";
-        else a << "(" << addr(r) << ")[" << c << "]";
+        else if (block_of(r) >= 0) {
+            const int64_t off = (int64_t)r.prime * ((int64_t)1 << ctx->primeShift);
+            a << "WL_[" << (off - omin) * STAGE_PITCH + (int64_t)((r.index + c) % STAGE_COLS) << "]";
+        } else a << "(" << addr(r) << ")[" << c << "]";
         return a.str();
     };
     for (size_t k = 0; k < ops.size(); k++) {
         const IOp &p = ops[k];
         if (p.op == GLX_LZ_BEGIN) { o << " for (int q = 0; q < 3; q++) for (int i = 0; i < 6; i++) LZ[q][i] = 0;\n"; continue; }
         if (p.op == GLX_LZ_MAD) {
+            stage(p.src[0]);
             o << " lz_mad(LZ, " << rd(p.src[0], 0) << ", LM + " << p.aux << ");";
             if (p.src[0].dim == 3) o << " lz_mad(LZ, " << rd(p.src[0], 1) << ", LM + " << p.aux + 9 << "); lz_mad(LZ, " << rd(p.src[0], 2) << ", LM + " << p.aux + 18 << ");";
             o << "\n"; continue;
         }
         const glx_ref &a = p.src[0], &b = p.src[1];
+        if (n_src(p.op) >= 1) stage(a);
+        if (n_src(p.op) == 2 && block_of(b) >= 0) {
+            if (block_of(a) >= 0 && (a.section != b.section || block_of(a) != block_of(b))) return jit_source(ops, nSlots, ctx, false);   // two tiles at once: not this generator
+            stage(b);
+        }
         std::string r[3];
         const u32 da = a.dim, db = b.dim;
         switch (p.op) {
@@ -476,8 +576,11 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
             if (da == 3 && db == 3) {
                 o << " { E3 x_ = { { " << rd(a, 0) << ", " << rd(a, 1) << ", " << rd(a, 2) << " } }, y_ = { { " << rd(b, 0) << ", " << rd(b, 1) << ", " << rd(b, 2) << " } }; E3 z_ = e3_mul_call(x_, y_);";
                 r[0] = "z_.v[0]"; r[1] = "z_.v[1]"; r[2] = "z_.v[2]";
-            } else if (da == 3) { for (int c = 0; c < 3; c++) r[c] = MUL + rd(a, c) + ", " + rd(b, 0) + ")"; }
-            else { for (int c = 0; c < 3; c++) r[c] = c < (int)db || c == 0 ? MUL + rd(a, 0) + ", " + rd(b, c) + ")" : "0ull"; }
+            } else {
+                const std::string &M = lazyOK[k] ? MULL : MULC, &ME = lazyOK[k] ? MULL_END : MULC_END;
+                if (da == 3) { for (int c = 0; c < 3; c++) r[c] = M + rd(a, c) + ", " + rd(b, 0) + ME; }
+                else { for (int c = 0; c < 3; c++) r[c] = c < (int)db || c == 0 ? M + rd(a, 0) + ", " + rd(b, c) + ME : "0ull"; }
+            }
             break;
         default: for (int c = 0; c < 3; c++) r[c] = rd(a, c); break;     // copy
         }
@@ -494,6 +597,7 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
         }
     }
     o << "}\n";
+    if (staging && nStages > 3 * blocksSeen.size() + 4) return jit_source(ops, nSlots, ctx, false);     // the program hops between blocks: direct reads
     return o.str();
 }
 
@@ -511,6 +615,9 @@ static std::string jit_arch() {
 }
 
 static int jit_build(const std::string &src, std::vector<char> &code) {
+    if (const char *dump = getenv("PIL2GL_EXPR_DUMP")) {        // debugging aid: the generated kernel's source, last program compiled
+        if (FILE *f = fopen(dump, "w")) { fwrite(src.data(), 1, src.size(), f); fclose(f); }
+    }
     hiprtcProgram prog;
     if (hiprtcCreateProgram(&prog, src.c_str(), "pil2gl_expr.hip", 0, nullptr, nullptr) != HIPRTC_SUCCESS) return fail(PIL2GL_EHIP, "hiprtcCreateProgram failed");
     const std::string arch = "--offload-arch=" + jit_arch();
@@ -605,6 +712,8 @@ extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *c
             for (u32 i = 0; i < ctx->nSections; i++) A.sec[i] = ctx->sections[i].ptr;
             size_t asz = sizeof A;
             void *cfg[] = { HIP_LAUNCH_PARAM_BUFFER_POINTER, &A, HIP_LAUNCH_PARAM_BUFFER_SIZE, &asz, HIP_LAUNCH_PARAM_END };
+            // (held to fewer resident waves by padding with unused LDS, the config-3 constraint kernel does not get faster: 39.8 ms at
+            // five and four waves per SIMD, 48.6 at two, 84.5 at one -- its 2x re-read of the trace is not an occupancy effect)
             HIP_TRY(hipModuleLaunchKernel(fn, (unsigned)((nRows + 255) / 256), 1, 1, 256, 1, 1, 0, st, nullptr, cfg));
             HIP_TRY(hipStreamSynchronize(st));
             return PIL2GL_OK;

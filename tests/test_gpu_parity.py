@@ -1079,17 +1079,20 @@ def test_rows_and_cols_dot_ext(gl, oracle, monkeypatch, mode):
             assert out[l, c].tolist() == oracle.eval_pol_at(buf, c, 1, nb, eb, levs[l]).tolist()
 
 
-@pytest.mark.parametrize("jit", ["0", "1"])
+@pytest.mark.parametrize("jit", ["0", "1", "staged"])
 def test_expression_evaluator_interpreter_and_jit_agree(gl, oracle, jit, monkeypatch):
-    """the same random programs through the interpreter (PIL2GL_EXPR_JIT=0) and the hiprtc-compiled kernel (=1)"""
+    """the same random programs through the interpreter (PIL2GL_EXPR_JIT=0), the hiprtc-compiled kernel (=1) and the compiled
+    kernel with its wide-section reads staged through LDS tiles (PIL2GL_EXPR_STAGE=1; sections of 20 and 33 columns, row offsets -2..2)"""
     import torch
     import ctypes as C
     from pil2gl import _lib
-    monkeypatch.setenv("PIL2GL_EXPR_JIT", jit)
+    monkeypatch.setenv("PIL2GL_EXPR_JIT", "0" if jit == "0" else "1")
+    if jit == "staged":
+        monkeypatch.setenv("PIL2GL_EXPR_STAGE", "1")
     for n_ops, prime_shift in [(40, 0), (300, 2)]:
         rng = np.random.default_rng(1000 + n_ops)
         n_bits = 10
-        widths = [5, 9, 1, 3]
+        widths = [5, 9, 1, 3] if jit != "staged" else [20, 33, 1, 3]
         secs = [rand_field(rng, (1 << n_bits, w)) for w in widths]; secs[-1][:] = 0
         scalars = rand_field(rng, 40)
         ops, n_tmp = _random_program(rng, n_ops, widths, scalars.size, len(widths) - 1)
@@ -1104,6 +1107,54 @@ def test_expression_evaluator_interpreter_and_jit_agree(gl, oracle, jit, monkeyp
         _lib.call("pil2gl_eval_program_dev", C.byref(prog), C.byref(ctx), None)
         torch.cuda.synchronize()
         assert (dsecs[-1].cpu().numpy().view(np.uint64).reshape(ref_secs[-1].shape) == ref_secs[-1]).all()
+
+
+@pytest.mark.parametrize("mulcall", ["0", "1"])
+def test_compiled_evaluator_lazy_products_reach_their_readers_non_canonical(gl, oracle, mulcall, monkeypatch):
+    """the run-time compiled kernel keeps a product lazy when only products and fused multiply-accumulates read it.  Random
+    operands give a representative >= p once in 2^32; here (2^32+1)(2^32-1) = 2^64-1 does in every row where the columns hold
+    those two, so the readers -- a product, a dim-3 scaling, a Horner chain fused into lazy multiply-accumulates -- all see it"""
+    import torch
+    import ctypes as C
+    from pil2gl import _lib
+    from gl_oracle import TMP, SEC, SCALAR
+    monkeypatch.setenv("PIL2GL_EXPR_JIT", "1")
+    monkeypatch.setenv("PIL2GL_EXPR_MULCALL", mulcall)
+    rng = np.random.default_rng(77)
+    n_bits = 8
+    widths = [6, 3, 3]
+    secs = [rand_field(rng, (1 << n_bits, w)) for w in widths]; secs[-1][:] = 0
+    secs[0][::2, 0] = (1 << 32) + 1; secs[0][::2, 1] = (1 << 32) - 1          # product 2^64 - 1 in the even rows
+    secs[0][1::4, 0] = P - 1; secs[0][1::4, 1] = P - 1                          # and (-1)(-1) = 1 via the largest operands
+    scalars = rand_field(rng, 12)
+    T = lambda i, d=1: (TMP, d, 0, 0, i)
+    S = lambda c, d=1, sec=0: (SEC, d, sec, 0, c)
+    ops = [("mul", T(0), S(0), S(1)),                  # lazy: read by products and multiply-accumulates only
+           ("mul", T(1), T(0), S(2)),                  # product of a lazy value (itself read by an addition: canonical)
+           ("mul", T(2, 3), S(0, 3, 1), T(0)),         # dim 3 x lazy dim 1
+           ("add", T(3), T(1), S(3))]
+    # Horner chain over the extension scalar X = scalars[0..2] with the lazy product as every c_i:  t <- X t + c
+    acc = 2
+    for i in range(6):
+        ops.append(("mul", T(4 + 2 * i, 3), (SCALAR, 3, 0, 0, 0), T(acc, 3)))
+        ops.append(("add", T(5 + 2 * i, 3), T(4 + 2 * i, 3), T(0) if i % 2 == 0 else T(1)))
+        acc = 5 + 2 * i
+    ops.append(("mul", T(16, 3), T(acc, 3), T(3)))
+    ops.append(("copy", (SEC, 3, 2, 0, 0), T(16, 3), None))
+    n_tmp = 17
+    ref = [x.copy() for x in secs]
+    oracle.eval_program(ops, n_tmp, ref, scalars, n_bits, 0)
+    dsecs = [torch.from_numpy(x.view(np.int64)).cuda() for x in secs]
+    prog = oracle.make_program(ops, n_tmp, struct_op=_lib.GlxOp, struct_prog=_lib.GlxProgram)
+    csecs = (_lib.GlxSection * len(dsecs))()
+    for i, x in enumerate(dsecs):
+        csecs[i].ptr = x.data_ptr(); csecs[i].width = widths[i]
+    ctx = _lib.GlxCtx(n_bits, 0, len(dsecs), scalars.size, csecs, scalars.ctypes.data_as(_lib.u64p))
+    _lib.call("pil2gl_eval_program_dev", C.byref(prog), C.byref(ctx), None)
+    torch.cuda.synchronize()
+    got = dsecs[-1].cpu().numpy().view(np.uint64).reshape(ref[-1].shape)
+    assert (got < np.uint64(P)).all()
+    assert (got == ref[-1]).all()
 
 
 def test_pols_file_to_device_and_back(gl, tmp_path):

@@ -459,22 +459,29 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
         }
         lazyOK[k] = ok;
     }
-    // PIL2GL_EXPR_STAGE=1 (an experiment, NOT the default): reads of WIDE sections through LDS.  A lane owns a row, so a direct read of
-    // column c touches 64 different cache lines for 8 bytes each, and the other 15 columns of those lines are wanted only so much
-    // later that the lines have left the L2 by then (config 3: 224 GB read for a 107 GB trace).  Staged, a wave copies a block of
-    // 16 columns of its rows -- and of the rows its row offsets reach -- into its own LDS tile with full-line reads (16 lanes per
-    // row) when the program first asks for a column of that block, and the lanes then read their operands from the tile: every
-    // line is read once.  One tile per wave: a program that keeps changing blocks restages every time, so the generator counts
-    // and falls back to direct reads when that gets silly, as it does for sections the program also writes, for offsets further
-    // than STAGE_MAX_SPAN rows apart and for domains under 256 rows.  Measured at config 3 (tools/probe_expr_ab.py, one box): 48.5 ms
-    // against 40.0 with direct reads -- the seven synchronous tile fills per wave cost more than the re-reads, which the other
-    // waves hide; a second tile per wave to fill ahead does not fit beside four waves per SIMD.  Kept because it is bit-exact,
-    // tested, and the right shape for a program with fewer operations per operand.
-    constexpr int STAGE_COLS = 16, STAGE_PITCH = 17, STAGE_MAX_SPAN = 32;
+    // PIL2GL_EXPR_STAGE=1 (an experiment, NOT the default): reads of WIDE sections through LDS tiles that are filled AHEAD.  A lane owns
+    // a row, so a direct read of column c touches 64 different cache lines for 8 bytes each, and the other columns of those lines
+    // are wanted only so much later that the lines have left the L2 by then (config 3: 236 GB requested for a 107 GB trace).  Staged,
+    // a wave owns two tiles of STAGE_COLS columns x the rows it and its row offsets reach.  The generator knows the order in which
+    // the program walks the column blocks, so at the first read of block i the kernel waits for tile i%2 (requested one block
+    // earlier), requests block i+1 into the other tile with direct-to-LDS loads (global_load_lds_dwordx4: 16 bytes per lane, 16
+    // rows of 64 bytes per instruction, no registers, nothing waits) and goes on computing; every operand read is then one ds_read
+    // at a constant offset from a per-lane base.  LDS slot l of a fill belongs to lane l, so the lane chooses WHICH 16 bytes it
+    // fetches: row 16j + l/4, column pair (l%4) ^ ((l/16)%4) -- the swizzle that spreads a column's 64 rows over all banks (the
+    // counters show no bank conflict).
+    // Why it is not the default (tools/pmc_expr.sh, config 3): bit-exact, no register cost to speak of (116 against 100), and 47.0 ms
+    // against 39.2 -- because the requests did NOT go down (249 GB): a 64-byte row piece still costs its whole 128-byte line, and the
+    // line's other half is requested one block (5 us) later, after the L2 has turned over.  Full lines need 16-column tiles, and two
+    // of those per wave leave room for two waves per SIMD, where this kernel is slower than its re-reads cost (a synchronous single
+    // 16-column tile was tried first: 48.5 ms).  Only a tiled trace layout removes the re-reads.
+    // Not staged in any case: sections the program also writes, odd or narrow (< STAGE_COLS) widths, offsets further than
+    // STAGE_MAX_SPAN rows apart, domains under 256 rows, reads that straddle two blocks, programs that hop between blocks.
+    constexpr int STAGE_COLS = 8, STAGE_MAX_SPAN = 32;
     const char *stEnv = getenv("PIL2GL_EXPR_STAGE");
     bool staging = allowStage && stEnv && stEnv[0] == '1' && ctx->nBits >= 8;
     std::vector<bool> stagedSec(GLX_MAX_SECTIONS, false);
     int64_t omin = 0, omax = 0;
+    auto row_off = [&](const glx_ref &r) { return (int64_t)r.prime * ((int64_t)1 << ctx->primeShift); };
     if (staging) {
         std::vector<bool> written(GLX_MAX_SECTIONS, false);
         for (const IOp &p : ops) if (has_dest(p.op) && p.dest.kind == GLX_SEC) written[p.dest.section] = true;
@@ -482,57 +489,88 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
         for (const IOp &p : ops)
             for (int t = 0; t < n_src(p.op); t++) {
                 const glx_ref &r = p.src[t];
-                if (r.kind != GLX_SEC || written[r.section] || ctx->sections[r.section].width < (u64)STAGE_COLS) continue;
-                const int64_t off = (int64_t)r.prime * ((int64_t)1 << ctx->primeShift);
+                const u64 w = r.kind == GLX_SEC ? ctx->sections[r.section].width : 0;
+                if (r.kind != GLX_SEC || written[r.section] || w < (u64)STAGE_COLS || (w & 1)) continue;
+                const int64_t off = row_off(r);
                 if (!any) { omin = omax = off; any = true; }
                 omin = std::min(omin, off); omax = std::max(omax, off);
                 stagedSec[r.section] = true;
             }
         if (!any || omax - omin > STAGE_MAX_SPAN) staging = false;
     }
-    const int64_t stageRows = (64 + (omax - omin) + 3) / 4 * 4;
-    if (staging) {
-        const int64_t trips = stageRows * STAGE_COLS / 64;                      // stageRows is a multiple of 4; constant, so the loops unroll
-        o << "__device__ __noinline__ void stage_call(u64 *W, const u64 *g, u64 row0, u64 mask, u64 width, u32 nc) {\n"
-          << " const u32 lane = threadIdx.x & 63, c = lane & 15, r0 = lane >> 4; u64 v[" << trips << "];\n"
-          << " if (c < nc) {\n"
-          << "  _Pragma(\"unroll\") for (u32 j = 0; j < " << trips << "u; j++) v[j] = g[((row0 + r0 + 4 * j) & mask) * width + c];\n"
-          << "  _Pragma(\"unroll\") for (u32 j = 0; j < " << trips << "u; j++) W[(r0 + 4 * j) * " << STAGE_PITCH << " + c] = v[j];\n"
-          << " } }\n";
-    }
-    o << "extern \"C\" __global__ void __launch_bounds__(256) jit_eval(JitArgs A) {\n";
-    o << " const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (row >= (1ull << A.nBits)) return;\n";
-    o << " const u64 mask = (1ull << A.nBits) - 1; const u64 *__restrict__ SC = A.scalars; const u32 *__restrict__ LM = A.limbs;\n";
-    if (staging) {
-        o << " __shared__ u64 STG_[4][" << stageRows * STAGE_PITCH << "]; u64 *W_ = STG_[threadIdx.x >> 6]; const u32 lane_ = threadIdx.x & 63;\n";
-        o << " const u64 row0_ = row - lane_ + (u64)(" << omin << "ll); const u64 *WL_ = W_ + lane_ * " << STAGE_PITCH << ";\n";
-    }
-    o << " u64 LZ[3][6];\n";
-    for (u32 s = 0; s < nSlots; s++) o << " u64 t" << s << "_0 = 0, t" << s << "_1 = 0, t" << s << "_2 = 0;\n";
-    auto addr = [&](const glx_ref &r) {
-        std::ostringstream a;
-        const int64_t off = (int64_t)r.prime * ((int64_t)1 << ctx->primeShift);
-        a << "A.sec[" << r.section << "] + ((row + (u64)(" << off << "ll)) & mask) * " << ctx->sections[r.section].width << "ull + " << r.index;
-        return a.str();
-    };
-    int curSec = -1; int64_t curBlk = -1; u32 nStages = 0;
-    std::set<std::pair<int, int64_t>> blocksSeen;
+    const int64_t stageRows = (64 + (omax - omin) + 15) / 16 * 16, nFills = stageRows / 16, tileBytes = stageRows * STAGE_COLS * 8;
     // the block holding every component of a staged read, or -1 (not staged / straddles two blocks: read directly)
     auto block_of = [&](const glx_ref &r) -> int64_t {
         if (!staging || r.kind != GLX_SEC || !stagedSec[r.section]) return -1;
         const int64_t b0 = r.index / STAGE_COLS, b1 = (r.index + r.dim - 1) / STAGE_COLS;
         return b0 == b1 ? b0 : -1;
     };
-    auto stage = [&](const glx_ref &r) {            // make the tile hold r's block
+    // the walk: (section, block) at every change, in program order
+    std::vector<std::pair<int, int64_t>> walk;
+    std::set<int64_t> offsets;
+    if (staging) {
+        for (const IOp &p : ops)
+            for (int t = 0; t < n_src(p.op); t++) {
+                const int64_t b = block_of(p.src[t]);
+                if (b < 0) continue;
+                offsets.insert(row_off(p.src[t]));
+                if (walk.empty() || walk.back() != std::make_pair((int)p.src[t].section, b)) walk.push_back({ (int)p.src[t].section, b });
+            }
+        std::set<std::pair<int, int64_t>> distinct(walk.begin(), walk.end());
+        if (walk.empty() || walk.size() > 3 * distinct.size() + 4) staging = false;      // the program hops between blocks: direct reads
+    }
+    o << "extern \"C\" __global__ void __launch_bounds__(256) jit_eval(JitArgs A) {\n";
+    o << " const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (row >= (1ull << A.nBits)) return;\n";
+    o << " const u64 mask = (1ull << A.nBits) - 1; const u64 *__restrict__ SC = A.scalars; const u32 *__restrict__ LM = A.limbs;\n";
+    auto fill = [&](size_t i) {                     // request walk[i] into tile i % 2
+        const int sec = walk[i].first; const int64_t b = walk[i].second;
+        const u64 width = ctx->sections[sec].width;
+        const int64_t nc = std::min<int64_t>(STAGE_COLS, (int64_t)width - b * STAGE_COLS);       // even: widths are
+        // a narrower last block: the lanes whose column pair lies beyond it fetch its last pair again (into slots nobody reads) --
+        // NOT a branch around the loads: divergent control flow in the middle of this one-block program costs hipcc its register
+        // allocation (256 registers and 500 spilled, against 116)
+        const std::string back = nc < STAGE_COLS ? " - 2 * (kp_ > " + std::to_string(nc / 2 - 1) + "u ? kp_ - " + std::to_string(nc / 2 - 1) + "u : 0u)" : "";
+        o << " {";
+        for (int64_t j = 0; j < nFills; j++)
+            o << " __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.sec[" << sec << "] + rw" << sec << "_" << j << "_ + " << b * STAGE_COLS << back
+              << "), (__attribute__((address_space(3))) void *)(TW_ + " << ((i % 2) * tileBytes + j * 1024) / 8 << "), 16, 0, 0);";
+        o << " }\n";
+    };
+    if (staging) {
+        o << " __shared__ u64 STG_[4][" << 2 * tileBytes / 8 << "]; const u32 lane_ = threadIdx.x & 63;\n";
+        o << " u64 *TW_ = STG_[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];\n";
+        o << " const u32 kp_ = (lane_ & 3) ^ ((lane_ >> 4) & 3);       // the column pair this lane fetches in every fill\n";
+        o << " const u64 row0_ = row - lane_ + (u64)(" << omin << "ll);\n";
+        std::set<int> secs;
+        for (auto &w : walk) secs.insert(w.first);
+        for (int sec : secs)
+            for (int64_t j = 0; j < nFills; j++)
+                o << " const u64 rw" << sec << "_" << j << "_ = ((row0_ + " << 16 * j << " + (lane_ >> 2)) & mask) * " << ctx->sections[sec].width << "ull + 2 * kp_;\n";
+        // per row offset: the lane's four slot addresses (bytes within a tile), one per column pair
+        for (int64_t off : offsets) {
+            const std::string nm = "bo" + std::to_string(off - omin) + "_";
+            o << " const u32 rr" << nm << " = lane_ + " << (off - omin) << "u;";
+            for (int kp = 0; kp < 4; kp++) o << " const u32 " << nm << kp << " = (rr" << nm << " * 4 + (" << kp << "u ^ ((rr" << nm << " >> 2) & 3))) * 16;";
+            o << "\n";
+        }
+        fill(0);
+    }
+    o << " u64 LZ[3][6];\n";
+    for (u32 s = 0; s < nSlots; s++) o << " u64 t" << s << "_0 = 0, t" << s << "_1 = 0, t" << s << "_2 = 0;\n";
+    auto addr = [&](const glx_ref &r) {
+        std::ostringstream a;
+        a << "A.sec[" << r.section << "] + ((row + (u64)(" << row_off(r) << "ll)) & mask) * " << ctx->sections[r.section].width << "ull + " << r.index;
+        return a.str();
+    };
+    size_t walkPos = 0; bool walkStarted = false;
+    auto stage = [&](const glx_ref &r) {            // first read of the walk's next block: its tile must have landed; request the one after
         const int64_t b = block_of(r);
-        if (b < 0 || (curSec == (int)r.section && curBlk == b)) return;
-        const u64 width = ctx->sections[r.section].width;
-        const int64_t nc = std::min<int64_t>(STAGE_COLS, (int64_t)width - b * STAGE_COLS);
-        // a CALL: the tile's reads in flight (18 values for 72 rows) then live in the callee, not across the caller's other calls, and
-        // the call orders the caller's tile reads against the callee's writes for the compiler; the LDS unit keeps one wave's
-        // instructions in order, which is all the ordering lanes of one wave need
-        o << " stage_call(W_, A.sec[" << r.section << "] + " << b * STAGE_COLS << ", row0_, mask, " << width << "ull, " << nc << "u);\n";
-        curSec = (int)r.section; curBlk = b; nStages++; blocksSeen.insert({ curSec, b });
+        if (b < 0) return;
+        if (walkStarted && walk[walkPos] == std::make_pair((int)r.section, b)) return;
+        if (walkStarted) walkPos++;
+        walkStarted = true;
+        o << " asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\");\n";
+        if (walkPos + 1 < walk.size()) fill(walkPos + 1);
     };
     auto rd = [&](const glx_ref &r, int c) {        // component c of an operand (0 beyond its dim)
         std::ostringstream a;
@@ -540,8 +578,8 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
         if (r.kind == GLX_TMP) a << "t" << r.index << "_" << c;
         else if (r.kind == GLX_SCALAR) a << "SC[" << (r.index + c) << "]";
         else if (block_of(r) >= 0) {
-            const int64_t off = (int64_t)r.prime * ((int64_t)1 << ctx->primeShift);
-            a << "WL_[" << (off - omin) * STAGE_PITCH + (int64_t)((r.index + c) % STAGE_COLS) << "]";
+            const int64_t cb = (r.index + c) % STAGE_COLS;
+            a << "*(const u64 *)((const char *)TW_ + bo" << (row_off(r) - omin) << "_" << cb / 2 << " + " << (walkPos % 2) * tileBytes + (cb & 1) * 8 << ")";
         } else a << "(" << addr(r) << ")[" << c << "]";
         return a.str();
     };
@@ -555,11 +593,10 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
             o << "\n"; continue;
         }
         const glx_ref &a = p.src[0], &b = p.src[1];
+        if (n_src(p.op) == 2 && block_of(a) >= 0 && block_of(b) >= 0 && (a.section != b.section || block_of(a) != block_of(b)))
+            return jit_source(ops, nSlots, ctx, false);         // one instruction reading two blocks (value numbering leaves none): direct reads
         if (n_src(p.op) >= 1) stage(a);
-        if (n_src(p.op) == 2 && block_of(b) >= 0) {
-            if (block_of(a) >= 0 && (a.section != b.section || block_of(a) != block_of(b))) return jit_source(ops, nSlots, ctx, false);   // two tiles at once: not this generator
-            stage(b);
-        }
+        if (n_src(p.op) == 2) stage(b);
         std::string r[3];
         const u32 da = a.dim, db = b.dim;
         switch (p.op) {
@@ -597,7 +634,6 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
         }
     }
     o << "}\n";
-    if (staging && nStages > 3 * blocksSeen.size() + 4) return jit_source(ops, nSlots, ctx, false);     // the program hops between blocks: direct reads
     return o.str();
 }
 

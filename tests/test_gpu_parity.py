@@ -1079,20 +1079,20 @@ def test_rows_and_cols_dot_ext(gl, oracle, monkeypatch, mode):
             assert out[l, c].tolist() == oracle.eval_pol_at(buf, c, 1, nb, eb, levs[l]).tolist()
 
 
-@pytest.mark.parametrize("jit", ["0", "1", "staged"])
+@pytest.mark.parametrize("jit", ["0", "1", "staged", "direct"])
 def test_expression_evaluator_interpreter_and_jit_agree(gl, oracle, jit, monkeypatch):
-    """the same random programs through the interpreter (PIL2GL_EXPR_JIT=0), the hiprtc-compiled kernel (=1) and the compiled
-    kernel with its wide-section reads staged through LDS tiles (PIL2GL_EXPR_STAGE=1; sections of 20 and 33 columns, row offsets -2..2)"""
+    """the same random programs through the interpreter (PIL2GL_EXPR_JIT=0), the hiprtc-compiled kernel (=1), and the compiled
+    kernel on WIDE sections (20 and 34 columns, row offsets -2..2 and -8..8) with their reads direct (the default) and staged through
+    LDS tiles filled ahead (PIL2GL_EXPR_STAGE=1)"""
     import torch
     import ctypes as C
     from pil2gl import _lib
     monkeypatch.setenv("PIL2GL_EXPR_JIT", "0" if jit == "0" else "1")
-    if jit == "staged":
-        monkeypatch.setenv("PIL2GL_EXPR_STAGE", "1")
+    monkeypatch.setenv("PIL2GL_EXPR_STAGE", "1" if jit == "staged" else "0")
     for n_ops, prime_shift in [(40, 0), (300, 2)]:
         rng = np.random.default_rng(1000 + n_ops)
         n_bits = 10
-        widths = [5, 9, 1, 3] if jit != "staged" else [20, 33, 1, 3]
+        widths = [5, 9, 1, 3] if jit in ("0", "1") else [20, 34, 1, 3]
         secs = [rand_field(rng, (1 << n_bits, w)) for w in widths]; secs[-1][:] = 0
         scalars = rand_field(rng, 40)
         ops, n_tmp = _random_program(rng, n_ops, widths, scalars.size, len(widths) - 1)

@@ -436,8 +436,10 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
     // copied or stored is made canonical (four more instructions).  PIL2GL_EXPR_LAZYMUL=0: every product canonical, hipcc's form.
     const char *lzEnv = getenv("PIL2GL_EXPR_LAZYMUL");
     const bool lazyMul = !(lzEnv && lzEnv[0] == '0');
-    const std::string MULC = mulCall ? "mul_call(" : (lazyMul ? "canon(mul_lazy_x(" : "mul("), MULC_END = (!mulCall && lazyMul) ? "))" : ")";
-    const std::string MULL = !lazyMul ? MULC : (mulCall ? "mull_call(" : "mul_lazy_x("), MULL_END = !lazyMul ? MULC_END : ")";
+    // (only in the called form: inlined, the asm products are slower than hipcc's own -- 59 against 39 ms for the config-3 constraint
+    // program, 60 against 49 for the permutation AIR's -- the scheduler can no longer interleave them with the loads around them)
+    const std::string MULC = mulCall ? "mul_call(" : "mul(", MULC_END = ")";
+    const std::string MULL = (mulCall && lazyMul) ? "mull_call(" : MULC, MULL_END = ")";
     if (mulCall) {
         o << "__device__ __noinline__ u64 mul_call(u64 a, u64 b) { return " << (lazyMul ? "canon(mul_lazy_x(a, b))" : "mul(a, b)") << "; }\n";
         if (lazyMul) o << "__device__ __noinline__ u64 mull_call(u64 a, u64 b) { return mul_lazy_x(a, b); }\n";

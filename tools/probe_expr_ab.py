@@ -12,9 +12,14 @@ n_bits, n_cols = int(os.environ.get("NBITS", 24)), int(os.environ.get("NCOLS", 1
 air = os.environ.get("AIR", "fib")
 ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 64, "verificationHashType": "GL", "splitLinearHash": False,
       "steps": [{"nBits": b} for b in bench.fri_steps_for(n_bits + 3)]}
-info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
 be = stark.GpuBackend(0, False)
-src, consts, publics = bench.fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
+if air == "perm":                      # the two-stage permutation-check AIR of bench.py --air perm
+    copies = max(1, n_cols // 11)
+    info, exprs, _ = stark.permutation_air(ss, copies)
+    src, consts, publics = bench.permutation_trace_gpu(dev, n_bits, copies)
+else:
+    info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
+    src, consts, publics = bench.fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
 setup = stark.build_const_tree(be, consts, info)
 roots = set()
 for rnd in range(2):
@@ -23,5 +28,5 @@ for rnd in range(2):
         t = {}
         res = stark.stark_gen(be, src, setup, info, exprs, publics, timings=t)
         roots.add(str(res["proof"]["root2"] if "root2" in res["proof"] else res["proof"].get("rootQ", "")))
-        print("round %d lazy=%s call=%s stage=%s: q_expr %.2f ms, fri_expr %.2f ms" % (rnd, lazy, call, stg, t["q_expr"] * 1e3, t["fri_expr"] * 1e3), flush=True)
+        print("round %d lazy=%s call=%s stage=%s: q_expr %.2f ms, fri_expr %.2f ms, stage2_witness %.2f ms" % (rnd, lazy, call, stg, t["q_expr"] * 1e3, t["fri_expr"] * 1e3, t.get("stage2_witness", 0) * 1e3), flush=True)
 print("distinct Q roots:", len(roots))

@@ -263,6 +263,21 @@ def load_pmc_lde_traffic(name):
         return None
 
 
+def clock_under_hash_load():
+    """shader clock (MHz: median, 5th, 95th percentile over the workgroups) while the chip runs Poseidon permutations
+    (pil2gl_selftest_clock: shader-clock counter against the 100 MHz counter inside the kernel).  sysfs reports the nominal DPM level
+    (2.4 GHz) throughout; under this load the MI355X runs near 1.9 GHz, and SIMD cycles priced at the nominal clock overstate what a
+    kernel spent by a quarter."""
+    try:
+        import ctypes as C
+        from pil2gl import _lib
+        mhz = (C.c_double * 3)()
+        _lib.call("pil2gl_selftest_clock", C.c_uint32(40), mhz)
+        return [round(x, 1) for x in mhz]
+    except Exception:
+        return None
+
+
 def pmc_file():
     for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
@@ -270,7 +285,7 @@ def pmc_file():
     return "pmc_traffic.json"
 
 
-def poseidon_int_roofline(perms, ms):
+def poseidon_int_roofline(perms, ms, clock_mhz=None):
     """integer-issue roofline of the Goldilocks Poseidon kernels (118 S-boxes x 4 = 472 modular
     multiplications + 30 MDS layers per permutation).  achieved = SIMD cycles per wave of 64 permutations; floor = what the
     multiplications and the matrix-core MDS cost if nothing but their irreducible instructions were issued:
@@ -279,10 +294,15 @@ def poseidon_int_roofline(perms, ms):
     achieved = N_SIMD * CLOCK_HZ * (ms * 1e-3) / (perms / 64.0)
     n_mfma = 10 * 18 + 5 * 54                                # 8 full-round layers + 2 single partial layers, 5 blocks of four partial rounds (poseidon_blocks.cuh)
     floor = 472 * 5 * CYC_MAD_U64_U32 + n_mfma * CYC_MFMA_ISSUE
-    return {"bound": "int-issue", "kernel": "linear_hash_kernel", "achieved": achieved, "floor": floor, "unit": "SIMD issue cycles per wave of 64 permutations",
-            "frac": floor / achieved, "clock_GHz_assumed": CLOCK_HZ / 1e9,
-            "floor_terms": {"v_mad_u64_u32": 472 * 5, "cycles_each": CYC_MAD_U64_U32, "v_mfma_i32_32x32x32_i8": n_mfma, "issue_cycles_each": CYC_MFMA_ISSUE},
-            "note": "reductions, carries, byte-plane recombination and round constants are overhead by this definition"}
+    out = {"bound": "int-issue", "kernel": "linear_hash_kernel", "achieved": achieved, "floor": floor, "unit": "SIMD issue cycles per wave of 64 permutations",
+           "frac": floor / achieved, "clock_GHz_assumed": CLOCK_HZ / 1e9,
+           "floor_terms": {"v_mad_u64_u32": 472 * 5, "cycles_each": CYC_MAD_U64_U32, "v_mfma_i32_32x32x32_i8": n_mfma, "issue_cycles_each": CYC_MFMA_ISSUE},
+           "note": "reductions, carries, byte-plane recombination and round constants are overhead by this definition"}
+    if clock_mhz:                                              # the same at the clock such a kernel actually runs at (measured inside a kernel of the same load)
+        out["clock_MHz_measured"] = {"median": clock_mhz[0], "p5": clock_mhz[1], "p95": clock_mhz[2]}
+        out["achieved_at_measured_clock"] = achieved * clock_mhz[0] * 1e6 / CLOCK_HZ
+        out["frac_at_measured_clock"] = floor / out["achieved_at_measured_clock"]
+    return out
 
 
 def lde_int_roofline(n_bits, n_cols, cosets, ms):
@@ -743,6 +763,7 @@ def main():
             lde = lambda: pil2gl.interpolate(ksrc, n_cols, n_bits, dst, n_bits + EXT_BITS)
         t_lde = ev_time(lde, iters)
         t_leaf = ev_time(lambda: pil2gl.linearHash(dst, n_cols, args.split, digests), iters)
+        leaf_clock_mhz = clock_under_hash_load()
         lvl = torch.empty(rows * 2, dtype=torch.int64, device=dev)
         t_lvl = ev_time(lambda: pil2gl.merkelizeLevel(digests, lvl), iters)
         leaf_perms = rows * ((n_cols + 7) // 8) if n_cols > 4 else 0
@@ -805,7 +826,7 @@ def main():
             "config": {"workload": workload, "mode": mode, "config": wl,
                        "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "GL-Poseidon-12",
                        "parallelism": ("coset-sharded x%d" % world) if sharded_mode else ("replicas x%d" % world if world > 1 else "single GPU")},
-            "roofline": roofline, "roofline_int_issue": poseidon_int_roofline(kernels[0]["perms"], kernels[0]["ms"]) if kernels[0]["perms"] else None,
+            "roofline": roofline, "roofline_int_issue": poseidon_int_roofline(kernels[0]["perms"], kernels[0]["ms"], leaf_clock_mhz) if kernels[0]["perms"] else None,
             "roofline_int_issue_lde": lde_int_roofline(n_bits, n_cols, cc, kernels[1]["ms"]),
             "kernels": kernels,
         }

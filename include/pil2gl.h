@@ -275,6 +275,10 @@ int pil2gl_selftest_mds(const uint64_t *states, uint64_t n, uint32_t layers, int
  * linear layer), 1 matrix-core MDS with one layer per round, 2 vector ALU only; 3 / 4 = rounds 4..25 ALONE (folded-constant
  * form: lane 0 + c, x^7, MDS) in the forms of 0 / 1 -- arbitrary states reach the partial rounds' recombination that way */
 int pil2gl_selftest_poseidon(const uint64_t *states, uint64_t n, int what, uint64_t *out);
+/* diagnostics: the shader clock (MHz) under the Poseidon kernels' own load -- every workgroup of a chip-filling launch runs `iters`
+   permutations between two readings of the shader-clock and the 100 MHz counters; mhz[3] = median, 5th, 95th percentile.
+   (sysfs reports the nominal DPM level; under this load the MI355X runs near 1.9 GHz, which is what issue-cycle figures need) */
+int pil2gl_selftest_clock(uint32_t iters, double *mhz);
 /* extension a*b and 1/a on the device (n triples) */
 int pil2gl_selftest_ext(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *inv);
 

@@ -214,6 +214,25 @@ __global__ void __launch_bounds__(256, 2) poseidon_selftest_kernel(const u64 *__
     for (int j = 0; j < 12; j++) out[12 * i + j] = canon(st[j]);
 }
 
+// diagnostics: the shader clock under the hashing kernels' own load.  Every workgroup runs `iters` permutations on all its lanes; its
+// first lane reads the shader-clock counter (s_memtime) and the constant 100 MHz counter (s_memrealtime) around them.
+__global__ void __launch_bounds__(256, 4) clock_probe_kernel(u64 *__restrict__ sink, int iters, u64 *__restrict__ clk) {
+    MdsMfma m;
+    poseidon_init(m);
+    u64 st[12];
+    const u64 id = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 12; j++) st[j] = ((id * 12 + j) * 0x9E3779B97F4A7C15ull) >> 1;
+    const u64 c0 = __builtin_readcyclecounter(), r0 = wall_clock64();
+    for (int i = 0; i < iters; i++) poseidon_perm<0>(st, m);
+    const u64 c1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+    u64 x = 0;
+#pragma unroll
+    for (int j = 0; j < 12; j++) x ^= st[j];
+    sink[id] = x;
+    if (threadIdx.x == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 // gather of query openings (merklehash_p.js:142-168) for many indices at once: one block per query copies the row
 // and the sibling digest of every level into a packed staging area
 __global__ void group_proofs_kernel(const u64 *__restrict__ elems, const u64 *__restrict__ nodes, u64 width, u64 height,
@@ -454,6 +473,23 @@ int pil2gl_selftest_poseidon(const uint64_t *states, uint64_t n, int what, uint6
                         KERNEL_CHECK();
                         return (int)PIL2GL_OK;
                     }, &a);
+}
+int pil2gl_selftest_clock(uint32_t iters, double *mhz /* [3]: median, 5th and 95th percentile over the workgroups */) {
+    P2_TRY(ensure_init());
+    if (!mhz || iters == 0 || iters > 4096) return fail(PIL2GL_EINVAL, "iters must be 1..4096");
+    const unsigned blocks = 256 * 4 * 8;                        // eight rounds of four workgroups per CU
+    u64 *d;
+    P2_TRY(scratch(5, (u64)blocks * 256 + 2ull * blocks, &d));
+    clock_probe_kernel<<<blocks, 256>>>(d, (int)iters, d + (u64)blocks * 256);
+    KERNEL_CHECK();
+    std::vector<u64> h(2 * blocks);
+    HIP_TRY(hipMemcpy(h.data(), d + (u64)blocks * 256, 16ull * blocks, hipMemcpyDeviceToHost));
+    std::vector<double> v;
+    for (unsigned i = 0; i < blocks; i++) if (h[2 * i + 1]) v.push_back(100.0 * (double)h[2 * i] / (double)h[2 * i + 1]);
+    if (v.empty()) return fail(PIL2GL_EHIP, "no clock samples");
+    std::sort(v.begin(), v.end());
+    mhz[0] = v[v.size() / 2]; mhz[1] = v[v.size() / 20]; mhz[2] = v[v.size() * 19 / 20];
+    return PIL2GL_OK;
 }
 int pil2gl_merkelize(const uint64_t *elems, uint64_t width, uint64_t height, int split, uint64_t *nodes) {
     if (height == 0) return fail(PIL2GL_EINVAL, "height must be > 0");

@@ -127,6 +127,7 @@ SIGNATURES = {
     "pil2gl_selftest_products": (_I, [vp, vp, _U64, vp, vp, vp]),
     "pil2gl_selftest_mds": (_I, [vp, _U64, _U32, _I, vp]),
     "pil2gl_selftest_poseidon": (_I, [vp, _U64, _I, vp]),
+    "pil2gl_selftest_clock": (_I, [C.c_uint32, vp]),
 }
 
 _lib = None

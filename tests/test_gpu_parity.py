@@ -1157,6 +1157,15 @@ def test_compiled_evaluator_lazy_products_reach_their_readers_non_canonical(gl, 
     assert (got == ref[-1]).all()
 
 
+def test_clock_probe_reports_a_plausible_shader_clock(gl):
+    """pil2gl_selftest_clock (what bench.py prices issue cycles with): a clock between the idle and the nominal one, spread sane"""
+    import ctypes as C
+    from pil2gl import _lib
+    mhz = (C.c_double * 3)()
+    _lib.call("pil2gl_selftest_clock", C.c_uint32(8), mhz)
+    assert 500 < mhz[1] <= mhz[0] <= mhz[2] < 3000
+
+
 def test_pols_file_to_device_and_back(gl, tmp_path):
     """`.commit`-style file (witnessCalculator.js:145-196) streamed into HBM, committed, written back"""
     import torch

@@ -1,0 +1,52 @@
+// The forward NTT passes' memory pattern without the transform: every workgroup reads 256 pieces of 128 bytes `lo` rows apart (a tile of
+// 256 rows x 16 columns of an R x C row-major matrix of u64), and writes them back.  lo = 2^8: the near-strided pass; 2^16: the far one.
+// Build: hipcc -O3 --offload-arch=gfx950 tools/stride_copy.hip -o tools/stride_copy      Run: tools/stride_copy [log2 rows (24)] [columns, a multiple of 16 (800)] [strides: log2 rows apart, comma separated]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+typedef unsigned long u64; typedef unsigned int u32;
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int XCD>
+__global__ void __launch_bounds__(256) k_tile(u64 *m, u64 C, u32 loBits, u32 nChunks, u32 nRowBits) {
+    u32 b = blockIdx.x;
+    if (XCD) { const u32 per = gridDim.x >> 3; b = (b & 7) * per + (b >> 3); }     // consecutive logical tiles on one XCD, as the library does
+    const u32 cc = b % nChunks; b /= nChunks;
+    const u32 gt = b & ((1u << loBits) - 1), hi = b >> loBits;                     // row = (hi << (loBits + 8)) + (t << loBits) + gt
+    const u32 x = threadIdx.x & 15, y = threadIdx.x >> 4;
+    u64 *base = m + ((u64)hi << (loBits + 8)) * C + (u64)gt * C + cc * 16 + x;
+    const u64 tStride = C << loBits;
+    u64 v[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) v[i] = base[(u64)(y + 16 * i) * tStride];
+#pragma unroll
+    for (int i = 0; i < 16; i++) base[(u64)(y + 16 * i) * tStride] = v[i] + 1;
+}
+
+int main(int argc, char **argv) {
+    const u32 nRowBits = argc > 1 ? atoi(argv[1]) : 24;
+    const u64 R = 1ull << nRowBits, C = argc > 2 ? strtoull(argv[2], 0, 10) : 800;   // 800: the extended config-3 matrix during the passes, N x (100 * 8)
+    u64 *m;
+    CHECK(hipMalloc(&m, R * C * 8));
+    CHECK(hipMemset(m, 0, R * C * 8));
+    const u32 nChunks = (u32)(C / 16);
+    const u32 blocks = (u32)((R >> 8) * nChunks);
+    std::vector<u32> los = { 0u, 8u, nRowBits - 8 };
+    if (argc > 3) { los.clear(); for (char *t = strtok(argv[3], ","); t; t = strtok(nullptr, ",")) los.push_back((u32)atoi(t)); }
+    hipEvent_t a, b; CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    for (int rep = 0; rep < 2; rep++)
+        for (u32 loBits : los)
+            for (int xcd = 1; xcd >= 0; xcd--) {
+                CHECK(hipEventRecord(a));
+                if (xcd) hipLaunchKernelGGL(k_tile<1>, dim3(blocks), dim3(256), 0, 0, m, C, loBits, nChunks, nRowBits);
+                else hipLaunchKernelGGL(k_tile<0>, dim3(blocks), dim3(256), 0, 0, m, C, loBits, nChunks, nRowBits);
+                CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
+                float ms; CHECK(hipEventElapsedTime(&ms, a, b));
+                printf("rows 2^%u x %lu columns (%.1f GB), pieces 2^%u rows apart, %s order: %.2f ms, %.2f TB/s read + written\n", nRowBits, (unsigned long)C, R * C * 8 / 1e9, loBits,
+                       xcd ? "XCD-local" : "plain", ms, 2.0 * R * C * 8 / ms / 1e9);
+            }
+    return 0;
+}

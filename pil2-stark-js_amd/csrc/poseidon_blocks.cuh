@@ -82,6 +82,11 @@ __device__ __forceinline__ void blk_chain4(v16i &L, v16i &H, v4i a0, v4i a1, v4i
 #endif
 }
 
+// PBLK_TIMING (never defined in the library build; wrong results): bit 0 the layers do not add their constants, bit 1 every biased single layer
+// runs a fourth K group -- the price and the prize of moving the constants into the matrix product (measured: see DESIGN section 4)
+#ifndef PBLK_TIMING
+#define PBLK_TIMING 0
+#endif
 static constexpr int BLK_A_DWORDS = POSEIDON_BLK_OPERANDS * 64 * 4;
 
 // all threads of the workgroup; returns this lane's column of the operand table
@@ -135,7 +140,12 @@ __device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m, cons
             L = PBLK_MFMA(r0, Bl[0], init); H = PBLK_MFMA(r0, Bh[0], init);
             L = PBLK_MFMA(r1, Bl[1], L);    H = PBLK_MFMA(r1, Bh[1], H);
             L = PBLK_MFMA(r2, Bl[2], L);    H = PBLK_MFMA(r2, Bh[2], H);
-        } else blk_chain3(L, H, r0, r1, r2, Bl, Bh);
+        }
+#if PBLK_TIMING & 2
+        else blk_chain4(L, H, r0, r1, r2, A[(256 + 64 * s)], Bl, Bh, A[320 + 64 * s], A[448 + 64 * s]);
+#else
+        else blk_chain3(L, H, r0, r1, r2, Bl, Bh);
+#endif
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             u32 xa = blk_pair(L[4 * ii], L[4 * ii + 1]), xc = blk_pair(L[4 * ii + 2], L[4 * ii + 3]);
@@ -145,7 +155,9 @@ __device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m, cons
             }
             u64 X = (u64)xc * m.sh16 + xa;
             u64 Y = (u64)yc * m.sh16 + ya;
+#if !(PBLK_TIMING & 1)
             if (!EXACT) { const u64 c = lc[4 * s + ii]; X += (u32)c; Y += c >> 32; }          // X, Y < 2^49 + 2^32
+#endif
             const u64 tt = (u64)(u32)(Y >> 32) * EPS + X;
             u32 th;
             asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(th), "=s"(cm[4 * s + ii]) : "v"((u32)(tt >> 32)), "v"((u32)Y));

@@ -29,6 +29,14 @@
 #ifndef NTT_MUL
 #define NTT_MUL(a, b) mul_lazy_x(a, b)   // the twiddle products of the tile kernels: the 16-instruction exact carry-out form (A/B: -DNTT_MUL=mul_lazy, 22 compiler instructions: 208.5 vs 201.5 ms per config-3 interpolate)
 #endif
+// experiments only (tools/lde_two_sweep.sh): larger workgroups for the any-geometry instances, so that 10-stage tiles (1024 rows x 16
+// slots, 128+ KB of LDS, one workgroup per CU) still put four waves on a SIMD
+#ifndef NTT_MAXTHREADS
+#define NTT_MAXTHREADS 256
+#endif
+#ifndef LDE_MAXTHREADS
+#define LDE_MAXTHREADS 512
+#endif
 using namespace gl;
 
 namespace {
@@ -156,7 +164,7 @@ struct PassParams {
 // one slot group: 16 slots for rows of 128 bytes and more in 16-column chunks, 15 for the 100-column matrices whose seven
 // chunks are 15 wide), with every stride, LDS offset and twiddle index a compile-time constant
 template <bool INV, bool DIT, int KC, int SC = 16>
-__global__ void __launch_bounds__(256) ntt_pass_kernel(PassParams P) {
+__global__ void __launch_bounds__(KC ? 256 : NTT_MAXTHREADS) ntt_pass_kernel(PassParams P) {
     extern __shared__ u64 lds[];
     const u32 k = KC ? KC : P.k, K = 1u << k, S = KC ? SC : blockDim.x, by = KC ? 16 : blockDim.y;
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
@@ -241,7 +249,7 @@ struct LdeParams {
 // SC = 0: any geometry; SC > 0: 8 stages, SC column slots x 16 sub-transform lanes, one slot group (EPT = 16) -- the geometry
 // of the wide matrices, with compile-time strides
 template <int EPT, int SC>
-__global__ void __launch_bounds__(512) lde_mid_kernel(LdeParams P) {
+__global__ void __launch_bounds__(SC ? 512 : LDE_MAXTHREADS) lde_mid_kernel(LdeParams P) {
     extern __shared__ u64 lds[];
     const u32 k = SC ? 8 : P.k, K = 1u << k, S = SC ? SC : blockDim.x, by = SC ? 16 : blockDim.y;
     const u32 x = threadIdx.x, y = threadIdx.y, tid = y * S + x, nth = S * by;
@@ -364,7 +372,7 @@ int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit,
     u32 nHi;
     if (lo > 0) { P.tStride = (C << lo); P.gStride = C; P.hiStride = (C << (lo + k)); totalGroups = 1ull << lo; nHi = 1u << (n - lo - k); }
     else { P.tStride = C; P.gStride = (C << k); P.hiStride = 0; totalGroups = 1ull << (n - k); nHi = 1; }
-    Geom g = make_geom(k, C, totalGroups, env_u32("PIL2GL_NTT_TILE", 4096), 256);
+    Geom g = make_geom(k, C, totalGroups, env_u32("PIL2GL_NTT_TILE", 4096), std::min<u32>(NTT_MAXTHREADS, env_u32("PIL2GL_NTT_THREADS", 256)));
     P.Wc = g.Wc; P.nbT = g.nbT; P.nColChunks = g.nColChunks; P.nGroupTiles = (u32)(totalGroups / g.nbT);
     u64 K = 1ull << k;
     const bool fixedGeom = k == 8 && (g.S == 16 || g.S == 15) && g.by == 16 && g.nbT == 1 && g.Wc == g.S && !env_u32("PIL2GL_NTT_GENERIC", 0);
@@ -459,7 +467,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
         P.C = C; P.ninv = h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb;
         P.cosetBegin = cosetBegin; P.cosetCount = cosetCount; P.canonOut = n > kf ? 0 : 1;
         u64 totalGroups = 1ull << (n - kf);
-        u32 nThreads = env_u32("PIL2GL_LDE_THREADS", 512);
+        u32 nThreads = std::min<u32>(LDE_MAXTHREADS, env_u32("PIL2GL_LDE_THREADS", 512));
         // LDS = tile (S*K) + two local twiddle tables (K) + coset scale tables (2*G*K); narrow matrices
         // (small C => many row groups per tile) are dominated by the scale tables, so shrink until it fits
         u64 K = 1ull << kf;

@@ -7,6 +7,7 @@ import pil2gl
 pil2gl.init(0)
 nBits = int(os.environ.get("NBITS", 24)); C = int(os.environ.get("NCOLS", 100)); eb = 3
 N, E = 1 << nBits, 1 << (nBits + eb)
+torch.manual_seed(0)
 src = torch.randint(0, 2**62, (N * C,), dtype=torch.int64, device="cuda")
 dst = torch.empty(E * C, dtype=torch.int64, device="cuda")
 def timeit(fn, n=3):
@@ -16,5 +17,9 @@ def timeit(fn, n=3):
     for _ in range(n): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n
+torch.manual_seed(1)
 for rnd in range(2):
-    print("%s: interpolate %.2f ms" % (os.path.basename(os.environ.get("PIL2GL_LIB", "in-tree")), timeit(lambda: pil2gl.interpolate(src, C, nBits, dst, nBits + eb))), flush=True)
+    print("%s %s: 2^%d x %d interpolate %.2f ms" % (os.path.basename(os.environ.get("PIL2GL_LIB", "in-tree")), os.environ.get("TAG", ""), nBits, C, timeit(lambda: pil2gl.interpolate(src, C, nBits, dst, nBits + eb))), flush=True)
+# a checksum of the result, so that builds and geometries timed in one call can be seen to agree (wrap-around sums of the words and of word * index)
+w = torch.arange(dst.numel(), dtype=torch.int64, device="cuda")
+print("   checksum %016x %016x" % (int(dst.sum()) & (2**64 - 1), int((dst * (2 * w + 1)).sum()) & (2**64 - 1)), flush=True)

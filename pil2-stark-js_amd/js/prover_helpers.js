@@ -59,11 +59,23 @@ function encode(code, dom, ctx, global) {
         }
     }
     // glx_op: u32 op, u32 pad, 3 x glx_ref{u8 kind,u8 dim,u16 section,i32 prime,u32 index,u32 pad} = 56 bytes
-    const buf = new ArrayBuffer(code.length * 56), dv = new DataView(buf);
-    const put = (o, r) => { dv.setUint8(o, r.kind); dv.setUint8(o + 1, r.dim); dv.setUint16(o + 2, r.section, true); dv.setInt32(o + 4, r.prime, true); dv.setUint32(o + 8, r.index, true); };
     let nTmp = 0;
-    for (let j = 0; j < code.length; j++) {
-        const c = code[j], o = j * 56;
+    for (const c of code) for (const r of [c.dest, ...c.src]) if (r.type === "tmp") nTmp = Math.max(nTmp, r.id + 1);
+    // `muladd` (verifier code only: codegen.js:137-165, stark_verify.js:234) = F.add(F.mul(a, b), c): two ops through one more temporary
+    const list = [];
+    let hasMulAdd = false;
+    for (const c of code) {
+        if (c.op === "muladd") {
+            hasMulAdd = true;
+            const prod = { type: "tmp", id: nTmp, dim: Math.max(c.src[0].dim || 1, c.src[1].dim || 1) };
+            list.push({ op: "mul", dest: prod, src: [c.src[0], c.src[1]] }, { op: "add", dest: c.dest, src: [prod, c.src[2]] });
+        } else list.push(c);
+    }
+    if (hasMulAdd) nTmp++;
+    const buf = new ArrayBuffer(list.length * 56), dv = new DataView(buf);
+    const put = (o, r) => { dv.setUint8(o, r.kind); dv.setUint8(o + 1, r.dim); dv.setUint16(o + 2, r.section, true); dv.setInt32(o + 4, r.prime, true); dv.setUint32(o + 8, r.index, true); };
+    for (let j = 0; j < list.length; j++) {
+        const c = list[j], o = j * 56;
         if (!(c.op in OP)) throw new Error("Invalid op:" + c.op);
         dv.setUint32(o, OP[c.op], true);
         const d = ref(c.dest, true);
@@ -72,9 +84,8 @@ function encode(code, dom, ctx, global) {
         put(o + 8, d);
         put(o + 24, ref(c.src[0], false));
         if (c.op !== "copy") put(o + 40, ref(c.src[1], false));
-        for (const r of [c.dest, ...c.src]) if (r.type === "tmp") nTmp = Math.max(nTmp, r.id + 1);
     }
-    return { ops: new BigUint64Array(buf), nOps: code.length, nTmp, sections, scalars: BigUint64Array.from(scalars.length ? scalars : [0n]) };
+    return { ops: new BigUint64Array(buf), nOps: list.length, nTmp, sections, scalars: BigUint64Array.from(scalars.length ? scalars : [0n]) };
 }
 
 module.exports.callCalculateExps = async function callCalculateExps(stage, code, dom, ctx, parallelExec, useThreads, debug, global = false) {

@@ -24,6 +24,10 @@ def pytest_configure(config):
 
 
 def golden(name):
+    if name.endswith(".gz"):
+        import gzip
+        with gzip.open(os.path.join(GOLDEN, name), "rt") as f:
+            return json.load(f)
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)
 

@@ -109,3 +109,84 @@ def test_reference_oplist_through_the_js_encoder(oracle, tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     got = np.array([int(v, 16) for v in json.loads(out.stdout.strip().splitlines()[-1])], dtype=np.uint64).reshape(-1, 3)
     assert (got == want).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# `muladd` (verifier code: codegen.js:137-165, executed as F.add(F.mul(a, b), c) at stark_verify.js:234) and `subproofValue`
+# operands (prover_helpers.js:214-216, stark_verify.js:258) through both encoders
+def _muladd_program():
+    ch = lambda s, i: {"type": "challenge", "stage": s, "stageId": i, "dim": 3}
+    t = lambda i, d=3: {"type": "tmp", "id": i, "dim": d}
+    return [
+        {"op": "muladd", "dest": t(0), "src": [ch(2, 0), {"type": "number", "value": "-5", "dim": 1}, {"type": "subproofValue", "id": 1, "dim": 1}]},
+        {"op": "muladd", "dest": t(1), "src": [t(0), ch(2, 1), {"type": "eval", "id": 0, "dim": 3}]},
+        {"op": "muladd", "dest": t(2, 1), "src": [{"type": "public", "id": 0, "dim": 1}, {"type": "subproofValue", "id": 0, "dim": 1}, {"type": "number", "value": "0x11", "dim": 1}]},
+        {"op": "sub", "dest": t(3), "src": [t(2, 1), t(1)]},
+        {"op": "muladd", "dest": t(4), "src": [t(3), {"type": "x", "dim": 3}, t(1)]},
+        {"op": "copy", "dest": {"type": "f", "dim": 3}, "src": [t(4)]},
+    ]
+
+
+def _muladd_ctx():
+    return {"pilInfo": {}, "publics": [123456789], "evals": [[5, 6, 7]], "challenges": [[], [[1, 2, 3], [P - 1, 0, 9]]],
+            "subproofValues": [77, P - 2]}
+
+
+def test_muladd_and_subproof_values_through_the_encoder(oracle):
+    from pil2gl import stark
+    from stark_backend import OracleBackend
+    code, ctx, n_bits = _muladd_program(), _muladd_ctx(), 3
+    ops, n_tmp, secs, scalars = stark.encode_code(code, "ext", ctx)
+    assert len(ops) == len(code) + 4 and n_tmp == 6                       # each muladd = mul into one shared extra temporary + add
+    x = rand_field(np.random.default_rng(5), (1 << n_bits, 3))
+    be = OracleBackend()
+    bufs = {"x_ext": be.from_host(x), "f_ext": be.zeros(3 << n_bits)}
+    be.eval_program(ops, n_tmp, [(bufs[s], 3) for s in secs], scalars, n_bits, 0)
+    got = np.asarray(be.to_host(bufs["f_ext"])).view(np.uint64).reshape(-1, 3)
+    for i in range(1 << n_bits):
+        def resolve(r, i=i):
+            ty = r["type"]
+            if ty == "number": return int(r["value"], 0) % P
+            if ty == "eval": return list(ctx["evals"][r["id"]])
+            if ty == "challenge": return list(ctx["challenges"][r["stage"] - 1][r["stageId"]])
+            if ty == "public": return ctx["publics"][r["id"]]
+            if ty == "subproofValue": return ctx["subproofValues"][r["id"]]
+            if ty == "x": return [int(v) for v in x[i]]
+            raise ValueError(ty)
+        assert [int(v) for v in got[i]] == stark.execute_code(code[:-1], resolve), i
+    # the global form indexes [subproofId][id]
+    g = dict(ctx, subproofValues=[[77, 2], [3, P - 2]]); g["global"] = True
+    where = {1: 1, 0: 0}                                                  # id -> subproofId holding the same value
+    code2 = [dict(c, src=[dict(r, subproofId=where[r["id"]]) if r["type"] == "subproofValue" else r for r in c["src"]]) for c in code]
+    assert (stark.encode_code(code2, "ext", g)[3] == scalars).all()
+    with pytest.raises(ValueError):
+        stark.encode_code([{"op": "divide", "dest": code[0]["dest"], "src": code[0]["src"][:2]}], "ext", ctx)
+
+
+def test_js_and_python_encoders_agree_on_muladd_and_subproof_values():
+    """js/prover_helpers.js::encode and pil2gl.stark.encode_code write the same glx_op records and the same scalar pool"""
+    import ctypes
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    from pil2gl import stark
+    node = shutil.which("node")
+    if node is None:
+        pytest.skip("node not installed")
+    code, ctx = _muladd_program(), _muladd_ctx()
+    ops, n_tmp, secs, scalars = stark.encode_code(code, "ext", ctx)
+    prog = stark.make_c_program(ops, n_tmp)
+    want = bytes(ctypes.string_at(prog._keep, ctypes.sizeof(prog._keep)))
+    js = ("const ph=require(%r);const code=%s;const c=%s;"
+          "const ctx={pilInfo:{},publics:c.publics.map(BigInt),evals:c.evals.map(e=>e.map(BigInt)),challenges:c.challenges.map(s=>s.map(e=>e.map(BigInt))),subproofValues:c.subproofValues.map(BigInt)};"
+          "const e=ph.encode(code,'ext',ctx,false);"
+          "console.log(JSON.stringify({nOps:e.nOps,nTmp:e.nTmp,ops:Buffer.from(e.ops.buffer).toString('hex'),scalars:Array.from(e.scalars).map(String),secs:e.sections.map(s=>s.name)}))"
+          ) % (os.path.join(ROOT, "pil2-stark-js_amd", "js", "prover_helpers.js"), json.dumps(code),
+               json.dumps({k: ([[str(v) for v in e] for e in ctx[k]] if k == "evals" else [[[str(v) for v in e] for e in s] for s in ctx[k]] if k == "challenges" else [str(v) for v in ctx[k]])
+                           for k in ("publics", "evals", "challenges", "subproofValues")}))
+    out = subprocess.run([node, "-e", js], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert (got["nOps"], got["nTmp"], got["secs"]) == (len(ops), n_tmp, secs)
+    assert [int(v) for v in got["scalars"]] == [int(v) for v in scalars]
+    assert bytes.fromhex(got["ops"]) == want

@@ -222,3 +222,146 @@ def test_reference_proof_full_device_verification(oracle):
         assert not ok, what
     ok, _ = stark.stark_verify(be, proof, [publics[0], (publics[1] + 1) % P, publics[2]], root_c, info, None, vinfo)
     assert not ok
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The BN128 twin: test/final/verifier.proof.zkin.json, the only proof in the reference tree written on the BN128 hash family
+# (Poseidon-BN254 trees of arity 4, BN128 transcript with 16 inputs; nBits 13, nBitsExt 17, FRI 17/14/11/7/4, 32 queries), with the
+# two programs of ITS verifier circuit (test/final/verifier.circom:290-2920 and :2921-3189, the older pil-stark generator:
+# 2 567 + 201 ops, `muladd` among them) -> tests/golden/ref_final_verifier_programs.json.gz by oracle/gen_final_verifier_programs.py.
+# The older layout differs from calculateTranscriptVerify.js in two places, both handled by handing stark_verify the challenges as
+# the reference's own fourth argument does (stark_verify.js:62-91): the constant root is not absorbed, and the query positions come
+# out of the main transcript (verifier.circom:18-246), not out of a fresh one.
+def _final():
+    g = golden("ref_final_verifier_programs.json.gz")
+    z = dict(golden("ref_final_verifier.proof.zkin.json"))
+    for old, new in (("rootQ", "root4"), ("s0_valsQ", "s0_vals4"), ("s0_siblingsQ", "s0_siblings4")):
+        z[new] = z.pop(old)                                   # the quotient is stage nStages+1 in today's naming (proof2zkin.js:16,45-48)
+    return g["starkInfo"], g["verifierInfo"], int(g["constRoot"]), z
+
+
+def _final_transcript(T, z, info):
+    """Transcript() of test/final/verifier.circom:18-246 on a TranscriptBN128(16) -> the reference's `challenges` argument"""
+    ints = lambda v: [int(x) for x in v]
+    T.put(ints(z["publics"])); T.put(int(z["root1"])); c2 = [T.getField(), T.getField()]
+    T.put(int(z["root2"])); c3 = [T.getField(), T.getField()]
+    T.put(int(z["root3"])); cq = [T.getField()]
+    T.put(int(z["root4"])); xi = [T.getField()]
+    T.put([ints(e) for e in z["evals"]]); cf = [T.getField(), T.getField()]
+    chF = [T.getField()]
+    for s in range(1, len(info["starkStruct"]["steps"])):
+        T.put(int(z["s%d_root" % s])); chF.append(T.getField())
+    T.put([ints(e) for e in z["finalPol"]])
+    queries = T.getPermutations(info["starkStruct"]["nQueries"], info["starkStruct"]["steps"][0]["nBits"])
+    return {"challenges": [[], [ints(c) for c in c2], [ints(c) for c in c3], [ints(c) for c in cq], [ints(c) for c in xi], [ints(c) for c in cf]],
+            "challengesFRISteps": [ints(c) for c in chF], "friQueries": [int(q) for q in queries]}
+
+
+def test_final_proof_programs_match_the_proof(oracle):
+    """host big integers: the constraint identity of the BN128 reference proof holds in the circuit's own form C(z) = Q(z) (z^N - 1)
+    and in stark_verify.js's form; the FRI polynomial computed at each of the 32 query points from the opened rows equals the value
+    the first FRI layer opens there; the same values through the oracle's expression evaluator"""
+    import bn128_oracle as bn
+    from pil2gl import stark, io
+    info, vinfo, root_c, z = _final()
+    ss = info["starkStruct"]
+    assert (ss["nBits"], ss["nBitsExt"], ss["nQueries"], ss["merkleTreeArity"]) == (13, 17, 32, 4)
+    assert sum(1 for c in vinfo["qVerifier"]["code"] if c["op"] == "muladd") == 129 and len(vinfo["queryVerifier"]["code"]) == 201
+    tr = _final_transcript(bn.TranscriptBN128(16), z, info)
+    challenges, queries = tr["challenges"], tr["friQueries"]
+    nb, nbe = ss["nBits"], ss["nBitsExt"]
+    xi = challenges[4][0]
+    xN = stark.ext_pow(xi, 1 << nb)
+    zh = [(xN[0] - 1) % P, xN[1], xN[2]]
+    Z = stark.ext_inv(zh)
+    evals = [[int(v) for v in e] for e in z["evals"]]
+    publics = [int(v) for v in z["publics"]]
+
+    def resolve(r, row=None):
+        ty = r["type"]
+        if ty == "eval": return evals[r["id"]]
+        if ty == "challenge": return challenges[r["stage"] - 1][r["stageId"]]
+        if ty == "public": return publics[r["id"]]
+        if ty == "number": return int(r["value"]) % P
+        if ty == "Zi": return list(Z)
+        if ty == "const": return int(row["C"][r["id"]])
+        if ty == "xDivXSubXi": return row["x"][r["id"]]
+        if ty.startswith("tree"):
+            v = row[int(ty[4:])]
+            return int(v[r["treePos"]]) if r["dim"] == 1 else [int(x) for x in v[r["treePos"]:r["treePos"] + 3]]
+        raise ValueError(ty)
+    code = vinfo["qVerifier"]["code"]
+    q_ev = [k for k, e in enumerate(info["evMap"]) if e["type"] == "cm" and info["cmPolsMap"][e["id"]]["stage"] == info["nStages"] + 1]
+    assert q_ev == list(range(76, 83))
+    q, xAcc = [0, 0, 0], [1, 0, 0]
+    for k in q_ev:
+        q = [(a + b) % P for a, b in zip(q, stark.ext_mul(xAcc, evals[k]))]; xAcc = stark.ext_mul(xAcc, xN)
+    assert stark.execute_code(code[:-1], resolve) == stark.ext_mul(q, zh), "the circuit's form: C(z) = Q(z) Z(z)"
+    assert stark.execute_code(code, resolve) == q, "Invalid evaluations"
+    keep = evals
+    evals = [list(e) for e in keep]; evals[41][2] = (evals[41][2] + 1) % P
+    assert stark.execute_code(code, resolve) != q
+    evals = keep
+    wN, wE = int(oracle.root(nb)), int(oracle.root(nbe))
+    step1 = ss["steps"][1]["nBits"]
+    for qi, idx in enumerate(queries):
+        x = 7 * pow(wE, idx, P) % P
+        xd = []
+        for o in info["openingPoints"]:
+            w = pow(wN, o, P)
+            den = [(x - xi[0] * w) % P, (-xi[1] * w) % P, (-xi[2] * w) % P]
+            xd.append([v * x % P for v in stark.ext_inv(den)])
+        row = {1: z["s0_vals1"][qi], 3: z["s0_vals3"][qi], 4: z["s0_vals4"][qi], "C": z["s0_valsC"][qi], "x": xd}
+        val = stark.execute_code(vinfo["queryVerifier"]["code"], lambda r: resolve(r, row))
+        grp = np.array([int(v) for v in z["s1_vals"][qi]], dtype=np.uint64).reshape(-1, 3)
+        assert [int(v) for v in grp[idx >> step1]] == val, qi
+    import stark_ref
+    proof = io.zkin2proof(z, info)
+    vals = stark.fri_values_at_queries(stark_ref.OracleBackend(), info, None, vinfo, proof, publics, challenges, queries)
+    for qi, idx in enumerate(queries):
+        grp = np.array([int(v) for v in z["s1_vals"][qi]], dtype=np.uint64).reshape(-1, 3)
+        assert [int(v) for v in grp[idx >> step1]] == [int(v) for v in vals[qi]], qi
+
+
+@pytest.mark.gpu
+def test_final_proof_full_device_verification():
+    """pil2gl.stark.stark_verify with verificationHashType BN128 accepts the proof the reference prover wrote -- BN128 transcript on the
+    device permutation, evaluation identity, every arity-4 Poseidon-BN254 Merkle path in one batch per tree, the 201-op query program on the
+    device evaluator, FRI.verify -- and rejects it after each of eight alterations"""
+    import copy
+    from pil2gl import stark, io
+    info, vinfo, root_c, z = _final()
+    ss = info["starkStruct"]
+    be = stark.GpuBackend(0, hash_type=ss["verificationHashType"], arity=ss["merkleTreeArity"], custom=ss["merkleTreeCustom"])
+    proof = io.zkin2proof(z, info)
+    publics = [int(v) for v in z["publics"]]
+    tr = _final_transcript(be.new_transcript(), z, info)
+    ok, why = stark.stark_verify(be, proof, publics, root_c, info, None, vinfo, challenges=tr)
+    assert ok, why
+
+    def tampered(what):
+        bad = copy.deepcopy(proof)
+        if what == "eval":
+            bad["evals"][41][0] = (bad["evals"][41][0] + 1) % P
+        elif what == "opened value":
+            bad["fri"][0]["polQueries"][3][0][0][2] = (bad["fri"][0]["polQueries"][3][0][0][2] + 1) % P
+        elif what == "constant":
+            bad["fri"][0]["polQueries"][30][4][0][35] = (bad["fri"][0]["polQueries"][30][4][0][35] + 1) % P
+        elif what == "sibling":
+            bad["fri"][0]["polQueries"][2][2][1][4][0] = int(bad["fri"][0]["polQueries"][2][2][1][4][0]) + 1
+        elif what == "fri layer value":
+            bad["fri"][1]["polQueries"][5][0][4] = (bad["fri"][1]["polQueries"][5][0][4] + 1) % P
+        elif what == "fri layer sibling":
+            bad["fri"][2]["polQueries"][0][1][0][0] = int(bad["fri"][2]["polQueries"][0][1][0][0]) + 1
+        elif what == "last polynomial":
+            bad["fri"][-1][1][2] = (bad["fri"][-1][1][2] + 1) % P
+        elif what == "root":
+            bad["root3"] = int(bad["root3"]) + 1
+        return bad
+    for what in ("eval", "opened value", "constant", "sibling", "fri layer value", "fri layer sibling", "last polynomial", "root"):
+        ok, why = stark.stark_verify(be, tampered(what), publics, root_c, info, None, vinfo, challenges=tr)
+        assert not ok, what
+    # a challenge that is not the transcript's: the identity no longer holds
+    bad_tr = dict(tr, challenges=[list(c) for c in tr["challenges"]]); bad_tr["challenges"][3] = [[1, 2, 3]]
+    ok, _ = stark.stark_verify(be, proof, publics, root_c, info, None, vinfo, challenges=bad_tr)
+    assert not ok

@@ -330,9 +330,9 @@ def bn128_mads(t):
     return full + partial
 
 
-def start_watchdog(Progress, rank):
+def start_watchdog(Progress):
     """A rank that has made no progress (stage boundary or collective, pil2gl.parallel.Progress) for PIL2GL_STALL_S seconds
-XX
+    dumps the stack of every thread and exits non-zero: faulthandler.dump_traceback_later(limit, exit=True), whose timer
     is a C thread that needs no interpreter lock: a main thread stuck inside a driver call (where round 2's 2-rank run on one
     GPU sat, silently, until it was killed) cannot keep it from firing.  torch.distributed.run tears the other ranks down."""
     import faulthandler
@@ -348,7 +348,7 @@ XX
     rearm(None, 0)
 
 
-def sharded_memory_estimate(mode, n_bits, n_cols, world, rank0_extra=True):
+def sharded_memory_estimate(mode, n_bits, n_cols, world):
     """device bytes one rank of a coset-sharded run holds at its peak (8-byte words), so that a configuration that cannot fit is
     refused with a message instead of found out by the allocator half-way (or, with ranks sharing a GPU, by a peer's collective
     timing out).  Counted: the replicated trace, the coefficient scratch of the LDE, the rank's slice of the extension, its share
@@ -615,7 +615,7 @@ def main():
     pil2gl.init(local_rank)
     from pil2gl.parallel import Progress
     if dist is not None:
-        start_watchdog(Progress, rank)
+        start_watchdog(Progress)
     if dist is not None:
         Progress.mark("process group up: %d ranks, backend %s%s; a rank without progress for %s s dumps its stacks and exits" % (
             world, backend, ", ranks share GPUs" if shared_gpu else "", os.environ.get("PIL2GL_STALL_S", "240")), rank, key=True)
@@ -643,8 +643,8 @@ def main():
     if sharded_mode:
         free, total_mem = torch.cuda.mem_get_info()
         sharers = (world + n_dev - 1) // n_dev if shared_gpu else 1
-        need = sharded_memory_estimate(mode, n_bits, n_cols, world, rank0_extra=(rank == 0))
-        need_all = need if sharers == 1 else sum(sharded_memory_estimate(mode, n_bits, n_cols, world, rank0_extra=(r == 0)) for r in range(sharers))
+        need = sharded_memory_estimate(mode, n_bits, n_cols, world)
+        need_all = need * sharers
         Progress.mark("set-up: %s %s, this rank needs about %.0f GB at its peak%s; device has %.0f GB" % (
             mode, wl, need / 1e9, (" (%.0f GB for the %d ranks sharing it)" % (need_all / 1e9, sharers)) if sharers > 1 else "", total_mem / 1e9), rank, key=True)
         if need_all > 0.97 * total_mem and os.environ.get("PIL2GL_SKIP_MEMCHECK", "0") in ("", "0"):
@@ -764,6 +764,8 @@ def main():
         t_lde = ev_time(lde, iters)
         t_leaf = ev_time(lambda: pil2gl.linearHash(dst, n_cols, args.split, digests), iters)
         leaf_clock_mhz = clock_under_hash_load()
+        # the other leaf form (splitLinearHash, linearhash_gpu.js:30-66: the reference's own *.starkstruct.gpu.json files set it), same rows
+        t_leaf_other = ev_time(lambda: pil2gl.linearHash(dst, n_cols, not args.split, digests), iters) if n_cols > 8 else None
         lvl = torch.empty(rows * 2, dtype=torch.int64, device=dev)
         t_lvl = ev_time(lambda: pil2gl.merkelizeLevel(digests, lvl), iters)
         leaf_perms = rows * ((n_cols + 7) // 8) if n_cols > 4 else 0
@@ -787,6 +789,13 @@ def main():
         if t_dot is not None:
             kernels.append({"kernel": "rows_dot_mfma_kernel (FRI polynomial: weighted sums of every row, 2 openings)", "ms": t_dot, "alg_bytes": 8 * rows * n_cols + 48 * rows,
                             "bound": "hbm"})
+        def split_perms(w):
+            batch = max(8, (w + 3) // 4); nb_ = (w + batch - 1) // batch
+            return sum((min(batch, w - b * batch) + 7) // 8 if min(batch, w - b * batch) > 4 else 0 for b in range(nb_)) + (((4 * nb_) + 7) // 8 if nb_ > 1 else 0)
+        if t_leaf_other is not None:
+            other_perms = rows * ((n_cols + 7) // 8 if args.split else split_perms(n_cols))
+            kernels.append({"kernel": "linear_hash_kernel (plain form)" if args.split else "linear_hash_split_kernel (splitLinearHash form of the same leaves)",
+                            "ms": t_leaf_other, "alg_bytes": 8 * rows * n_cols + 32 * rows, "perms": other_perms})
         if wl == "c3" and not sharded_mode:                    # the committed PMC passes were taken at config 3, one GPU
             pf = pmc_file()
             kernels[0]["traffic"] = load_pmc(pf, "linear_hash_kernel")
@@ -799,7 +808,7 @@ def main():
             k["hbm_frac"] = k["GBps"] / HBM_PEAK_GBS
             if k.get("perms"):
                 k["Gperm_s"] = k["perms"] / k["ms"] / 1e6
-        dom = max(kernels, key=lambda k: k["ms"])
+        dom = max(kernels[:3] + [k for k in kernels[3:] if k.get("bound") == "hbm"], key=lambda k: k["ms"])
         roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": dom["GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": dom["hbm_frac"], "traffic": dom.get("traffic"), "traffic_source": dom.get("traffic_source"),
                     "note": "Poseidon hashing is integer-issue bound (no 64-bit multiplier on gfx950): its HBM fraction is small by nature; roofline_int_issue prices it against its own roof, kernels[1] is the HBM-bound LDE"}
@@ -830,6 +839,8 @@ def main():
             "roofline_int_issue_lde": lde_int_roofline(n_bits, n_cols, cc, kernels[1]["ms"]),
             "kernels": kernels,
         }
+        if t_leaf_other is not None:
+            out["leaf_plain_ms" if args.split else "leaf_split_ms"] = t_leaf_other
         if dist is not None:
             out["n_ranks"] = dist.get_world_size()
             out["ranks_share_gpus"] = bool(shared_gpu)

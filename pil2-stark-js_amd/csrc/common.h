@@ -11,6 +11,9 @@ namespace pil2gl {
 typedef uint64_t u64;
 typedef uint32_t u32;
 
+// largest transform (rows = 2^this) the NTT / LDE / FRI-fold entry points accept on one device
+#define PIL2GL_MAX_NTT_BITS 30
+
 // error plumbing ------------------------------------------------------------
 int  fail(int code, const char *fmt, ...);          // records the message, returns code
 int  hip_fail(hipError_t e, const char *what);      // -> PIL2GL_EHIP

@@ -211,7 +211,7 @@ int pil2gl_fri_fold_dev(const uint64_t *pol, uint32_t polBits, uint32_t outBits,
                         const uint64_t challenge[3], uint64_t *out, void *stream) {
     P2_TRY(ensure_init());
     if (!pol || !out || !challenge) return fail(PIL2GL_EINVAL, "null buffer");
-    if (outBits > polBits || polBits > 27) return fail(PIL2GL_EINVAL, "Invalid polynomial size");
+    if (outBits > polBits || polBits > PIL2GL_MAX_NTT_BITS) return fail(PIL2GL_EINVAL, "Invalid polynomial size");
     hipStream_t st = as_stream(stream);
     const u64 n = 1ull << polBits;
     u64 *coef;
@@ -269,7 +269,7 @@ static int host3(const uint64_t *in, u64 nIn, uint64_t *out, u64 nOut, int (*fn)
 }
 struct FoldArgs { u32 polBits, outBits; u64 shiftInv; const u64 *ch; };
 int pil2gl_fri_fold(const uint64_t *pol, uint32_t polBits, uint32_t outBits, uint64_t shiftInv, const uint64_t challenge[3], uint64_t *out) {
-    if (outBits > polBits || polBits > 27) return fail(PIL2GL_EINVAL, "Invalid polynomial size");
+    if (outBits > polBits || polBits > PIL2GL_MAX_NTT_BITS) return fail(PIL2GL_EINVAL, "Invalid polynomial size");
     FoldArgs a = { polBits, outBits, shiftInv, challenge };
     return host3(pol, 3ull << polBits, out, 3ull << outBits,
                  [](const u64 *i, u64 *o, void *p) { FoldArgs *a = (FoldArgs *)p; return pil2gl_fri_fold_dev(i, a->polBits, a->outBits, a->shiftInv, a->ch, o, nullptr); }, &a);
@@ -402,7 +402,7 @@ int pil2gl_x_div_x_sub_xi_cosets_dev(uint32_t nBitsExt, uint32_t extBits, const 
 }
 int pil2gl_build_lev_dev(uint32_t nBits, const uint64_t xi[3], uint64_t *lev, void *stream) {
     P2_TRY(ensure_init());
-    if (!xi || !lev || nBits > 27) return fail(PIL2GL_EINVAL, "bad LEv arguments");
+    if (!xi || !lev || nBits > PIL2GL_MAX_NTT_BITS) return fail(PIL2GL_EINVAL, "bad LEv arguments");
     std::vector<u64> xp(3 * (nBits ? nBits : 1));
     u64 cur[3] = { xi[0], xi[1], xi[2] };
     for (u32 b = 0; b < nBits; b++) { xp[3 * b] = cur[0]; xp[3 * b + 1] = cur[1]; xp[3 * b + 2] = cur[2]; h_e3_mul(cur, cur, cur); }

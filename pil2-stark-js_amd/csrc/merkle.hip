@@ -42,33 +42,78 @@ __device__ __forceinline__ void linear_hash_plain(const u64 *__restrict__ v, u32
     sponge(v, width, digest, m);
 }
 
-// FOUR waves per SIMD: the permutation wants ~160 registers, so at 128 the compiler spills 130 of them to scratch -- and the kernel
-// is still 3.4 % faster than at three waves without spills (516 vs 534 ms at config 3, same box): the fourth wave covers the S-box
-// chains' carry wait states, and scratch traffic is cheap for a kernel at 0.3 TB/s (round 2's kernel ran at the same rate either way)
-// (SPLIT is a template parameter so that the plain kernel does not carry the split form's sixteen intermediate digest words)
-template <bool SPLIT>
+// FOUR waves per SIMD at 124 registers and no scratch (the accumulator bias of every matrix-instruction chain is an inline constant and the
+// operands of every layer come from the LDS table: poseidon_blocks.cuh); five waves spill 26 registers and are 8 % slower.
 __global__ void __launch_bounds__(256, 4) linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, u64 *__restrict__ out) {
     const u64 row0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = row0 < height;
-    const u64 row = live ? row0 : height - 1;       // width, split are uniform: every lane takes the same path
+    const u64 row = live ? row0 : height - 1;       // width is uniform: every lane takes the same path
     const u64 *v = in + row * width;
     MdsMfma m;
     poseidon_init(m);
     u64 d[4];
-    if (!SPLIT || width <= 4) {
-        linear_hash_plain(v, (u32)width, d, m);
-    } else {                                        // linearhash_gpu.js:30-66, glwasm.js:879-1087
-        u32 w = (u32)width;
-        u32 batch = max(8u, (w + 3) / 4);
-        u64 hs[16];
-        u32 nh = 0;
-        for (u32 b = 0; b < w; b += batch) { linear_hash_plain(v + b, min(batch, w - b), hs + nh, m); nh += 4; }
-        if (nh <= 4) { d[0] = hs[0]; d[1] = hs[1]; d[2] = hs[2]; d[3] = hs[3]; }
-        else sponge(hs, nh, d, m);
-    }
+    linear_hash_plain(v, (u32)width, d, m);
     if (!live) return;
     u64 *o = out + 4 * row;
     o[0] = d[0]; o[1] = d[1]; o[2] = d[2]; o[3] = d[3];
+}
+
+// The split form (linearhash_gpu.js:30-66, glwasm.js:879-1087): up to four batches of max(8, ceil(width / 4)) columns hashed on their
+// own, then their digests hashed.  Nothing but the row pointer lives in registers across a permutation: a batch digest waits in LDS
+// (eight words per lane) and the second sponge runs as soon as its chunk is there -- P(d0 | d1, 0), then P(d2 | d3, capacity) -- instead
+// of sixteen digest words held through eighteen permutations (round 3: 128 registers + 172 bytes of scratch per lane).
+// 512-thread workgroups: two per CU share 160 KB of LDS (31 KB operand table + 32 KB of digests each), four waves per SIMD as above.
+constexpr u32 SPLIT_BLOCK = 512;
+__global__ void __launch_bounds__(SPLIT_BLOCK, 4) linear_hash_split_kernel(const u64 *__restrict__ in, u64 width, u64 height, u64 *__restrict__ out) {
+    __shared__ u64 park[8][SPLIT_BLOCK];
+    const u32 tid = threadIdx.x;
+    const u64 row0 = (u64)blockIdx.x * blockDim.x + tid;
+    const bool live = row0 < height;
+    const u64 row = live ? row0 : height - 1;
+    const u64 *v = in + row * width;
+    MdsMfma m;
+    poseidon_init(m);
+    const u32 w = (u32)width, batch = max(8u, (w + 3) / 4), nb = (w + batch - 1) / batch;   // 2 <= nb <= 4 (width > 8), uniform
+    // ONE permutation call site (several inlined copies cost the register allocation of all of them: 444 bytes of scratch per lane):
+    // batch b absorbs its chunks; the batch that completes a pair (odd b, or the last one) then also runs the pair's second-level
+    // permutation P(d_even | d_odd, capacity of the pair before)
+    u64 st[12];
+    for (u32 b = 0; b < nb; b++) {
+        const u32 bw = min(batch, w - b * batch);
+        const u64 *vb = v + (u64)b * batch;
+        const u32 nChunks = bw <= 4 ? 0 : (bw + 7) / 8;                          // a batch of <= 4 columns is its own digest (linearhash.js:22-28)
+        const bool closes = (b & 1) || b == nb - 1;
+        for (u32 i = 0; i < nChunks + (closes ? 1 : 0); i++) {
+            if (i < nChunks) {
+                const u32 n = min(8u, bw - 8 * i);
+#pragma unroll
+                for (u32 j = 0; j < 8; j++) st[j] = j < n ? vb[8 * i + j] : 0;
+                if (i == 0) st[8] = st[9] = st[10] = st[11] = 0;
+            } else {
+                u64 d[4];
+#pragma unroll
+                for (u32 j = 0; j < 4; j++) d[j] = nChunks ? canon(st[8 + j]) : (j < bw ? vb[j] : 0);
+#pragma unroll
+                for (u32 j = 0; j < 4; j++) {
+                    st[j] = (b & 1) ? park[j][tid] : d[j];
+                    st[4 + j] = (b & 1) ? d[j] : 0;
+                    st[8 + j] = b >= 2 ? park[4 + j][tid] : 0;
+                }
+            }
+            poseidon_perm<0>(st, m);
+            st[8] = st[0]; st[9] = st[1]; st[10] = st[2]; st[11] = st[3];
+        }
+        if (!closes) {                                                          // an even batch with a partner to come: its digest waits in LDS
+#pragma unroll
+            for (u32 j = 0; j < 4; j++) park[j][tid] = nChunks ? canon(st[8 + j]) : (j < bw ? vb[j] : 0);
+        } else if (b < nb - 1) {                                                // the first pair's output is the second pair's capacity (lazy, as sponge() keeps it)
+#pragma unroll
+            for (u32 j = 0; j < 4; j++) park[4 + j][tid] = st[8 + j];
+        }
+    }
+    if (!live) return;
+    u64 *o = out + 4 * row;
+    o[0] = canon(st[8]); o[1] = canon(st[9]); o[2] = canon(st[10]); o[3] = canon(st[11]);
 }
 
 // glwasm.js:1220-1254: out[i] = Poseidon(in[8i..8i+7], capacity 0)[0..3]
@@ -277,8 +322,8 @@ int pil2gl_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64_t hei
     if (width >= (1ull << 31)) return fail(PIL2GL_EINVAL, "row width too large");
     u64 blocks = (height + 255) / 256;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
-    if (split) linear_hash_kernel<true><<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(in, width, height, out);
-    else linear_hash_kernel<false><<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(in, width, height, out);
+    if (split && width > 8) linear_hash_split_kernel<<<(unsigned)((height + SPLIT_BLOCK - 1) / SPLIT_BLOCK), SPLIT_BLOCK, 0, as_stream(stream)>>>(in, width, height, out);
+    else linear_hash_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(in, width, height, out);     // one batch: the split form IS the plain one
     KERNEL_CHECK();
     return PIL2GL_OK;
 }

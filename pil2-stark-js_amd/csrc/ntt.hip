@@ -523,7 +523,9 @@ using namespace pil2gl;
 
 static int check_ntt_args(const void *src, const void *dst, uint32_t nBits, uint32_t nBitsExt) {
     if (!src || !dst) return fail(PIL2GL_EINVAL, "null buffer");
-    if (nBits > 27 || nBitsExt > 27) return fail(PIL2GL_EINVAL, "domain of 2^%u rows is not supported (max 2^27)", nBits > nBitsExt ? nBits : nBitsExt);
+    // the reference's transforms take any nBits <= 32 (f3g.js:40, fft.js:39-50); here row indices, twiddle exponents and grid sizes are
+    // 32-bit quantities that have been checked to 2^30 rows (four passes of 8/8/7/7 stages; 2^30 x 1 column is 8.6 GB each way)
+    if (nBits > PIL2GL_MAX_NTT_BITS || nBitsExt > PIL2GL_MAX_NTT_BITS) return fail(PIL2GL_EINVAL, "domain of 2^%u rows is not supported (max 2^%d)", nBits > nBitsExt ? nBits : nBitsExt, PIL2GL_MAX_NTT_BITS);
     if (nBitsExt < nBits) return fail(PIL2GL_EINVAL, "nBitsExt (%u) < nBits (%u)", nBitsExt, nBits);
     return PIL2GL_OK;
 }
@@ -532,9 +534,9 @@ static int check_ntt_args(const void *src, const void *dst, uint32_t nBits, uint
 static int check_coset_args(const void *src, const void *dst, uint32_t nBits, uint32_t nBitsExt, uint32_t cosetBegin, uint32_t cosetCount) {
     if (!src || !dst) return fail(PIL2GL_EINVAL, "null buffer");
     if (nBitsExt < nBits) return fail(PIL2GL_EINVAL, "nBitsExt (%u) < nBits (%u)", nBitsExt, nBits);
-    if (nBits > 27 || nBitsExt > 31) return fail(PIL2GL_EINVAL, "domain of 2^%u rows (extended 2^%u) is not supported", nBits, nBitsExt);
+    if (nBits > PIL2GL_MAX_NTT_BITS || nBitsExt > 31) return fail(PIL2GL_EINVAL, "domain of 2^%u rows (extended 2^%u) is not supported", nBits, nBitsExt);
     if (cosetCount == 0 || (uint64_t)cosetBegin + cosetCount > (1ull << (nBitsExt - nBits))) return fail(PIL2GL_EINVAL, "coset range [%u,%u) outside 2^%u", cosetBegin, cosetBegin + cosetCount, nBitsExt - nBits);
-    if (((uint64_t)cosetCount << nBits) > (1ull << 27)) return fail(PIL2GL_EINVAL, "slice of %u cosets x 2^%u rows exceeds 2^27 local rows", cosetCount, nBits);
+    if (((uint64_t)cosetCount << nBits) > (1ull << PIL2GL_MAX_NTT_BITS)) return fail(PIL2GL_EINVAL, "slice of %u cosets x 2^%u rows exceeds 2^%d local rows", cosetCount, nBits, PIL2GL_MAX_NTT_BITS);
     return PIL2GL_OK;
 }
 

@@ -116,44 +116,90 @@ def test_ntt_fixed_geometry_kernels(gl, oracle, nBits, nPols, extBits, monkeypat
     assert np.array_equal(f0[:, :3], oracle.fft_cols(np.ascontiguousarray(a[:, :3]), nBits))
 
 
-def test_ntt_at_the_largest_domain(gl, oracle):
-    """2^27 rows, the largest domain the transforms take (config 3's extended domain; the quotient's iNTT / NTT run there):
-    fft then ifft returns the input bit for bit; the transform of the coefficient vector (0, c, 0, ...) is c w^i (closed form,
-    rows sampled up to the last one); the transform is linear on sampled rows; one row more is refused"""
+@pytest.mark.parametrize("nb,C", [(27, 3), (29, 3), (30, 1)])
+def test_ntt_at_the_largest_domain(gl, oracle, nb, C):
+    """2^27 rows (config 3's extended domain), 2^29 x 3 (config 5's: the quotient's transforms run there; 12.9 GB a buffer) and
+    2^30 x 1, the largest domain the transforms take -- the reference's take any nBits <= 32 (f3g.js:40, fft_p.js:178): fft
+    then ifft returns the input bit for bit; the transform of the coefficient vector (0, c, 0, ...) is c w^i (closed form,
+    rows sampled up to the last one); the transform is linear on sampled rows; one bit more than 2^30 is refused"""
     import torch
-    from pil2gl import _lib
-    nb, C = 27, 3
+    import gc
     n = 1 << nb
-    g = torch.Generator(device="cuda"); g.manual_seed(27)
-    a = torch.randint(0, 1 << 62, (n * C,), dtype=torch.int64, device="cuda", generator=g)
-    cvals = [5, P - 2, 0x123456789ABCDEF]
+    gc.collect(); torch.cuda.empty_cache()
+    if torch.cuda.mem_get_info()[0] < 6.5 * 8 * n * C + 4e9:
+        pytest.skip("needs %.0f GB of free device memory" % ((6.5 * 8 * n * C + 4e9) / 1e9))
+    g = torch.Generator(device="cuda"); g.manual_seed(nb)
+    a = torch.empty(n * C, dtype=torch.int64, device="cuda")
+    for o in range(0, n * C, 1 << 28):
+        m = min(1 << 28, n * C - o)
+        a[o:o + m] = torch.randint(0, 1 << 62, (m,), dtype=torch.int64, device="cuda", generator=g)
+    cvals = [5, P - 2, 0x123456789ABCDEF][:C]
     av = a.view(n, C)
     f = torch.empty_like(a); back = torch.empty_like(a)
     gl.fft(a, C, nb, f)
     gl.ifft(f, C, nb, back)
     assert torch.equal(back, a)
+    del back
     e = torch.zeros(n * C, dtype=torch.int64, device="cuda")
     ev = e.view(n, C)
     for c_, v in enumerate(cvals):
         ev[1, c_] = np.array([v], dtype=np.uint64).view(np.int64)[0]
     fe = torch.empty_like(e)
     gl.fft(e, C, nb, fe)
+    del e, ev
     w = int(oracle.root(nb))
-    rows = [0, 1, 2, 12345, n // 2, n - 2, n - 1]
+    rows = [0, 1, 2, 12345, n // 2, n // 2 + 1, (n // 3) | 1, n - 2, n - 1]
     got = fe.view(n, C)[rows].cpu().numpy().view(np.uint64)
+    del fe
     for k, i in enumerate(rows):
         assert [int(x) for x in got[k]] == [v * pow(w, i, P) % P for v in cvals], i
     # linearity on the same rows: fft(a + e) = fft(a) + fft(e)   (a + e differs from a in row 1 only)
-    s_ = a.clone(); sv = s_.view(n, C)
     row1 = [(int(x) + v) % P for x, v in zip(av[1].cpu().numpy().view(np.uint64), cvals)]
-    sv[1] = torch.from_numpy(np.array(row1, dtype=np.uint64).view(np.int64)).cuda()
-    fs = torch.empty_like(a)
-    gl.fft(s_, C, nb, fs)
-    fa = f.view(n, C)[rows].cpu().numpy().view(np.uint64); fsv = fs.view(n, C)[rows].cpu().numpy().view(np.uint64)
+    av[1] = torch.from_numpy(np.array(row1, dtype=np.uint64).view(np.int64)).cuda()
+    fa = f.view(n, C)[rows].cpu().numpy().view(np.uint64)
+    gl.fft(a, C, nb, f)
+    fsv = f.view(n, C)[rows].cpu().numpy().view(np.uint64)
     for k in range(len(rows)):
         assert [int(x) for x in fsv[k]] == [(int(x) + int(y)) % P for x, y in zip(fa[k], got[k])]
     with pytest.raises(Exception):
-        gl.fft(a, 1, 28, f)
+        gl.fft(a, 1, 31, f)
+    with pytest.raises(Exception):
+        gl.interpolate(a, 1, 28, f, 31)
+
+
+def test_interpolate_at_the_largest_domain(gl, oracle):
+    """config 5's shape on one device, three columns: 2^26 rows extended to 2^29.  The trace c w_N^i is the polynomial c x, whose
+    extension is c 7 w_E^i in natural row order (stark_gen_helpers.js:139-144); and the sum of two traces extends to the sum"""
+    import torch
+    nb, nbe, C = 26, 29, 3
+    N, E = 1 << nb, 1 << nbe
+    from pil2gl import stark
+    be = stark.GpuBackend(0)
+    cvals = [3, P - 5, 0xFEDCBA987654321]
+    x = be.build_x(nb, 1)                                          # w_N^i
+    src = be.empty(N * C)
+    ops = [(stark.OPC["mul"], (stark.SEC, 1, 1, 0, k), (stark.SEC, 1, 0, 0, 0), (stark.SCALAR, 1, 0, 0, k)) for k in range(C)]
+    be.eval_program(ops, 0, [(x, 1), (src, C)], np.array(cvals, dtype=np.uint64), nb, 0)
+    dst = be.empty(E * C)
+    gl.interpolate(src, C, nb, dst, nbe)
+    wE = int(oracle.root(nbe))
+    rows = [0, 1, 7, 8, 9, 123456789, E // 2, E - 9, E - 1]
+    got = dst.view(E, C)[rows].cpu().numpy().view(np.uint64)
+    for k, i in enumerate(rows):
+        assert [int(v) for v in got[k]] == [c * 7 * pow(wE, i, P) % P for c in cvals], i
+    # a second trace: random; extension of the sum = sum of the extensions on sampled rows
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    r = torch.randint(0, 1 << 62, (N * C,), dtype=torch.int64, device="cuda", generator=g)
+    d2 = be.empty(E * C)
+    gl.interpolate(r, C, nb, d2, nbe)
+    er = d2.view(E, C)[rows].cpu().numpy().view(np.uint64)
+    s_ = be.empty(N * C)
+    ops = [(stark.OPC["add"], (stark.SEC, 1, 2, 0, k), (stark.SEC, 1, 0, 0, k), (stark.SEC, 1, 1, 0, k)) for k in range(C)]
+    be.eval_program(ops, 0, [(src, C), (r, C), (s_, C)], np.zeros(1, np.uint64), nb, 0)
+    gl.interpolate(s_, C, nb, d2, nbe)
+    es = d2.view(E, C)[rows].cpu().numpy().view(np.uint64)
+    for k in range(len(rows)):
+        assert [int(v) for v in es[k]] == [(int(a_) + int(b_)) % P for a_, b_ in zip(got[k], er[k])]
 
 
 def test_interpolate_golden_kat(gl):
@@ -490,6 +536,22 @@ def test_merkelize_level_and_rows(gl, oracle):
     d = gl.linearHash(rows, 21, False)
     for i in (0, 7, 512):
         assert d[4 * i:4 * i + 4].tolist() == oracle.linear_hash(rows[i], False).tolist()
+
+
+@pytest.mark.parametrize("width", [5, 8, 9, 12, 16, 17, 27, 32, 33, 36, 47, 100, 131])
+def test_split_linear_hash_rows_against_oracle(gl, oracle, width):
+    """splitLinearHash (linearhash_gpu.js:30-66) on whole row blocks: two, three and four batches, a last batch of <= 4 columns
+    (its own digest, unhashed), one batch only (the plain sponge), heights that leave the 512-row workgroups ragged"""
+    rng = np.random.default_rng(width)
+    for h in (1, 511, 513, 1500):
+        rows = rand_field(rng, (h, width))
+        d = gl.linearHash(rows, width, True).reshape(h, 4)
+        for i in sorted({0, min(1, h - 1), h // 2, max(0, h - 2), h - 1}):
+            assert d[i].tolist() == oracle.linear_hash(rows[i], True).tolist(), (width, h, i)
+    rows = rand_field(rng, (4096, width))
+    d = gl.linearHash(rows, width, True).reshape(-1, 4)
+    want = np.array([oracle.linear_hash(r, True) for r in rows[1000:1064]], dtype=np.uint64)
+    assert (d[1000:1064] == want).all()
 
 
 # ------------------------------------------------------------------ transcript + reference proof, through the product

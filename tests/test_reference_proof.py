@@ -347,12 +347,14 @@ def test_final_proof_full_device_verification():
             bad["fri"][0]["polQueries"][3][0][0][2] = (bad["fri"][0]["polQueries"][3][0][0][2] + 1) % P
         elif what == "constant":
             bad["fri"][0]["polQueries"][30][4][0][35] = (bad["fri"][0]["polQueries"][30][4][0][35] + 1) % P
-        elif what == "sibling":
-            bad["fri"][0]["polQueries"][2][2][1][4][0] = int(bad["fri"][0]["polQueries"][2][2][1][4][0]) + 1
+        elif what == "sibling":                                   # (a level of an arity-4 path lists four nodes; the one at the path's own
+            slot = ((tr["friQueries"][2] >> 8) % 4 + 1) % 4        #  position is recomputed, not read: alter a true sibling)
+            bad["fri"][0]["polQueries"][2][2][1][4][slot] = int(bad["fri"][0]["polQueries"][2][2][1][4][slot]) + 1
         elif what == "fri layer value":
             bad["fri"][1]["polQueries"][5][0][4] = (bad["fri"][1]["polQueries"][5][0][4] + 1) % P
         elif what == "fri layer sibling":
-            bad["fri"][2]["polQueries"][0][1][0][0] = int(bad["fri"][2]["polQueries"][0][1][0][0]) + 1
+            slot = ((tr["friQueries"][0] % (1 << ss["steps"][2]["nBits"])) % 4 + 1) % 4
+            bad["fri"][2]["polQueries"][0][1][0][slot] = int(bad["fri"][2]["polQueries"][0][1][0][slot]) + 1
         elif what == "last polynomial":
             bad["fri"][-1][1][2] = (bad["fri"][-1][1][2] + 1) % P
         elif what == "root":

@@ -150,6 +150,9 @@ int pil2gl_fri_transpose_dev(const uint64_t *pol, uint32_t polBits, uint32_t tra
 /* ---- STARK step helpers: src/stark/stark_gen_helpers.js, src/helpers/polutils.js ---- */
 /* x_n / x_ext tables  stark_gen_helpers.js:111-116,139-144: x[i] = shift * w[nBits]^i */
 int pil2gl_build_x_dev(uint32_t nBits, uint64_t shift, uint64_t *x, void *stream);
+/* out[i] = first * ratio^i, i < n: one coset's rows of x_ext (first = 7 w_E^j, ratio = w_N; stark_gen_helpers.js:139-144) or any other
+ * table of powers, without building the whole 2^nBitsExt-row table (a rank of a coset-sharded proof holds its own cosets only) */
+int pil2gl_geometric_dev(uint64_t first, uint64_t ratio, uint64_t n, uint64_t *out, void *stream);
 /* buildZhInv(stark=true)  polutils.js:39-55 */
 int pil2gl_build_zhinv_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t *out, void *stream);
 /* buildOneRowZerofierInv(stark=true)  polutils.js:57-71 */

@@ -51,6 +51,15 @@ __global__ void build_x_kernel(u32 nBits, u64 shift, const u64 *__restrict__ pow
     if (i >= (1ull << nBits)) return;
     x[i] = mul(shift, root_pow(powW, nBits, (u32)i));
 }
+// out[i] = first * ratio^i: ratio^(2^b) by value, one product per set bit of i
+struct GeomPow { u64 p[40]; };
+__global__ void geometric_kernel(u64 first, GeomPow R, u64 n, u64 *__restrict__ out) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 acc = first;
+    for (u32 b = 0; (i >> b) != 0; b++) if ((i >> b) & 1) acc = mul(acc, R.p[b]);
+    out[i] = acc;
+}
 __global__ void periodic_kernel(const u64 *__restrict__ tab, u64 period, u64 n, u64 *__restrict__ out) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = tab[i % period];
@@ -303,6 +312,22 @@ int pil2gl_build_x_dev(uint32_t nBits, uint64_t shift, uint64_t *x, void *stream
     P2_TRY(ensure_init());
     if (nBits > 31) return fail(PIL2GL_EINVAL, "nBits too large");
     build_x_kernel<<<nblk(1ull << nBits), 256, 0, as_stream(stream)>>>(nBits, shift, tables().powW, x);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
+
+// A geometric sequence out[i] = first * ratio^i, i < n: the x table of ONE coset (first = 7 w_E^j, ratio = w_N: rows (pos << b) + j of
+// x_ext, stark_gen_helpers.js:139-144) or the twiddles w_E^(-i j) of the coset-wise quotient transform, without the 2^nBitsExt-row
+// table they would otherwise be gathered from (a rank of a coset-sharded proof never holds a whole extended column)
+int pil2gl_geometric_dev(uint64_t first, uint64_t ratio, uint64_t n, uint64_t *out, void *stream) {
+    P2_TRY(ensure_init());
+    if (n == 0) return PIL2GL_OK;
+    if (!out || n > (1ull << 40)) return fail(PIL2GL_EINVAL, "bad geometric-sequence arguments");
+    const u64 p = 0xFFFFFFFF00000001ull;
+    GeomPow R;
+    u64 cur = ratio % p;
+    for (int b = 0; b < 40; b++) { R.p[b] = cur; cur = h_mul(cur, cur); }
+    geometric_kernel<<<nblk(n), 256, 0, as_stream(stream)>>>(first % p, R, n, out);
     KERNEL_CHECK();
     return PIL2GL_OK;
 }

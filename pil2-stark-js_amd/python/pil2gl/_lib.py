@@ -90,6 +90,7 @@ SIGNATURES = {
     "pil2gl_fri_transpose": (_I, [vp, _U32, _U32, vp]),
     "pil2gl_fri_transpose_dev": (_I, [vp, _U32, _U32, vp, vp]),
     "pil2gl_build_x_dev": (_I, [_U32, _U64, vp, vp]),
+    "pil2gl_geometric_dev": (_I, [_U64, _U64, _U64, vp, vp]),
     "pil2gl_build_zhinv_dev": (_I, [_U32, _U32, vp, vp]),
     "pil2gl_build_one_row_zerofier_inv_dev": (_I, [_U32, _U32, _U64, vp, vp]),
     "pil2gl_build_frame_zerofier_dev": (_I, [_U32, _U32, _U64, _U64, vp, vp]),

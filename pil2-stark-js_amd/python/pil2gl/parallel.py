@@ -431,6 +431,47 @@ def coset_slice(be, full, n_bits, ext_bits, cb, cc, width):
     return be.from_torch(t[:, cb:cb + cc, :].contiguous().reshape(-1))
 
 
+def x_slice(be, n_bits, ext_bits, cb, cc, shift):
+    """rows of cosets [cb, cb+cc) of x_ext (stark_gen_helpers.js:139-144: x[i] = shift w_E^i) in local-slice order, built coset by
+    coset -- column jl is the geometric sequence (shift w_E^(cb+jl)) w_N^pos -- where the backend can (a rank then never holds a
+    whole extended column: at config 5 that table alone is 4.3 GB); sliced out of the full table otherwise"""
+    from . import stark as S
+    if not hasattr(be, "geometric"):
+        return coset_slice(be, be.build_x(n_bits + ext_bits, shift), n_bits, ext_bits, cb, cc, 1)
+    wE, wN = S.root_of_unity(n_bits + ext_bits), S.root_of_unity(n_bits)
+    cols = [be.geometric(shift * pow(wE, cb + jl, S.P) % S.P, wN, 1 << n_bits) for jl in range(cc)]
+    if cc == 1:
+        return cols[0]
+    return be.from_torch(torch.stack([be.as_torch(c) for c in cols], dim=1).reshape(-1))
+
+
+def zhinv_slice(be, n_bits, ext_bits, cb, cc):
+    """the same rows of buildZhInv's table (polutils.js:39-55): 1 / ((7 w_E^row)^N - 1) depends on the coset of the row only"""
+    from . import stark as S
+    sN = pow(S.SHIFT, 1 << n_bits, S.P)
+    wc = S.root_of_unity(ext_bits) if ext_bits else 1                      # w_E^N
+    z = [S._inv((sN * pow(wc, cb + jl, S.P) - 1) % S.P) for jl in range(cc)]
+    return be.from_host(np.tile(np.array(z, dtype=np.uint64), 1 << n_bits))
+
+
+def build_const_tree_sharded(be, consts, info, group=None, rehearse_world=None, comm=None):
+    """buildConstTree (stark_buildConstTree.js:13-35) for a coset-sharded proof: every rank extends the constants on its own cosets
+    and hashes its own leaves; the tree above them is split by leaf blocks (ShardedTree).  Same root as the single tree; no rank
+    holds the extended constants or the node array whole (config 5, two constant columns: 8.6 + 34 GB otherwise).  Collective:
+    every rank of the group calls it.  -> setup for stark_gen_sharded"""
+    comm = _comm_of(comm, group, rehearse_world)
+    ss = info["starkStruct"]
+    nb, nbe, nC = ss["nBits"], ss["nBitsExt"], info["nConstants"]
+    eb = nbe - nb
+    cb, cc = coset_range(comm.rank, comm.world, eb)
+    const_n = be.from_host(consts) if isinstance(consts, np.ndarray) else consts
+    local = be.empty((nC << nb) * cc)
+    be.interpolate_cosets(const_n, nC, nb, local, nbe, cb, cc, None)
+    tree = commit_local_slice(be, local, nC, nb, cc, comm, split_tree=True)
+    shard = {"local": local, "width": nC, "height": 1 << nbe, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
+    return {"constTree": None, "constRoot": tree.root, "const_n": const_n, "constShard": shard, "constTreeSharded": tree}
+
+
 def all_gather_rows(be, local, n_bits, cc, width, comm):
     """local slices (N*cc rows x width) of every rank -> the full buffer in natural row order, on every rank"""
     parts = comm.all_gather(be.as_torch(local).reshape(-1))
@@ -452,22 +493,25 @@ def quotient_coefficients_sharded(be, q_loc, nb, eb, cb, cc, qDim, qDeg, comm):
     N, E, w = 1 << nb, 1 << (nb + eb), comm.world
     nblk = N // w
     qt = be.as_torch(q_loc).reshape(N, cc, qDim)
-    x_e = be.as_torch(be.build_x(nb + eb, 1))                           # w_E^i
-    ar = torch.arange(N, dtype=torch.int64, device=x_e.device)
-    tws = []
+    geo = hasattr(be, "geometric")
+    wE_inv = S._inv(S.root_of_unity(nb + eb))
+    if not geo:
+        x_e = be.as_torch(be.build_x(nb + eb, 1))                       # w_E^i
+        ar = torch.arange(N, dtype=torch.int64, device=x_e.device)
     T = []
     for jl in range(cc):
         j = cb + jl
         qj = be.from_torch(qt[:, jl, :].contiguous().reshape(-1))
         Cj = be.empty(qDim << nb)
         be.ifft(qj, qDim, nb, Cj)
-        tw = be.from_torch(x_e[((E - j) * ar) % E].contiguous())           # w_E^(-i j)
+        tw = be.geometric(1, pow(wE_inv, j, S.P), N) if geo else be.from_torch(x_e[((E - j) * ar) % E].contiguous())   # w_E^(-i j)
         Tj = be.empty(qDim << nb)
         ops = [(S.OPC["mul"], (S.SEC, 1, 2, 0, k), (S.SEC, 1, 0, 0, k), (S.SEC, 1, 1, 0, 0)) for k in range(qDim)]
         be.eval_program(ops, 1, [(Cj, qDim), (tw, 1), (Tj, qDim)], np.zeros(1, np.uint64), nb, 0)
         T.append(be.as_torch(Tj).reshape(w, nblk, qDim))
-        tws.append(tw)
-    del x_e, ar, tws
+        del tw, Cj, qj
+    if not geo:
+        del x_e, ar
     mine = torch.stack(T, dim=1).reshape(-1).contiguous()               # [w][cc][nblk][qDim]: chunk s = my cosets' rows of block s
     parts = comm.all_to_all(mine)                                       # parts[s] = [cc][nblk][qDim] of rank s's cosets
     G = torch.stack([p_.reshape(cc, nblk, qDim) for p_ in parts], dim=0).reshape(w * cc, nblk, qDim).permute(1, 0, 2).contiguous()   # [nblk][2^eb][qDim]
@@ -491,14 +535,19 @@ def quotient_coefficients_sharded(be, q_loc, nb, eb, cb, cc, qDim, qDeg, comm):
     return be.from_torch(torch.cat([p_.reshape(-1) for p_ in comm.all_gather(be.as_torch(blk).reshape(-1))]))
 
 
-def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None, timings=None, comm=None):
+def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None, timings=None, comm=None, overwrite_trace=False, samples=None):
     """pil2gl.stark.stark_gen with every witness stage, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
     single-process one.  Replicated: the N-row transform of the split quotient and the FRI steps after the first fold (the
     quotient's coefficients come from per-coset transforms combined by row blocks, the first FRI tree's leaves and the first
     fold are computed by cosets); the stage trees above the leaves are split by leaf blocks (ShardedTree).
     rehearse_world=K: rank 0's share of a K-rank proof run alone (own slices stand in for the gathered ones, so the
-    result is not a valid proof): per-GPU time and memory on one GPU.  timings: dict that receives seconds per stage."""
+    result is not a valid proof): per-GPU time and memory on one GPU.  timings: dict that receives seconds per stage.
+    setup: stark.build_const_tree's (the constant tree whole on every rank) or build_const_tree_sharded's (split like the witness
+    trees: what a domain beyond one device's memory needs).  overwrite_trace: the last witness stage's trace buffer doubles as its
+    LDE's coefficient workspace and is destroyed (config 5: 107 GB trace + 107 GB slice per GPU, no room for a third buffer).
+    samples: {"rows": [local rows]} -> receives those rows of the rank's slices (cm1_ext, const_ext, x_ext, Zi_ext, q_ext): the
+    full-size rehearsal test checks them against closed forms."""
     from . import stark as S
     import time
     t_last = [time.perf_counter()]
@@ -511,10 +560,6 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     rank, world = comm.rank, comm.world
     rehearse_world = world if comm.mode == "rehearse" else None
     ss = info["starkStruct"]
-    if ss["nBitsExt"] > 27 and comm.mode != "rehearse":
-        # the replicated iNTT of q runs on the whole extended domain; the library's transforms stop at 2^27 rows
-        raise ValueError("a sharded PROOF needs nBitsExt <= 27 (got %d): the quotient's iNTT is replicated; "
-                         "the sharded COMMIT (extend_and_merkelize_sharded) has no such limit" % ss["nBitsExt"])
     nb, nbe = ss["nBits"], ss["nBitsExt"]
     eb, N, E = nbe - nb, 1 << ss["nBits"], 1 << ss["nBitsExt"]
     cb, cc = coset_range(rank, world, eb)
@@ -526,14 +571,16 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     nQ, nC = info["mapSectionsN"]["cm%d" % qStage], info["nConstants"]
     assert ss["steps"][0]["nBits"] == nbe
     ctx = {"pilInfo": info, "publics": list(publics), "challenges": [[] for _ in range(nStages + 3)], "evals": []}
-    constTree = setup["constTree"]
+    constTree = setup.get("constTree")
+    constShard, constSTree = setup.get("constShard"), setup.get("constTreeSharded")
     transcript = be.new_transcript()
     hash_commits = bool(ss.get("hashCommits", False))
     transcript.put(setup["constRoot"]); S.put_commit(be, transcript, list(publics), hash_commits)
 
     sl = lambda full, w: coset_slice(be, full, nb, eb, cb, cc, w)
-    loc = {"const_ext": sl(constTree["elements"], nC), "x_ext": sl(be.build_x(nbe, S.SHIFT), 1),
-           "Zi_ext#0": sl(be.build_zhinv(nb, nbe), 1)}
+    # the rank's rows of the domain tables, built per coset: no buffer of this function has 2^nBitsExt rows
+    loc = {"const_ext": constShard["local"] if constShard is not None else sl(constTree["elements"], nC),
+           "x_ext": x_slice(be, nb, eb, cb, cc, S.SHIFT), "Zi_ext#0": zhinv_slice(be, nb, eb, cb, cc)}
     widths = {"const_n": nC, "const_ext": nC, "q_ext": qDim, "f_ext": 3, "x_ext": 1, "x_n": 1, "Zi_ext#0": 1,
               "xDivXSubXi_ext": 3 * len(info["openingPoints"])}
     for s_ in range(1, qStage + 1):
@@ -562,7 +609,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
                 be.eval_program(ops, n_tmp, [(trace[x], widths[x]) for x in secs], scalars, nb, 0)
             S.resolve_hints(be, info, s_, trace, widths, nb, ctx)
         loc[name + "_ext"] = be.empty(w << nloc)
-        be.interpolate_cosets(trace[name + "_n"], w, nb, loc[name + "_ext"], nbe, cb, cc, None)
+        be.interpolate_cosets(trace[name + "_n"], w, nb, loc[name + "_ext"], nbe, cb, cc, trace[name + "_n"] if (overwrite_trace and s_ == nStages) else None)
         lap("stage%d_lde" % s_)
         strees[s_] = commit_local_slice(be, loc[name + "_ext"], w, nb, cc, comm, split_tree=True)
         shards[s_] = {"local": loc[name + "_ext"], "width": w, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}
@@ -574,6 +621,11 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     ctx["challenges"][qStage - 1] = [transcript.getField()]
     loc["q_ext"] = be.empty(qDim << nloc)
     run_local(exprs["expressionsCode"][info["cExpId"]]["code"])
+    if samples is not None:
+        ri = torch.tensor(list(samples["rows"]))
+        for k in ("cm1_ext", "const_ext", "x_ext", "Zi_ext#0", "q_ext"):
+            t_ = be.as_torch(loc[k]).reshape(1 << nloc, -1)
+            samples[k] = t_[ri.to(t_.device)].cpu().numpy().view(np.uint64)
     lap("q_expr")
     import os
     split_q = os.environ.get("PIL2GL_Q_GATHER", "0") != "1" and N % world == 0 and (N // world) >= 2 and cc & (cc - 1) == 0
@@ -704,6 +756,9 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         w = shards[s_]["width"]
         pieces.append(open_rows_local(be, shards[s_], queries, rank, world).cpu().reshape(-1) if not rehearse_world else torch.zeros(len(queries) * w, dtype=torch.int64))
         pieces.append(strees[s_].siblings_local(queries).reshape(-1))
+    if constSTree is not None:                                         # the constant tree is split like the others: its rows and lower siblings too
+        pieces.append(open_rows_local(be, constShard, queries, rank, world).cpu().reshape(-1) if not rehearse_world else torch.zeros(len(queries) * nC, dtype=torch.int64))
+        pieces.append(constSTree.siblings_local(queries).reshape(-1))
     if fri_first is not None:                                          # the opened groups of the first FRI tree, from the cosets' owners
         tbs, w1, nodes1, h1 = fri_first
         g1 = torch.zeros((len(q1), w1), dtype=torch.int64)
@@ -722,7 +777,11 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     for k, s_ in enumerate(range(1, qStage + 1)):
         rows = parts[2 * k].numpy().view(np.uint64).reshape(len(queries), shards[s_]["width"])
         opened.append((rows, strees[s_].siblings_finish(queries, parts[2 * k + 1])))
-    pc = be.group_proofs(constTree, queries)
+    if constSTree is not None:
+        pc = list(zip([[int(v) for v in r] for r in parts[2 * qStage].numpy().view(np.uint64).reshape(len(queries), nC)],
+                      constSTree.siblings_finish(queries, parts[2 * qStage + 1])))
+    else:
+        pc = be.group_proofs(constTree, queries)
     friProof[0]["polQueries"] = [[[[int(v) for v in rows[i]], sib[i]] for rows, sib in opened] + [list(pc[i])] for i in range(len(queries))]
     q = list(queries)
     for step in range(1, len(ss["steps"])):

@@ -66,6 +66,19 @@ def test_sharded_proof_equals_single_process_proof_cpu(oracle, world):
     _launch(world, "--backend", "oracle", worker=PROVE_WORKER)
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_proof_with_sharded_constant_tree_cpu(oracle, world):
+    """the constant tree split over the ranks like the witness trees (what a domain beyond one device's memory needs): same root,
+    same proof -- the constants' opened rows and lower siblings travel in the one batched sum with the others"""
+    _launch(world, "--backend", "oracle", "--shardsetup", "1", worker=PROVE_WORKER)
+
+
+@pytest.mark.gpu
+def test_sharded_proof_with_sharded_constant_tree_gpu_ranks(oracle):
+    """the same with the HIP library: the rank's rows of x_ext come from pil2gl_geometric_dev, coset by coset"""
+    _launch(4, "--backend", "gpu", "--nbits", "10", "--pairs", "20", "--steps", "13,9,4", "--shardsetup", "1", worker=PROVE_WORKER)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("world,nbits,pairs,steps", [(2, 8, 3, "11,7,3"), (4, 10, 20, "13,9,4")])
 def test_sharded_proof_gpu_ranks(oracle, world, nbits, pairs, steps):

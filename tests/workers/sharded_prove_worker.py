@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--air", default="fib", help="fib: one witness stage; perm: two (stage 2 = grand-product hint)")
     ap.add_argument("--hashcommits", type=int, default=0, help="starkStruct.hashCommits")
     ap.add_argument("--pg", default="gloo", help="process-group backend; nccl (= RCCL) needs one GPU per rank")
+    ap.add_argument("--shardsetup", type=int, default=0, help="1: the constant tree is split over the ranks too (parallel.build_const_tree_sharded)")
     a = ap.parse_args()
     if a.pg == "nccl":
         import torch
@@ -53,7 +54,11 @@ def main():
         from stark_backend import OracleBackend
         be = OracleBackend()
     setup = stark.build_const_tree(be, consts, info)
-    got = parallel.stark_gen_sharded(be, be.from_host(cm), setup, info, exprs, publics)
+    setup_sh = setup
+    if a.shardsetup:
+        setup_sh = parallel.build_const_tree_sharded(be, consts, info)
+        assert list(setup_sh["constRoot"]) == list(setup["constRoot"]), "rank %d: sharded constant tree has another root" % rank
+    got = parallel.stark_gen_sharded(be, be.from_host(cm), setup_sh, info, exprs, publics)
     want = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
     for k in ("challenges", "challengesFRISteps", "queries", "publics"):
         assert got[k] == want[k], "rank %d: %s differ" % (rank, k)

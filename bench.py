@@ -340,15 +340,21 @@ def start_watchdog(Progress):
     if limit <= 0:
         return
 
+    last = [-1e9]
+
     def rearm(what, now):
+        # at most once every two seconds: a re-arm cancels and restarts faulthandler's timer thread, and a sharded proof passes ~30
+        # marks (every stage and collective) inside the timed region -- the single-GPU line passes none
+        if now - last[0] < 2.0:
+            return
+        last[0] = now
         faulthandler.cancel_dump_traceback_later()
-        sys.stderr.write(""); sys.stderr.flush()
         faulthandler.dump_traceback_later(limit, exit=True)
     Progress.on_mark = rearm
     rearm(None, 0)
 
 
-def sharded_memory_estimate(mode, n_bits, n_cols, world):
+def sharded_memory_estimate(mode, n_bits, n_cols, world, overwrite_trace=False):
     """device bytes one rank of a coset-sharded run holds at its peak (8-byte words), so that a configuration that cannot fit is
     refused with a message instead of found out by the allocator half-way (or, with ranks sharing a GPU, by a peer's collective
     timing out).  Counted: the replicated trace, the coefficient scratch of the LDE, the rank's slice of the extension, its share
@@ -358,19 +364,82 @@ def sharded_memory_estimate(mode, n_bits, n_cols, world):
     w = 8
     trace = w * N * n_cols
     slice_ = trace * cc
-    scratch = trace                                            # coefficient matrix of the LDE
+    scratch = 0 if overwrite_trace else trace                  # coefficient matrix of the LDE (the witness buffer itself when it may be destroyed)
     nodes = 2 * w * 4 * N * cc * 2                             # leaf digests + subtree, two committed stages
     exchange = 2 * w * 4 * N * cc * 2                          # digests sent + received (all-to-all), windows when ranks share a GPU
     if mode == "prove-sharded":
         q = w * 3 * N * cc * 4 + w * 6 * N * cc * 2            # q slice, its coefficients and blocks; split quotient slice (qDim*qDeg = 6)
         fri = w * 3 * N * cc * 4 + w * 6 * N * cc              # xDivXSubXi (2 openings), f, accumulators, transposed copy
-        const_ = w * 2 * N * (1 + cc) + w * 8 * N * cc
+        const_ = w * 2 * N * (1 + cc) + w * 8 * N * cc         # constants (trace domain + own cosets), their leaves and subtree, x and ZhInv slices
     else:
         q = fri = const_ = 0
     total = trace + slice_ + scratch + nodes + exchange + q + fri + const_ + (2 << 30)
     # (rank 0's per-kernel timing pass after the timed steps takes one more slice, but from the blocks the proof has released
     # to torch's caching allocator: not additive)
     return int(total * 1.08)                                   # allocator granularity / fragmentation
+
+
+def _digest_words(obj):
+    """sha256 of the canonical text of a proof (or any nest of lists / dicts / integers) -> four 62-bit words"""
+    import hashlib
+
+    def canon(v):
+        if isinstance(v, dict):
+            return "{" + ",".join('"%s":%s' % (k, canon(v[k])) for k in sorted(v)) + "}"
+        if isinstance(v, (list, tuple)):
+            return "[" + ",".join(canon(x) for x in v) + "]"
+        return str(int(v))
+    h = hashlib.sha256(canon(obj).encode()).digest()
+    return [int.from_bytes(h[8 * i:8 * i + 8], "little") >> 2 for i in range(4)]
+
+
+def sharded_identity_check(be, comm, dev, rank, world, mode, args):
+    """What a multi-rank run does FIRST, whatever the exchange backend: the sharded path must produce the single-process result before
+    anything is timed.  prove-sharded: ONE proof of a config-2-size trace (2^20 x 8) split over the ranks -- every rank ends with a
+    complete proof -- and, on rank 0, the ordinary single-process proof of the same trace (its own, unsharded constant tree); the
+    digests of all world + 1 proofs must agree.  commit-sharded: the root of the sharded tree against the root of the single-device
+    extendAndMerkelize.  -> a dict for the JSON line; on disagreement every rank exits non-zero (they all see all the digests)."""
+    from pil2gl import stark, parallel
+    import pil2gl
+    n_bits, n_cols = WORKLOADS["c2"]
+    t0 = time.perf_counter()
+    if mode == "prove-sharded":
+        ss = {"nBits": n_bits, "nBitsExt": n_bits + EXT_BITS, "nQueries": 64, "verificationHashType": "GL", "splitLinearHash": bool(args.split),
+              "steps": [{"nBits": b} for b in fri_steps_for(n_bits + EXT_BITS)]}
+        info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
+        src, consts, publics = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
+        setup_sh = parallel.build_const_tree_sharded(be, consts, info, comm=comm)
+        mine = _digest_words(parallel.stark_gen_sharded(be, src, setup_sh, info, exprs, publics, comm=comm)["proof"])
+        want = None
+        if rank == 0:
+            setup = stark.build_const_tree(be, consts, info)
+            want = _digest_words(stark.stark_gen(be, src, setup, info, exprs, publics)["proof"])
+        what = "proof of 2^%d x %d (FRI %s, 64 queries)" % (n_bits, n_cols, "/".join(str(x["nBits"]) for x in ss["steps"]))
+    else:
+        src = make_trace(1 << n_bits, n_cols, 0x5EED0000, dev)
+        st = parallel.extend_and_merkelize_sharded(be, src, n_cols, n_bits, n_bits + EXT_BITS, split_tree=not args.full_tree, comm=comm)
+        mine = _digest_words(st["tree"].root if not args.full_tree else be.root({"nodes": st["nodes"]}))
+        want = None
+        if rank == 0:
+            E = 1 << (n_bits + EXT_BITS)
+            dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
+            pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
+            MH = pil2gl.buildMerkleHash(args.split)
+            want = _digest_words(MH.root(MH.merkelize(dst, n_cols, E)))
+            del dst
+        what = "root of extendAndMerkelize 2^%d x %d" % (n_bits, n_cols)
+    t = torch.zeros((world + 1) * 4, dtype=torch.int64)
+    t[4 * rank:4 * rank + 4] = torch.tensor(mine, dtype=torch.int64)
+    if rank == 0:
+        t[4 * world:] = torch.tensor(want, dtype=torch.int64)
+    t = comm.all_reduce_sum(t).reshape(world + 1, 4)
+    ref = [int(v) for v in t[world]]
+    bad = [r for r in range(world) if [int(v) for v in t[r]] != ref]
+    if bad:
+        sys.stderr.write("bench.py rank %d: SHARDED RESULT DIFFERS from the single-process one on rank(s) %s (%s): nothing timed\n" % (rank, bad, what)); sys.stderr.flush()
+        sys.exit(3)
+    return {"result": "ok", "checked": what + ", sharded over %d ranks on every rank == single process on rank 0" % world,
+            "digest": "%016x" % ref[0], "seconds": round(time.perf_counter() - t0, 2)}
 
 
 def self_launch(args):
@@ -415,7 +484,10 @@ def rehearse_shard(args):
 
 def rehearse_prove(args):
     """--mode prove-sharded --shard-of K on one GPU: rank 0's share of a K-GPU sharded proof (own slices standing in for the
-    gathered q / FRI polynomial / digests; the evaluations are computed here anyway because rank 0 owns coset 0)"""
+    gathered q / FRI polynomial / digests; the evaluations are computed here anyway because rank 0 owns coset 0).  Config 5
+    (2^26 x 200 -> 2^29 rows) runs this way too: constant tree split like the others, per-coset domain tables, and the witness
+    buffer doubling as the LDE's workspace (107 GB trace + 107 GB slice; the witness is generated again before every step,
+    outside the timing)."""
     from pil2gl import stark, parallel
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
@@ -426,24 +498,39 @@ def rehearse_prove(args):
           "steps": [{"nBits": b} for b in fri_steps_for(n_bits + EXT_BITS)]}
     info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
     be = stark.GpuBackend(0, args.split)
+    need = sharded_memory_estimate("prove-sharded", n_bits, n_cols, K)
+    overwrite = need > 0.97 * torch.cuda.mem_get_info()[1]          # no room for trace + coefficient scratch + slice: the trace is the scratch
+    if overwrite:
+        need = sharded_memory_estimate("prove-sharded", n_bits, n_cols, K, overwrite_trace=True)
     src, consts, publics = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
-    setup = stark.build_const_tree(be, consts, info)
+    comm = parallel.Comm(rehearse_world=K)
+    setup = parallel.build_const_tree_sharded(be, consts, info, comm=comm)
     times = []
     for i in range(args.warmup + args.steps):
+        if overwrite and i:
+            del src
+            src, _, _ = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        parallel.stark_gen_sharded(be, src, setup, info, exprs, publics, rehearse_world=K)
+        parallel.stark_gen_sharded(be, src, setup, info, exprs, publics, comm=comm, overwrite_trace=overwrite)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         if i >= args.warmup:
             times.append(dt)
     dt = sum(times) / len(times)
     stages = {}
-    r = parallel.stark_gen_sharded(be, src, setup, info, exprs, publics, rehearse_world=K, timings=stages)      # one more, instrumented
+    if overwrite:
+        del src
+        src, _, _ = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
+    comm.reset_stats()
+    r = parallel.stark_gen_sharded(be, src, setup, info, exprs, publics, comm=comm, timings=stages, overwrite_trace=overwrite)      # one more, instrumented
+    free, total = torch.cuda.mem_get_info()
     print(json.dumps({"metric": "per-GPU time of ONE proof split over %d GPUs (rank 0's share run alone, exchanges stood in)" % K,
                       "value": (1 << n_bits) * n_cols / dt, "unit": "trace-cells/s (the job rate if the %d ranks run in parallel and the exchanges are free)" % K,
                       "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "dtype": "u64", "data": "synthetic",
                       "config": {"workload": "full proof of 2^%d rows x %d cols, blow-up 8, %d of %d cosets on this GPU" % (n_bits, n_cols, (1 << EXT_BITS) // K, 1 << EXT_BITS),
-                                 "mode": "prove-sharded rehearsal", "shard_of": K}, "stages_s": {k: round(v, 4) for k, v in stages.items()},
-                      "exchange_per_proof": r["exchange"], "peak_torch_GB": torch.cuda.max_memory_allocated() / 1e9}), flush=True)
+                                 "mode": "prove-sharded rehearsal", "shard_of": K, "witness_buffer_is_lde_workspace": bool(overwrite)},
+                      "stages_s": {k: round(v, 4) for k, v in stages.items()},
+                      "exchange_per_proof": r["exchange"], "peak_torch_GB": torch.cuda.max_memory_allocated() / 1e9, "device_GB_in_use_at_end": (total - free) / 1e9,
+                      "estimated_peak_GB": need / 1e9}), flush=True)
 
 
 def h2d_sample(dev, total_bytes):
@@ -638,8 +725,6 @@ def main():
         return bench_bn128(args, dev, wl, n_bits, n_cols)
     if sharded_mode and (1 << EXT_BITS) % world:
         raise SystemExit("a sharded mode needs a world size dividing the %d cosets" % (1 << EXT_BITS))
-    if mode == "prove-sharded" and n_bits + EXT_BITS > 27:
-        raise SystemExit("--mode prove-sharded needs nBitsExt <= 27 (the quotient's iNTT and the first fold are replicated); use --mode commit-sharded for %s" % wl)
     if sharded_mode:
         free, total_mem = torch.cuda.mem_get_info()
         sharers = (world + n_dev - 1) // n_dev if shared_gpu else 1
@@ -655,6 +740,11 @@ def main():
     comm = parallel.Comm() if dist is not None else None
     prove_ctx = None
     be = stark.GpuBackend(local_rank, args.split)
+    identity = None
+    if sharded_mode and world > 1 and os.environ.get("PIL2GL_BENCH_IDENTITY", "1") != "0":
+        Progress.mark("identity check: sharded result against the single-process one", rank, key=True)
+        identity = sharded_identity_check(be, comm, dev, rank, world, mode, args)
+        Progress.mark("identity check %s (%s s)" % (identity["result"], identity["seconds"]), rank, key=True)
     if mode in ("prove", "prove-sharded"):
         n_cols -= n_cols & 1                                   # pairs of columns
         ss = {"nBits": n_bits, "nBitsExt": n_bits + EXT_BITS, "nQueries": 64, "verificationHashType": "GL",
@@ -667,7 +757,8 @@ def main():
         else:
             info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
             src, consts, publics = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0 if mode == "prove-sharded" else rank)   # sharded: ONE trace
-        setup = stark.build_const_tree(be, consts, info)
+        # sharded: the constant tree is split over the ranks like the witness trees (no rank holds an extended column whole)
+        setup = parallel.build_const_tree_sharded(be, consts, info, comm=comm) if mode == "prove-sharded" else stark.build_const_tree(be, consts, info)
         prove_ctx = (setup, info, exprs, publics)
     elif mode == "commit-sharded":                             # ONE trace, replicated; the cosets of its extension are split
         src = make_trace(N, n_cols, 0x5EED0000, dev)
@@ -846,6 +937,9 @@ def main():
             out["ranks_share_gpus"] = bool(shared_gpu)
         if exchange is not None:
             out["exchange_per_step"] = exchange
+        if identity is not None:
+            out["sharded_identity"] = identity["result"]
+            out["sharded_identity_check"] = identity
         if prove_ctx is not None:
             cexp = prove_ctx[2]["expressionsCode"][prove_ctx[1]["cExpId"]]["code"]["code"]
             fexp = prove_ctx[2]["expressionsCode"][prove_ctx[1]["friExpId"]]["code"]["code"]

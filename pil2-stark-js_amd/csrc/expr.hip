@@ -30,7 +30,8 @@ struct DevOp { u32 op; u32 aux; DevRef dest, src[2]; };      // 56 bytes; aux: l
 // a Horner chain  t = X*t + c_i  over an extension constant X is evaluated as sum_i c_i * X^(n-i) with the lazy
 // 22-bit-limb accumulation of csrc/dot.hip: LZ_BEGIN zeroes the 3x6 partial sums, LZ_MAD adds value * weight
 // (the weight's limbs come from the limb pool), LZ_END folds them into the destination.
-enum { GLX_LZ_BEGIN = 4, GLX_LZ_MAD = 5, GLX_LZ_END = 6 };
+enum { GLX_LZ_BEGIN = 4, GLX_LZ_MAD = 5, GLX_LZ_END = 6,
+       GLX_JIT_FENCE = 7 };       // run-time compiled kernels only: nothing is scheduled across it (group_loads)
 
 #define GLX_MAX_SECTIONS 24
 struct DevCtx {
@@ -367,11 +368,46 @@ static int allocate_slots(std::vector<IOp> &ops, u32 nVal, u32 &nSlots) {
     return PIL2GL_OK;
 }
 
-static int compile_program(const glx_program *prog, const glx_ctx *ctx, std::vector<IOp> &ops, u32 &nSlots, std::vector<u32> &limbPool, bool fuse) {
+// Pass 2b (run-time compiled kernels, PIL2GL_EXPR_GROUP=G): the loads of one G-column piece of a read-only section -- this row's and the
+// offset rows' -- are issued together where the first of them stood, between two fences.  A lane owns a row, so every load of a wave
+// touches 64 lines for 8 bytes each; issued one by one at their first uses, the sixteen columns of a line are asked for over a seventh of
+// the program and the line has left L1 and L2 in between (config 3: 224 GB requested for 115 GB of operands).  Values are
+// single-assignment here and the sections are not written, so moving a load earlier changes nothing but its live range.
+static void group_loads(std::vector<IOp> &ops, const glx_ctx *ctx, u32 G) {
+    std::vector<bool> written(GLX_MAX_SECTIONS, false);
+    for (const IOp &p : ops) if (has_dest(p.op) && p.dest.kind == GLX_SEC && p.dest.section < GLX_MAX_SECTIONS) written[p.dest.section] = true;
+    auto is_load = [&](const IOp &p) {
+        return p.op == GLX_OP_COPY && p.dest.kind == GLX_TMP && p.src[0].kind == GLX_SEC && p.src[0].section < GLX_MAX_SECTIONS && !written[p.src[0].section]
+               && ctx->sections[p.src[0].section].width >= G;
+    };
+    std::map<std::pair<u32, u32>, std::vector<u32>> groups;
+    for (u32 k = 0; k < ops.size(); k++) if (is_load(ops[k])) groups[{ ops[k].src[0].section, ops[k].src[0].index / G }].push_back(k);
+    std::vector<bool> moved(ops.size(), false);
+    std::vector<IOp> res;
+    IOp fence; memset(&fence, 0, sizeof fence); fence.op = GLX_JIT_FENCE;
+    for (u32 k = 0; k < ops.size(); k++) {
+        if (moved[k]) continue;
+        if (is_load(ops[k])) {
+            std::vector<u32> &g = groups[{ ops[k].src[0].section, ops[k].src[0].index / G }];
+            if (g.size() > 1) {
+                std::sort(g.begin(), g.end(), [&](u32 a, u32 b) { return ops[a].src[0].prime != ops[b].src[0].prime ? ops[a].src[0].prime < ops[b].src[0].prime : ops[a].src[0].index < ops[b].src[0].index; });
+                res.push_back(fence);
+                for (u32 m : g) { res.push_back(ops[m]); moved[m] = true; }
+                res.push_back(fence);
+                continue;
+            }
+        }
+        res.push_back(ops[k]);
+    }
+    ops.swap(res);
+}
+
+static int compile_program(const glx_program *prog, const glx_ctx *ctx, std::vector<IOp> &ops, u32 &nSlots, std::vector<u32> &limbPool, bool fuse, u32 groupCols = 0) {
     P2_TRY(validate_program(prog, ctx));
     u32 nVal = 0;
     P2_TRY(value_number(prog, ctx, ops, nVal));
     if (fuse && ctx && ctx->scalars) fuse_horner(ops, nVal, ctx, limbPool);
+    if (groupCols && ctx) group_loads(ops, ctx, groupCols);
     return allocate_slots(ops, nVal, nSlots);
 }
 
@@ -587,6 +623,7 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
     };
     for (size_t k = 0; k < ops.size(); k++) {
         const IOp &p = ops[k];
+        if (p.op == GLX_JIT_FENCE) { o << " __builtin_amdgcn_sched_barrier(0);\n"; continue; }
         if (p.op == GLX_LZ_BEGIN) { o << " for (int q = 0; q < 3; q++) for (int i = 0; i < 6; i++) LZ[q][i] = 0;\n"; continue; }
         if (p.op == GLX_LZ_MAD) {
             stage(p.src[0]);
@@ -734,16 +771,26 @@ extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *c
         const bool want = e ? atoi(e) != 0 : (ops.size() >= 64 && ctx->nBits >= 16);
         if (want && nSlots <= 200) {
             hipFunction_t fn;
-            if (jit_get(jit_source(ops, nSlots, ctx), &fn) != PIL2GL_OK) {
+            // PIL2GL_EXPR_GROUP=G: the same program with its section loads issued G columns at a time (group_loads); slots are allocated again
+            std::vector<IOp> gops; u32 gSlots = 0;
+            const char *ge = getenv("PIL2GL_EXPR_GROUP");
+            const u32 G = ge ? (u32)atoi(ge) : 0;
+            if (G) {
+                std::vector<u32> pool2;                          // (the limb pool comes out the same: grouping follows the Horner fusion)
+                P2_TRY(compile_program(prog, ctx, gops, gSlots, pool2, getenv("PIL2GL_EXPR_NOFUSE") == nullptr, G));
+                if (gSlots > 200 || pool2 != limbPool) gops.clear();
+            }
+            const bool grouped = !gops.empty();
+            if (jit_get(grouped ? jit_source(gops, gSlots, ctx) : jit_source(ops, nSlots, ctx), &fn) != PIL2GL_OK) {
                 static bool warned = false;
                 if (!warned) { fprintf(stderr, "pil2gl: run-time compilation unavailable (%s); using the interpreter kernel\n", pil2gl_last_error()); warned = true; }
                 goto interpreter;
             }
-            if (getenv("PIL2GL_JIT_INFO")) {
+            if (getenv("PIL2GL_JIT_INFO") && getenv("PIL2GL_JIT_INFO")[0] == '1') {
                 int regs = 0, lds = 0, loc = 0, maxt = 0;
                 (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn); (void)hipFuncGetAttribute(&lds, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn);
                 (void)hipFuncGetAttribute(&loc, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn); (void)hipFuncGetAttribute(&maxt, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, fn);
-                fprintf(stderr, "pil2gl jit_eval: %zu ops, regs %d, lds %d, scratch %d, max threads %d\n", ops.size(), regs, lds, loc, maxt);
+                fprintf(stderr, "pil2gl jit_eval: %zu ops%s, regs %d, lds %d, scratch %d, max threads %d\n", grouped ? gops.size() : ops.size(), grouped ? " (loads grouped)" : "", regs, lds, loc, maxt);
             }
             JitArgs A; memset(&A, 0, sizeof A);
             A.scalars = c.scalars; A.limbs = c.limbs; A.nBits = ctx->nBits;

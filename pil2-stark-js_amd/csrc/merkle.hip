@@ -207,7 +207,8 @@ __global__ void __launch_bounds__(64) sponge_chain_kernel(const u64 *__restrict_
 }
 
 // batch of independent permutations (glwasm.js:216 `poseidon`, hash/poseidon/poseidon.js:57)
-__global__ void __launch_bounds__(256, 3) poseidon_batch_kernel(const u64 *__restrict__ in, const u64 *__restrict__ cap, u64 count, u32 nOut, u64 *__restrict__ out) {
+// (four waves per SIMD like the leaf and tree kernels: 124 registers, no scratch, since the permutation is forced inline)
+__global__ void __launch_bounds__(256, 4) poseidon_batch_kernel(const u64 *__restrict__ in, const u64 *__restrict__ cap, u64 count, u32 nOut, u64 *__restrict__ out) {
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = i0 < count;
     const u64 i = live ? i0 : count - 1;

@@ -66,6 +66,24 @@ def test_dense_statement_of_the_permutation_agrees():
     assert r.returncode == 0 and "dense ok" in r.stdout, r.stdout + r.stderr
 
 
+def test_prefetching_instances_of_the_permutation_agree():
+    """PIL2GL_BN128_WIDE=1 selects the kernel instances that request the next term's LDS operand and table entry before multiplying the
+    current one (round 1's default for states of >= 10 elements; since round 3 the plain instances run everywhere and these are an A/B
+    switch): permutations of every width class, the arity-16 leaf rule and a small tree must still be the oracle's"""
+    import subprocess
+    import sys
+    code = ("import sys, os; sys.path[:0] = [%r, %r]; import numpy as np; import pil2gl; pil2gl.init(0); from pil2gl import bn128; import bn128_oracle as o\n"
+            "for n in (1, 2, 4, 8, 9, 10, 12, 16):\n"
+            "    a = [(5 ** (k + 7)) %% o.R for k in range(n)]\n"
+            "    assert bn128.poseidon(a, 3, n + 1) == o.poseidon(a, 3, n + 1), n\n"
+            "rows = [[(i * 131 + j * 7 + 1) %% 0xFFFFFFFF00000001 for j in range(100)] for i in range(70)]\n"
+            "t = bn128.buildMerkleHash(16, False).merkelize(np.array(rows, dtype=np.uint64).reshape(-1), 100, 70)\n"
+            "assert bn128.from_montgomery(t['nodes']) == o.merkelize(rows, 16, False)\n"
+            "print('wide ok')\n") % (os.path.join(os.path.dirname(GOLDEN), "..", "pil2-stark-js_amd", "python"), os.path.join(os.path.dirname(GOLDEN), "..", "oracle"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, PIL2GL_BN128_WIDE="1"))
+    assert r.returncode == 0 and "wide ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_montgomery_conversion(bn, orc):
     vals = [0, 1, orc.R - 1, 1 << 200, 0x123456789ABCDEF << 100]
     m = bn.to_montgomery(vals)

@@ -188,3 +188,77 @@ def test_config5_rank_share_on_one_gpu(oracle):
         assert cur == [int(v) for v in tree.root], leaf
     del local, digests, tree
     torch.cuda.empty_cache()
+
+
+@pytest.mark.gpu
+def test_config5_proof_rank_share_on_one_gpu(oracle):
+    """BASELINE config 5 PROVED sharded, in rehearsal: rank 0's share of an 8-rank proof of a 2^26 x 200 trace (2^29 extended rows: no
+    single device holds one extended column set) run alone on one GPU -- constant tree split like the witness trees, x / ZhInv built per
+    coset, the witness buffer doubling as the LDE's workspace, the quotient's coefficients from per-coset transforms.  The exchanges
+    are stood in by the rank's own data, so the result is not a proof; what IS checked, on sampled slice rows up to the last one, is
+    everything the rank computes from its own data, against closed forms on host integers: the witness is column c = w^(s_c) X, so
+    its extension on coset 0 is 7 w^(s_c + pos); L1(x) = (x^N - 1) / (N (x - 1)), LLAST(x) = L1(w x); x = 7 w^pos; ZhInv = 1 / (7^N - 1);
+    and the 2 600-op constraint expression of the AIR on those rows (big-integer interpreter, stark_verify.js:222-298 restated)
+    equals the rank's q_ext there."""
+    import numpy as np
+    import torch
+    import gc
+    sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
+    import pil2gl
+    from pil2gl import stark, parallel
+    pil2gl.shutdown(); pil2gl.init(0)
+    gc.collect(); torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 250e9:
+        pytest.skip("needs 250 GB of free device memory (%.0f GB free)" % (free / 1e9))
+    P = 0xFFFFFFFF00000001
+    nb, C, eb, world = 26, 200, 3, 8
+    N = 1 << nb
+    ss = {"nBits": nb, "nBitsExt": nb + eb, "nQueries": 16, "verificationHashType": "GL", "steps": [{"nBits": b} for b in (29, 24, 19, 14, 9, 4)]}
+    info, exprs, _ = stark.fibonacci_air(C // 2, ss)
+    be = stark.GpuBackend(0, False)
+    x = be.build_x(nb, 1)
+    trace = be.empty(N * C)
+    shifts = [(c * 7919 + 1 + (c % 3) * (N // 3)) % N for c in range(C)]
+    tv = trace.view(N, C)
+    for c in range(C):
+        tv[:, c] = torch.roll(x, -shifts[c])
+    del x, tv
+    consts = np.zeros((N, 2), dtype=np.uint64); consts[0, 0] = 1; consts[N - 1, 1] = 1
+    publics = [5, 6, 7]
+    comm = parallel.Comm(rehearse_world=world)
+    setup = parallel.build_const_tree_sharded(be, consts, info, comm=comm)
+    rows = [0, 1, 2, 77, N // 2 + 12345, N - 2, N - 1]
+    samples = {"rows": rows}
+    r = parallel.stark_gen_sharded(be, trace, setup, info, exprs, publics, comm=comm, overwrite_trace=True, samples=samples)
+    assert torch.cuda.max_memory_allocated() < 262e9
+    w = stark.root_of_unity(nb)
+    inv = lambda a: pow(a % P, P - 2, P)
+    s7N = pow(7, N, P)
+    L1 = lambda xx: (s7N - 1) * inv(N * (xx - 1)) % P            # xx on the coset 7 <w>: xx^N = 7^N
+    vc = [int(v) for v in r["challenges"][info["nStages"]][0]]
+    code = exprs["expressionsCode"][info["cExpId"]]["code"]["code"]
+    for k, pos in enumerate(rows):
+        xx = 7 * pow(w, pos, P) % P
+        assert [int(v) for v in samples["cm1_ext"][k]] == [7 * pow(w, shifts[c] + pos, P) % P for c in range(C)], pos
+        assert [int(v) for v in samples["const_ext"][k]] == [L1(xx), L1(xx * w % P)], pos
+        assert int(samples["x_ext"][k][0]) == xx and int(samples["Zi_ext#0"][k][0]) == inv(s7N - 1), pos
+
+        def resolve(ref):
+            ty = ref["type"]
+            xp = xx * pow(w, ref.get("prime", 0), P) % P           # "next row" of a slice row is the same coset one step on
+            if ty == "cm":
+                pm = info["cmPolsMap"][ref["id"]]
+                assert pm["stage"] == 1 and pm["dim"] == 1
+                return pow(w, shifts[pm["stagePos"]], P) * xp % P
+            if ty == "const": return L1(xp) if ref["id"] == 0 else L1(xp * w % P)
+            if ty == "challenge": return [int(v) for v in r["challenges"][ref["stage"] - 1][ref["stageId"]]]
+            if ty == "public": return publics[ref["id"]]
+            if ty == "number": return int(ref["value"]) % P
+            if ty == "Zi": return inv(s7N - 1)
+            if ty == "x": return xx
+            raise ValueError(ty)
+        want = stark.execute_code(code, resolve)
+        want = want if isinstance(want, list) else [want, 0, 0]
+        assert [int(v) for v in samples["q_ext"][k]] == want, pos
+    assert len(vc) == 3 and len(r["proof"]["evals"]) == len(info["evMap"])

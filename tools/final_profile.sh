@@ -1,3 +1,4 @@
+set -eu; : "${GRAFT_REPO_ROOT:?run on the GPU box: gpurun -- bash tools/final_profile.sh}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final_r03; mkdir -p $O
 python3 $R/bench.py --steps 10 --warmup 2 > $O/bench_c3.json 2> $O/bench_c3.err || exit 1

@@ -1,4 +1,5 @@
 # counters of the run-time compiled constraint kernel (jit_eval) at config 3, staged and direct reads: gpurun -- bash tools/pmc_expr.sh
+set -eu; : "${GRAFT_REPO_ROOT:?run on the GPU box: gpurun -- bash tools/pmc_expr.sh}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_expr; mkdir -p $O
 for st in 0 1; do

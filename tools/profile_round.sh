@@ -1,4 +1,5 @@
 #!/bin/bash
+set -eu; : "${GRAFT_REPO_ROOT:?run on the GPU box: gpurun -- bash tools/profile_round.sh}"
 # The rocprofv3 passes the round's profiles/ files come from (run on the GPU box: gpurun -- bash tools/profile_round.sh r03).
 #  1. kernel trace + stats of the default bench line (config-3 proof)        -> gpurun_out/prof_<tag>/stats
 #  2. PMC passes over one config-3 commit (interpolate + leaf hash + tree) and the leaf-hash probe, each counter set in its

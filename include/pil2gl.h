@@ -20,8 +20,18 @@
  *    copy out): drop-in for the reference's BigUint64Array/BigBuffer calls.
  *    Functions with suffix _dev take DEVICE pointers (hipMalloc / pil2gl_dev_alloc /
  *    torch tensor.data_ptr()) plus a hipStream_t passed as void* (NULL = default
- *    stream); they enqueue work and do not synchronise, so buffers can stay
- *    resident in HBM across the prover's steps.
+ *    stream), so buffers can stay resident in HBM across the prover's steps.
+ *    Most of them only ENQUEUE work on that stream and return:
+ *      interpolate / interpolate_cosets[_ws] / extend_cosets_unshifted / fft / ifft, linear_hash_rows, merkelize,
+ *      merkelize_level, merkelize_digests, poseidon, fri_fold, fri_verify_fold, fri_transpose, build_x, geometric,
+ *      x_div_x_sub_xi[_cosets], gprod, gsum, dev_zero, and their bn128_ twins.
+ *    The following _dev calls BLOCK until their work on the stream has finished, because they hand a result to the host or
+ *    stage host-side tables in a scratch slot the next call reuses:
+ *      eval_program (op-list and scalar pool are host temporaries), rows_dot_ext / rows_dot_ext_multi / cols_dot_ext /
+ *      cols_dot_ext_multi / fri_combine / fri_combine_order (host-side weights), compute_evals (returns the evaluations),
+ *      build_zhinv, build_one_row_zerofier_inv, build_frame_zerofier, compute_q_split, build_lev (small host tables),
+ *      h1h2, synth_fibonacci, group_proof / group_proofs and bn128_group_proof (openings copied to host memory).
+ *    A whole config-3 proof keeps the GPU busy 99.3 % of its wall time with these.
  *  - Every function returns 0 on success, a negative PIL2GL_E* code otherwise;
  *    pil2gl_last_error() describes the failure (the reference throws Error /
  *    rejects the Promise; the addon converts the code back into a JS exception).

@@ -30,8 +30,7 @@ struct DevOp { u32 op; u32 aux; DevRef dest, src[2]; };      // 56 bytes; aux: l
 // a Horner chain  t = X*t + c_i  over an extension constant X is evaluated as sum_i c_i * X^(n-i) with the lazy
 // 22-bit-limb accumulation of csrc/dot.hip: LZ_BEGIN zeroes the 3x6 partial sums, LZ_MAD adds value * weight
 // (the weight's limbs come from the limb pool), LZ_END folds them into the destination.
-enum { GLX_LZ_BEGIN = 4, GLX_LZ_MAD = 5, GLX_LZ_END = 6,
-       GLX_JIT_FENCE = 7 };       // run-time compiled kernels only: nothing is scheduled across it (group_loads)
+enum { GLX_LZ_BEGIN = 4, GLX_LZ_MAD = 5, GLX_LZ_END = 6 };
 
 #define GLX_MAX_SECTIONS 24
 struct DevCtx {
@@ -368,46 +367,11 @@ static int allocate_slots(std::vector<IOp> &ops, u32 nVal, u32 &nSlots) {
     return PIL2GL_OK;
 }
 
-// Pass 2b (run-time compiled kernels, PIL2GL_EXPR_GROUP=G): the loads of one G-column piece of a read-only section -- this row's and the
-// offset rows' -- are issued together where the first of them stood, between two fences.  A lane owns a row, so every load of a wave
-// touches 64 lines for 8 bytes each; issued one by one at their first uses, the sixteen columns of a line are asked for over a seventh of
-// the program and the line has left L1 and L2 in between (config 3: 224 GB requested for 115 GB of operands).  Values are
-// single-assignment here and the sections are not written, so moving a load earlier changes nothing but its live range.
-static void group_loads(std::vector<IOp> &ops, const glx_ctx *ctx, u32 G) {
-    std::vector<bool> written(GLX_MAX_SECTIONS, false);
-    for (const IOp &p : ops) if (has_dest(p.op) && p.dest.kind == GLX_SEC && p.dest.section < GLX_MAX_SECTIONS) written[p.dest.section] = true;
-    auto is_load = [&](const IOp &p) {
-        return p.op == GLX_OP_COPY && p.dest.kind == GLX_TMP && p.src[0].kind == GLX_SEC && p.src[0].section < GLX_MAX_SECTIONS && !written[p.src[0].section]
-               && ctx->sections[p.src[0].section].width >= G;
-    };
-    std::map<std::pair<u32, u32>, std::vector<u32>> groups;
-    for (u32 k = 0; k < ops.size(); k++) if (is_load(ops[k])) groups[{ ops[k].src[0].section, ops[k].src[0].index / G }].push_back(k);
-    std::vector<bool> moved(ops.size(), false);
-    std::vector<IOp> res;
-    IOp fence; memset(&fence, 0, sizeof fence); fence.op = GLX_JIT_FENCE;
-    for (u32 k = 0; k < ops.size(); k++) {
-        if (moved[k]) continue;
-        if (is_load(ops[k])) {
-            std::vector<u32> &g = groups[{ ops[k].src[0].section, ops[k].src[0].index / G }];
-            if (g.size() > 1) {
-                std::sort(g.begin(), g.end(), [&](u32 a, u32 b) { return ops[a].src[0].prime != ops[b].src[0].prime ? ops[a].src[0].prime < ops[b].src[0].prime : ops[a].src[0].index < ops[b].src[0].index; });
-                res.push_back(fence);
-                for (u32 m : g) { res.push_back(ops[m]); moved[m] = true; }
-                res.push_back(fence);
-                continue;
-            }
-        }
-        res.push_back(ops[k]);
-    }
-    ops.swap(res);
-}
-
-static int compile_program(const glx_program *prog, const glx_ctx *ctx, std::vector<IOp> &ops, u32 &nSlots, std::vector<u32> &limbPool, bool fuse, u32 groupCols = 0) {
+static int compile_program(const glx_program *prog, const glx_ctx *ctx, std::vector<IOp> &ops, u32 &nSlots, std::vector<u32> &limbPool, bool fuse) {
     P2_TRY(validate_program(prog, ctx));
     u32 nVal = 0;
     P2_TRY(value_number(prog, ctx, ops, nVal));
     if (fuse && ctx && ctx->scalars) fuse_horner(ops, nVal, ctx, limbPool);
-    if (groupCols && ctx) group_loads(ops, ctx, groupCols);
     return allocate_slots(ops, nVal, nSlots);
 }
 
@@ -450,7 +414,7 @@ void jit_clear() {
 }
 }
 
-static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx_ctx *ctx, bool allowStage = true) {
+static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx_ctx *ctx) {
     std::ostringstream o;
     // no #include: hiprtc pre-includes its built-in device runtime header; only the fixed-width typedefs are needed
     o << "typedef unsigned long uint64_t; typedef unsigned int uint32_t; typedef long int64_t; typedef int int32_t;\n" << kFieldSrc << "\nusing namespace gl;\n";
@@ -497,102 +461,12 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
         }
         lazyOK[k] = ok;
     }
-    // PIL2GL_EXPR_STAGE=1 (an experiment, NOT the default): reads of WIDE sections through LDS tiles that are filled AHEAD.  A lane owns
-    // a row, so a direct read of column c touches 64 different cache lines for 8 bytes each, and the other columns of those lines
-    // are wanted only so much later that the lines have left the L2 by then (config 3: 236 GB requested for a 107 GB trace).  Staged,
-    // a wave owns two tiles of STAGE_COLS columns x the rows it and its row offsets reach.  The generator knows the order in which
-    // the program walks the column blocks, so at the first read of block i the kernel waits for tile i%2 (requested one block
-    // earlier), requests block i+1 into the other tile with direct-to-LDS loads (global_load_lds_dwordx4: 16 bytes per lane, 16
-    // rows of 64 bytes per instruction, no registers, nothing waits) and goes on computing; every operand read is then one ds_read
-    // at a constant offset from a per-lane base.  LDS slot l of a fill belongs to lane l, so the lane chooses WHICH 16 bytes it
-    // fetches: row 16j + l/4, column pair (l%4) ^ ((l/16)%4) -- the swizzle that spreads a column's 64 rows over all banks (the
-    // counters show no bank conflict).
-    // Why it is not the default (tools/pmc_expr.sh, config 3): bit-exact, no register cost to speak of (116 against 100), and 47.0 ms
-    // against 39.2 -- because the requests did NOT go down (249 GB): a 64-byte row piece still costs its whole 128-byte line, and the
-    // line's other half is requested one block (5 us) later, after the L2 has turned over.  Full lines need 16-column tiles, and two
-    // of those per wave leave room for two waves per SIMD, where this kernel is slower than its re-reads cost (a synchronous single
-    // 16-column tile was tried first: 48.5 ms).  Only a tiled trace layout removes the re-reads.
-    // Not staged in any case: sections the program also writes, odd or narrow (< STAGE_COLS) widths, offsets further than
-    // STAGE_MAX_SPAN rows apart, domains under 256 rows, reads that straddle two blocks, programs that hop between blocks.
-    constexpr int STAGE_COLS = 8, STAGE_MAX_SPAN = 32;
-    const char *stEnv = getenv("PIL2GL_EXPR_STAGE");
-    bool staging = allowStage && stEnv && stEnv[0] == '1' && ctx->nBits >= 8;
-    std::vector<bool> stagedSec(GLX_MAX_SECTIONS, false);
-    int64_t omin = 0, omax = 0;
+    // (Reads through LDS tiles -- synchronous 16-column tiles, direct-to-LDS 8-column tiles filled ahead -- and loads grouped by line
+    // between scheduling fences were built, were bit-exact, and lost (48.5 / 47.0 / 39.5-47.9 ms against 39.2-39.6): LAB_NOTES.md 9.5, 10.)
     auto row_off = [&](const glx_ref &r) { return (int64_t)r.prime * ((int64_t)1 << ctx->primeShift); };
-    if (staging) {
-        std::vector<bool> written(GLX_MAX_SECTIONS, false);
-        for (const IOp &p : ops) if (has_dest(p.op) && p.dest.kind == GLX_SEC) written[p.dest.section] = true;
-        bool any = false;
-        for (const IOp &p : ops)
-            for (int t = 0; t < n_src(p.op); t++) {
-                const glx_ref &r = p.src[t];
-                const u64 w = r.kind == GLX_SEC ? ctx->sections[r.section].width : 0;
-                if (r.kind != GLX_SEC || written[r.section] || w < (u64)STAGE_COLS || (w & 1)) continue;
-                const int64_t off = row_off(r);
-                if (!any) { omin = omax = off; any = true; }
-                omin = std::min(omin, off); omax = std::max(omax, off);
-                stagedSec[r.section] = true;
-            }
-        if (!any || omax - omin > STAGE_MAX_SPAN) staging = false;
-    }
-    const int64_t stageRows = (64 + (omax - omin) + 15) / 16 * 16, nFills = stageRows / 16, tileBytes = stageRows * STAGE_COLS * 8;
-    // the block holding every component of a staged read, or -1 (not staged / straddles two blocks: read directly)
-    auto block_of = [&](const glx_ref &r) -> int64_t {
-        if (!staging || r.kind != GLX_SEC || !stagedSec[r.section]) return -1;
-        const int64_t b0 = r.index / STAGE_COLS, b1 = (r.index + r.dim - 1) / STAGE_COLS;
-        return b0 == b1 ? b0 : -1;
-    };
-    // the walk: (section, block) at every change, in program order
-    std::vector<std::pair<int, int64_t>> walk;
-    std::set<int64_t> offsets;
-    if (staging) {
-        for (const IOp &p : ops)
-            for (int t = 0; t < n_src(p.op); t++) {
-                const int64_t b = block_of(p.src[t]);
-                if (b < 0) continue;
-                offsets.insert(row_off(p.src[t]));
-                if (walk.empty() || walk.back() != std::make_pair((int)p.src[t].section, b)) walk.push_back({ (int)p.src[t].section, b });
-            }
-        std::set<std::pair<int, int64_t>> distinct(walk.begin(), walk.end());
-        if (walk.empty() || walk.size() > 3 * distinct.size() + 4) staging = false;      // the program hops between blocks: direct reads
-    }
     o << "extern \"C\" __global__ void __launch_bounds__(256) jit_eval(JitArgs A) {\n";
     o << " const u64 row = (u64)blockIdx.x * blockDim.x + threadIdx.x; if (row >= (1ull << A.nBits)) return;\n";
     o << " const u64 mask = (1ull << A.nBits) - 1; const u64 *__restrict__ SC = A.scalars; const u32 *__restrict__ LM = A.limbs;\n";
-    auto fill = [&](size_t i) {                     // request walk[i] into tile i % 2
-        const int sec = walk[i].first; const int64_t b = walk[i].second;
-        const u64 width = ctx->sections[sec].width;
-        const int64_t nc = std::min<int64_t>(STAGE_COLS, (int64_t)width - b * STAGE_COLS);       // even: widths are
-        // a narrower last block: the lanes whose column pair lies beyond it fetch its last pair again (into slots nobody reads) --
-        // NOT a branch around the loads: divergent control flow in the middle of this one-block program costs hipcc its register
-        // allocation (256 registers and 500 spilled, against 116)
-        const std::string back = nc < STAGE_COLS ? " - 2 * (kp_ > " + std::to_string(nc / 2 - 1) + "u ? kp_ - " + std::to_string(nc / 2 - 1) + "u : 0u)" : "";
-        o << " {";
-        for (int64_t j = 0; j < nFills; j++)
-            o << " __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A.sec[" << sec << "] + rw" << sec << "_" << j << "_ + " << b * STAGE_COLS << back
-              << "), (__attribute__((address_space(3))) void *)(TW_ + " << ((i % 2) * tileBytes + j * 1024) / 8 << "), 16, 0, 0);";
-        o << " }\n";
-    };
-    if (staging) {
-        o << " __shared__ u64 STG_[4][" << 2 * tileBytes / 8 << "]; const u32 lane_ = threadIdx.x & 63;\n";
-        o << " u64 *TW_ = STG_[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];\n";
-        o << " const u32 kp_ = (lane_ & 3) ^ ((lane_ >> 4) & 3);       // the column pair this lane fetches in every fill\n";
-        o << " const u64 row0_ = row - lane_ + (u64)(" << omin << "ll);\n";
-        std::set<int> secs;
-        for (auto &w : walk) secs.insert(w.first);
-        for (int sec : secs)
-            for (int64_t j = 0; j < nFills; j++)
-                o << " const u64 rw" << sec << "_" << j << "_ = ((row0_ + " << 16 * j << " + (lane_ >> 2)) & mask) * " << ctx->sections[sec].width << "ull + 2 * kp_;\n";
-        // per row offset: the lane's four slot addresses (bytes within a tile), one per column pair
-        for (int64_t off : offsets) {
-            const std::string nm = "bo" + std::to_string(off - omin) + "_";
-            o << " const u32 rr" << nm << " = lane_ + " << (off - omin) << "u;";
-            for (int kp = 0; kp < 4; kp++) o << " const u32 " << nm << kp << " = (rr" << nm << " * 4 + (" << kp << "u ^ ((rr" << nm << " >> 2) & 3))) * 16;";
-            o << "\n";
-        }
-        fill(0);
-    }
     o << " u64 LZ[3][6];\n";
     for (u32 s = 0; s < nSlots; s++) o << " u64 t" << s << "_0 = 0, t" << s << "_1 = 0, t" << s << "_2 = 0;\n";
     auto addr = [&](const glx_ref &r) {
@@ -600,42 +474,23 @@ static std::string jit_source(const std::vector<IOp> &ops, u32 nSlots, const glx
         a << "A.sec[" << r.section << "] + ((row + (u64)(" << row_off(r) << "ll)) & mask) * " << ctx->sections[r.section].width << "ull + " << r.index;
         return a.str();
     };
-    size_t walkPos = 0; bool walkStarted = false;
-    auto stage = [&](const glx_ref &r) {            // first read of the walk's next block: its tile must have landed; request the one after
-        const int64_t b = block_of(r);
-        if (b < 0) return;
-        if (walkStarted && walk[walkPos] == std::make_pair((int)r.section, b)) return;
-        if (walkStarted) walkPos++;
-        walkStarted = true;
-        o << " asm volatile(\"s_waitcnt vmcnt(0) lgkmcnt(0)\" ::: \"memory\");\n";
-        if (walkPos + 1 < walk.size()) fill(walkPos + 1);
-    };
     auto rd = [&](const glx_ref &r, int c) {        // component c of an operand (0 beyond its dim)
         std::ostringstream a;
         if (c >= (int)r.dim) { a << "0ull"; return a.str(); }
         if (r.kind == GLX_TMP) a << "t" << r.index << "_" << c;
         else if (r.kind == GLX_SCALAR) a << "SC[" << (r.index + c) << "]";
-        else if (block_of(r) >= 0) {
-            const int64_t cb = (r.index + c) % STAGE_COLS;
-            a << "*(const u64 *)((const char *)TW_ + bo" << (row_off(r) - omin) << "_" << cb / 2 << " + " << (walkPos % 2) * tileBytes + (cb & 1) * 8 << ")";
-        } else a << "(" << addr(r) << ")[" << c << "]";
+        else a << "(" << addr(r) << ")[" << c << "]";
         return a.str();
     };
     for (size_t k = 0; k < ops.size(); k++) {
         const IOp &p = ops[k];
-        if (p.op == GLX_JIT_FENCE) { o << " __builtin_amdgcn_sched_barrier(0);\n"; continue; }
         if (p.op == GLX_LZ_BEGIN) { o << " for (int q = 0; q < 3; q++) for (int i = 0; i < 6; i++) LZ[q][i] = 0;\n"; continue; }
         if (p.op == GLX_LZ_MAD) {
-            stage(p.src[0]);
             o << " lz_mad(LZ, " << rd(p.src[0], 0) << ", LM + " << p.aux << ");";
             if (p.src[0].dim == 3) o << " lz_mad(LZ, " << rd(p.src[0], 1) << ", LM + " << p.aux + 9 << "); lz_mad(LZ, " << rd(p.src[0], 2) << ", LM + " << p.aux + 18 << ");";
             o << "\n"; continue;
         }
         const glx_ref &a = p.src[0], &b = p.src[1];
-        if (n_src(p.op) == 2 && block_of(a) >= 0 && block_of(b) >= 0 && (a.section != b.section || block_of(a) != block_of(b)))
-            return jit_source(ops, nSlots, ctx, false);         // one instruction reading two blocks (value numbering leaves none): direct reads
-        if (n_src(p.op) >= 1) stage(a);
-        if (n_src(p.op) == 2) stage(b);
         std::string r[3];
         const u32 da = a.dim, db = b.dim;
         switch (p.op) {
@@ -771,17 +626,7 @@ extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *c
         const bool want = e ? atoi(e) != 0 : (ops.size() >= 64 && ctx->nBits >= 16);
         if (want && nSlots <= 200) {
             hipFunction_t fn;
-            // PIL2GL_EXPR_GROUP=G: the same program with its section loads issued G columns at a time (group_loads); slots are allocated again
-            std::vector<IOp> gops; u32 gSlots = 0;
-            const char *ge = getenv("PIL2GL_EXPR_GROUP");
-            const u32 G = ge ? (u32)atoi(ge) : 0;
-            if (G) {
-                std::vector<u32> pool2;                          // (the limb pool comes out the same: grouping follows the Horner fusion)
-                P2_TRY(compile_program(prog, ctx, gops, gSlots, pool2, getenv("PIL2GL_EXPR_NOFUSE") == nullptr, G));
-                if (gSlots > 200 || pool2 != limbPool) gops.clear();
-            }
-            const bool grouped = !gops.empty();
-            if (jit_get(grouped ? jit_source(gops, gSlots, ctx) : jit_source(ops, nSlots, ctx), &fn) != PIL2GL_OK) {
+            if (jit_get(jit_source(ops, nSlots, ctx), &fn) != PIL2GL_OK) {
                 static bool warned = false;
                 if (!warned) { fprintf(stderr, "pil2gl: run-time compilation unavailable (%s); using the interpreter kernel\n", pil2gl_last_error()); warned = true; }
                 goto interpreter;
@@ -790,7 +635,7 @@ extern "C" int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *c
                 int regs = 0, lds = 0, loc = 0, maxt = 0;
                 (void)hipFuncGetAttribute(&regs, HIP_FUNC_ATTRIBUTE_NUM_REGS, fn); (void)hipFuncGetAttribute(&lds, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, fn);
                 (void)hipFuncGetAttribute(&loc, HIP_FUNC_ATTRIBUTE_LOCAL_SIZE_BYTES, fn); (void)hipFuncGetAttribute(&maxt, HIP_FUNC_ATTRIBUTE_MAX_THREADS_PER_BLOCK, fn);
-                fprintf(stderr, "pil2gl jit_eval: %zu ops%s, regs %d, lds %d, scratch %d, max threads %d\n", grouped ? gops.size() : ops.size(), grouped ? " (loads grouped)" : "", regs, lds, loc, maxt);
+                fprintf(stderr, "pil2gl jit_eval: %zu ops, regs %d, lds %d, scratch %d, max threads %d\n", ops.size(), regs, lds, loc, maxt);
             }
             JitArgs A; memset(&A, 0, sizeof A);
             A.scalars = c.scalars; A.limbs = c.limbs; A.nBits = ctx->nBits;

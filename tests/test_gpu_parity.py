@@ -1141,16 +1141,14 @@ def test_rows_and_cols_dot_ext(gl, oracle, monkeypatch, mode):
             assert out[l, c].tolist() == oracle.eval_pol_at(buf, c, 1, nb, eb, levs[l]).tolist()
 
 
-@pytest.mark.parametrize("jit", ["0", "1", "staged", "direct"])
+@pytest.mark.parametrize("jit", ["0", "1", "wide0", "wide"])
 def test_expression_evaluator_interpreter_and_jit_agree(gl, oracle, jit, monkeypatch):
-    """the same random programs through the interpreter (PIL2GL_EXPR_JIT=0), the hiprtc-compiled kernel (=1), and the compiled
-    kernel on WIDE sections (20 and 34 columns, row offsets -2..2 and -8..8) with their reads direct (the default) and staged through
-    LDS tiles filled ahead (PIL2GL_EXPR_STAGE=1)"""
+    """the same random programs through the interpreter (PIL2GL_EXPR_JIT=0) and the hiprtc-compiled kernel (=1), on narrow sections and
+    on WIDE ones (20 and 34 columns, row offsets -2..2 and -8..8: interpreter "wide0", compiled "wide")"""
     import torch
     import ctypes as C
     from pil2gl import _lib
-    monkeypatch.setenv("PIL2GL_EXPR_JIT", "0" if jit == "0" else "1")
-    monkeypatch.setenv("PIL2GL_EXPR_STAGE", "1" if jit == "staged" else "0")
+    monkeypatch.setenv("PIL2GL_EXPR_JIT", "0" if jit in ("0", "wide0") else "1")
     for n_ops, prime_shift in [(40, 0), (300, 2)]:
         rng = np.random.default_rng(1000 + n_ops)
         n_bits = 10

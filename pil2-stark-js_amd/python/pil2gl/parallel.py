@@ -451,7 +451,7 @@ def zhinv_slice(be, n_bits, ext_bits, cb, cc):
     sN = pow(S.SHIFT, 1 << n_bits, S.P)
     wc = S.root_of_unity(ext_bits) if ext_bits else 1                      # w_E^N
     z = [S._inv((sN * pow(wc, cb + jl, S.P) - 1) % S.P) for jl in range(cc)]
-    return be.from_host(np.tile(np.array(z, dtype=np.uint64), 1 << n_bits))
+    return be.from_torch(be.as_torch(be.from_host(np.array(z, dtype=np.uint64))).repeat(1 << n_bits))     # tiled where the backend's memory is
 
 
 def build_const_tree_sharded(be, consts, info, group=None, rehearse_world=None, comm=None):

@@ -17,6 +17,9 @@ for o in range(0, E * C, 1 << 28):
 dig = torch.empty(E * 4, dtype=torch.int64, device="cuda")
 for _ in range(2):
     pil2gl.linearHash(dst, C, False, dig)
+if os.environ.get("SPLIT", "0") != "0":      # the splitLinearHash form of the same leaves (linear_hash_split_kernel)
+    for _ in range(2):
+        pil2gl.linearHash(dst, C, True, dig)
 torch.cuda.synchronize()
 s = 0
 for o in range(0, E * C, 1 << 30):          # 8 GiB pieces: reduce kernels reading each byte once

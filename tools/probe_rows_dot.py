@@ -13,7 +13,7 @@ acc = torch.zeros(n_rows * n_out * 3, dtype=torch.int64, device="cuda")
 def run():
     _lib.call("pil2gl_rows_dot_ext_dev", pil2gl._ptr(dm), width, n_rows, pil2gl._ptr(coef), n_out, pil2gl._ptr(acc), 0, None)
 for rnd in range(2):
-    for mode in ("tile", "stream", "mfma"):
+    for mode in os.environ.get("MODES", "tile,stream,mfma").split(","):
         os.environ["PIL2GL_ROWS_DOT_MFMA"] = "1" if mode == "mfma" else "0"
         os.environ["PIL2GL_ROWS_DOT_STREAM"] = "0" if mode == "tile" else "1"
         run(); torch.cuda.synchronize(); t0 = time.time()

@@ -1,4 +1,4 @@
-# counters of the run-time compiled constraint kernel (jit_eval) at config 3, staged and direct reads: gpurun -- bash tools/pmc_expr.sh
+# HISTORICAL (round 3; PIL2GL_EXPR_STAGE was removed in round 4): counters of the run-time compiled constraint kernel (jit_eval) at config 3, staged and direct reads: gpurun -- bash tools/pmc_expr.sh
 set -eu; : "${GRAFT_REPO_ROOT:?run on the GPU box: gpurun -- bash tools/pmc_expr.sh}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_expr; mkdir -p $O

@@ -1,4 +1,5 @@
 # HBM-side read requests (by size) and L2 hits / misses of the run-time compiled constraint kernel (jit_eval) at config 3 with its
+# HISTORICAL (the switch was removed after this measurement: build commit a1d7ce2 and point PIL2GL_LIB at it to repeat):
 # section loads issued at first use (PIL2GL_EXPR_GROUP=0) and 8 / 16 columns at a time: gpurun -- bash tools/pmc_expr_group.sh
 set -eu; : "${GRAFT_REPO_ROOT:?run on the GPU box: gpurun -- bash tools/pmc_expr_group.sh}"
 cd /tmp && export TMPDIR=/tmp

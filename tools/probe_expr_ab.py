@@ -1,5 +1,6 @@
 """constraint evaluation (q_expr) of the config-3 proof with the run-time compiled kernel's switches flipped inside ONE process:
-   PIL2GL_EXPR_LAZYMUL x PIL2GL_EXPR_MULCALL x PIL2GL_EXPR_STAGE (COMBOS="l,c,s;...") (the kernels are cached by source, so every combination compiles its own)"""
+   PIL2GL_EXPR_LAZYMUL x PIL2GL_EXPR_MULCALL x PIL2GL_EXPR_STAGE (COMBOS="l,c,s;...") (the kernels are cached by source, so every combination compiles its own).
+   PIL2GL_EXPR_STAGE was removed in round 4 (the staged variants lost: LAB_NOTES 9.5, 10); the third field is ignored by today's library."""
 import os, sys, itertools
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

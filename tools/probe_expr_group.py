@@ -1,5 +1,7 @@
 """constraint evaluation (q_expr) of the config-3 proof with the run-time compiled kernel's section loads issued G columns at a time
-(PIL2GL_EXPR_GROUP = 0: at first use, as shipped; 4, 8, 16, 32), all inside ONE process; the quotient root must not move"""
+(PIL2GL_EXPR_GROUP = 0: at first use, as shipped; 4, 8, 16, 32), all inside ONE process; the quotient root must not move.
+HISTORICAL: the switch was removed after this measurement (profiles/r04_jit_eval_grouped_loads.txt); build the library of commit a1d7ce2
+(PIL2GL_LIB) to repeat it -- with today's library every setting runs the shipped kernel."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

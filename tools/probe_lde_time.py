@@ -21,5 +21,9 @@ torch.manual_seed(1)
 for rnd in range(2):
     print("%s %s: 2^%d x %d interpolate %.2f ms" % (os.path.basename(os.environ.get("PIL2GL_LIB", "in-tree")), os.environ.get("TAG", ""), nBits, C, timeit(lambda: pil2gl.interpolate(src, C, nBits, dst, nBits + eb))), flush=True)
 # a checksum of the result, so that builds and geometries timed in one call can be seen to agree (wrap-around sums of the words and of word * index)
-w = torch.arange(dst.numel(), dtype=torch.int64, device="cuda")
-print("   checksum %016x %016x" % (int(dst.sum()) & (2**64 - 1), int((dst * (2 * w + 1)).sum()) & (2**64 - 1)), flush=True)
+s0 = s1 = 0
+for o in range(0, dst.numel(), 1 << 28):          # in pieces: the weighted sum's temporaries are as large as what they are taken of
+    d = dst[o:o + (1 << 28)]
+    w = torch.arange(o, o + d.numel(), dtype=torch.int64, device="cuda")
+    s0 += int(d.sum()); s1 += int((d * (2 * w + 1)).sum())
+print("   checksum %016x %016x" % (s0 & (2**64 - 1), s1 & (2**64 - 1)), flush=True)

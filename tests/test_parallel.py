@@ -101,6 +101,8 @@ def test_sharded_proof_over_rccl_one_rank(oracle):
     per chunk of hashed leaves, sums on the device): all the box's one GPU allows is a group of ONE rank, which still runs every
     collective call of the N-rank schedule; 2^16 rows so that the chunked path is taken"""
     _launch(1, "--backend", "gpu", "--pg", "nccl", "--nbits", "16", "--pairs", "4", "--steps", "19,14,9,4", worker=PROVE_WORKER)
+    # and with the constant tree split too (its all-to-all, root sum and opened rows through the same RCCL calls)
+    _launch(1, "--backend", "gpu", "--pg", "nccl", "--nbits", "16", "--pairs", "4", "--steps", "19,14,9,4", "--shardsetup", "1", worker=PROVE_WORKER)
 
 
 @pytest.mark.parametrize("steps", ["9,2", "9"])

@@ -741,7 +741,8 @@ def main():
     prove_ctx = None
     be = stark.GpuBackend(local_rank, args.split)
     identity = None
-    if sharded_mode and world > 1 and os.environ.get("PIL2GL_BENCH_IDENTITY", "1") != "0":
+    # (PIL2GL_BENCH_IDENTITY=0 skips the check; =force runs it at one rank too: the RCCL group of one a single-GPU box allows)
+    if sharded_mode and (world > 1 or os.environ.get("PIL2GL_BENCH_IDENTITY") == "force") and os.environ.get("PIL2GL_BENCH_IDENTITY", "1") != "0":
         Progress.mark("identity check: sharded result against the single-process one", rank, key=True)
         identity = sharded_identity_check(be, comm, dev, rank, world, mode, args)
         Progress.mark("identity check %s (%s s)" % (identity["result"], identity["seconds"]), rank, key=True)

@@ -13,14 +13,14 @@ typedef unsigned long u64; typedef unsigned int u32;
 // MODE 0: read and write back; 1: read only (one word per lane written to `sink`); 2: write only; 3: read pieces `loBits` rows apart and
 // write them 2^8 rows apart (an out-of-place pass that gathers far and stores near); 4: the reverse
 template <int XCD, int MODE = 0>
-__global__ void __launch_bounds__(256) k_tile(u64 *m, u64 C, u32 loBits, u32 nChunks, u32 nRowBits, u64 *sink = nullptr) {
+__global__ void __launch_bounds__(256) k_tile(u64 *m, u64 C, u32 loBits, u32 nChunks, u32 nRowBits, u64 *sink = nullptr, u32 skewRows = 0) {
     u32 b = blockIdx.x;
     if (XCD) { const u32 per = gridDim.x >> 3; b = (b & 7) * per + (b >> 3); }     // consecutive logical tiles on one XCD, as the library does
     const u32 cc = b % nChunks; b /= nChunks;
     const u32 gt = b & ((1u << loBits) - 1), hi = b >> loBits;                     // row = (hi << (loBits + 8)) + (t << loBits) + gt
     const u32 x = threadIdx.x & 15, y = threadIdx.x >> 4;
     u64 *base = m + ((u64)hi << (loBits + 8)) * C + (u64)gt * C + cc * 16 + x;
-    const u64 tStride = C << loBits;
+    const u64 tStride = C * ((1ull << loBits) + skewRows);      // skewRows: pieces (2^lo + skew) rows apart -- the same span, other low address bits
     // the same tile of the NEAR pattern (pieces 2^8 rows apart), for the mixed modes
     u32 b2 = blockIdx.x; if (XCD) { const u32 per = gridDim.x >> 3; b2 = (b2 & 7) * per + (b2 >> 3); }
     b2 /= nChunks;
@@ -43,8 +43,9 @@ int main(int argc, char **argv) {
     const u32 nRowBits = argc > 1 ? atoi(argv[1]) : 24;
     const u64 R = 1ull << nRowBits, C = argc > 2 ? strtoull(argv[2], 0, 10) : 800;   // 800: the extended config-3 matrix during the passes, N x (100 * 8)
     u64 *m;
-    CHECK(hipMalloc(&m, R * C * 8));
-    CHECK(hipMemset(m, 0, R * C * 8));
+    const u32 skewRows = argc > 4 ? (u32)atoi(argv[4]) : 0;
+    CHECK(hipMalloc(&m, (R + 256ull * skewRows + 256) * C * 8));
+    CHECK(hipMemset(m, 0, (R + 256ull * skewRows + 256) * C * 8));
     const u32 nChunks = (u32)(C / 16);
     const u32 blocks = (u32)((R >> 8) * nChunks);
     std::vector<u32> los = { 0u, 8u, nRowBits - 8 };
@@ -54,7 +55,7 @@ int main(int argc, char **argv) {
         for (u32 loBits : los)
             for (int xcd = 1; xcd >= 0; xcd--) {
                 CHECK(hipEventRecord(a));
-                if (xcd) hipLaunchKernelGGL(k_tile<1>, dim3(blocks), dim3(256), 0, 0, m, C, loBits, nChunks, nRowBits);
+                if (xcd) hipLaunchKernelGGL(k_tile<1>, dim3(blocks), dim3(256), 0, 0, m, C, loBits, nChunks, nRowBits, (u64 *)nullptr, skewRows);
                 else hipLaunchKernelGGL(k_tile<0>, dim3(blocks), dim3(256), 0, 0, m, C, loBits, nChunks, nRowBits);
                 CHECK(hipEventRecord(b)); CHECK(hipEventSynchronize(b));
                 float ms; CHECK(hipEventElapsedTime(&ms, a, b));
@@ -71,7 +72,7 @@ int main(int argc, char **argv) {
                         printf("    pieces 2^%u rows apart, %s: %.2f ms, %.2f TB/s\n", loBits, names[mode], ms2, (mode <= 2 ? 1.0 : 2.0) * R * C * 8 / ms2 / 1e9);
                     }
                 }
-                printf("rows 2^%u x %lu columns (%.1f GB), pieces 2^%u rows apart, %s order: %.2f ms, %.2f TB/s read + written\n", nRowBits, (unsigned long)C, R * C * 8 / 1e9, loBits,
+                printf("rows 2^%u x %lu columns (%.1f GB), pieces 2^%u%s rows apart, %s order: %.2f ms, %.2f TB/s read + written\n", nRowBits, (unsigned long)C, R * C * 8 / 1e9, loBits, skewRows && xcd ? " + skew" : "",
                        xcd ? "XCD-local" : "plain", ms, 2.0 * R * C * 8 / ms / 1e9);
             }
     return 0;

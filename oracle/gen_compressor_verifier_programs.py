@@ -29,7 +29,6 @@ Temporaries are renumbered in order of definition.  No reference source text is 
 import json
 import os
 import re
-import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("PIL2_REFERENCE", "/root/reference")

@@ -4,10 +4,8 @@ helpers.js / generateParser.js / binFile.js (the reference's own encoder needs c
 parity unpinned by execution for this row), and read by the product's pil2gl.chelpers."""
 import copy
 
-import numpy as np
 import pytest
 
-from conftest import P
 
 
 def _airs():

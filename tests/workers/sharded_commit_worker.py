@@ -16,7 +16,6 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
 
-import torch
 import torch.distributed as dist
 import datetime
 TIMEOUT = datetime.timedelta(seconds=120)      # a lost peer fails the test within two minutes instead of ten

@@ -1,5 +1,5 @@
 """interpolate timing sweep over planner knobs (env read per call by the library)"""
-import os, sys, itertools
+import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))

@@ -311,6 +311,7 @@ int pil2gl_fri_transpose(const uint64_t *pol, uint32_t polBits, uint32_t transpo
 int pil2gl_build_x_dev(uint32_t nBits, uint64_t shift, uint64_t *x, void *stream) {
     P2_TRY(ensure_init());
     if (nBits > 31) return fail(PIL2GL_EINVAL, "nBits too large");
+    if (!x) return fail(PIL2GL_EINVAL, "null buffer");
     build_x_kernel<<<nblk(1ull << nBits), 256, 0, as_stream(stream)>>>(nBits, shift, tables().powW, x);
     KERNEL_CHECK();
     return PIL2GL_OK;
@@ -351,6 +352,7 @@ static int upload_small(const std::vector<u64> &h, u32 slot, u64 **d, hipStream_
 int pil2gl_build_zhinv_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t *out, void *stream) {
     P2_TRY(ensure_init());
     if (nBitsExt < nBits || nBitsExt > 31 || nBitsExt - nBits > 20) return fail(PIL2GL_EINVAL, "bad domain sizes");
+    if (!out) return fail(PIL2GL_EINVAL, "null buffer");
     std::vector<u64> zh; zh_table(nBits, nBitsExt, zh, true);
     u64 *d; P2_TRY(upload_small(zh, 2, &d, as_stream(stream)));
     periodic_kernel<<<nblk(1ull << nBitsExt), 256, 0, as_stream(stream)>>>(d, zh.size(), 1ull << nBitsExt, out);
@@ -361,6 +363,7 @@ int pil2gl_build_zhinv_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t *out, voi
 int pil2gl_build_one_row_zerofier_inv_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t rowIndex, uint64_t *out, void *stream) {
     P2_TRY(ensure_init());
     if (nBitsExt < nBits || nBitsExt > 31 || nBitsExt - nBits > 20) return fail(PIL2GL_EINVAL, "bad domain sizes");
+    if (!out) return fail(PIL2GL_EINVAL, "null buffer");
     std::vector<u64> zh; zh_table(nBits, nBitsExt, zh, false);
     u64 *d; P2_TRY(upload_small(zh, 2, &d, as_stream(stream)));
     u64 root = h_pow(h_root(nBits), rowIndex);
@@ -371,7 +374,7 @@ int pil2gl_build_one_row_zerofier_inv_dev(uint32_t nBits, uint32_t nBitsExt, uin
 }
 int pil2gl_build_frame_zerofier_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t offsetMin, uint64_t offsetMax, uint64_t *out, void *stream) {
     P2_TRY(ensure_init());
-    if (nBitsExt < nBits || nBitsExt > 31 || offsetMin + offsetMax > 4096) return fail(PIL2GL_EINVAL, "bad frame zerofier arguments");
+    if (nBitsExt < nBits || nBitsExt > 31 || offsetMin + offsetMax > 4096 || !out) return fail(PIL2GL_EINVAL, "bad frame zerofier arguments");
     std::vector<u64> roots;
     u64 w = h_root(nBits), N = 1ull << nBits;
     for (u64 i = 0; i < offsetMin; i++) roots.push_back(h_pow(w, i));

@@ -333,6 +333,7 @@ int pil2gl_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint64_t *out,
     P2_TRY(ensure_init());
     if (nOps == 0) return PIL2GL_OK;
     if (!in || !out) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nOps > (0x7fffffffull << 8)) return fail(PIL2GL_EINVAL, "grid too large");
     merkle_level_kernel<<<(unsigned)((nOps + 255) / 256), 256, 0, as_stream(stream)>>>(in, nOps, out);
     KERNEL_CHECK();
     return PIL2GL_OK;
@@ -343,6 +344,7 @@ int pil2gl_poseidon_dev(const uint64_t *in, const uint64_t *cap, uint64_t count,
     if (count == 0) return PIL2GL_OK;
     if (!in || !out) return fail(PIL2GL_EINVAL, "null buffer");
     if (nOut < 1 || nOut > 12) return fail(PIL2GL_EINVAL, "nOut must be 1..12");
+    if (count > (0x7fffffffull << 8)) return fail(PIL2GL_EINVAL, "grid too large");
     poseidon_batch_kernel<<<(unsigned)((count + 255) / 256), 256, 0, as_stream(stream)>>>(in, cap, count, nOut, out);
     KERNEL_CHECK();
     return PIL2GL_OK;
@@ -382,6 +384,7 @@ int pil2gl_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_
                            uint64_t idx, uint64_t *hostVals, uint64_t *hostSiblings, uint32_t *nLevels) {
     P2_TRY(ensure_init());
     if (idx >= height) return fail(PIL2GL_EINVAL, "Out of range");      // merklehash_p.js:143
+    if (!nodes || !hostSiblings || (width && (!elems || !hostVals))) return fail(PIL2GL_EINVAL, "null buffer");
     if (width) HIP_TRY(hipMemcpy(hostVals, elems + idx * width, width * 8, hipMemcpyDeviceToHost));
     u64 offset = 0, n = height * 4;
     uint32_t lvl = 0;

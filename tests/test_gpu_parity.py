@@ -233,6 +233,39 @@ def test_fft_in_place_and_errors(gl, oracle):
         gl.fft(a, 4, 13, a)                                              # buffer too small
 
 
+def test_bad_arguments_are_refused_before_any_launch(gl):
+    """every entry point validates pointers and sizes on the host and returns PIL2GL_EINVAL (the addon: a thrown Error) -- a bad call
+    must never reach a kernel.  Null pointers with non-zero sizes, domains beyond the limits, ranges outside their bounds."""
+    import torch
+    from pil2gl import _lib
+    d = torch.zeros(4096, dtype=torch.int64, device="cuda")
+    ok = d.data_ptr()
+    ch = np.zeros(3, np.uint64)
+    bad = [("pil2gl_fft_dev", (None, 1, 4, ok, None)), ("pil2gl_fft_dev", (ok, 1, 31, ok, None)), ("pil2gl_fft_dev", (ok, 1, 4, None, None)),
+           ("pil2gl_interpolate_cosets_dev", (ok, 1, 4, ok, 6, 3, 2, None)),                 # cosets [3, 5) of 4
+           ("pil2gl_interpolate_cosets_dev", (ok, 1, 4, ok, 3, 0, 1, None)),                 # nBitsExt < nBits
+           ("pil2gl_poseidon_dev", (ok, None, 4, 13, ok, None)), ("pil2gl_poseidon_dev", (None, None, 4, 4, ok, None)),
+           ("pil2gl_linear_hash_rows_dev", (None, 9, 16, 0, ok, None)), ("pil2gl_linear_hash_rows_dev", (ok, 1 << 31, 1, 0, ok, None)),
+           ("pil2gl_merkelize_dev", (ok, 4, 0, 0, ok, None)), ("pil2gl_merkelize_dev", (ok, 4, 8, 0, None, None)),
+           ("pil2gl_fri_fold_dev", (ok, 5, 6, 1, gl._ptr(ch), ok, None)), ("pil2gl_fri_fold_dev", (ok, 31, 6, 1, gl._ptr(ch), ok, None)),
+           ("pil2gl_fri_fold_dev", (ok, 5, 3, 1, None, ok, None)),
+           ("pil2gl_build_x_dev", (32, 1, ok, None)), ("pil2gl_build_x_dev", (4, 1, None, None)),
+           ("pil2gl_geometric_dev", (1, 2, 8, None, None)),
+           ("pil2gl_build_zhinv_dev", (5, 4, ok, None)), ("pil2gl_build_zhinv_dev", (4, 6, None, None)),
+           ("pil2gl_compute_q_split_dev", (ok, 4, 5, 3, 3, ok, None)),                        # qDeg * N > E
+           ("pil2gl_compute_q_split_dev", (None, 4, 5, 3, 2, ok, None)),
+           ("pil2gl_x_div_x_sub_xi_cosets_dev", (6, 2, gl._ptr(ch), 2, 2, 0, 1, ok, None)),   # iOpen >= nOpen
+           ("pil2gl_x_div_x_sub_xi_cosets_dev", (6, 2, gl._ptr(ch), 2, 0, 3, 2, ok, None)),   # cosets [3, 5) of 4
+           ("pil2gl_rows_dot_ext_dev", (None, 8, 8, gl._ptr(ch), 1, ok, 0, None)),
+           ("pil2gl_gprod_dev", (ok, 2, ok, 1, 8, ok, None)), ("pil2gl_gprod_dev", (None, 1, ok, 1, 8, ok, None)),
+           ("pil2gl_dev_upload", (None, gl._ptr(ch), 3))]
+    for name, args in bad:
+        with pytest.raises(gl.Pil2glError):
+            _lib.call(name, *args)
+    torch.cuda.synchronize()
+    assert int(d.sum()) == 0                      # and nothing was written
+
+
 # ------------------------------------------------------------------ Poseidon / linear hash / Merkle
 def test_poseidon_kats(gl):
     g = H(golden("poseidon.json"))

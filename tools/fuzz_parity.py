@@ -200,8 +200,45 @@ def case_bn128():
     check("bn128_tree", ok, (arity, custom, w, h))
 
 
+def case_proof_bn128():
+    """whole proofs with BN128 trees and transcript (verificationHashType BN128): random arity / custom mode, small traces (the checker's
+    BN254 Poseidon is Python integers)"""
+    from stark_backend import OracleBackend
+    nb = int(rng.integers(3, 7)); eb = int(rng.integers(1, 4)); nbe = nb + eb
+    steps = [nbe]
+    while steps[-1] > 2 and len(steps) < 4:
+        nxt = steps[-1] - int(rng.integers(1, 5))
+        if nxt < 1:
+            break
+        steps.append(nxt)
+    arity = int(rng.choice([2, 4, 8, 16])); custom = bool(rng.integers(0, 2)); pairs = int(rng.integers(1, 4))
+    ss = {"nBits": nb, "nBitsExt": nbe, "nQueries": int(rng.integers(1, 6)), "verificationHashType": "BN128", "steps": [{"nBits": b} for b in steps]}
+    if rng.random() < 0.3:
+        ss["hashCommits"] = True
+    info, exprs, vinfo = stark.fibonacci_air(pairs, ss)
+    cm, consts, publics = stark.fibonacci_trace(nb, pairs)
+    what = ("bn128", nb, eb, steps, ss["nQueries"], arity, custom, pairs, bool(ss.get("hashCommits")))
+    try:
+        res = {}
+        for name, be in (("gpu", stark.GpuBackend(0, False, "BN128", arity, custom)), ("oracle", OracleBackend(False, "BN128", arity, custom))):
+            setup = stark.build_const_tree(be, consts, info)
+            res[name] = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+            res[name + "_root"] = setup["constRoot"]
+        same = res["gpu_root"] == res["oracle_root"] and all(res["gpu"][k] == res["oracle"][k] for k in ("challenges", "challengesFRISteps", "queries")) and res["gpu"]["proof"] == res["oracle"]["proof"]
+        check("proof_bn128", same, what)
+        # and the device verifier takes it -- except where the REFERENCE's own prover and verifier disagree: a 4-column stage is hashed by
+        # the Merkle worker as ONE 256-bit integer (merklehash_bn128_worker.js:45-50) and by LinearHashBN.hash, which the verifier uses,
+        # as two elements through Poseidon (linearhash.bn128.js:13-59): such a proof is rejected by the reference too (quirk kept)
+        widths = [info["mapSectionsN"].get(k) for k in ("const", "cm1", "cm2", "cm3")]
+        if same and 4 not in widths:
+            gpu = stark.GpuBackend(0, False, "BN128", arity, custom)
+            check("verify_bn128", stark.stark_verify(gpu, res["gpu"]["proof"], publics, res["gpu_root"], info, exprs, vinfo)[0], what)
+    except Exception as e:
+        check("proof_bn128", False, what + (repr(e)[:200],))
+
+
 ONLY = os.environ.get("FUZZ_ONLY", "").split(",") if os.environ.get("FUZZ_ONLY") else None
-CASES = [(f, w) for f, w in [(case_transform, 4), (case_hash_tree, 4), (case_fri_fold, 2), (case_proof, 3), (case_evaluator, 3), (case_hints, 2), (case_rows_dot, 3), (case_bn128, 1)]
+CASES = [(f, w) for f, w in [(case_transform, 4), (case_hash_tree, 4), (case_fri_fold, 2), (case_proof, 3), (case_evaluator, 3), (case_hints, 2), (case_rows_dot, 3), (case_bn128, 1), (case_proof_bn128, 1)]
          if ONLY is None or f.__name__[5:] in ONLY]
 t0 = time.time(); last = t0
 order = [f for f, w in CASES for _ in range(w)]

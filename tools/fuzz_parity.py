@@ -45,9 +45,13 @@ def check(name, ok, what):
 
 
 def case_transform():
-    nb = int(rng.integers(0, 15)); C = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 64, 100, 129])); eb = int(rng.integers(0, 5))
-    while (C << (nb + eb)) > (1 << 23):
-        nb = max(0, nb - 1)
+    big = os.environ.get("FUZZ_BIG") == "1"            # FUZZ_BIG=1: 2^12..2^22 rows, up to 2^27 extended elements (three- and four-pass transforms)
+    nb = int(rng.integers(12, 23) if big else rng.integers(0, 15)); C = int(rng.choice([1, 2, 3, 5, 8, 15, 16, 17, 31, 33, 64, 100, 129])); eb = int(rng.integers(0, 5))
+    while (C << (nb + eb)) > (1 << (27 if big else 23)):
+        if eb > 1 and rng.random() < 0.5:
+            eb -= 1
+        else:
+            nb = max(0, nb - 1)
     a = field((1 << nb, C))
     out = np.zeros_like(a)
     pil2gl.fft(a, C, nb, out); check("fft", (out == orc.fft_cols(a, nb)).all(), (nb, C))

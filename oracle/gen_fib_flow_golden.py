@@ -34,16 +34,16 @@ def strs(v):
     return v
 
 
-def write(name, hash_commits, prev_row=False):
+def write(name, hash_commits, prev_row=False, im_pols=False):
     n_bits, pairs = 6, 2
     ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 9}, {"nBits": 5}, {"nBits": 2}]}
     if hash_commits:
         ss["hashCommits"] = True                  # the transcript absorbs hashes of publics / evaluations / last polynomial
-    info, exprs, _ = stark.fibonacci_air(pairs, ss, prev_row)
-    cm, consts, publics = stark.fibonacci_trace(n_bits, pairs)
+    info, exprs, _ = stark.fibonacci_air(pairs, ss, prev_row, im_pols=im_pols)
+    cm, consts, publics = stark.fibonacci_trace(n_bits, pairs, im_pols=im_pols)      # (im_pols: the witness goes out with those columns empty)
     be = OracleBackend()
     setup = stark.build_const_tree(be, consts, info)
-    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)          # (from_host copies: cm itself stays as generated)
     out = {"pilInfo": info, "expressionsInfo": exprs, "cm1": [str(int(v)) for v in cm.reshape(-1)], "consts": [str(int(v)) for v in consts.reshape(-1)],
            "publics": [str(v) for v in publics], "constRoot": [str(v) for v in setup["constRoot"]],
            "proof": json.loads(json.dumps(res["proof"], default=int)), "challenges": res["challenges"], "queries": res["queries"]}
@@ -57,3 +57,5 @@ write("fib_flow.json", False)
 write("fib_flow_hashcommits.json", True)
 # an AIR that also reads the PREVIOUS row: openings [-1, 0, 1], FRI polynomial terms in the reference's key order 0, 1, -1
 write("fib_flow_prevrow.json", False, True)
+# intermediate polynomials: imPolsCode with destinations of type cm, filled by the prover on the trace domain (prover.js:212-214)
+write("fib_flow_impols.json", False, False, True)

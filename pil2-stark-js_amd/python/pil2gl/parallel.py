@@ -608,6 +608,10 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
                 ops, n_tmp, secs, scalars = S.encode_code(sc["code"], "n", ctx)
                 be.eval_program(ops, n_tmp, [(trace[x], widths[x]) for x in secs], scalars, nb, 0)
             S.resolve_hints(be, info, s_, trace, widths, nb, ctx)
+        im = exprs.get("imPolsCode", [])
+        if s_ == nStages and len(im) >= s_ and im[s_ - 1].get("code"):      # intermediate polynomials (prover.js:212-214), replicated like the stage code
+            ops, n_tmp, secs, scalars = S.encode_code(im[s_ - 1]["code"], "n", ctx)
+            be.eval_program(ops, n_tmp, [(trace[x], widths[x]) for x in secs], scalars, nb, 0)
         loc[name + "_ext"] = be.empty(w << nloc)
         be.interpolate_cosets(trace[name + "_n"], w, nb, loc[name + "_ext"], nbe, cb, cc, trace[name + "_n"] if (overwrite_trace and s_ == nStages) else None)
         lap("stage%d_lde" % s_)

@@ -60,6 +60,9 @@ async function prove(g, resident) {
     const transcript = new Transcript(poseidon);
     transcript.put(MH.root(ctx.constTree));                                                     // prover.js:148-189
     transcript.put(ss.hashCommits ? await SGH.calculateHashStark(ctx, ctx.publics) : ctx.publics);
+    // intermediate polynomials of the last witness stage (prover.js:212-214): op-lists with destinations of type cm, trace domain
+    const im = (ctx.expressionsInfo.imPolsCode || [])[0];
+    if (im && im.code.length) await callCalculateExps(1, im, "n", ctx, false, false);
     // stage 1: extendAndMerkelize (stark_gen_helpers.js:388-412)
     await interpolate(ctx.cm1_n, pilInfo.mapSectionsN.cm1, nBits, ctx.cm1_ext, nBitsExt);
     ctx.trees[1] = await MH.merkelize(ctx.cm1_ext, pilInfo.mapSectionsN.cm1, extN);
@@ -115,7 +118,7 @@ function freeCtx(ctx, keep = []) {
 module.exports = { prove, freeCtx };
 
 if (require.main === module) (async () => {
-    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json"]) {
+    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json", "fib_flow_impols.json"]) {
         const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden", name)));
         await prove(g, false);
         await prove(g, true);

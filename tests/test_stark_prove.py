@@ -86,6 +86,52 @@ def test_previous_row_opening_proof_on_oracle_backend(oracle):
     assert not stark_ref.stark_verify(res2, setup["constRoot"], info, vinfo)[0]
 
 
+def _im_case(n_bits, n_pairs, steps, prev_row=False):
+    from pil2gl import stark
+    ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
+    info, exprs, vinfo = stark.fibonacci_air(n_pairs, ss, prev_row, im_pols=True)
+    cm, consts, publics = stark.fibonacci_trace(n_bits, n_pairs, im_pols=True)
+    return stark, info, exprs, vinfo, cm, consts, publics
+
+
+def test_intermediate_polynomials_are_computed_by_the_prover_on_oracle_backend(oracle):
+    """expressionsInfo.imPolsCode (prover.js:212-214): the last witness stage's intermediate polynomials are op-lists with destinations
+    of type cm, run on the trace domain before the stage is extended; the witness arrives with those columns empty"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _im_case(6, 2, [9, 5, 2])
+    assert info["mapSectionsN"]["cm1"] == 6 and len(exprs["imPolsCode"][0]["code"]) == 6 and not cm[:, 4:].any()
+    be = stark_ref.OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    w = be.from_host(cm)
+    res = stark.stark_gen(be, w, setup, info, exprs, publics)
+    wm = w.reshape(-1, 6)
+    for r in (0, 1, 63):
+        for i in range(2):
+            assert int(wm[r, 4 + i]) == (int(wm[r, 2 * i]) ** 2 + int(wm[r, 2 * i + 1]) ** 2) % P
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    # without the prover's own computation the columns stay empty and the binding identity im - (l1^2 + l2^2) = 0 fails
+    res2 = stark.stark_gen(be, be.from_host(cm), setup, info, {**exprs, "imPolsCode": [{"tmpUsed": 0, "code": []}]}, publics)
+    assert not stark_ref.stark_verify(res2, setup["constRoot"], info, vinfo)[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bits,n_pairs,steps,prev_row", [(6, 2, [9, 5, 2], False), (12, 7, [15, 10, 5], True), (16, 33, [19, 14, 9, 4], False)])
+def test_gpu_proof_with_intermediate_polynomials_is_identical_to_oracle_proof(oracle, n_bits, n_pairs, steps, prev_row):
+    """the same through the device evaluator (the 2^16 x 99 case: the run-time compiled kernel writes 33 columns of a stage buffer)"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _im_case(n_bits, n_pairs, steps, prev_row)
+    gpu = stark.GpuBackend(0)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    cpu = stark_ref.OracleBackend()
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, publics)
+    assert r_gpu["proof"] == r_cpu["proof"]
+    ok, why = stark.stark_verify(gpu, r_gpu["proof"], publics, s_gpu["constRoot"], info, exprs, vinfo)
+    assert ok, why
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("n_bits,n_pairs,steps", [(6, 2, [9, 5, 2]), (12, 5, [15, 10, 5])])
 def test_gpu_previous_row_opening_proof_is_identical_to_oracle_proof(oracle, n_bits, n_pairs, steps):

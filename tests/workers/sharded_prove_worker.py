@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--air", default="fib", help="fib: one witness stage; perm: two (stage 2 = grand-product hint)")
     ap.add_argument("--hashcommits", type=int, default=0, help="starkStruct.hashCommits")
     ap.add_argument("--pg", default="gloo", help="process-group backend; nccl (= RCCL) needs one GPU per rank")
+    ap.add_argument("--impols", type=int, default=0, help="fib: intermediate polynomials computed by the prover (fibonacci_air im_pols)")
     ap.add_argument("--shardsetup", type=int, default=0, help="1: the constant tree is split over the ranks too (parallel.build_const_tree_sharded)")
     a = ap.parse_args()
     if a.pg == "nccl":
@@ -46,8 +47,8 @@ def main():
         info, exprs, _ = stark.permutation_air(ss)
         cm, consts, publics = stark.permutation_trace(a.nbits)
     else:
-        info, exprs, _ = stark.fibonacci_air(a.pairs, ss)
-        cm, consts, publics = stark.fibonacci_trace(a.nbits, a.pairs)
+        info, exprs, _ = stark.fibonacci_air(a.pairs, ss, im_pols=bool(a.impols))
+        cm, consts, publics = stark.fibonacci_trace(a.nbits, a.pairs, im_pols=bool(a.impols))
     if a.backend == "gpu":
         be = stark.GpuBackend(0)
     else:

@@ -59,9 +59,9 @@ while time.time() - t0 < BUDGET:
         info, exprs, vinfo = stark.permutation_air(ss, copies)
         cm, consts, publics = stark.permutation_trace(nb, copies=copies)
     else:
-        pairs = int(rng.integers(1, 6)); prev = bool(rng.random() < 0.3)
-        info, exprs, vinfo = stark.fibonacci_air(pairs, ss, prev)
-        cm, consts, publics = stark.fibonacci_trace(nb, pairs)
+        pairs = int(rng.integers(1, 6)); prev = bool(rng.random() < 0.3); im = bool(rng.random() < 0.3)
+        info, exprs, vinfo = stark.fibonacci_air(pairs, ss, prev, im_pols=im)
+        cm, consts, publics = stark.fibonacci_trace(nb, pairs, im_pols=im)
     what = (air, nb, eb, steps, ss["nQueries"], split, bool(ss.get("hashCommits")))
     be = stark.GpuBackend(0, split)
     setup = stark.build_const_tree(be, consts, info)

@@ -34,12 +34,12 @@ def strs(v):
     return v
 
 
-def write(name, hash_commits, prev_row=False, im_pols=False):
+def write(name, hash_commits, prev_row=False, im_pols=False, boundaries=False):
     n_bits, pairs = 6, 2
     ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 9}, {"nBits": 5}, {"nBits": 2}]}
     if hash_commits:
         ss["hashCommits"] = True                  # the transcript absorbs hashes of publics / evaluations / last polynomial
-    info, exprs, _ = stark.fibonacci_air(pairs, ss, prev_row, im_pols=im_pols)
+    info, exprs, _ = stark.fibonacci_air(pairs, ss, prev_row, im_pols=im_pols, boundaries=boundaries)
     cm, consts, publics = stark.fibonacci_trace(n_bits, pairs, im_pols=im_pols)      # (im_pols: the witness goes out with those columns empty)
     be = OracleBackend()
     setup = stark.build_const_tree(be, consts, info)
@@ -59,3 +59,5 @@ write("fib_flow_hashcommits.json", True)
 write("fib_flow_prevrow.json", False, True)
 # intermediate polynomials: imPolsCode with destinations of type cm, filled by the prover on the trace domain (prover.js:212-214)
 write("fib_flow_impols.json", False, False, True)
+# pil2 boundaries (everyFrame, firstRow, lastRow) instead of selector constants: one zerofier column of Zi_ext per boundary
+write("fib_flow_boundaries.json", False, False, True, True)

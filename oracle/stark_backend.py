@@ -111,6 +111,8 @@ class OracleBackend:
     def poseidon(self, inp, cap, n): return [int(v) for v in orc.poseidon([int(v) % P for v in inp], [int(v) % P for v in cap], n)]
     def build_x(self, nb, shift): return orc.build_x(nb, shift)
     def build_zhinv(self, nb, nbe): return orc.build_zhinv(nb, nbe)
+    def build_one_row_zerofier_inv(self, nb, nbe, row): return orc.build_one_row_zerofier_inv(nb, nbe, row)
+    def build_frame_zerofier(self, nb, nbe, off_min, off_max): return orc.build_frame_zerofier(nb, nbe, off_min, off_max)
     def q_split(self, qq1, nb, nbe, qDim, qDeg): return orc.compute_q_split(qq1, nb, nbe, qDim, qDeg).reshape(-1)
     def x_div_x_sub_xi(self, nbe, xis): return orc.x_div_x_sub_xi(nbe, np.array(xis, dtype=np.uint64)).reshape(-1)
     def build_lev(self, nb, xi): return orc.lev(nb, np.array(xi, dtype=np.uint64)).reshape(-1)

@@ -580,9 +580,14 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     sl = lambda full, w: coset_slice(be, full, nb, eb, cb, cc, w)
     # the rank's rows of the domain tables, built per coset: no buffer of this function has 2^nBitsExt rows
     loc = {"const_ext": constShard["local"] if constShard is not None else sl(constTree["elements"], nC),
-           "x_ext": x_slice(be, nb, eb, cb, cc, S.SHIFT), "Zi_ext#0": zhinv_slice(be, nb, eb, cb, cc)}
-    widths = {"const_n": nC, "const_ext": nC, "q_ext": qDim, "f_ext": 3, "x_ext": 1, "x_n": 1, "Zi_ext#0": 1,
+           "x_ext": x_slice(be, nb, eb, cb, cc, S.SHIFT)}
+    widths = {"const_n": nC, "const_ext": nC, "q_ext": qDim, "f_ext": 3, "x_ext": 1, "x_n": 1,
               "xDivXSubXi_ext": 3 * len(info["openingPoints"])}
+    for bi, boundary in enumerate(info.get("boundaries", [{"name": "everyRow"}])):
+        # everyRow's table depends on the coset only; the one-row and frame zerofiers are built whole and sliced (2^nBitsExt words
+        # for the moment of the slicing: AIRs that use those boundaries at config-5 size would want them built per coset too)
+        loc["Zi_ext#%d" % bi] = zhinv_slice(be, nb, eb, cb, cc) if boundary["name"] == "everyRow" else sl(S.build_zi_table(be, boundary, nb, nbe), 1)
+        widths["Zi_ext#%d" % bi] = 1
     for s_ in range(1, qStage + 1):
         widths["cm%d_n" % s_] = widths["cm%d_ext" % s_] = info["mapSectionsN"]["cm%d" % s_]
 

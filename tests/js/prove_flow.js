@@ -17,7 +17,7 @@ const Transcript = require(J("transcript.js"));
 const FRI = require(J("fri.js"));
 const { callCalculateExps } = require(J("prover_helpers.js"));
 const SGH = require(J("stark_gen_helpers.js"));
-const { buildZhInv } = require(J("polutils.js"));
+const { buildZhInv, buildOneRowZerofierInv, buildFrameZerofierInv } = require(J("polutils.js"));
 const { DevBuffer } = require(J("native.js"));
 
 const big = (v) => (Array.isArray(v) ? v.map(big) : (typeof v === "string" && /^[0-9]+$/.test(v) ? BigInt(v) : v));
@@ -53,7 +53,13 @@ async function prove(g, resident) {
     ctx.Zi_ext = alloc(pilInfo.boundaries.length * extN);
     ctx.xDivXSubXi_ext = alloc(3 * extN * pilInfo.openingPoints.length);
     SGH.buildXTables(ctx);
-    buildZhInv(ctx.Zi_ext, 0, null, nBits, nBitsExt, true);
+    for (let i = 0; i < pilInfo.boundaries.length; i++) {                                        // stark_gen_helpers.js:146-160
+        const bd = pilInfo.boundaries[i];
+        if (bd.name === "everyRow") buildZhInv(ctx.Zi_ext, i * extN, null, nBits, nBitsExt, true);
+        else if (bd.name === "firstRow") buildOneRowZerofierInv(ctx.Zi_ext, i * extN, null, null, nBits, nBitsExt, 0, true);
+        else if (bd.name === "lastRow") buildOneRowZerofierInv(ctx.Zi_ext, i * extN, null, null, nBits, nBitsExt, N - 1, true);
+        else if (bd.name === "everyFrame") buildFrameZerofierInv(ctx.Zi_ext, i * extN, null, null, nBits, nBitsExt, bd, true);
+    }
     ctx.fri = new FRI(ss, MH);
     require(J("native.js")).addon.sync();
     const tStart = process.hrtime.bigint();
@@ -118,7 +124,7 @@ function freeCtx(ctx, keep = []) {
 module.exports = { prove, freeCtx };
 
 if (require.main === module) (async () => {
-    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json", "fib_flow_impols.json"]) {
+    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json", "fib_flow_impols.json", "fib_flow_boundaries.json"]) {
         const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden", name)));
         await prove(g, false);
         await prove(g, true);

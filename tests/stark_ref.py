@@ -139,6 +139,21 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
     # evaluations, stark_verify.js:95-152
     xN = _pow3(xi, N)
     Z = [int(v) for v in orc.inv3([(xN[0] - 1) % P, xN[1], xN[2]])]
+    # one zerofier per boundary (stark_verify.js:99-136): Z; Z_fr = zh / (xi - 1); Z_lr = zh / (xi - w^(N-1)); Z_frame = prod (xi - root)
+    zh = [(xN[0] - 1) % P, xN[1], xN[2]]
+    w = root_of_unity(nb)
+    xi_minus = lambda r: [(int(xi[0]) - r) % P, int(xi[1]), int(xi[2])]
+    m3 = lambda a_, b_: [int(v) for v in orc.mul3(a_, b_)]
+    Zs = []
+    for bd in info.get("boundaries", [{"name": "everyRow"}]):
+        if bd["name"] == "everyRow": Zs.append(Z)
+        elif bd["name"] == "firstRow": Zs.append(m3(zh, [int(v) for v in orc.inv3(xi_minus(1))]))
+        elif bd["name"] == "lastRow": Zs.append(m3(zh, [int(v) for v in orc.inv3(xi_minus(pow(w, N - 1, P)))]))
+        else:
+            z = [1, 0, 0]
+            for j in range(bd["offsetMin"]): z = m3(z, xi_minus(pow(w, j, P)))
+            for j in range(bd["offsetMax"]): z = m3(z, xi_minus(pow(w, N - j - 1, P)))
+            Zs.append(z)
 
     def resolve(r):
         ty = r["type"]
@@ -146,7 +161,7 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
         if ty == "challenge": return list(challenges[(r["stage"], r["stageId"])])
         if ty == "public": return publics[r["id"]]
         if ty == "number": return int(r["value"]) % P
-        if ty == "Zi": return list(Z)
+        if ty == "Zi": return list(Zs[r.get("boundaryId", 0)])
         raise ValueError(ty)
     lhs = exec_code(verifierInfo["qVerifier"]["code"], resolve)
     q_ids = [k for k, pm in enumerate(info["cmPolsMap"]) if pm["stage"] == qStage]

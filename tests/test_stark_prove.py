@@ -86,12 +86,53 @@ def test_previous_row_opening_proof_on_oracle_backend(oracle):
     assert not stark_ref.stark_verify(res2, setup["constRoot"], info, vinfo)[0]
 
 
-def _im_case(n_bits, n_pairs, steps, prev_row=False):
+def _im_case(n_bits, n_pairs, steps, prev_row=False, im_pols=True, boundaries=False):
     from pil2gl import stark
     ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
-    info, exprs, vinfo = stark.fibonacci_air(n_pairs, ss, prev_row, im_pols=True)
-    cm, consts, publics = stark.fibonacci_trace(n_bits, n_pairs, im_pols=True)
+    info, exprs, vinfo = stark.fibonacci_air(n_pairs, ss, prev_row, im_pols=im_pols, boundaries=boundaries)
+    cm, consts, publics = stark.fibonacci_trace(n_bits, n_pairs, im_pols=im_pols)
     return stark, info, exprs, vinfo, cm, consts, publics
+
+
+def test_boundary_constraints_on_oracle_backend(oracle):
+    """pil2 boundaries (constraintPolynomial.js:21-45): transitions on everyFrame{0, 1}, inputs on firstRow, output on lastRow -- Zi_ext carries
+    one zerofier column per boundary (stark_gen_helpers.js:146-160) and the verifier one value per boundary (stark_verify.js:99-136);
+    a violation on the first row, on the last row or in between is rejected"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _im_case(6, 2, [9, 5, 2], im_pols=False, boundaries=True)
+    assert [b["name"] for b in info["boundaries"]] == ["everyRow", "everyFrame", "firstRow", "lastRow"]
+    be = stark_ref.OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    for r, c in ((0, 1), (63, 0), (7, 0)):
+        cm2 = cm.copy(); cm2[r, c] ^= 1
+        res2 = stark.stark_gen(be, be.from_host(cm2), setup, info, exprs, publics)
+        assert not stark_ref.stark_verify(res2, setup["constRoot"], info, vinfo)[0], (r, c)
+    # the zerofier values of the verifier are the table columns' own polynomials: Zi(firstRow) * (x - 1) = Zh on the extended domain
+    zfr = be.build_one_row_zerofier_inv(6, 9, 0); zh_inv = be.build_zhinv(6, 9); x = be.build_x(9, stark.SHIFT)
+    for i in (0, 1, 77, 511):
+        assert int(zfr[i]) * ((int(x[i]) - 1) % P) % P * int(zh_inv[i]) % P == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bits,n_pairs,steps,im", [(6, 2, [9, 5, 2], False), (13, 9, [16, 11, 6], True)])
+def test_gpu_proof_with_boundary_constraints_is_identical_to_oracle_proof(oracle, n_bits, n_pairs, steps, im):
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _im_case(n_bits, n_pairs, steps, im_pols=im, boundaries=True)
+    gpu = stark.GpuBackend(0)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    cpu = stark_ref.OracleBackend()
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, publics)
+    assert r_gpu["proof"] == r_cpu["proof"]
+    ok, why = stark.stark_verify(gpu, r_gpu["proof"], publics, s_gpu["constRoot"], info, exprs, vinfo)
+    assert ok, why
+    bad = {**r_gpu["proof"], "evals": [list(e) for e in r_gpu["proof"]["evals"]]}
+    bad["evals"][0][0] ^= 1
+    assert not stark.stark_verify(gpu, bad, publics, s_gpu["constRoot"], info, exprs, vinfo)[0]
 
 
 def test_intermediate_polynomials_are_computed_by_the_prover_on_oracle_backend(oracle):

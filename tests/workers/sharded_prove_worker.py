@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--hashcommits", type=int, default=0, help="starkStruct.hashCommits")
     ap.add_argument("--pg", default="gloo", help="process-group backend; nccl (= RCCL) needs one GPU per rank")
     ap.add_argument("--impols", type=int, default=0, help="fib: intermediate polynomials computed by the prover (fibonacci_air im_pols)")
+    ap.add_argument("--boundaries", type=int, default=0, help="fib: constraints on pil2 boundaries (everyFrame / firstRow / lastRow) instead of selector constants")
     ap.add_argument("--shardsetup", type=int, default=0, help="1: the constant tree is split over the ranks too (parallel.build_const_tree_sharded)")
     a = ap.parse_args()
     if a.pg == "nccl":
@@ -47,7 +48,7 @@ def main():
         info, exprs, _ = stark.permutation_air(ss)
         cm, consts, publics = stark.permutation_trace(a.nbits)
     else:
-        info, exprs, _ = stark.fibonacci_air(a.pairs, ss, im_pols=bool(a.impols))
+        info, exprs, _ = stark.fibonacci_air(a.pairs, ss, im_pols=bool(a.impols), boundaries=bool(a.boundaries))
         cm, consts, publics = stark.fibonacci_trace(a.nbits, a.pairs, im_pols=bool(a.impols))
     if a.backend == "gpu":
         be = stark.GpuBackend(0)

@@ -41,11 +41,11 @@ for i in range(CASES):
         if nxt < 1:
             break
         steps.append(nxt)
-    pairs = rnd.randint(1, 6); prev = rnd.random() < 0.3; im = rnd.random() < 0.3
+    pairs = rnd.randint(1, 6); prev = rnd.random() < 0.3; im = rnd.random() < 0.3; bd = rnd.random() < 0.3
     ss = {"nBits": nb, "nBitsExt": nbe, "nQueries": rnd.randint(1, 16), "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
     if rnd.random() < 0.3:
         ss["hashCommits"] = True
-    info, exprs, _ = stark.fibonacci_air(pairs, ss, prev, im_pols=im)
+    info, exprs, _ = stark.fibonacci_air(pairs, ss, prev, im_pols=im, boundaries=bd)
     cm, consts, publics = stark.fibonacci_trace(nb, pairs, im_pols=im)
     be = OracleBackend()
     setup = stark.build_const_tree(be, consts, info)
@@ -55,7 +55,7 @@ for i in range(CASES):
            "proof": strs(json.loads(json.dumps(res["proof"], default=int))), "challenges": strs(res["challenges"]), "queries": res["queries"]}
     name = os.path.join(tmp, "g%03d.json" % i)
     json.dump(out, open(name, "w")); names.append(name)
-    print("case %d: nBits %d ext %d pairs %d steps %s queries %d hashCommits %s prevRow %s imPols %s" % (i, nb, eb, pairs, steps, ss["nQueries"], bool(ss.get("hashCommits")), prev, im), flush=True)
+    print("case %d: nBits %d ext %d pairs %d steps %s queries %d hashCommits %s prevRow %s imPols %s boundaries %s" % (i, nb, eb, pairs, steps, ss["nQueries"], bool(ss.get("hashCommits")), prev, im, bd), flush=True)
 js = """
 const fs = require("fs");
 const { prove, freeCtx } = require(%r);

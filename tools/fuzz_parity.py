@@ -118,8 +118,8 @@ def case_proof():
         info, exprs, _ = stark.permutation_air(ss, copies)
         cm, consts, publics = stark.permutation_trace(nb, copies=copies)
     else:
-        pairs = int(rng.integers(1, 9)); prev = bool(rng.random() < 0.3); im = bool(rng.random() < 0.3)
-        info, exprs, _ = stark.fibonacci_air(pairs, ss, prev, im_pols=im)
+        pairs = int(rng.integers(1, 9)); prev = bool(rng.random() < 0.3); im = bool(rng.random() < 0.3); bd = bool(rng.random() < 0.3)
+        info, exprs, _ = stark.fibonacci_air(pairs, ss, prev, im_pols=im, boundaries=bd)
         cm, consts, publics = stark.fibonacci_trace(nb, pairs, im_pols=im)
     what = (air, nb, eb, steps, ss["nQueries"], bool(ss.get("hashCommits")), split, cm.shape[1])
     try:

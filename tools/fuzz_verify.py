@@ -59,8 +59,8 @@ while time.time() - t0 < BUDGET:
         info, exprs, vinfo = stark.permutation_air(ss, copies)
         cm, consts, publics = stark.permutation_trace(nb, copies=copies)
     else:
-        pairs = int(rng.integers(1, 6)); prev = bool(rng.random() < 0.3); im = bool(rng.random() < 0.3)
-        info, exprs, vinfo = stark.fibonacci_air(pairs, ss, prev, im_pols=im)
+        pairs = int(rng.integers(1, 6)); prev = bool(rng.random() < 0.3); im = bool(rng.random() < 0.3); bd = bool(rng.random() < 0.3)
+        info, exprs, vinfo = stark.fibonacci_air(pairs, ss, prev, im_pols=im, boundaries=bd)
         cm, consts, publics = stark.fibonacci_trace(nb, pairs, im_pols=im)
     what = (air, nb, eb, steps, ss["nQueries"], split, bool(ss.get("hashCommits")))
     be = stark.GpuBackend(0, split)

@@ -34,6 +34,7 @@ function encode(code, dom, ctx, global) {
     function ref(r, isDest) {
         switch (r.type) {
             case "tmp": return { kind: TMP, dim: r.dim, section: 0, prime: 0, index: r.id };
+            case "$ret": return { kind: SEC, dim: r.dim, section: section("$ret", r.dim), prime: 0, index: 0 };      // calculateExps(..., ret = true)
             case "const": return { kind: SEC, dim: 1, section: section("const_" + dom, info.nConstants), prime: r.prime || 0, index: r.id };
             case "cm": return cmRef(r);
             case "q": if (dom !== "ext") throw new Error("Accessing q in domain n");
@@ -88,14 +89,26 @@ function encode(code, dom, ctx, global) {
     return { ops: new BigUint64Array(buf), nOps: list.length, nTmp, sections, scalars: BigUint64Array.from(scalars.length ? scalars : [0n]) };
 }
 
-module.exports.callCalculateExps = async function callCalculateExps(stage, code, dom, ctx, parallelExec, useThreads, debug, global = false) {
-    if (debug) throw new Error("debug (constraint checking) mode is not offloaded; use the reference evaluator");
-    const enc = encode(code.code, dom, ctx, global);
+// calculateExps(ctx, code, dom, debug, ret, global)   (prover_helpers.js:31-72).  ret: the value the LAST op produced, for every row of
+// the domain -- an array of BigInt (dim 1) or of [a, b, c] (dim 3) -- which is how the hints read a numerator / denominator / lookup
+// column that is an expression rather than a committed polynomial (getHintField op "tmp", hints_helpers.js:32).  The last op's
+// destination is redirected to a scratch column on the device; nothing else of the program changes.
+function run(code, dom, ctx, global, ret) {
+    let ops = code.code, retDim = 0;
+    if (ret) {
+        if (!ops.length) throw new Error("calculateExps: an empty program returns nothing");
+        const last = ops[ops.length - 1];
+        retDim = last.dest.dim || 1;
+        ops = ops.slice(0, -1).concat([{ op: last.op, dest: { type: "$ret", dim: retDim }, src: last.src }]);
+    }
+    const enc = encode(ops, dom, ctx, global);
     const nBits = dom === "n" ? ctx.nBits : ctx.nBitsExt;
     const rows = 2 ** nBits;
     const ptrs = new BigUint64Array(enc.sections.length), widths = new BigUint64Array(enc.sections.length), devs = [];
+    let out;
     try {
         enc.sections.forEach((s, i) => {
+            if (s.name === "$ret") { const d = addon.devAlloc(rows * s.width); devs.push(d); ptrs[i] = d; widths[i] = BigInt(s.width); return; }
             const host = ctx[s.name];
             if (!host) throw new Error("ctx." + s.name + " is not allocated");
             const n = rows * s.width, base = s.zi === undefined ? 0 : s.zi * rows;
@@ -107,9 +120,37 @@ module.exports.callCalculateExps = async function callCalculateExps(stage, code,
             ptrs[i] = d; widths[i] = BigInt(s.width);
         });
         addon.evalProgramDev(enc.ops, enc.nOps, enc.nTmp, nBits, dom === "n" ? 0 : ctx.extendBits, ptrs, widths, enc.scalars);
-        enc.sections.forEach((s, i) => { if (s.written && devs[i] !== null) download(ctx[s.name], devs[i], rows * s.width); });
+        enc.sections.forEach((s, i) => {
+            if (s.name === "$ret") {
+                const flat = new BigUint64Array(rows * retDim);
+                addon.devDownload(flat, devs[i], 0);
+                out = new Array(rows);
+                if (retDim === 1) for (let r = 0; r < rows; r++) out[r] = flat[r];
+                else for (let r = 0; r < rows; r++) out[r] = [flat[3 * r], flat[3 * r + 1], flat[3 * r + 2]];
+            } else if (s.written && devs[i] !== null) {
+                const base = s.zi === undefined ? 0 : s.zi * rows;
+                if (base === 0) download(ctx[s.name], devs[i], rows * s.width);
+                else { const t = new BigUint64Array(rows * s.width); addon.devDownload(t, devs[i], 0); ctx[s.name].set(t, base); }
+            }
+        });
     } finally {
         for (const d of devs) if (d !== null) addon.devFree(d);
     }
+    return out;
+}
+module.exports.calculateExps = function calculateExps(ctx, code, dom, debug, ret, global) {
+    if (debug) throw new Error("debug (constraint checking) mode is not offloaded; use the reference evaluator");
+    return run(code, dom, ctx, !!global, !!ret);
+};
+// calculateExpression(ctx, expId)   (prover_helpers.js:10-16): the expression's column on the trace domain
+module.exports.calculateExpression = function calculateExpression(ctx, expId, debug = false) {
+    const expressionCode = ctx.expressionsInfo.expressionsCode.find((e) => e && e.expId === expId);
+    if (!expressionCode) throw new Error("expression " + expId + " not found");
+    return module.exports.calculateExps(ctx, expressionCode.code, "n", debug, true);
+};
+
+module.exports.callCalculateExps = async function callCalculateExps(stage, code, dom, ctx, parallelExec, useThreads, debug, global = false) {
+    if (debug) throw new Error("debug (constraint checking) mode is not offloaded; use the reference evaluator");
+    run(code, dom, ctx, global, false);
 };
 module.exports.encode = encode;

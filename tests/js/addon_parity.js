@@ -155,6 +155,39 @@ class ChunkedBuffer {
             assert.deepStrictEqual([ctx.q_ext[3 * i], ctx.q_ext[3 * i + 1], ctx.q_ext[3 * i + 2]], [mod(t * 3n), mod(t * 1n), mod(t * 4n)], "callCalculateExps row " + i);
         }
     }
+    // --- calculateExpression / calculateExps(ret = true) (prover_helpers.js:10-16,31-72): the column an expression takes on the trace
+    //     domain, as the hints read their numerators / denominators (hints_helpers.js:32); base and extension results, host and resident buffers
+    {
+        const PH = require(path.join(root, "pil2-stark-js_amd/js/prover_helpers.js"));
+        const { DevBuffer } = require(path.join(root, "pil2-stark-js_amd/js/native.js"));
+        const P = 0xFFFFFFFF00000001n, nBits = 5, N = 32;
+        const mod = (a) => ((a % P) + P) % P;
+        const cm1 = new BigUint64Array(N * 3), cn = new BigUint64Array(N * 2), xn = new BigUint64Array(N);
+        for (let i = 0; i < N; i++) { cm1[3 * i] = BigInt(i * i + 3); cm1[3 * i + 2] = P - BigInt(i + 1); cn[2 * i + 1] = BigInt(7 * i + 1); xn[i] = BigInt(900 + i); }
+        const code1 = { tmpUsed: 3, code: [
+            { op: "sub", dest: { type: "tmp", id: 0, dim: 1 }, src: [{ type: "cm", id: 0, prime: 1, dim: 1 }, { type: "cm", id: 1, prime: 0, dim: 1 }] },
+            { op: "mul", dest: { type: "tmp", id: 1, dim: 1 }, src: [{ type: "tmp", id: 0, dim: 1 }, { type: "const", id: 1, prime: 0, dim: 1 }] },
+            { op: "add", dest: { type: "tmp", id: 2, dim: 1 }, src: [{ type: "tmp", id: 1, dim: 1 }, { type: "x", dim: 1 }] } ] };
+        const code3 = { tmpUsed: 4, code: code1.code.concat([
+            { op: "mul", dest: { type: "tmp", id: 3, dim: 3 }, src: [{ type: "tmp", id: 2, dim: 1 }, { type: "challenge", stage: 2, stageId: 0, id: 0, dim: 3 }] } ]) };
+        for (const resident of [false, true]) {
+            const B = (a) => (resident ? DevBuffer.from(a) : a);
+            const ctx = { nBits, nBitsExt: 7, extendBits: 2, publics: [], challenges: [[], [[3n, 1n, 4n]]], evals: [], subproofValues: [],
+                pilInfo: { nConstants: 2, qDim: 3, openingPoints: [0, 1], boundaries: [{ name: "everyRow" }], mapSectionsN: { cm1: 3 },
+                    cmPolsMap: [{ stage: 1, dim: 1, stagePos: 0 }, { stage: 1, dim: 1, stagePos: 2 }] },
+                expressionsInfo: { expressionsCode: [{ expId: 7, code: code1 }, undefined, { expId: 9, code: code3 }] },
+                const_n: B(cn), cm1_n: B(cm1), x_n: B(xn) };
+            const col1 = PH.calculateExpression(ctx, 7), col3 = PH.calculateExpression(ctx, 9);
+            assert.strictEqual(col1.length, N); assert.strictEqual(col3.length, N);
+            for (let i = 0; i < N; i++) {
+                const nx = (i + 1) % N;
+                const t = mod(mod(cm1[3 * nx] - cm1[3 * i + 2]) * cn[2 * i + 1] + xn[i]);
+                assert.strictEqual(col1[i], t, "calculateExpression dim 1 row " + i);
+                assert.deepStrictEqual(col3[i], [mod(t * 3n), mod(t * 1n), mod(t * 4n)], "calculateExpression dim 3 row " + i);
+            }
+            assert.throws(() => PH.calculateExpression(ctx, 8), /not found/);
+        }
+    }
     // --- stark_gen_helpers.js / polutils.js drop-ins against BigInt restatements of the reference loops (small sizes)
     {
         const SGH = require(path.join(root, "pil2-stark-js_amd/js/stark_gen_helpers.js"));

@@ -35,6 +35,7 @@ function encode(code, dom, ctx, global) {
         switch (r.type) {
             case "tmp": return { kind: TMP, dim: r.dim, section: 0, prime: 0, index: r.id };
             case "$ret": return { kind: SEC, dim: r.dim, section: section("$ret", r.dim), prime: 0, index: 0 };      // calculateExps(..., ret = true)
+            case "$arg": return { kind: SEC, dim: r.dim, section: section("$arg", r.dim), prime: 0, index: 0 };      // setPol: the caller's column, staged
             case "const": return { kind: SEC, dim: 1, section: section("const_" + dom, info.nConstants), prime: r.prime || 0, index: r.id };
             case "cm": return cmRef(r);
             case "q": if (dom !== "ext") throw new Error("Accessing q in domain n");
@@ -109,6 +110,7 @@ function run(code, dom, ctx, global, ret) {
     try {
         enc.sections.forEach((s, i) => {
             if (s.name === "$ret") { const d = addon.devAlloc(rows * s.width); devs.push(d); ptrs[i] = d; widths[i] = BigInt(s.width); return; }
+            if (s.name === "$arg") { const d = addon.devAlloc(rows * s.width); devs.push(d); addon.devUpload(d, 0, ctx.$arg); ptrs[i] = d; widths[i] = BigInt(s.width); return; }
             const host = ctx[s.name];
             if (!host) throw new Error("ctx." + s.name + " is not allocated");
             const n = rows * s.width, base = s.zi === undefined ? 0 : s.zi * rows;
@@ -147,6 +149,52 @@ module.exports.calculateExpression = function calculateExpression(ctx, expId, de
     const expressionCode = ctx.expressionsInfo.expressionsCode.find((e) => e && e.expId === expId);
     if (!expressionCode) throw new Error("expression " + expId + " not found");
     return module.exports.calculateExps(ctx, expressionCode.code, "n", debug, true);
+};
+
+// getPolRef / getPol / setPol / getFixedPol (prover_helpers.js:261-358): one column of a stage buffer as an array of BigInt (dim 1) or
+// [a, b, c] (dim 3).  The reference walks the column with getElement / setElement, one element at a time; on a buffer that lives in
+// HBM (native.js DevBuffer) that would be one transfer per row, so there the column is gathered / scattered by a one-op program of
+// the evaluator and crosses PCIe once.  Host buffers are walked directly.
+module.exports.getPolRef = function getPolRef(ctx, idPol, dom, isFixed = false) {
+    if (!["n", "ext"].includes(dom)) throw new Error("invalid stage");
+    const deg = dom === "ext" ? 2 ** ctx.nBitsExt : 2 ** ctx.nBits;
+    const p = isFixed ? (ctx.pilInfo.constPolsMap || [])[idPol] || { dim: 1 } : ctx.pilInfo.cmPolsMap[idPol];
+    const st = isFixed ? "const" : "cm" + p.stage;
+    const stage = st + "_" + dom;
+    return { stage, buffer: ctx[stage], deg, offset: isFixed ? idPol : p.stagePos, size: isFixed ? ctx.pilInfo.nConstants : ctx.pilInfo.mapSectionsN[st], dim: p.dim };
+};
+module.exports.getPol = function getPol(ctx, idPol, dom, isFixed = false) {
+    const p = module.exports.getPolRef(ctx, idPol, dom, isFixed);
+    if (p.dim !== 1 && p.dim !== 3) throw new Error("invalid dim" + p.dim);
+    if (isDev(p.buffer))
+        return run({ code: [{ op: "copy", dest: { type: "tmp", id: 0, dim: p.dim }, src: [{ type: isFixed ? "const" : "cm", id: idPol, prime: 0, dim: p.dim }] }] }, dom, ctx, false, true);
+    const res = new Array(p.deg), b = p.buffer, flat = b instanceof BigUint64Array;
+    const at = flat ? (k) => b[k] : (k) => b.getElement(k);
+    if (p.dim === 1) for (let i = 0; i < p.deg; i++) res[i] = at(p.offset + i * p.size);
+    else for (let i = 0; i < p.deg; i++) { const k = p.offset + i * p.size; res[i] = [at(k), at(k + 1), at(k + 2)]; }
+    return res;
+};
+module.exports.getFixedPol = function getFixedPol(ctx, idPol) { return module.exports.getPol(ctx, idPol, "n", true); };
+module.exports.setPol = function setPol(ctx, idPol, pol, dom, options) {
+    const p = module.exports.getPolRef(ctx, idPol, dom);
+    if (p.dim !== 1 && p.dim !== 3) throw new Error("invalid dim" + p.dim);
+    const word = (v) => { let x = BigInt(v) % P; if (x < 0n) x += P; return x; };
+    if (isDev(p.buffer)) {
+        const col = new BigUint64Array(p.deg * p.dim);
+        if (p.dim === 1) for (let i = 0; i < p.deg; i++) col[i] = word(pol[i]);
+        else for (let i = 0; i < p.deg; i++) { const v = Array.isArray(pol[i]) ? pol[i] : [pol[i], 0n, 0n]; col[3 * i] = word(v[0]); col[3 * i + 1] = word(v[1]); col[3 * i + 2] = word(v[2]); }
+        ctx.$arg = col;
+        try { run({ code: [{ op: "copy", dest: { type: "cm", id: idPol, dim: p.dim }, src: [{ type: "$arg", dim: p.dim }] }] }, dom, ctx, false, false); }
+        finally { delete ctx.$arg; }
+        return;
+    }
+    const b = p.buffer, flat = b instanceof BigUint64Array;
+    const put = flat ? (k, v) => { b[k] = word(v); } : (k, v) => b.setElement(k, word(v));
+    if (p.dim === 1) for (let i = 0; i < p.deg; i++) put(p.offset + i * p.size, pol[i]);
+    else for (let i = 0; i < p.deg; i++) {
+        const v = Array.isArray(pol[i]) ? pol[i] : [pol[i], 0n, 0n], k = p.offset + i * p.size;
+        put(k, v[0]); put(k + 1, v[1]); put(k + 2, v[2]);
+    }
 };
 
 module.exports.callCalculateExps = async function callCalculateExps(stage, code, dom, ctx, parallelExec, useThreads, debug, global = false) {

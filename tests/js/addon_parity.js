@@ -186,6 +186,24 @@ class ChunkedBuffer {
                 assert.deepStrictEqual(col3[i], [mod(t * 3n), mod(t * 1n), mod(t * 4n)], "calculateExpression dim 3 row " + i);
             }
             assert.throws(() => PH.calculateExpression(ctx, 8), /not found/);
+            // getPol / setPol / getFixedPol (prover_helpers.js:261-358): a column out of / into a stage buffer; its neighbours stay
+            ctx.pilInfo.cmPolsMap.push({ stage: 2, dim: 3, stagePos: 1 }); ctx.pilInfo.mapSectionsN.cm2 = 5;
+            const cm2 = new BigUint64Array(N * 5); for (let i = 0; i < cm2.length; i++) cm2[i] = BigInt(5000 + i);
+            ctx.cm2_n = B(cm2);
+            assert.deepStrictEqual(PH.getPol(ctx, 0, "n"), Array.from({ length: N }, (_, i) => cm1[3 * i]));
+            assert.deepStrictEqual(PH.getPol(ctx, 1, "n"), Array.from({ length: N }, (_, i) => cm1[3 * i + 2]));
+            assert.deepStrictEqual(PH.getFixedPol(ctx, 1), Array.from({ length: N }, (_, i) => cn[2 * i + 1]));
+            assert.deepStrictEqual(PH.getPol(ctx, 2, "n")[3], [cm2[16], cm2[17], cm2[18]]);
+            const newCol = Array.from({ length: N }, (_, i) => (i % 2 ? [BigInt(i), P - 1n, 7n] : BigInt(i) + P));      // base values land as [v, 0, 0]; values are reduced
+            PH.setPol(ctx, 2, newCol, "n");
+            const after = resident ? ctx.cm2_n.toHost() : ctx.cm2_n;
+            for (let i = 0; i < N; i++) {
+                assert.deepStrictEqual([after[5 * i], after[5 * i + 4]], [BigInt(5000 + 5 * i), BigInt(5000 + 5 * i + 4)], "setPol neighbours row " + i);
+                assert.deepStrictEqual([after[5 * i + 1], after[5 * i + 2], after[5 * i + 3]], i % 2 ? [BigInt(i), P - 1n, 7n] : [BigInt(i), 0n, 0n], "setPol row " + i);
+            }
+            PH.setPol(ctx, 1, Array.from({ length: N }, (_, i) => BigInt(3 * i)), "n");
+            assert.deepStrictEqual(PH.getPol(ctx, 1, "n"), Array.from({ length: N }, (_, i) => BigInt(3 * i)));
+            assert.deepStrictEqual(PH.getPol(ctx, 0, "n"), Array.from({ length: N }, (_, i) => cm1[3 * i]));
         }
     }
     // --- stark_gen_helpers.js / polutils.js drop-ins against BigInt restatements of the reference loops (small sizes)

@@ -34,13 +34,17 @@ def strs(v):
     return v
 
 
-def write(name, hash_commits, prev_row=False, im_pols=False, boundaries=False):
+def write(name, hash_commits, prev_row=False, im_pols=False, boundaries=False, perm_copies=0):
     n_bits, pairs = 6, 2
     ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": 9}, {"nBits": 5}, {"nBits": 2}]}
     if hash_commits:
         ss["hashCommits"] = True                  # the transcript absorbs hashes of publics / evaluations / last polynomial
-    info, exprs, _ = stark.fibonacci_air(pairs, ss, prev_row, im_pols=im_pols, boundaries=boundaries)
-    cm, consts, publics = stark.fibonacci_trace(n_bits, pairs, im_pols=im_pols)      # (im_pols: the witness goes out with those columns empty)
+    if perm_copies:                                   # two witness stages; the stage-2 column comes from a gprod hint in the reference's shape
+        info, exprs, _ = stark.permutation_air(ss, perm_copies, ref_hints=True)
+        cm, consts, publics = stark.permutation_trace(n_bits, copies=perm_copies)
+    else:
+        info, exprs, _ = stark.fibonacci_air(pairs, ss, prev_row, im_pols=im_pols, boundaries=boundaries)
+        cm, consts, publics = stark.fibonacci_trace(n_bits, pairs, im_pols=im_pols)  # (im_pols: the witness goes out with those columns empty)
     be = OracleBackend()
     setup = stark.build_const_tree(be, consts, info)
     res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)          # (from_host copies: cm itself stays as generated)
@@ -61,3 +65,5 @@ write("fib_flow_prevrow.json", False, True)
 write("fib_flow_impols.json", False, False, True)
 # pil2 boundaries (everyFrame, firstRow, lastRow) instead of selector constants: one zerofier column of Zi_ext per boundary
 write("fib_flow_boundaries.json", False, False, True, True)
+# two witness stages: expressionsInfo.hintsInfo in the reference's shape, numerator / denominator as expressions (hints_helpers.js:21-33,102-113)
+write("perm_flow_hints.json", False, perm_copies=2)

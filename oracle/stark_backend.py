@@ -70,6 +70,12 @@ class OracleBackend:
     def gprod(self, num, dn, den, dd): return orc.gprod(num, den, dn, dd)
     def gsum(self, num, dn, den, dd): return orc.gsum(num, den, dn, dd)
 
+    def h1h2(self, f, t, dim):
+        key = (lambda r: int(r[0])) if dim == 1 else (lambda r: tuple(int(x) for x in r))
+        w1, w2 = orc.h1h2([key(r) for r in f.reshape(-1, dim)], [key(r) for r in t.reshape(-1, dim)])
+        arr = lambda w: np.array([[v] if dim == 1 else list(v) for v in w], dtype=np.uint64).reshape(-1)
+        return arr(w1), arr(w2)
+
     def merkle_siblings(self, nodes, height, idxs):
         return [[[int(x) for x in s] for s in orc.group_proof(nodes, height, i)] for i in idxs]
 

@@ -612,7 +612,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
             for sc in exprs.get("stageCode", {}).get(s_, []):
                 ops, n_tmp, secs, scalars = S.encode_code(sc["code"], "n", ctx)
                 be.eval_program(ops, n_tmp, [(trace[x], widths[x]) for x in secs], scalars, nb, 0)
-            S.resolve_hints(be, info, s_, trace, widths, nb, ctx)
+            S.resolve_hints(be, info, s_, trace, widths, nb, ctx, exprs)
         im = exprs.get("imPolsCode", [])
         if s_ == nStages and len(im) >= s_ and im[s_ - 1].get("code"):      # intermediate polynomials (prover.js:212-214), replicated like the stage code
             ops, n_tmp, secs, scalars = S.encode_code(im[s_ - 1]["code"], "n", ctx)

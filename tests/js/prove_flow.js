@@ -15,7 +15,9 @@ const buildMH = require(J("merklehash_p.js"));
 const getPoseidon = require(J("poseidon.js"));
 const Transcript = require(J("transcript.js"));
 const FRI = require(J("fri.js"));
-const { callCalculateExps } = require(J("prover_helpers.js"));
+const PH = require(J("prover_helpers.js"));
+const PU = require(J("polutils.js"));
+const { callCalculateExps } = PH;
 const SGH = require(J("stark_gen_helpers.js"));
 const { buildZhInv, buildOneRowZerofierInv, buildFrameZerofierInv } = require(J("polutils.js"));
 const { DevBuffer } = require(J("native.js"));
@@ -36,7 +38,9 @@ async function prove(g, resident) {
     const poseidon = getPoseidon(), MH = await buildMH(false);
     const nBits = ss.nBits, nBitsExt = ss.nBitsExt, N = 1 << nBits, extN = 1 << nBitsExt;
     const ctx = { prover: "stark", pilInfo, expressionsInfo: g.expressionsInfo, nBits, nBitsExt, extendBits: nBitsExt - nBits, N, extN, MH,
-        publics: g.publics.map(BigInt), challenges: [[], [], [], []], evals: [], subproofValues: [], trees: [] };
+        publics: g.publics.map(BigInt), challenges: [], evals: [], subproofValues: [], trees: [] };
+    const nStages = pilInfo.nStages, qStage = nStages + 1;
+    for (let i = 0; i < nStages + 3; i++) ctx.challenges.push([]);
     // setup (stark_buildConstTree.js:6-43) and initProverStark (stark_gen_helpers.js:104-160)
     const asBuf = (v) => (v instanceof DevBuffer ? v : fromHost(v instanceof BigUint64Array ? v : BigUint64Array.from(v, BigInt)));
     ctx.const_n = asBuf(g.consts);
@@ -45,8 +49,10 @@ async function prove(g, resident) {
     ctx.constTree = await MH.merkelize(ctx.const_ext, pilInfo.nConstants, extN);
     assert.deepStrictEqual(MH.root(ctx.constTree), g.constRoot.map(BigInt), "constant tree root");
     ctx.cm1_n = asBuf(g.cm1);
-    ctx.cm1_ext = alloc(pilInfo.mapSectionsN.cm1 * extN);
-    ctx.cm2_ext = alloc(pilInfo.mapSectionsN.cm2 * extN);
+    for (let st = 1; st <= qStage; st++) {
+        if (st > 1 && st <= nStages) { ctx["cm" + st + "_n"] = alloc(pilInfo.mapSectionsN["cm" + st] * N); if (resident) ctx["cm" + st + "_n"].zero(); }
+        ctx["cm" + st + "_ext"] = alloc(pilInfo.mapSectionsN["cm" + st] * extN);
+    }
     ctx.q_ext = alloc(pilInfo.qDim * extN);
     ctx.f_ext = alloc(3 * extN);
     ctx.x_n = alloc(N); ctx.x_ext = alloc(extN);
@@ -66,22 +72,41 @@ async function prove(g, resident) {
     const transcript = new Transcript(poseidon);
     transcript.put(MH.root(ctx.constTree));                                                     // prover.js:148-189
     transcript.put(ss.hashCommits ? await SGH.calculateHashStark(ctx, ctx.publics) : ctx.publics);
-    // intermediate polynomials of the last witness stage (prover.js:212-214): op-lists with destinations of type cm, trace domain
-    const im = (ctx.expressionsInfo.imPolsCode || [])[0];
-    if (im && im.code.length) await callCalculateExps(1, im, "n", ctx, false, false);
-    // stage 1: extendAndMerkelize (stark_gen_helpers.js:388-412)
-    await interpolate(ctx.cm1_n, pilInfo.mapSectionsN.cm1, nBits, ctx.cm1_ext, nBitsExt);
-    ctx.trees[1] = await MH.merkelize(ctx.cm1_ext, pilInfo.mapSectionsN.cm1, extN);
-    const root1 = MH.root(ctx.trees[1]); transcript.put(root1);
-    // stage 2: quotient (challenges are stored at [stage - 1], setChallengesStark :414-431)
-    ctx.challenges[1] = [transcript.getField()];
-    await callCalculateExps(2, ctx.expressionsInfo.expressionsCode.find((e) => e.expId === pilInfo.cExpId).code, "ext", ctx, false, false, false);
-    const [root2] = await SGH.computeQStark(ctx, {}); transcript.put(root2);
+    // witness stages (prover.js:41-66, computeStage :193-228): challenges of the stage, its hints (hints_helpers.js:81-123 restated on the
+    // drop-ins: calculateExpression for fields that are expressions, calculateZ / calculateS, setPol), the intermediate polynomials of the
+    // last witness stage (:212-214: op-lists with destinations of type cm, trace domain), then extendAndMerkelize (stark_gen_helpers.js:388-412)
+    const roots = {};
+    for (let st = 1; st <= nStages; st++) {
+        if (st > 1) {
+            const nCh = pilInfo.challengesMap.filter((c) => c.stage === st).length;
+            ctx.challenges[st - 1] = [];
+            for (let k = 0; k < nCh; k++) ctx.challenges[st - 1].push(transcript.getField());
+            for (const hint of ctx.expressionsInfo.hintsInfo || []) {
+                const fld = (name) => hint.fields.find((f) => f.name === name);
+                const ref = fld("reference");
+                if (!ref || pilInfo.cmPolsMap[ref.id].stage !== st) continue;
+                const col = (f) => (f.op === "cm" ? PH.getPol(ctx, f.id, "n") : f.op === "const" ? PH.getFixedPol(ctx, f.id) : f.op === "tmp" ? PH.calculateExpression(ctx, f.id) : BigInt(f.value));
+                if (hint.name === "gprod") PH.setPol(ctx, ref.id, await PU.calculateZ(null, col(fld("numerator")), col(fld("denominator"))), "n");
+                else if (hint.name === "gsum") PH.setPol(ctx, ref.id, await PU.calculateS(null, col(fld("numerator")), col(fld("denominator"))), "n");
+                else throw new Error("hint " + hint.name + " is not part of this flow");
+            }
+        }
+        const im = (ctx.expressionsInfo.imPolsCode || [])[st - 1];
+        if (st === nStages && im && im.code.length) await callCalculateExps(st, im, "n", ctx, false, false);
+        const w = pilInfo.mapSectionsN["cm" + st];
+        await interpolate(ctx["cm" + st + "_n"], w, nBits, ctx["cm" + st + "_ext"], nBitsExt);
+        ctx.trees[st] = await MH.merkelize(ctx["cm" + st + "_ext"], w, extN);
+        roots[st] = MH.root(ctx.trees[st]); transcript.put(roots[st]);
+    }
+    // quotient stage (challenges are stored at [stage - 1], setChallengesStark :414-431)
+    ctx.challenges[qStage - 1] = [transcript.getField()];
+    await callCalculateExps(qStage, ctx.expressionsInfo.expressionsCode.find((e) => e.expId === pilInfo.cExpId).code, "ext", ctx, false, false, false);
+    [roots[qStage]] = await SGH.computeQStark(ctx, {}); transcript.put(roots[qStage]);
     // evaluations
-    ctx.challenges[2] = [transcript.getField()];
+    ctx.challenges[qStage] = [transcript.getField()];
     const evals = await SGH.computeEvalsStark(ctx, {});
     transcript.put(evals);          // prover.js absorbs them one by one (addTranscriptStark); as one list the drop-in transcript chains the permutations in one device call -- same state
-    ctx.challenges[3] = [transcript.getField(), transcript.getField()];
+    ctx.challenges[qStage + 1] = [transcript.getField(), transcript.getField()];
     await SGH.computeFRIStark(ctx, { parallelExec: false, useThreads: false });
     // FRI folding (computeFRIFolding :337-356) and queries (:474-493, fri.js:83-105)
     for (let step = 0; step < ss.steps.length; step++) {
@@ -96,14 +121,15 @@ async function prove(g, resident) {
     const friQueries = tq.getPermutations(ss.nQueries, ss.steps[0].nBits);
     assert.deepStrictEqual(friQueries, g.queries, "query positions");
     ctx.fri.proofQueries(ctx.friProof, ctx.friTrees, friQueries.slice());
-    const proof = { root1, root2, evals: ctx.evals, fri: ctx.friProof };                         // genProofStark :362-386
+    const proof = {};                                                                            // genProofStark :362-386: roots, evaluations, FRI
+    for (let st = 1; st <= qStage; st++) proof["root" + st] = roots[st];
+    proof.evals = ctx.evals; proof.fri = ctx.friProof;
     require(J("native.js")).addon.sync();
     const seconds = Number(process.hrtime.bigint() - tStart) / 1e9;
     if (!g.proof) return { proof, ctx, seconds };
     const want = bigProof(g.proof);
     assert.deepStrictEqual(ctx.challenges, bigProof(g.challenges), "challenges");
-    assert.deepStrictEqual(proof.root1, want.root1, "root1");
-    assert.deepStrictEqual(proof.root2, want.root2, "root2");
+    for (let st = 1; st <= qStage; st++) assert.deepStrictEqual(proof["root" + st], want["root" + st], "root" + st);
     assert.deepStrictEqual(proof.evals, want.evals, "evals");
     assert.deepStrictEqual(proof.fri.length, want.fri.length);
     for (let s = 0; s < want.fri.length; s++) assert.deepStrictEqual(proof.fri[s], want.fri[s], "fri[" + s + "]");
@@ -124,7 +150,7 @@ function freeCtx(ctx, keep = []) {
 module.exports = { prove, freeCtx };
 
 if (require.main === module) (async () => {
-    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json", "fib_flow_impols.json", "fib_flow_boundaries.json"]) {
+    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json", "fib_flow_impols.json", "fib_flow_boundaries.json", "perm_flow_hints.json"]) {
         const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden", name)));
         await prove(g, false);
         await prove(g, true);

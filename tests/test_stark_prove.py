@@ -454,6 +454,54 @@ def test_gpu_bn128_proof_is_identical_to_oracle_proof(oracle, arity, custom, n_b
         assert not stark.stark_verify(gpu, _tampered(r_gpu, what), publics, s_gpu["constRoot"], info, exprs, vinfo)[0], what
 
 
+def _perm_ref_case(n_bits=6, steps=(9, 5, 2), copies=1):
+    from pil2gl import stark
+    ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
+    info, exprs, vinfo = stark.permutation_air(ss, copies, ref_hints=True)
+    cm, consts, publics = stark.permutation_trace(n_bits, copies=copies)
+    return stark, info, exprs, vinfo, cm, consts, publics
+
+
+def test_hints_in_the_references_shape_with_expression_fields_on_oracle_backend(oracle):
+    """expressionsInfo.hintsInfo as the reference writes it (hints_helpers.js:21-33,102-113): a gprod hint whose numerator and
+    denominator are EXPRESSIONS (fields of op tmp, evaluated on the trace domain by calculateExpression) and whose reference is the
+    only committed stage-2 column"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _perm_ref_case(6, (9, 5, 2), 2)
+    assert info["mapSectionsN"]["cm2"] == 6 and [f["op"] for f in exprs["hintsInfo"][0]["fields"]] == ["tmp", "tmp", "cm"]
+    be = stark_ref.OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    cm2 = cm.copy(); cm2[3, 1] ^= 1                        # b is no longer a permutation of a: the product does not close
+    res2 = stark.stark_gen(be, be.from_host(cm2), setup, info, exprs, publics)
+    assert not stark_ref.stark_verify(res2, setup["constRoot"], info, vinfo)[0]
+    # the expression column itself: a + gamma on the trace domain
+    ctx = {"pilInfo": info, "publics": [], "challenges": [[], [[5, 6, 7]], [], [], []], "evals": []}
+    bufs = {"cm1_n": be.from_host(cm), "const_n": be.from_host(consts)}
+    col, dim = stark.calculate_expression(be, exprs, 2, bufs, {"cm1_n": 4, "const_n": 2}, 6, ctx)
+    assert dim == 3 and col.reshape(-1, 3)[9].tolist() == [(int(cm[9, 0]) + 5) % P, 6, 7]
+    with pytest.raises(ValueError, match="not found"):
+        stark.calculate_expression(be, exprs, 99, bufs, {"cm1_n": 4, "const_n": 2}, 6, ctx)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_bits,steps,copies", [(6, (9, 5, 2), 1), (14, (17, 12, 7), 5)])
+def test_gpu_proof_with_reference_shaped_hints_is_identical_to_oracle_proof(oracle, n_bits, steps, copies):
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _perm_ref_case(n_bits, steps, copies)
+    gpu = stark.GpuBackend(0)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    cpu = stark_ref.OracleBackend()
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, publics)
+    assert r_gpu["proof"] == r_cpu["proof"]
+    ok, why = stark.stark_verify(gpu, r_gpu["proof"], publics, s_gpu["constRoot"], info, exprs, vinfo)
+    assert ok, why
+
+
 def _perm_case(n_bits=6, steps=(9, 5, 2)):
     from pil2gl import stark
     ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}

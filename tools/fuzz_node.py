@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random proofs driven from Node through the JS drop-in modules (tests/js/prove_flow.js: the reference's function boundaries, host
+"""Random proofs (one witness stage, or two with hints in the reference's shape) driven from Node through the JS drop-in modules (tests/js/prove_flow.js: the reference's function boundaries, host
 buffers and device-resident DevBuffers) against the proof the CPU checker backend writes for the same AIR and witness: random trace
 size, blow-up, machine count, FRI steps, query count, hashCommits, previous-row opening.  Test infrastructure (imports oracle/).
   gpurun -- python tools/fuzz_node.py [cases] [seed]"""
@@ -45,8 +45,13 @@ for i in range(CASES):
     ss = {"nBits": nb, "nBitsExt": nbe, "nQueries": rnd.randint(1, 16), "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
     if rnd.random() < 0.3:
         ss["hashCommits"] = True
-    info, exprs, _ = stark.fibonacci_air(pairs, ss, prev, im_pols=im, boundaries=bd)
-    cm, consts, publics = stark.fibonacci_trace(nb, pairs, im_pols=im)
+    perm = rnd.random() < 0.25
+    if perm:                                              # two witness stages, gprod hints in the reference's shape (expression fields)
+        info, exprs, _ = stark.permutation_air(ss, min(pairs, 3), ref_hints=True)
+        cm, consts, publics = stark.permutation_trace(nb, copies=min(pairs, 3))
+    else:
+        info, exprs, _ = stark.fibonacci_air(pairs, ss, prev, im_pols=im, boundaries=bd)
+        cm, consts, publics = stark.fibonacci_trace(nb, pairs, im_pols=im)
     be = OracleBackend()
     setup = stark.build_const_tree(be, consts, info)
     res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
@@ -55,7 +60,7 @@ for i in range(CASES):
            "proof": strs(json.loads(json.dumps(res["proof"], default=int))), "challenges": strs(res["challenges"]), "queries": res["queries"]}
     name = os.path.join(tmp, "g%03d.json" % i)
     json.dump(out, open(name, "w")); names.append(name)
-    print("case %d: nBits %d ext %d pairs %d steps %s queries %d hashCommits %s prevRow %s imPols %s boundaries %s" % (i, nb, eb, pairs, steps, ss["nQueries"], bool(ss.get("hashCommits")), prev, im, bd), flush=True)
+    print("case %d: nBits %d ext %d pairs %d steps %s queries %d hashCommits %s prevRow %s imPols %s boundaries %s twoStage %s" % (i, nb, eb, pairs, steps, ss["nQueries"], bool(ss.get("hashCommits")), prev, im, bd, perm), flush=True)
 js = """
 const fs = require("fs");
 const { prove, freeCtx } = require(%r);

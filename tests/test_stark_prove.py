@@ -593,3 +593,62 @@ def test_gpu_hash_commits_proof_is_identical_to_oracle_proof(oracle, hash_type, 
     assert ok, why
     ok, why = stark.stark_verify(gpu, r_gpu["proof"], publics, s_gpu["constRoot"], info, exprs, vinfo)
     assert ok, why
+
+
+def _hint_fixture(be, n_bits=6):
+    """a fake two-stage context for resolve_hints_info: stage 1 holds f (dim 1), t (dim 1), a (dim 1), d (dim 3); stage 2 receives the hints' columns"""
+    from pil2gl import stark
+    N = 1 << n_bits
+    rng = np.random.default_rng(5)
+    t = rng.integers(1, 1 << 40, size=N, dtype=np.uint64)
+    f = t[rng.integers(0, N, size=N)]
+    a = rng.integers(1, 1 << 62, size=N, dtype=np.uint64)
+    d = rng.integers(1, 1 << 62, size=(N, 3), dtype=np.uint64)
+    cm1 = np.concatenate([f[:, None], t[:, None], a[:, None], d], axis=1)
+    cmap = [{"stage": 1, "dim": 1, "stagePos": 0}, {"stage": 1, "dim": 1, "stagePos": 1}, {"stage": 1, "dim": 1, "stagePos": 2}, {"stage": 1, "dim": 3, "stagePos": 3},
+            {"stage": 2, "dim": 1, "stagePos": 0}, {"stage": 2, "dim": 1, "stagePos": 1},            # h1, h2
+            {"stage": 2, "dim": 3, "stagePos": 2}, {"stage": 2, "dim": 3, "stagePos": 5}]            # gsum column, gprod column
+    info = {"cmPolsMap": cmap, "mapSectionsN": {"cm1": 6, "cm2": 8}}
+    # expression 4: a * a + 7 (dim 1) -- a numerator that is not a committed column
+    code = {"tmpUsed": 2, "code": [{"op": "mul", "dest": {"type": "tmp", "id": 0, "dim": 1}, "src": [{"type": "cm", "id": 2, "prime": 0, "dim": 1}, {"type": "cm", "id": 2, "prime": 0, "dim": 1}]},
+                                   {"op": "add", "dest": {"type": "tmp", "id": 1, "dim": 1}, "src": [{"type": "tmp", "id": 0, "dim": 1}, {"type": "number", "value": "7", "dim": 1}]}]}
+    exprs = {"expressionsCode": [None, {"expId": 4, "code": code}], "hintsInfo": [
+        {"name": "h1h2", "fields": [{"name": "f", "op": "cm", "id": 0}, {"name": "t", "op": "cm", "id": 1}, {"name": "referenceH1", "op": "cm", "id": 4}, {"name": "referenceH2", "op": "cm", "id": 5}]},
+        {"name": "gsum", "fields": [{"name": "numerator", "op": "number", "value": "3"}, {"name": "denominator", "op": "cm", "id": 3}, {"name": "reference", "op": "cm", "id": 6},
+                                    {"name": "result", "op": "subproofValue", "id": 1}]},
+        {"name": "gprod", "fields": [{"name": "numerator", "op": "tmp", "id": 4}, {"name": "denominator", "op": "cm", "id": 2}, {"name": "reference", "op": "cm", "id": 7},
+                                     {"name": "result", "op": "subproofValue", "id": 0}]},
+        {"name": "public", "fields": [{"name": "expression", "op": "tmp", "id": 4}, {"name": "row_index", "op": "number", "value": "5"}, {"name": "reference", "op": "public", "id": 2}]},
+        {"name": "subproofValue", "fields": [{"name": "expression", "op": "cm", "id": 3}, {"name": "reference", "op": "subproofValue", "id": 2}]}]}
+    bufs = {"cm1_n": be.from_host(cm1), "cm2_n": be.zeros(8 * N)}
+    widths = {"cm1_n": 6, "cm2_n": 8}
+    ctx = {"pilInfo": info, "publics": [11], "challenges": [[], []], "evals": []}
+    stark.resolve_hints_info(be, info, exprs, 2, bufs, widths, n_bits, ctx)
+    return cm1, be.to_host(bufs["cm2_n"]).reshape(N, 8), ctx
+
+
+def _check_hint_fixture(oracle, cm1, cm2, ctx):
+    N = cm1.shape[0]
+    f, t, a, d = cm1[:, 0], cm1[:, 1], cm1[:, 2], cm1[:, 3:6]
+    w1, w2 = oracle.h1h2([int(v) for v in f], [int(v) for v in t])
+    assert cm2[:, 0].tolist() == w1 and cm2[:, 1].tolist() == w2                                   # calculateH1H2, polutils.js:105-126
+    gs = oracle.gsum(np.array([3], dtype=np.uint64), d.reshape(-1).copy(), 1, 3).reshape(N, 3)
+    assert (cm2[:, 2:5] == gs).all()                                                                 # calculateS, :147-164
+    num = np.array([(int(v) * int(v) + 7) % P for v in a], dtype=np.uint64)
+    gp = oracle.gprod(num, a.copy(), 1, 1).reshape(N, -1)
+    assert (cm2[:, 5] == gp[:, 0]).all() and not cm2[:, 6:8].any()                                    # a base result lands in an extension column as [v, 0, 0]
+    assert ctx["subproofValues"][0] == int(gp[N - 1, 0]) and ctx["subproofValues"][1] == [int(v) for v in gs[N - 1]]   # `result`: the last row
+    assert ctx["publics"] == [11, 0, int(num[5])] and ctx["subproofValues"][2] == [int(v) for v in d[N - 1]]
+
+
+def test_reference_shaped_hint_kinds_on_oracle_backend(oracle):
+    """resolve_hints_info over every hint kind and field kind of hints_helpers.js:21-123: h1h2, gsum with a `result`, gprod whose numerator is
+    an expression, a public taken from one row of an expression, a subproof value from a column's last row"""
+    import stark_ref
+    _check_hint_fixture(oracle, *_hint_fixture(stark_ref.OracleBackend()))
+
+
+@pytest.mark.gpu
+def test_reference_shaped_hint_kinds_on_gpu_backend(oracle):
+    from pil2gl import stark
+    _check_hint_fixture(oracle, *_hint_fixture(stark.GpuBackend(0)))

@@ -575,7 +575,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     constShard, constSTree = setup.get("constShard"), setup.get("constTreeSharded")
     transcript = be.new_transcript()
     hash_commits = bool(ss.get("hashCommits", False))
-    transcript.put(setup["constRoot"]); S.put_commit(be, transcript, list(publics), hash_commits)
+    transcript.put(setup["constRoot"])
 
     sl = lambda full, w: coset_slice(be, full, nb, eb, cb, cc, w)
     # the rank's rows of the domain tables, built per coset: no buffer of this function has 2^nBitsExt rows
@@ -613,6 +613,10 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
                 ops, n_tmp, secs, scalars = S.encode_code(sc["code"], "n", ctx)
                 be.eval_program(ops, n_tmp, [(trace[x], widths[x]) for x in secs], scalars, nb, 0)
             S.resolve_hints(be, info, s_, trace, widths, nb, ctx, exprs)
+        else:                                              # stage 1: its hints (publics read off the witness), then the publics (prover.js:41-52)
+            if exprs.get("hintsInfo"):
+                S.resolve_hints(be, info, 1, trace, widths, nb, ctx, exprs)
+            S.put_commit(be, transcript, list(ctx["publics"]), hash_commits)
         im = exprs.get("imPolsCode", [])
         if s_ == nStages and len(im) >= s_ and im[s_ - 1].get("code"):      # intermediate polynomials (prover.js:212-214), replicated like the stage code
             ops, n_tmp, secs, scalars = S.encode_code(im[s_ - 1]["code"], "n", ctx)
@@ -629,7 +633,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     # quotient: the constraint expression on the local rows, then one all-gather of q
     ctx["challenges"][qStage - 1] = [transcript.getField()]
     loc["q_ext"] = be.empty(qDim << nloc)
-    run_local(exprs["expressionsCode"][info["cExpId"]]["code"])
+    run_local(S.expr_code(exprs, info["cExpId"]))
     if samples is not None:
         ri = torch.tensor(list(samples["rows"]))
         for k in ("cm1_ext", "const_ext", "x_ext", "Zi_ext#0", "q_ext"):
@@ -713,7 +717,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         loc["xDivXSubXi_ext"] = sl(be.x_div_x_sub_xi(nbe, xis), widths["xDivXSubXi_ext"])
     loc["f_ext"] = be.empty(3 << nloc)
     if not (hasattr(be, "fri_polynomial_fast") and be.fri_polynomial_fast(info, loc, widths, ctx["evals"], vfs[0], vfs[1], nloc, loc["f_ext"])):
-        run_local(exprs["expressionsCode"][info["friExpId"]]["code"])
+        run_local(S.expr_code(exprs, info["friExpId"]))
     lap("fri_expr")
     # Folding.  The first FRI tree commits the UNFOLDED polynomial in groups {i 2^b1 + g : i < 2^(b0-b1)} (fri.js:62-74 at
     # step 0, where nothing is folded), and the first fold combines exactly those groups (fri.js:45-60 at step 1).  A group
@@ -804,5 +808,5 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     lap("queries")
     proof = {"root%d" % s_: roots[s_] for s_ in range(1, qStage + 1)}
     proof["evals"] = ctx["evals"]; proof["fri"] = friProof
-    return {"proof": proof, "publics": list(publics), "challenges": ctx["challenges"], "challengesFRISteps": challengesFRI, "queries": queries,
+    return {"proof": proof, "publics": list(ctx["publics"]), "challenges": ctx["challenges"], "challengesFRISteps": challengesFRI, "queries": queries,
             "exchange": comm.stats()}

@@ -623,7 +623,10 @@ def _hint_fixture(be, n_bits=6):
     bufs = {"cm1_n": be.from_host(cm1), "cm2_n": be.zeros(8 * N)}
     widths = {"cm1_n": 6, "cm2_n": 8}
     ctx = {"pilInfo": info, "publics": [11], "challenges": [[], []], "evals": []}
-    stark.resolve_hints_info(be, info, exprs, 2, bufs, widths, n_bits, ctx)
+    for stage in (1, 2):                                   # as the stage loop does: the public / subproof value read off stage-1 columns resolve with stage 1
+        stark.resolve_hints_info(be, info, exprs, stage, bufs, widths, n_bits, ctx)
+        if stage == 1:
+            assert ctx["publics"] == [11, 0, (int(a[5]) * int(a[5]) + 7) % P] and not be.to_host(bufs["cm2_n"]).any()
     return cm1, be.to_host(bufs["cm2_n"]).reshape(N, 8), ctx
 
 
@@ -652,3 +655,41 @@ def test_reference_shaped_hint_kinds_on_oracle_backend(oracle):
 def test_reference_shaped_hint_kinds_on_gpu_backend(oracle):
     from pil2gl import stark
     _check_hint_fixture(oracle, *_hint_fixture(stark.GpuBackend(0)))
+
+
+def _pub_case(n_bits=6, pairs=2, steps=(9, 5, 2)):
+    from pil2gl import stark
+    ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
+    info, exprs, vinfo = stark.fibonacci_air(pairs, ss, public_hints=True)
+    cm, consts, publics = stark.fibonacci_trace(n_bits, pairs)
+    return stark, info, exprs, vinfo, cm, consts, publics
+
+
+def test_publics_read_off_the_witness_by_stage_1_hints_on_oracle_backend(oracle):
+    """hints of kind "public" (hints_helpers.js:83-90) resolved with stage 1, before the publics enter the transcript (prover.js:41-52): the
+    prover is handed NO publics; the proof and the publics it reports equal those of the proof that was handed them"""
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _pub_case()
+    be = stark_ref.OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, [0, 0, 0])
+    assert res["publics"] == publics
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    given = stark.stark_gen(be, be.from_host(cm), setup, info, {k: v for k, v in exprs.items() if k != "hintsInfo"}, publics)
+    assert given["proof"] == res["proof"]
+
+
+@pytest.mark.gpu
+def test_publics_read_off_the_witness_on_gpu_backend(oracle):
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _pub_case(10, 3, (13, 9, 4))
+    gpu = stark.GpuBackend(0)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, [0, 0, 0])
+    cpu = stark_ref.OracleBackend()
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, [0, 0, 0])
+    assert r_gpu["publics"] == publics and r_gpu["proof"] == r_cpu["proof"]
+    ok, why = stark.stark_verify(gpu, r_gpu["proof"], r_gpu["publics"], s_gpu["constRoot"], info, exprs, vinfo)
+    assert ok, why

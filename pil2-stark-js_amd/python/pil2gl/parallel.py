@@ -570,7 +570,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     qStage = nStages + 1
     nQ, nC = info["mapSectionsN"]["cm%d" % qStage], info["nConstants"]
     assert ss["steps"][0]["nBits"] == nbe
-    ctx = {"pilInfo": info, "publics": list(publics), "challenges": [[] for _ in range(nStages + 3)], "evals": []}
+    ctx = {"pilInfo": info, "publics": list(publics), "challenges": [[] for _ in range(nStages + 3)], "evals": [], "subproofValues": [0] * info.get("nSubproofValues", 0)}
     constTree = setup.get("constTree")
     constShard, constSTree = setup.get("constShard"), setup.get("constTreeSharded")
     transcript = be.new_transcript()
@@ -808,5 +808,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     lap("queries")
     proof = {"root%d" % s_: roots[s_] for s_ in range(1, qStage + 1)}
     proof["evals"] = ctx["evals"]; proof["fri"] = friProof
+    if info.get("nSubproofValues"):
+        proof["subproofValues"] = list(ctx.get("subproofValues", []))
     return {"proof": proof, "publics": list(ctx["publics"]), "challenges": ctx["challenges"], "challengesFRISteps": challengesFRI, "queries": queries,
             "exchange": comm.stats()}

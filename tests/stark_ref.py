@@ -162,6 +162,9 @@ def stark_verify(res, constRoot, info, verifierInfo, split=False, check_transcri
         if ty == "public": return publics[r["id"]]
         if ty == "number": return int(r["value"]) % P
         if ty == "Zi": return list(Zs[r.get("boundaryId", 0)])
+        if ty == "subproofValue":                            # stark_verify.js:19,256
+            v = proof["subproofValues"][r["id"]]
+            return [int(x) % P for x in v] if isinstance(v, (list, tuple)) else int(v) % P
         raise ValueError(ty)
     lhs = exec_code(verifierInfo["qVerifier"]["code"], resolve)
     q_ids = [k for k, pm in enumerate(info["cmPolsMap"]) if pm["stage"] == qStage]

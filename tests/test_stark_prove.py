@@ -454,10 +454,10 @@ def test_gpu_bn128_proof_is_identical_to_oracle_proof(oracle, arity, custom, n_b
         assert not stark.stark_verify(gpu, _tampered(r_gpu, what), publics, s_gpu["constRoot"], info, exprs, vinfo)[0], what
 
 
-def _perm_ref_case(n_bits=6, steps=(9, 5, 2), copies=1):
+def _perm_ref_case(n_bits=6, steps=(9, 5, 2), copies=1, ref_hints=True):
     from pil2gl import stark
     ss = {"nBits": n_bits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
-    info, exprs, vinfo = stark.permutation_air(ss, copies, ref_hints=True)
+    info, exprs, vinfo = stark.permutation_air(ss, copies, ref_hints=ref_hints)
     cm, consts, publics = stark.permutation_trace(n_bits, copies=copies)
     return stark, info, exprs, vinfo, cm, consts, publics
 
@@ -693,3 +693,38 @@ def test_publics_read_off_the_witness_on_gpu_backend(oracle):
     assert r_gpu["publics"] == publics and r_gpu["proof"] == r_cpu["proof"]
     ok, why = stark.stark_verify(gpu, r_gpu["proof"], r_gpu["publics"], s_gpu["constRoot"], info, exprs, vinfo)
     assert ok, why
+
+
+def test_subproof_values_travel_in_the_proof_and_are_bound_on_oracle_backend(oracle):
+    """a gprod hint's `result` field (hints_helpers.js:109-112) puts the column's last row into ctx.subproofValues, genProofStark (:369)
+    into the proof, and the verifier reads it from there (stark_verify.js:19,256); the constraint LLAST * (z - subproofValue) binds it"""
+    import copy
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _perm_ref_case(6, (9, 5, 2), 2, ref_hints="result")
+    assert info["nSubproofValues"] == 2
+    be = stark_ref.OracleBackend()
+    setup = stark.build_const_tree(be, consts, info)
+    res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
+    assert len(res["proof"]["subproofValues"]) == 2 and all(len(v) == 3 for v in res["proof"]["subproofValues"])
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo)
+    assert ok, why
+    bad = copy.deepcopy(res); bad["proof"]["subproofValues"][1][2] ^= 1
+    assert not stark_ref.stark_verify(bad, setup["constRoot"], info, vinfo, check_transcript=False)[0]
+
+
+@pytest.mark.gpu
+def test_subproof_values_on_gpu_backend(oracle):
+    import copy
+    import stark_ref
+    stark, info, exprs, vinfo, cm, consts, publics = _perm_ref_case(11, (14, 9, 4), 3, ref_hints="result")
+    gpu = stark.GpuBackend(0)
+    s_gpu = stark.build_const_tree(gpu, consts, info)
+    r_gpu = stark.stark_gen(gpu, gpu.from_host(cm), s_gpu, info, exprs, publics)
+    cpu = stark_ref.OracleBackend()
+    s_cpu = stark.build_const_tree(cpu, consts, info)
+    r_cpu = stark.stark_gen(cpu, cpu.from_host(cm), s_cpu, info, exprs, publics)
+    assert r_gpu["proof"] == r_cpu["proof"] and len(r_gpu["proof"]["subproofValues"]) == 3
+    ok, why = stark.stark_verify(gpu, r_gpu["proof"], publics, s_gpu["constRoot"], info, exprs, vinfo)
+    assert ok, why
+    bad = copy.deepcopy(r_gpu["proof"]); bad["subproofValues"][0][0] ^= 1
+    assert not stark.stark_verify(gpu, bad, publics, s_gpu["constRoot"], info, exprs, vinfo)[0]

@@ -44,8 +44,8 @@ def main():
     ss = {"nBits": a.nbits, "nBitsExt": steps[0], "nQueries": 8, "verificationHashType": "GL", "steps": [{"nBits": b} for b in steps]}
     if a.hashcommits:
         ss["hashCommits"] = True
-    if a.air == "permref":                                  # hints in the reference's shape: numerator / denominator are expressions
-        info, exprs, _ = stark.permutation_air(ss, max(1, a.pairs // 2), ref_hints=True)
+    if a.air in ("permref", "permres"):                     # hints in the reference's shape: numerator / denominator are expressions; permres: + subproof values
+        info, exprs, _ = stark.permutation_air(ss, max(1, a.pairs // 2), ref_hints="result" if a.air == "permres" else True)
         cm, consts, publics = stark.permutation_trace(a.nbits, copies=max(1, a.pairs // 2))
     elif a.air == "perm":
         info, exprs, _ = stark.permutation_air(ss)

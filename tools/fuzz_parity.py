@@ -115,7 +115,7 @@ def case_proof():
     ss["splitLinearHash"] = split
     if air == "perm":
         copies = int(rng.integers(1, 4))
-        info, exprs, _ = stark.permutation_air(ss, copies, ref_hints=bool(rng.random() < 0.5))
+        info, exprs, _ = stark.permutation_air(ss, copies, ref_hints=[False, True, "result"][int(rng.integers(0, 3))])
         cm, consts, publics = stark.permutation_trace(nb, copies=copies)
     else:
         pairs = int(rng.integers(1, 9)); prev = bool(rng.random() < 0.3); im = bool(rng.random() < 0.3); bd = bool(rng.random() < 0.3)

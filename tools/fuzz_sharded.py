@@ -20,7 +20,7 @@ while time.time()-t0 < float(sys.argv[1]):
         nxt=steps[-1]-rnd.randint(1,5)
         if nxt<1: break
         steps.append(nxt)
-    air=rnd.choice(["fib","fib","perm","permref"]); hc=rnd.choice([0,0,1]); ss=rnd.choice([0,1]); pairs=rnd.randint(1,5); im=rnd.choice([0,0,1]); bd=rnd.choice([0,0,1])
+    air=rnd.choice(["fib","fib","perm","permref","permres"]); hc=rnd.choice([0,0,1]); ss=rnd.choice([0,1]); pairs=rnd.randint(1,5); im=rnd.choice([0,0,1]); bd=rnd.choice([0,0,1])
     args=["--backend",BACKEND,"--nbits",str(nb),"--pairs",str(pairs),"--steps",",".join(map(str,steps)),"--air",air,"--hashcommits",str(hc),"--shardsetup",str(ss),"--impols",str(im),"--boundaries",str(bd)]
     cmd=[sys.executable,"-m","torch.distributed.run","--nnodes=1","--nproc-per-node",str(world),"--master-addr","127.0.0.1","--master-port",str(port()),W,*args]
     r=subprocess.run(cmd,capture_output=True,text=True,timeout=600,env=dict(os.environ,OMP_NUM_THREADS="1"))

@@ -56,7 +56,7 @@ while time.time() - t0 < BUDGET:
         ss["hashCommits"] = True
     if air == "perm":
         copies = int(rng.integers(1, 3))
-        info, exprs, vinfo = stark.permutation_air(ss, copies, ref_hints=bool(rng.random() < 0.5))
+        info, exprs, vinfo = stark.permutation_air(ss, copies, ref_hints=[False, True, "result"][int(rng.integers(0, 3))])
         cm, consts, publics = stark.permutation_trace(nb, copies=copies)
     else:
         pairs = int(rng.integers(1, 6)); prev = bool(rng.random() < 0.3); im = bool(rng.random() < 0.3); bd = bool(rng.random() < 0.3)

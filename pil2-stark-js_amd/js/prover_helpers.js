@@ -100,7 +100,9 @@ function run(code, dom, ctx, global, ret) {
         if (!ops.length) throw new Error("calculateExps: an empty program returns nothing");
         const last = ops[ops.length - 1];
         retDim = last.dest.dim || 1;
-        ops = ops.slice(0, -1).concat([{ op: last.op, dest: { type: "$ret", dim: retDim }, src: last.src }]);
+        // a temporary is simply redirected; any other destination is written as the program says AND copied out (compileCode returns getRef(dest))
+        if (last.dest.type === "tmp") ops = ops.slice(0, -1).concat([{ op: last.op, dest: { type: "$ret", dim: retDim }, src: last.src }]);
+        else ops = ops.concat([{ op: "copy", dest: { type: "$ret", dim: retDim }, src: [last.dest] }]);
     }
     const enc = encode(ops, dom, ctx, global);
     const nBits = dom === "n" ? ctx.nBits : ctx.nBitsExt;

@@ -186,6 +186,20 @@ class ChunkedBuffer {
                 assert.deepStrictEqual(col3[i], [mod(t * 3n), mod(t * 1n), mod(t * 4n)], "calculateExpression dim 3 row " + i);
             }
             assert.throws(() => PH.calculateExpression(ctx, 8), /not found/);
+            // ret with a last op that writes a COLUMN: the column is written as the program says and its values are returned as well
+            {
+                const codeW = { tmpUsed: 3, code: code1.code.slice(0, 2).concat([{ op: "add", dest: { type: "cm", id: 1, dim: 1 }, src: [{ type: "tmp", id: 1, dim: 1 }, { type: "x", dim: 1 }] }]) };
+                const before = resident ? ctx.cm1_n.toHost() : ctx.cm1_n.slice();
+                const got = PH.calculateExps(ctx, codeW, "n", false, true);
+                const now = resident ? ctx.cm1_n.toHost() : ctx.cm1_n;
+                for (let i = 0; i < N; i++) {
+                    const t = mod(mod(before[3 * ((i + 1) % N)] - before[3 * i + 2]) * cn[2 * i + 1] + xn[i]);
+                    assert.strictEqual(got[i], t, "ret + column row " + i);
+                    assert.deepStrictEqual([now[3 * i], now[3 * i + 1], now[3 * i + 2]], [before[3 * i], before[3 * i + 1], t], "column written row " + i);
+                }
+                if (!resident) for (let i = 0; i < N; i++) cm1[3 * i + 2] = now[3 * i + 2];       // (the host arrays ARE the ctx buffers: keep the model in step)
+                else (resident ? ctx.cm1_n.toHost() : cm1).forEach((v, i) => { cm1[i] = v; });
+            }
             // getPol / setPol / getFixedPol (prover_helpers.js:261-358): a column out of / into a stage buffer; its neighbours stay
             ctx.pilInfo.cmPolsMap.push({ stage: 2, dim: 3, stagePos: 1 }); ctx.pilInfo.mapSectionsN.cm2 = 5;
             const cm2 = new BigUint64Array(N * 5); for (let i = 0; i < cm2.length; i++) cm2[i] = BigInt(5000 + i);

@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
         for (int q = 0; q < 4; q++) { const u64 w = v[4 * k + q]; x[2 * q] = (u32)w; x[2 * q + 1] = (u32)(w >> 32); }
         lds_store(st, 1 + k, x);
     }
-    const int cur = bn_perm<WIDE>(st, 0, full);
+    (void)bn_perm<WIDE>(st, 0, full);
     if (live) digest_out(st, 0, out + 4 * i0);
 }
 
@@ -498,7 +498,7 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
         for (int q = 0; q < 4; q++) w[q] = in[(i * nIn + k) * 4 + q];
         to_mont_store(st, 1 + k, w);
     }
-    const int cur = bn_perm<WIDE>(st, 0, full);
+    (void)bn_perm<WIDE>(st, 0, full);
     if (!live) return;
     for (int k = 0; k < nOut; k++) {                 // out of Montgomery form: multiply by 1
         u32 x[8], one[8] = { 1, 0, 0, 0, 0, 0, 0, 0 }, o[8];

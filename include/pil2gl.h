@@ -22,14 +22,14 @@
  *    torch tensor.data_ptr()) plus a hipStream_t passed as void* (NULL = default
  *    stream), so buffers can stay resident in HBM across the prover's steps.
  *    Most of them only ENQUEUE work on that stream and return:
- *      interpolate / interpolate_cosets[_ws] / extend_cosets_unshifted / fft / ifft, linear_hash_rows, merkelize,
+ *      interpolate / interpolate_cosets[_ws] / extend_cosets_unshifted / extend_coefs_brev / fft / ifft, linear_hash_rows, merkelize,
  *      merkelize_level, merkelize_digests, poseidon, fri_fold, fri_verify_fold, fri_transpose, build_x, geometric,
  *      x_div_x_sub_xi[_cosets], gprod, gsum, dev_zero, and their bn128_ twins.
  *    The following _dev calls BLOCK until their work on the stream has finished, because they hand a result to the host or
  *    stage host-side tables in a scratch slot the next call reuses:
  *      eval_program (op-list and scalar pool are host temporaries), rows_dot_ext / rows_dot_ext_multi / cols_dot_ext /
  *      cols_dot_ext_multi / fri_combine / fri_combine_order (host-side weights), compute_evals (returns the evaluations),
- *      build_zhinv, build_one_row_zerofier_inv, build_frame_zerofier, compute_q_split, build_lev (small host tables),
+ *      build_zhinv, build_one_row_zerofier_inv, build_frame_zerofier, compute_q_split[_brev], build_lev (small host tables),
  *      h1h2, synth_fibonacci, group_proof / group_proofs and bn128_group_proof (openings copied to host memory).
  *    A whole config-3 proof keeps the GPU busy 99.3 % of its wall time with these.
  *  - Every function returns 0 on success, a negative PIL2GL_E* code otherwise;
@@ -84,6 +84,10 @@ int pil2gl_interpolate_cosets_dev(const uint64_t *src, uint64_t nPols, uint32_t 
  * coefficients (no coset shift).  This is how a rank extends its part of the split quotient (stark_gen_helpers.js:192). */
 int pil2gl_extend_cosets_unshifted_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
                                        uint32_t cosetBegin, uint32_t cosetCount, void *stream);
+/* The whole plain extension from COEFFICIENTS: coefBrev is 2^nBits x nPols with coefficient m of every column at row bitrev(m)
+ * (pil2gl_compute_q_split_brev_dev writes that order); dst = fft(nBitsExt) of the zero-padded coefficient matrix, natural order
+ * (stark_gen_helpers.js:192) -- without the padded 2^nBitsExt-row input and its first nBitsExt - nBits stages. */
+int pil2gl_extend_coefs_brev_dev(const uint64_t *coefBrev, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt, void *stream);
 /* Same with a caller-provided workspace of 2^nBits x nPols words for the coefficient matrix instead of the library's own
  * scratch; workspace == src is allowed (src is then overwritten): at config 5 a rank holds the 107 GB trace and its
  * 107 GB coset slice and nothing else. */
@@ -171,6 +175,8 @@ int pil2gl_build_one_row_zerofier_inv_dev(uint32_t nBits, uint32_t nBitsExt, uin
 int pil2gl_build_frame_zerofier_dev(uint32_t nBits, uint32_t nBitsExt, uint64_t offsetMin, uint64_t offsetMax, uint64_t *out, void *stream);
 /* computeQStark split/scale  stark_gen_helpers.js:179-190: qq2[i][p*qDim+k] = qq1[p*N+i][k] * (7^-N)^p, rows >= N zero */
 int pil2gl_compute_q_split_dev(const uint64_t *qq1, uint32_t nBits, uint32_t nBitsExt, uint32_t qDim, uint32_t qDeg, uint64_t *qq2, void *stream);
+/* the same pieces as the 2^nBits-row coefficient matrix alone, row bitrev(i) = coefficient i: coefBrev[bitrev(i)][p*qDim+k] = qq1[p*N+i][k] * (7^-N)^p */
+int pil2gl_compute_q_split_brev_dev(const uint64_t *qq1, uint32_t nBits, uint32_t nBitsExt, uint32_t qDim, uint32_t qDeg, uint64_t *coefBrev, void *stream);
 /* computeFRIStark xDivXSubXi  stark_gen_helpers.js:293-322: out[3*(k*nOpen+iOpen)+c] = (x_k / (x_k - xi))_c */
 int pil2gl_x_div_x_sub_xi_dev(uint32_t nBitsExt, const uint64_t xi[3], uint64_t nOpen, uint64_t iOpen, uint64_t *out, void *stream);
 /* the rows of cosets [cosetBegin, cosetBegin + cosetCount) of the 2^extBits only (one rank's slice of a coset-sharded proof), in

@@ -189,6 +189,14 @@ FN(ComputeQSplitDev) { // (dQq1, nBits, nBitsExt, qDim, qDeg, dQq2)  stark_gen_h
     Args a(env, info); uint64_t *q1 = DP(0); uint32_t nb = (uint32_t)a.u64(1), nbe = (uint32_t)a.u64(2), qDim = (uint32_t)a.u64(3), qDeg = (uint32_t)a.u64(4); uint64_t *q2 = DP(5); if (!a.ok) return nullptr;
     P2(env, pil2gl_compute_q_split_dev(q1, nb, nbe, qDim, qDeg, q2, a.stream(6))); return mk_undefined(env);
 }
+FN(ComputeQSplitBrevDev) { // (dQq1, nBits, nBitsExt, qDim, qDeg, dCoefBrev): the pieces as N coefficient rows, row bitrev(i) = coefficient i
+    Args a(env, info); uint64_t *q1 = DP(0); uint32_t nb = (uint32_t)a.u64(1), nbe = (uint32_t)a.u64(2), qDim = (uint32_t)a.u64(3), qDeg = (uint32_t)a.u64(4); uint64_t *c = DP(5); if (!a.ok) return nullptr;
+    P2(env, pil2gl_compute_q_split_brev_dev(q1, nb, nbe, qDim, qDeg, c, a.stream(6))); return mk_undefined(env);
+}
+FN(ExtendCoefsBrevDev) { // (dCoefBrev, nPols, nBits, dDst, nBitsExt): fft(nBitsExt) of the zero-padded coefficients (stark_gen_helpers.js:192)
+    Args a(env, info); uint64_t s = a.u64(0), nPols = a.u64(1), nBits = a.u64(2), d = a.u64(3), nBitsExt = a.u64(4); if (!a.ok) return nullptr;
+    P2(env, pil2gl_extend_coefs_brev_dev((const uint64_t *)(uintptr_t)s, nPols, (uint32_t)nBits, (uint64_t *)(uintptr_t)d, (uint32_t)nBitsExt, a.stream(5))); return mk_undefined(env);
+}
 FN(XDivXSubXiDev) {    // (nBitsExt, xi BigUint64Array(3), nOpen, iOpen, dOut)  stark_gen_helpers.js:293-322
     Args a(env, info); uint32_t nbe = (uint32_t)a.u64(0); uint64_t *xi = a.arr(1, 3); uint64_t nOpen = a.u64(2), iOpen = a.u64(3); uint64_t *o = DP(4); if (!a.ok) return nullptr;
     P2(env, pil2gl_x_div_x_sub_xi_dev(nbe, xi, nOpen, iOpen, o, a.stream(5))); return mk_undefined(env);
@@ -361,7 +369,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "bn128Poseidon", Bn128Poseidon }, { "bn128SpongeAbsorb", Bn128SpongeAbsorb }, { "bn128LinearHashRows", Bn128LinearHashRows }, { "bn128MerkleNumNodes", Bn128MerkleNumNodes },
         { "bn128Merkelize", Bn128Merkelize }, { "bn128MerkelizeDev", Bn128MerkelizeDev }, { "bn128Convert", Bn128Convert },
         { "buildXDev", BuildXDev }, { "buildZhInvDev", BuildZhInvDev }, { "buildOneRowZerofierInvDev", BuildOneRowZerofierInvDev },
-        { "buildFrameZerofierDev", BuildFrameZerofierDev }, { "computeQSplitDev", ComputeQSplitDev }, { "xDivXSubXiDev", XDivXSubXiDev },
+        { "buildFrameZerofierDev", BuildFrameZerofierDev }, { "computeQSplitDev", ComputeQSplitDev }, { "computeQSplitBrevDev", ComputeQSplitBrevDev }, { "extendCoefsBrevDev", ExtendCoefsBrevDev }, { "xDivXSubXiDev", XDivXSubXiDev },
         { "buildLevDev", BuildLevDev }, { "computeEvalsDev", ComputeEvalsDev }, { "gprodDev", GprodDev }, { "gsumDev", GsumDev }, { "h1h2Dev", H1H2Dev },
         { "rowsDotExtDev", RowsDotExtDev }, { "rowsDotExtMultiDev", RowsDotExtMultiDev }, { "friCombineDev", FriCombineDev }, { "colsDotExtDev", ColsDotExtDev }, { "colsDotExtMultiDev", ColsDotExtMultiDev }, { "synthFibonacciDev", SynthFibonacciDev },
         { "friFoldDev", FriFoldDev }, { "friTransposeDev", FriTransposeDev },

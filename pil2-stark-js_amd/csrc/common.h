@@ -59,6 +59,6 @@ hipStream_t as_stream(void *s);
 
 // internal launchers shared between translation units --------------------------------------
 int ntt_launch(const u64 *src, u64 nPols, u32 nBits, u64 *dst, bool inverse, hipStream_t st);
-int lde_launch(const u64 *src, u64 nPols, u32 nBits, u64 *dst, u32 nBitsExt, hipStream_t st, u32 cosetBegin, u32 cosetCount, u64 *work, bool unitShift);
+int lde_launch(const u64 *src, u64 nPols, u32 nBits, u64 *dst, u32 nBitsExt, hipStream_t st, u32 cosetBegin, u32 cosetCount, u64 *work, bool unitShift, bool coefIn = false);
 
 }  // namespace pil2gl

@@ -111,6 +111,16 @@ __global__ void q_split_kernel(const u64 *__restrict__ qq1, u32 nBits, u32 nBits
     const u64 p = r / qDim, k = r - p * qDim;
     qq2[o] = mul(qq1[(p * N + i) * qDim + k], sPow[p]);
 }
+// the same pieces as an N-row COEFFICIENT matrix in bit-reversed row order (row bitrev(i) = coefficient i of every piece): the input of
+// pil2gl_extend_coefs_brev_dev, which then replaces the plain transform of the zero-padded matrix (stark_gen_helpers.js:192)
+__global__ void q_split_brev_kernel(const u64 *__restrict__ qq1, u32 nBits, u32 qDim, u32 qDeg, const u64 *__restrict__ sPow, u64 *__restrict__ out) {
+    const u64 o = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 W = (u64)qDim * qDeg, N = 1ull << nBits;
+    if (o >= W * N) return;
+    const u64 i = o / W, r = o - i * W;
+    const u64 p = r / qDim, k = r - p * qDim;
+    out[(u64)bitrev32((u32)i, nBits) * W + r] = mul(qq1[(p * N + i) * qDim + k], sPow[p]);
+}
 // stark_gen_helpers.js:302-322: (x_k - xi)^-1 * x_k with F.sub(scalar, triple) (f3g.js:66).
 // The denominator (a, b, c) = (x_k - xi_0, -xi_1, -xi_2) varies in its first component only, so the extension inverse
 // (f3g.js:136-172: adjugate (i1, i2, i3) over the norm t) is a polynomial in a with per-call constants:
@@ -394,6 +404,19 @@ int pil2gl_compute_q_split_dev(const uint64_t *qq1, uint32_t nBits, uint32_t nBi
     for (u32 p = 0; p < qDeg; p++) { sp[p] = cur; cur = h_mul(cur, shiftIn); }
     u64 *d; P2_TRY(upload_small(sp, 2, &d, as_stream(stream)));
     q_split_kernel<<<nblk(((u64)qDim * qDeg) << nBitsExt), 256, 0, as_stream(stream)>>>(qq1, nBits, nBitsExt, qDim, qDeg, d, qq2);
+    KERNEL_CHECK();
+    HIP_TRY(hipStreamSynchronize(as_stream(stream)));
+    return PIL2GL_OK;
+}
+int pil2gl_compute_q_split_brev_dev(const uint64_t *qq1, uint32_t nBits, uint32_t nBitsExt, uint32_t qDim, uint32_t qDeg, uint64_t *coefBrev, void *stream) {
+    P2_TRY(ensure_init());
+    if (!qq1 || !coefBrev) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nBitsExt < nBits || nBitsExt > 31 || !qDim || !qDeg || ((u64)qDeg << nBits) > (1ull << nBitsExt)) return fail(PIL2GL_EINVAL, "bad q split arguments");
+    std::vector<u64> sp(qDeg);
+    u64 shiftIn = h_pow(h_inv(7), 1ull << nBits), cur = 1;
+    for (u32 p = 0; p < qDeg; p++) { sp[p] = cur; cur = h_mul(cur, shiftIn); }
+    u64 *d; P2_TRY(upload_small(sp, 2, &d, as_stream(stream)));
+    q_split_brev_kernel<<<nblk(((u64)qDim * qDeg) << nBits), 256, 0, as_stream(stream)>>>(qq1, nBits, qDim, qDeg, d, coefBrev);
     KERNEL_CHECK();
     HIP_TRY(hipStreamSynchronize(as_stream(stream)));
     return PIL2GL_OK;

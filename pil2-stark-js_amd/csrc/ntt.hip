@@ -242,6 +242,7 @@ struct LdeParams {
     u32 n, k, extBits;
     u32 canonOut;                   // 1: no pass follows (n <= k): the stored values are the result
     u32 cosetBegin, cosetCount;     // this call produces cosets [cosetBegin, cosetBegin+cosetCount) of the 2^extBits (multi-GPU: one slice per rank)
+    u32 coefIn;                     // 1: src already holds COEFFICIENTS, coefficient m at row bitrev_n(m) (what the inverse passes + the stages below leave): no inverse stages here
     u32 Wc, G, nColChunks;
 };
 
@@ -278,13 +279,15 @@ __global__ void __launch_bounds__(SC ? 512 : LDE_MAXTHREADS) lde_mid_kernel(LdeP
         if (P.cosetBegin) s0 = mul(s0, root_pow(P.twf, P.n + P.extBits, m * P.cosetBegin));   // (w_E^m)^cosetBegin, m*cb < 2^(n+b)
         Sc[idx] = s0;
     }
+    if (!P.coefIn) {                                // (uniform for the launch)
 #pragma unroll
-    for (int i = 0; i < EPT; i++) { const u32 t = y + i * by; if (t < K) tile[(y + i * rowStep) * S + x] = coef[i]; }
-    __syncthreads();
-    if constexpr (SC != 0) { dif_step<4, true, true>(tile, TWi, 8, 8, SC, x, y, 16); dif_step<4, true, true>(tile, TWi, 8, 4, SC, x, y, 16); }
-    else dif_stages<true>(tile, TWi, k, S, x, y, by);
+        for (int i = 0; i < EPT; i++) { const u32 t = y + i * by; if (t < K) tile[(y + i * rowStep) * S + x] = coef[i]; }
+        __syncthreads();
+        if constexpr (SC != 0) { dif_step<4, true, true>(tile, TWi, 8, 8, SC, x, y, 16); dif_step<4, true, true>(tile, TWi, 8, 4, SC, x, y, 16); }
+        else dif_stages<true>(tile, TWi, k, S, x, y, by);
 #pragma unroll
-    for (int i = 0; i < EPT; i++) { u32 t = y + i * by; coef[i] = t < K ? tile[(y + i * rowStep) * S + x] : 0; }
+        for (int i = 0; i < EPT; i++) { u32 t = y + i * by; coef[i] = t < K ? tile[(y + i * rowStep) * S + x] : 0; }
+    }
     __syncthreads();
     const u32 nCosets = P.cosetCount;
     for (u32 j = 0; j < nCosets; j++) {
@@ -432,7 +435,7 @@ int ntt_launch(const u64 *src, u64 C, u32 n, u64 *dst, bool inverse, hipStream_t
     return PIL2GL_OK;
 }
 
-int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st, u32 cosetBegin, u32 cosetCount, u64 *work, bool unitShift) {
+int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st, u32 cosetBegin, u32 cosetCount, u64 *work, bool unitShift, bool coefIn) {
     if (C == 0) return PIL2GL_OK;
     u32 eb = nExt - n;
     if (cosetCount == 0) { cosetBegin = 0; cosetCount = 1u << eb; }
@@ -443,12 +446,15 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
         KERNEL_CHECK();
         return PIL2GL_OK;
     }
+    // the forward passes run on dst viewed as N x (C * cosets): a narrow matrix (rows under 128 bytes) that becomes wide there takes
+    // 8-stage passes on that side (PIL2GL_LDE_WIDEFWD=0: the narrow matrix's 7 everywhere, as before)
     u32 kmax = pick_kmax(C);
-    u32 nfp = (n + kmax - 1) / kmax;
+    const u32 kmaxF = env_u32("PIL2GL_LDE_WIDEFWD", 1) ? std::max(kmax, pick_kmax(C * cosetCount)) : kmax;
+    u32 nfp = (n + kmaxF - 1) / kmaxF;
     u32 kf = (n + nfp - 1) / nfp;       // bits done by the mid kernel (both directions)
     // 1. iNTT, decimation in frequency, bits [kf, n) from the top down: src -> tmp, then in place
     const u64 *coef = src;
-    if (n > kf) {
+    if (n > kf && !coefIn) {
         u32 ks[32];
         int np = split_bits(n - kf, kmax, ks);
         u64 *tmp = work;                            // caller's workspace (may be src itself: every pass is in place)
@@ -464,7 +470,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
     {
         LdeParams P;
         P.src = coef; P.dst = dst; P.twi = tables().powWi; P.twf = tables().powW; P.twKi = tables().tw1024i; P.twKf = tables().tw1024; P.pow7 = unitShift ? nullptr : tables().pow7;
-        P.C = C; P.ninv = h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb;
+        P.C = C; P.ninv = coefIn ? 1 : h_inv(N % 0xFFFFFFFF00000001ull); P.n = n; P.k = kf; P.extBits = eb; P.coefIn = coefIn ? 1 : 0;
         P.cosetBegin = cosetBegin; P.cosetCount = cosetCount; P.canonOut = n > kf ? 0 : 1;
         u64 totalGroups = 1ull << (n - kf);
         u32 nThreads = std::min<u32>(LDE_MAXTHREADS, env_u32("PIL2GL_LDE_THREADS", 512));
@@ -507,7 +513,7 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
     //    dst viewed as N x (C * 2^eb)
     if (n > kf) {
         u32 ks[32];
-        int np = split_bits(n - kf, kmax, ks);
+        int np = split_bits(n - kf, kmaxF, ks);
         u32 lo = kf;
         for (int i = 0; i < np; i++) {
             P2_TRY(launch_pass(dst, dst, C * cosetCount, n, lo, ks[i], true, false, 0, false, i == np - 1, st));
@@ -560,6 +566,15 @@ int pil2gl_extend_cosets_unshifted_dev(const uint64_t *src, uint64_t nPols, uint
     P2_TRY(ensure_init());
     P2_TRY(check_coset_args(src, dst, nBits, nBitsExt, cosetBegin, cosetCount));
     return lde_launch(src, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount, nullptr, true);
+}
+// The evaluations, on the UNSHIFTED domain of 2^nBitsExt points in natural order, of polynomials handed over as COEFFICIENTS:
+// coefBrev is a 2^nBits x nPols matrix whose row bitrev(m) holds coefficient m (the order the inverse passes leave, and the one
+// pil2gl_compute_q_split_brev_dev writes) -- fft of the zero-padded coefficient matrix (stark_gen_helpers.js:192) without the
+// 2^nBitsExt-row padded input and without its first nBitsExt - nBits stages.
+int pil2gl_extend_coefs_brev_dev(const uint64_t *coefBrev, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt, void *stream) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_ntt_args(coefBrev, dst, nBits, nBitsExt));
+    return lde_launch(coefBrev, nPols, nBits, dst, nBitsExt, as_stream(stream), 0, 0, nullptr, true, true);
 }
 int pil2gl_interpolate_cosets_ws_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
                                      uint32_t cosetBegin, uint32_t cosetCount, uint64_t *workspace, void *stream) {

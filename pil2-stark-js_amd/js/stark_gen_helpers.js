@@ -42,14 +42,17 @@ module.exports.computeQStark = async function computeQStark(ctx, options) {
     const qStage = ctx.pilInfo.nStages + 1, qDim = ctx.pilInfo.qDim, qDeg = ctx.pilInfo.qDeg, extN = ctx.extN;
     const qIn = ctx.q_ext, qOut = ctx["cm" + qStage + "_ext"];
     const dQ = isDev(qIn) ? null : devTmp(qDim * extN), dQ1 = devTmp(qDim * extN), dQ2 = isDev(qOut) ? null : devTmp(qDim * qDeg * extN);
+    const dC = devTmp(qDim * qDeg * ctx.N);
     try {
         if (dQ !== null) upload(dQ, qIn, qDim * extN);
         const pQ = dQ !== null ? dQ : qIn.ptr, pQ2 = dQ2 !== null ? dQ2 : qOut.ptr;
         addon.ifftDev(pQ, qDim, ctx.nBitsExt, dQ1);                                         // :177
-        addon.computeQSplitDev(dQ1, ctx.nBits, ctx.nBitsExt, qDim, qDeg, pQ2);              // :179-190
-        addon.fftDev(pQ2, qDim * qDeg, ctx.nBitsExt, pQ2);                                  // :192
+        // :179-192, same values: the pieces as their N coefficient rows (bit-reversed order), extended from there -- the zero-padded
+        // 2^nBitsExt-row matrix of the reference is never built and its first extendBits stages are not run
+        addon.computeQSplitBrevDev(dQ1, ctx.nBits, ctx.nBitsExt, qDim, qDeg, dC);
+        addon.extendCoefsBrevDev(dC, qDim * qDeg, ctx.nBits, pQ2, ctx.nBitsExt);
         if (dQ2 !== null) download(qOut, dQ2, qDim * qDeg * extN);
-    } finally { if (dQ !== null) addon.devFree(dQ); addon.devFree(dQ1); if (dQ2 !== null) addon.devFree(dQ2); }
+    } finally { if (dQ !== null) addon.devFree(dQ); addon.devFree(dQ1); addon.devFree(dC); if (dQ2 !== null) addon.devFree(dQ2); }
     const nPolsQ = ctx.pilInfo.mapSectionsN["cm" + qStage] || 0;
     ctx.trees[qStage] = await ctx.MH.merkelize(ctx["cm" + qStage + "_ext"], nPolsQ, extN);   // :197
     return [ctx.MH.root(ctx.trees[qStage])];

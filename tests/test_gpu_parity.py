@@ -1315,3 +1315,40 @@ def test_randomised_differential_run():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "25", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "failures: 0" in r.stdout and "'proof'" in r.stdout and "'eval_program'" in r.stdout
+
+
+@pytest.mark.parametrize("nb,eb,qDim,qDeg", [(3, 1, 3, 2), (8, 3, 3, 2), (9, 2, 3, 3), (12, 3, 3, 2), (16, 3, 3, 2), (17, 1, 1, 2), (10, 4, 3, 5), (20, 3, 3, 2)])
+def test_quotient_pieces_extended_from_their_coefficients(gl, oracle, nb, eb, qDim, qDeg):
+    """pil2gl_compute_q_split_brev_dev + pil2gl_extend_coefs_brev_dev == computeQStark's split and plain transform of the zero-padded
+    matrix (stark_gen_helpers.js:179-192), against the oracle's q_split + fft; sizes with one, two and three forward sweeps"""
+    import torch
+    from pil2gl import _lib
+    nbe = nb + eb
+    rng = np.random.default_rng(nb * 10 + eb)
+    qq1 = rand_field(rng, (1 << nbe, qDim))
+    want = oracle.fft_cols(oracle.compute_q_split(qq1, nb, nbe, qDim, qDeg), nbe)
+    d1 = torch.from_numpy(qq1.view(np.int64).reshape(-1)).cuda()
+    W = qDim * qDeg
+    c = torch.zeros(W << nb, dtype=torch.int64, device="cuda"); out = torch.zeros(W << nbe, dtype=torch.int64, device="cuda")
+    _lib.call("pil2gl_compute_q_split_brev_dev", gl._ptr(d1), nb, nbe, qDim, qDeg, gl._ptr(c), None)
+    _lib.call("pil2gl_extend_coefs_brev_dev", gl._ptr(c), W, nb, gl._ptr(out), nbe, None)
+    assert (out.cpu().numpy().view(np.uint64).reshape(1 << nbe, W) == want).all()
+    # the coefficient matrix itself: row bitrev(i) = coefficient i of every piece
+    full = oracle.compute_q_split(qq1, nb, nbe, qDim, qDeg)[:1 << nb]
+    br = np.array([int(format(i, "0%db" % nb)[::-1], 2) if nb else 0 for i in range(1 << nb)])
+    assert (c.cpu().numpy().view(np.uint64).reshape(1 << nb, W)[br] == full).all()
+    with pytest.raises(gl.Pil2glError):
+        _lib.call("pil2gl_extend_coefs_brev_dev", gl._ptr(c), W, nb, gl._ptr(out), 40, None)
+
+
+@pytest.mark.parametrize("wide", ["1", "0"])
+def test_narrow_interpolate_with_wide_forward_passes(gl, oracle, wide, monkeypatch):
+    """a matrix whose rows are under 128 bytes takes 7-stage passes, but its extension viewed as N x (C * cosets) is wide: the forward passes
+    then take 8 stages (PIL2GL_LDE_WIDEFWD, default on; 17-26 % on narrow interpolates at 2^24 rows) -- same values either way"""
+    monkeypatch.setenv("PIL2GL_LDE_WIDEFWD", wide)
+    rng = np.random.default_rng(77)
+    for nb, C, eb in [(15, 2, 3), (17, 6, 3), (16, 8, 2), (18, 3, 1), (14, 12, 4), (16, 1, 3)]:
+        a = rand_field(rng, (1 << nb, C))
+        out = np.zeros((1 << (nb + eb), C), np.uint64)
+        gl.interpolate(a, C, nb, out, nb + eb)
+        assert (out == oracle.interpolate(a, nb, nb + eb)).all(), (nb, C, eb)

@@ -2,7 +2,7 @@
 """Random proofs (one witness stage, or two with hints in the reference's shape) driven from Node through the JS drop-in modules (tests/js/prove_flow.js: the reference's function boundaries, host
 buffers and device-resident DevBuffers) against the proof the CPU checker backend writes for the same AIR and witness: random trace
 size, blow-up, machine count, FRI steps, query count, hashCommits, previous-row opening.  Test infrastructure (imports oracle/).
-  gpurun -- python tools/fuzz_node.py [cases] [seed]"""
+  gpurun -- python tests/fuzz/fuzz_node.py [cases] [seed]"""
 import json
 import os
 import random
@@ -10,7 +10,7 @@ import subprocess
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "oracle"), os.path.join(ROOT, "pil2-stark-js_amd", "python")]
 import gl_oracle
 gl_oracle.build(); gl_oracle.set_threads(8)

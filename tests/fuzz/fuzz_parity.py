@@ -3,14 +3,14 @@
 parametrised tests do not enumerate: transforms of any row / column / blow-up count, coset slices, leaf hashes of any width (plain and
 split), trees of any height with openings, FRI folds of any step, random evaluator programs, hint columns, row sums, BN128 trees, and WHOLE PROOFS of random starkStructs (both synthetic AIRs,
 hashCommits, split leaves) whose every field must equal the proof of the same prove loop over the oracle backend.
-Test infrastructure (it imports oracle/): not part of the product.   gpurun -- python tools/fuzz_parity.py [seconds] [seed]
+Test infrastructure (it imports oracle/): not part of the product.   gpurun -- python tests/fuzz/fuzz_parity.py [seconds] [seed]
 Prints one line per failing case (and exits 1), a count per operator otherwise."""
 import os
 import sys
 import time
 import collections
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for d in ("oracle", "tests", os.path.join("pil2-stark-js_amd", "python")):
     sys.path.insert(0, os.path.join(ROOT, d))
 import numpy as np

@@ -2,10 +2,10 @@
 """Randomised runs of the sharded prover against the single-process one: random world size (2 / 4 / 8 dividing the cosets), trace size,
 blow-up, FRI steps (incl. groups that straddle cosets), AIR (one or two witness stages), hashCommits, sharded or replicated constant
 tree -- every rank of tests/workers/sharded_prove_worker.py asserts that the proof it receives equals the ordinary proof, field by field.
-  python tools/fuzz_sharded.py SECONDS [oracle|gpu]     oracle: CPU checker backend over gloo (runs anywhere); gpu: the HIP library, every
+  python tests/fuzz/fuzz_sharded.py SECONDS [oracle|gpu]     oracle: CPU checker backend over gloo (runs anywhere); gpu: the HIP library, every
   rank on cuda:0 exchanging through HIP-IPC windows (worlds of 2 and 4 only: the GPU box allows six processes on its card)"""
 import os, sys, subprocess, random, socket, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 BACKEND = sys.argv[2] if len(sys.argv) > 2 else "oracle"
 W=os.path.join(ROOT,"tests","workers","sharded_prove_worker.py")
 def port():

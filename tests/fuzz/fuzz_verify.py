@@ -2,13 +2,13 @@
 """The device verifier (pil2gl.stark.stark_verify: transcript, evaluation identity, batched Merkle paths, the FRI polynomial at the
 query points through the device evaluator, FRI.verify) on random proofs: every proof of the GPU prover must be ACCEPTED, and the same
 proof with ONE word altered anywhere -- a root, an evaluation, an opened value, a sibling, a FRI layer, the last polynomial -- must
-be REJECTED (an accepted alteration would be a word the verifier does not bind).  gpurun -- python tools/fuzz_verify.py [seconds] [seed]"""
+be REJECTED (an accepted alteration would be a word the verifier does not bind).  gpurun -- python tests/fuzz/fuzz_verify.py [seconds] [seed]"""
 import copy
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "pil2-stark-js_amd", "python"))
 import numpy as np
 from pil2gl import stark

@@ -1308,11 +1308,11 @@ def test_pols_file_to_device_and_back(gl, tmp_path):
 
 
 def test_randomised_differential_run():
-    """tools/fuzz_parity.py for 25 s with a fixed seed: every operator and whole proofs on shapes drawn at random, each against the oracle
+    """tests/fuzz/fuzz_parity.py for 25 s with a fixed seed: every operator and whole proofs on shapes drawn at random, each against the oracle
     (the long runs of the round are recorded in profiles/r04_fuzz_parity.txt)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "25", "7"], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_parity.py"), "25", "7"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "failures: 0" in r.stdout and "'proof'" in r.stdout and "'eval_program'" in r.stdout
 

@@ -40,17 +40,19 @@ def write(name, hash_commits, prev_row=False, im_pols=False, boundaries=False, p
     if hash_commits:
         ss["hashCommits"] = True                  # the transcript absorbs hashes of publics / evaluations / last polynomial
     if perm_copies:                                   # two witness stages; the stage-2 column comes from a gprod hint in the reference's shape
-        info, exprs, _ = stark.permutation_air(ss, perm_copies, ref_hints=True)
+        info, exprs, vinfo = stark.permutation_air(ss, perm_copies, ref_hints=True)
         cm, consts, publics = stark.permutation_trace(n_bits, copies=perm_copies)
     else:
-        info, exprs, _ = stark.fibonacci_air(pairs, ss, prev_row, im_pols=im_pols, boundaries=boundaries)
+        info, exprs, vinfo = stark.fibonacci_air(pairs, ss, prev_row, im_pols=im_pols, boundaries=boundaries)
         cm, consts, publics = stark.fibonacci_trace(n_bits, pairs, im_pols=im_pols)  # (im_pols: the witness goes out with those columns empty)
     be = OracleBackend()
     setup = stark.build_const_tree(be, consts, info)
     res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)          # (from_host copies: cm itself stays as generated)
     out = {"pilInfo": info, "expressionsInfo": exprs, "cm1": [str(int(v)) for v in cm.reshape(-1)], "consts": [str(int(v)) for v in consts.reshape(-1)],
            "publics": [str(v) for v in publics], "constRoot": [str(v) for v in setup["constRoot"]],
-           "proof": json.loads(json.dumps(res["proof"], default=int)), "challenges": res["challenges"], "queries": res["queries"]}
+           "proof": json.loads(json.dumps(res["proof"], default=int)), "challenges": res["challenges"], "queries": res["queries"],
+           # what starkVerify takes besides the proof (stark_verify.js:8): the two verifier programs, in the reference's shape
+           "verifierInfo": {"qVerifier": vinfo["qVerifier"], "queryVerifier": stark.query_verifier_of(info, exprs)}}
     for k in ("proof", "challenges"):
         out[k] = strs(out[k])
     json.dump(out, open(os.path.join(ROOT, "tests/golden", name), "w"))

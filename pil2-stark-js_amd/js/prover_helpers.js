@@ -57,7 +57,12 @@ function encode(code, dom, ctx, global) {
             case "challenge": { const [o] = scalar(ctx.challenges[r.stage - 1][r.stageId]); return { kind: SCALAR, dim: 3, section: 0, prime: 0, index: o }; }
             case "subproofValue": { const v = global ? ctx.subproofValues[r.subproofId][r.id] : ctx.subproofValues[r.id]; const [o, d] = scalar(v); return { kind: SCALAR, dim: d, section: 0, prime: 0, index: o }; }
             case "eval": { const [o] = scalar(ctx.evals[r.id]); return { kind: SCALAR, dim: 3, section: 0, prime: 0, index: o }; }
-            default: throw new Error((isDest ? "Invalid reference type set: " : "Invalid reference type get: ") + r.type);
+            default:
+                if (!isDest && /^tree[0-9]+$/.test(r.type)) {       // verifierInfo.queryVerifier: a witness column by its place in the stage-N opening (stark_verify.js:245-246)
+                    const st = "cm" + r.type.slice(4);
+                    return { kind: SEC, dim: r.dim, section: section(st + "_" + dom, info.mapSectionsN[st]), prime: 0, index: r.treePos };
+                }
+                throw new Error((isDest ? "Invalid reference type set: " : "Invalid reference type get: ") + r.type);
         }
     }
     // glx_op: u32 op, u32 pad, 3 x glx_ref{u8 kind,u8 dim,u16 section,i32 prime,u32 index,u32 pad} = 56 bytes

@@ -47,34 +47,38 @@ for i in range(CASES):
         ss["hashCommits"] = True
     perm = rnd.random() < 0.25
     if perm:                                              # two witness stages, gprod hints in the reference's shape (expression fields)
-        info, exprs, _ = stark.permutation_air(ss, min(pairs, 3), ref_hints=True)
+        info, exprs, vinfo = stark.permutation_air(ss, min(pairs, 3), ref_hints=True)
         cm, consts, publics = stark.permutation_trace(nb, copies=min(pairs, 3))
     else:
-        info, exprs, _ = stark.fibonacci_air(pairs, ss, prev, im_pols=im, boundaries=bd)
+        info, exprs, vinfo = stark.fibonacci_air(pairs, ss, prev, im_pols=im, boundaries=bd)
         cm, consts, publics = stark.fibonacci_trace(nb, pairs, im_pols=im)
     be = OracleBackend()
     setup = stark.build_const_tree(be, consts, info)
     res = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
     out = {"pilInfo": info, "expressionsInfo": exprs, "cm1": [str(int(v)) for v in cm.reshape(-1)], "consts": [str(int(v)) for v in consts.reshape(-1)],
            "publics": [str(v) for v in publics], "constRoot": [str(v) for v in setup["constRoot"]],
-           "proof": strs(json.loads(json.dumps(res["proof"], default=int))), "challenges": strs(res["challenges"]), "queries": res["queries"]}
+           "proof": strs(json.loads(json.dumps(res["proof"], default=int))), "challenges": strs(res["challenges"]), "queries": res["queries"],
+           "verifierInfo": {"qVerifier": vinfo["qVerifier"], "queryVerifier": stark.query_verifier_of(info, exprs)}}
     name = os.path.join(tmp, "g%03d.json" % i)
     json.dump(out, open(name, "w")); names.append(name)
     print("case %d: nBits %d ext %d pairs %d steps %s queries %d hashCommits %s prevRow %s imPols %s boundaries %s twoStage %s" % (i, nb, eb, pairs, steps, ss["nQueries"], bool(ss.get("hashCommits")), prev, im, bd, perm), flush=True)
 js = """
 const fs = require("fs");
 const { prove, freeCtx } = require(%r);
+const starkVerify = require(%r);
+const bigP = (p) => (Array.isArray(p) ? p.map(bigP) : (p && typeof p === "object" ? Object.fromEntries(Object.entries(p).map(([k, v]) => [k, bigP(v)])) : (typeof p === "string" && /^[0-9]+$/.test(p) ? BigInt(p) : p)));
 (async () => {
   let n = 0;
   for (const f of %s) {
     const g = JSON.parse(fs.readFileSync(f));
     await prove(g, false);
     const r = await prove(g, true); freeCtx(r.ctx);
+    if (!(await starkVerify(r.proof, g.publics.map(BigInt), bigP(g.constRoot), undefined, g.pilInfo, g.verifierInfo))) throw new Error("the verifier drop-in rejects the proof of " + f);
     n++;
   }
-  console.log("node fuzz: " + n + " proofs (host buffers and device-resident) identical to the checker's");
+  console.log("node fuzz: " + n + " proofs (host buffers and device-resident) identical to the checker's, each accepted by the verifier drop-in");
 })().catch((e) => { console.error(e); process.exit(1); });
-""" % (os.path.join(ROOT, "tests", "js", "prove_flow.js"), json.dumps(names))
+""" % (os.path.join(ROOT, "tests", "js", "prove_flow.js"), os.path.join(ROOT, "pil2-stark-js_amd", "js", "stark_verify.js"), json.dumps(names))
 r = subprocess.run(["node", "-e", js], capture_output=True, text=True, timeout=1500)
 print(r.stdout[-2000:], r.stderr[-3000:])
 sys.exit(r.returncode)

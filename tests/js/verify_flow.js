@@ -1,0 +1,77 @@
+// The verifier drop-in (pil2-stark-js_amd/js/stark_verify.js: starkVerify with the reference's argument list) from Node:
+//  (1) every golden proof of the CPU checker (tests/golden/*_flow*.json: one and two witness stages, hashCommits, a previous-row
+//      opening, intermediate polynomials, pil2 boundaries, hints) is ACCEPTED with its own verifier programs, and REJECTED once an
+//      evaluation, an opened value, a sibling, a FRI layer value, the last polynomial, a root or a public input is altered;
+//  (2) node tests/js/verify_flow.js <case.json>: a case prepared by the caller -- {proof, publics, constRoot, starkInfo,
+//      verifierInfo, challenges?} -- e.g. the proofs the REFERENCE prover wrote (tests/test_node_boundary.py builds them from the
+//      fixtures); prints "verify case OK <accepted> <rejected alterations>".
+"use strict";
+const fs = require("fs");
+const path = require("path");
+const assert = require("assert");
+const root = path.join(__dirname, "..", "..");
+const starkVerify = require(path.join(root, "pil2-stark-js_amd/js/stark_verify.js"));
+
+const P = 0xFFFFFFFF00000001n;
+function bigProof(p) {      // decimal strings -> BigInt, everything else untouched
+    if (Array.isArray(p)) return p.map(bigProof);
+    if (p && typeof p === "object") { const o = {}; for (const k of Object.keys(p)) o[k] = bigProof(p[k]); return o; }
+    return typeof p === "string" && /^[0-9]+$/.test(p) ? BigInt(p) : (typeof p === "number" ? BigInt(p) : p);
+}
+const clone = (v) => (Array.isArray(v) ? v.map(clone) : (v && typeof v === "object" ? Object.fromEntries(Object.entries(v).map(([k, x]) => [k, clone(x)])) : v));
+const bump = (v) => (BigInt(v) + 1n) % P;
+
+// single-word alterations, each at a place every proof has; BN128 roots / siblings are field elements, not 4-word digests
+function alterations(proof, bn) {
+    const out = [];
+    const alt = (name, fn) => { const p = clone(proof); fn(p); out.push([name, p]); };
+    alt("evaluation", (p) => { p.evals[0][0] = bump(p.evals[0][0]); });
+    alt("opened value", (p) => { p.fri[0].polQueries[0][0][0][0] = bump(p.fri[0].polQueries[0][0][0][0]); });
+    alt("constant opened", (p) => { const q = p.fri[0].polQueries[0]; q[q.length - 1][0][0] = bump(q[q.length - 1][0][0]); });
+    if (proof.fri[0].polQueries[0][0][1].length)
+        alt("sibling", (p) => { const s = p.fri[0].polQueries[0][0][1][0]; if (bn) s[(Number(p.__idx0 || 0) % s.length + 1) % s.length] = bump(s[(Number(p.__idx0 || 0) % s.length + 1) % s.length]); else s[0] = bump(s[0]); });
+    if (proof.fri.length > 2) alt("fri layer value", (p) => { p.fri[1].polQueries[0][0][0] = bump(p.fri[1].polQueries[0][0][0]); });
+    alt("last polynomial", (p) => { const l = p.fri[p.fri.length - 1]; l[l.length - 1][1] = bump(l[l.length - 1][1]); });
+    alt("root", (p) => { if (bn) p.root1 = bump(p.root1); else p.root1[0] = bump(p.root1[0]); });
+    return out;
+}
+
+async function runCase(c, label) {
+    const bn = c.starkInfo.starkStruct.verificationHashType === "BN128";
+    const proof = bigProof(c.proof), publics = c.publics.map(BigInt), constRoot = bigProof(c.constRoot);
+    const challenges = c.challenges ? bigProof(c.challenges) : undefined;
+    if (challenges && challenges.friQueries) challenges.friQueries = challenges.friQueries.map(Number);
+    assert.strictEqual(await starkVerify(proof, publics, constRoot, challenges, c.starkInfo, c.verifierInfo), true, label + ": a valid proof is rejected");
+    let rejected = 0;
+    if (challenges && challenges.friQueries) proof.__idx0 = challenges.friQueries[0];
+    for (const [name, bad] of alterations(proof, bn)) {
+        delete bad.__idx0;
+        let ok;
+        try { ok = await starkVerify(bad, publics, constRoot, challenges, c.starkInfo, c.verifierInfo); } catch (e) { ok = false; }
+        // with the caller's challenges the transcript is not replayed: an altered root / evaluation is then caught by nothing but the
+        // openings and the evaluation identity -- both of which bind them
+        assert.strictEqual(ok, false, label + ": altered " + name + " accepted");
+        rejected++;
+    }
+    if (publics.length && !challenges) {
+        const wp = publics.slice(); wp[0] = bump(wp[0]);
+        assert.strictEqual(await starkVerify(proof, wp, constRoot, undefined, c.starkInfo, c.verifierInfo), false, label + ": altered public input accepted");
+        rejected++;
+    }
+    return rejected;
+}
+
+(async () => {
+    if (process.argv[2]) {
+        const c = JSON.parse(fs.readFileSync(process.argv[2]));
+        const n = await runCase(c, path.basename(process.argv[2]));
+        console.log("verify case OK 1 " + n);
+        return;
+    }
+    let total = 0;
+    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json", "fib_flow_impols.json", "fib_flow_boundaries.json", "perm_flow_hints.json"]) {
+        const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden", name)));
+        total += await runCase({ proof: g.proof, publics: g.publics, constRoot: g.constRoot, starkInfo: g.pilInfo, verifierInfo: g.verifierInfo }, name);
+    }
+    console.log("verify flow OK (" + total + " alterations rejected)");
+})().catch((e) => { console.error(e); process.exit(1); });

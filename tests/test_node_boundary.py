@@ -2,6 +2,7 @@
 import os
 import shutil
 import subprocess
+import sys
 
 import pytest
 
@@ -113,3 +114,49 @@ def test_config3_proof_driven_from_node(tmp_path):
     print("config 3 proof: python-driven %.3f s, node-driven %.3f s" % (t_py, t_node))
     assert same
     assert t_node < 1.10 * t_py, (t_py, t_node)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_verifier_drop_in_on_checker_proofs_from_node():
+    """js/stark_verify.js (starkVerify with the reference's argument list; batched openings, the query program on the device evaluator,
+    FRI.verify): accepts the six golden proofs of the CPU checker with their own verifier programs and rejects every alteration"""
+    out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "verify_flow.js")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0 and "verify flow OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def _strs(v):
+    if isinstance(v, dict):
+        return {k: _strs(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_strs(x) for x in v]
+    if isinstance(v, int) and not isinstance(v, bool):
+        return str(v)
+    return v
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_reference_written_proofs_verified_from_node(tmp_path):
+    """BOTH proofs the reference prover wrote -- test/compressor (Goldilocks Poseidon, transcript replayed) and test/final (BN128 Poseidon,
+    arity 4, the older transcript layout: challenges handed over as starkVerify's fourth argument) -- accepted whole by the JS verifier
+    drop-in with the programs of their own verifier circuits, and rejected after every alteration"""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_reference_proof as R
+    from conftest import golden
+    from pil2gl import io, stark
+    info, vinfo, root_c = R._programs()
+    z = golden("ref_compressor_verifier.proof.zkin.json")
+    case = {"proof": io.zkin2proof(z, info), "publics": [int(v) for v in z["publics"]], "constRoot": root_c, "starkInfo": info, "verifierInfo": vinfo}
+    big = lambda c: {k: (_strs(v) if k in ("proof", "publics", "constRoot", "challenges") else v) for k, v in c.items()}     # field elements as decimal strings; the infos keep their numbers
+    f1 = tmp_path / "compressor.json"; f1.write_text(json.dumps(big(case)))
+    info2, vinfo2, root_c2, z2 = R._final()
+    ss = info2["starkStruct"]
+    be = stark.GpuBackend(0, hash_type=ss["verificationHashType"], arity=ss["merkleTreeArity"], custom=ss["merkleTreeCustom"])
+    tr = R._final_transcript(be.new_transcript(), z2, info2)
+    case2 = {"proof": io.zkin2proof(z2, info2), "publics": [int(v) for v in z2["publics"]], "constRoot": root_c2, "starkInfo": info2, "verifierInfo": vinfo2, "challenges": tr}
+    f2 = tmp_path / "final.json"; f2.write_text(json.dumps(big(case2)))
+    for f in (f1, f2):
+        out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "verify_flow.js"), str(f)], capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "verify case OK 1" in out.stdout, f.name + ": " + out.stdout[-2000:] + out.stderr[-4000:]

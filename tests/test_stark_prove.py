@@ -254,22 +254,8 @@ def test_device_verifier_agrees_with_restated_verifier(oracle, n_bits, n_pairs, 
 
 
 def _query_verifier_of(info, exprs):
-    """verifierInfo.queryVerifier as generateCode.js:239-249 builds it: the FRI expression's op-list with every witness
-    operand turned into {type: "tree<stage>", treePos, dim} (codegen.js:249-255) and the value left in the last temporary"""
-    import copy
-    code = copy.deepcopy(exprs["expressionsCode"][info["friExpId"]]["code"]["code"])
-    n_tmp = 1 + max([r["id"] for c in code for r in [c["dest"]] + c["src"] if r["type"] == "tmp"], default=-1)
-    for c in code:
-        for r in [c["dest"]] + c["src"]:
-            if r["type"] == "cm":
-                p = info["cmPolsMap"][r["id"]]
-                r.update(type="tree%d" % p["stage"], treePos=p["stagePos"], dim=p["dim"], stageId=0)
-                r.pop("id"); r.pop("prime", None)
-            elif r["type"] == "const":
-                r.pop("prime", None)
-    assert code[-1]["dest"]["type"] == "f"
-    code[-1]["dest"] = {"type": "tmp", "id": n_tmp, "dim": 3}
-    return {"code": code}
+    from pil2gl import stark
+    return stark.query_verifier_of(info, exprs)
 
 
 @pytest.mark.gpu

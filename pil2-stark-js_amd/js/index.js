@@ -12,4 +12,6 @@ module.exports = {
     prover_helpers: require("./prover_helpers.js"),
     stark_gen_helpers: require("./stark_gen_helpers.js"),
     polutils: require("./polutils.js"),
+    Transcript: require("./transcript.js"),
+    starkVerify: require("./stark_verify.js"),
 };

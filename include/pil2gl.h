@@ -272,6 +272,12 @@ int pil2gl_bn128_convert_dev(const uint64_t *in, uint64_t n, int toMontgomery, u
  * cm is 2^nBits x (2*nPairs) row-major (l1_k, l2_k), hostInit = 2*nPairs canonical start values (host pointer). */
 int pil2gl_synth_fibonacci_dev(uint32_t nBits, uint32_t nPairs, const uint64_t *hostInit, uint64_t *cm, void *stream);
 
+/* ---- the WASM module's scalar exports (glwasm.js:47-96,1269-1275: add, mul, square of field elements) ------------
+ * Host arithmetic, one element per call (the reference calls them from JS for twiddles and shifts); no device needed. */
+uint64_t pil2gl_add(uint64_t a, uint64_t b);
+uint64_t pil2gl_mul(uint64_t a, uint64_t b);
+uint64_t pil2gl_square(uint64_t a);
+
 /* ---- diagnostics used by the parity tests ---------------------------------- */
 /* element-wise a*b, a+b, a-b on the device (n elements, host pointers) */
 int pil2gl_selftest_field(const uint64_t *a, const uint64_t *b, uint64_t n, uint64_t *mul, uint64_t *add, uint64_t *sub);

@@ -171,6 +171,11 @@ int pil2gl_dev_free(uint64_t *p) { if (p) HIP_TRY(hipFree(p)); return PIL2GL_OK;
 int pil2gl_dev_zero(uint64_t *p, uint64_t nWords, void *stream) { if (!nWords) return PIL2GL_OK; if (!p) return fail(PIL2GL_EINVAL, "null buffer"); HIP_TRY(hipMemsetAsync(p, 0, nWords * 8, as_stream(stream))); return PIL2GL_OK; }
 int pil2gl_dev_upload(uint64_t *dst, const uint64_t *hostSrc, uint64_t nWords) { if (!nWords) return PIL2GL_OK; if (!dst || !hostSrc) return fail(PIL2GL_EINVAL, "null buffer"); HIP_TRY(hipMemcpy(dst, hostSrc, nWords * 8, hipMemcpyHostToDevice)); return PIL2GL_OK; }
 int pil2gl_dev_download(uint64_t *hostDst, const uint64_t *src, uint64_t nWords) { if (!nWords) return PIL2GL_OK; if (!hostDst || !src) return fail(PIL2GL_EINVAL, "null buffer"); HIP_TRY(hipMemcpy(hostDst, src, nWords * 8, hipMemcpyDeviceToHost)); return PIL2GL_OK; }
+// The scalar exports of the reference's WASM module (glwasm.js:1269-1275: add, mul, square on i64 words): host arithmetic on canonical
+// operands, the same the library's own planners use for twiddles and shifts.  Not a compute path: one element per call, no device involved.
+uint64_t pil2gl_add(uint64_t a, uint64_t b) { return h_add(a % 0xFFFFFFFF00000001ull, b % 0xFFFFFFFF00000001ull); }
+uint64_t pil2gl_mul(uint64_t a, uint64_t b) { return h_mul(a % 0xFFFFFFFF00000001ull, b % 0xFFFFFFFF00000001ull); }
+uint64_t pil2gl_square(uint64_t a) { return h_mul(a % 0xFFFFFFFF00000001ull, a % 0xFFFFFFFF00000001ull); }
 int pil2gl_sync(void *stream) { HIP_TRY(hipStreamSynchronize(as_stream(stream))); return PIL2GL_OK; }
 
 }  // extern "C"

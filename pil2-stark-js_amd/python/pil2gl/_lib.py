@@ -57,6 +57,9 @@ SIGNATURES = {
     "pil2gl_dev_free": (_I, [vp]),
     "pil2gl_dev_zero": (_I, [vp, _U64, vp]),
     "pil2gl_dev_upload": (_I, [vp, vp, _U64]),
+    "pil2gl_add": (_U64, [_U64, _U64]),
+    "pil2gl_mul": (_U64, [_U64, _U64]),
+    "pil2gl_square": (_U64, [_U64]),
     "pil2gl_dev_download": (_I, [vp, vp, _U64]),
     "pil2gl_sync": (_I, [vp]),
     "pil2gl_interpolate": (_I, [vp, _U64, _U32, vp, _U32]),

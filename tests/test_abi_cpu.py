@@ -41,6 +41,17 @@ def test_merkle_num_nodes_host_only(oracle):
         assert lib.pil2gl_merkle_num_nodes(h) == oracle.merkle_num_nodes(h)
 
 
+def test_scalar_field_exports_against_the_references_vectors():
+    """pil2gl_add / _mul / _square = the WASM module's scalar exports (glwasm.js:47-96,1269-1275): host arithmetic, against the products
+    and sums the reference's f3g.js wrote into tests/golden/field.json; operands above p are reduced first"""
+    from conftest import golden, H, P
+    lib = _lib.load()
+    g = golden("field.json")
+    for a, b, m, s, d in H(g["mul"]):
+        assert lib.pil2gl_mul(a, b) == m and lib.pil2gl_add(a, b) == s and lib.pil2gl_square(a) == a * a % P
+    assert lib.pil2gl_mul(P + 5, 3) == 15 and lib.pil2gl_add(2 ** 64 - 1, 1) == (2 ** 64) % P and lib.pil2gl_square(P - 1) == 1
+
+
 def _have_gpu():
     try:
         import torch

@@ -168,3 +168,19 @@ class MerkleHash {
     }
 }
 module.exports.MerkleHash = MerkleHash;
+// The reference's own operator granularity (merklehash_worker.js:37-117, the functions its worker pool runs on slices of the rows):
+//   linearHash(buffIn, width, st_i, st_n, splitLinearHash) -> BigUint64Array(height * 4)      one digest per row of buffIn
+//   merkelizeLevel(buffIn, st_i, st_n)                     -> BigUint64Array(nOps * 4)        one parent per 8 input words
+// st_i / st_n (the slice's position, used there for logging only) are accepted and ignored.
+module.exports.linearHash = async function linearHash(buffIn, width, st_i, st_n, splitLinearHash) {
+    const height = width ? buffIn.length / width : 0;
+    const out = new BigUint64Array(height * 4);
+    if (height) addon.linearHashRows(buffIn, width, height, splitLinearHash ? 1 : 0, out);
+    return out;
+};
+module.exports.merkelizeLevel = async function merkelizeLevel(buffIn, st_i, st_n) {
+    const nOps = buffIn.length / 8;
+    const out = new BigUint64Array(nOps * 4);
+    if (nOps) addon.merkelizeLevel(buffIn, nOps, out);
+    return out;
+};

@@ -126,6 +126,20 @@ class ChunkedBuffer {
         assert.strictEqual(fri.verify(chs, queries.slice(), friProof, checkQuery), true);
         assert.throws(() => fri.verify(chs, queries.slice(), friProof.slice(0, 3), checkQuery), /Invalid proof size/);
     }
+    // --- the worker-level operators (merklehash_worker.js:37-117) = the first two levels of the tree merkelize builds
+    {
+        const buildMH = require(path.join(root, "pil2-stark-js_amd/js/merklehash_p.js"));
+        for (const [split, width, height] of [[false, 9, 64], [true, 20, 32], [false, 3, 16]]) {
+            const MH = await buildMH(split);
+            const rows = new BigUint64Array(width * height);
+            for (let i = 0; i < rows.length; i++) rows[i] = BigInt(i * 7 + 3) * 0x9E3779B97F4A7C15n % 0xFFFFFFFF00000001n;
+            const tree = await MH.merkelize(rows, width, height);
+            const leaves = await buildMH.linearHash(rows, width, 0, 1, split);
+            assert.deepStrictEqual(Array.from(leaves), Array.from(tree.nodes.subarray(0, 4 * height)), "linearHash worker op");
+            const level1 = await buildMH.merkelizeLevel(leaves, 0, 1);
+            assert.deepStrictEqual(Array.from(level1), Array.from(tree.nodes.subarray(4 * height, 4 * height + 2 * height)), "merkelizeLevel worker op");
+        }
+    }
     // --- callCalculateExps: a small op-list over a fake ctx (prover_helpers.js:23-259 operand kinds), checked by BigInt math
     {
         const { callCalculateExps } = require(path.join(root, "pil2-stark-js_amd/js/prover_helpers.js"));

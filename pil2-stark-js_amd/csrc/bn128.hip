@@ -17,6 +17,7 @@
 // Nodes are stored as the reference stores them: 4 little-endian u64 words of the Montgomery form.
 #include "common.h"
 #include "bn_field.cuh"
+#include "bn_mfma.cuh"
 #include <mutex>
 #include <vector>
 #include <string.h>
@@ -100,7 +101,9 @@ struct Grain {
 //   C8[8][t]  constants of the 4+4 full rounds (the first of the second half also carries what the partial rounds pushed out)
 //   M[t][t]   dense MDS;  D[t-1][t-1] = Mhat^RP;  S[RP] scalar constants;  V[RP][t-1], W[RP][t-1] sparse rows / columns
 //   Cd[(8+RP)][t] the original constants, for the dense (test) form
-struct Params { int t = 0, rp = 0; u32 *base = nullptr, *C8, *M, *D, *S, *V, *W, *Cd; u32 m00[8]; };
+//   Mt / Dt   the same two dense layers as matrix-core operand tiles (bn_mfma.cuh), MK / DK their per-row constants
+struct Params { int t = 0, rp = 0; u32 *base = nullptr, *C8, *M, *D, *S, *V, *W, *Cd; u32 m00[8];
+                const bnm::v4i *Mt = nullptr, *Dt = nullptr; const u32 *MK = nullptr, *DK = nullptr; };
 Params g_params[18];
 std::mutex g_mu;
 
@@ -179,6 +182,48 @@ int derive_sparse(int t, int rp, const Vec &C, const Vec &M, Vec &C8, Vec &D, Ve
     return PIL2GL_OK;
 }
 
+// Operand tiles and row constants of one constant layer for the matrix cores (layout and derivation: bn_mfma.cuh).
+// A: rows x cols entries in Montgomery form.  tiles: rows*cols KB in lane order; K: rows plain integers mod r.
+void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &tiles, Vec &K) {
+    U256 P[32];                                      // 2^(8b+32) mod r, plain
+    {
+        U256 v = { { 1, 0, 0, 0 } };
+        for (int e = 0; e < 32; e++) v = h_addmod(v, v);
+        for (int b = 0; b < 32; b++) { P[b] = v; for (int e = 0; e < 8; e++) v = h_addmod(v, v); }
+    }
+    U256 off = { { 0, 0, 0, 0 } };                   // sum_k 2^25 256^k mod r
+    {
+        U256 v = { { (u64)bnm::ACC_BIAS, 0, 0, 0 } };
+        for (int k = 0; k < 32; k++) { off = h_addmod(off, v); for (int e = 0; e < 8; e++) v = h_addmod(v, v); }
+    }
+    const U256 inv32 = { { 0, 0, 0, 1ull << 32 } };  // 2^224: h_mont(a, 2^224) = a / 2^32
+    tiles.assign((size_t)rows * cols * 1024, 0);
+    K.resize((size_t)rows);
+    for (int i = 0; i < rows; i++) {
+        U256 tot = { { 0, 0, 0, 0 } };
+        for (int j = 0; j < cols; j++) {
+            int8_t *tile = tiles.data() + ((size_t)i * cols + j) * 1024;
+            for (int b = 0; b < 32; b++) {
+                const U256 c = h_mont(A[(size_t)i * cols + j], P[b]);        // A_ij 2^(8b+32) mod r as a plain integer
+                tot = h_addmod(tot, c);
+                int d[32], carry = 0;
+                for (int k = 0; k < 32; k++) {
+                    int v = (int)((c.w[k / 8] >> (8 * (k % 8))) & 255) + carry;
+                    carry = v >= 128;
+                    d[k] = carry ? v - 256 : v;
+                }                                     // c < 2^254: the top digit takes the last carry
+                const int g = b / 16, sl = b % 16;
+                for (int m = 0; m < 32; m++) {
+                    const int pos = 16 * ((m / 4) % 2) + 4 * (m / 8) + m % 4;
+                    tile[(size_t)(g * 32 + m) * 16 + sl] = (int8_t)d[pos];
+                }
+            }
+        }
+        for (int e = 0; e < 7; e++) tot = h_addmod(tot, tot);
+        K[i] = h_mont(h_submod(tot, off), inv32);
+    }
+}
+
 int get_params(int t, const Params **out) {
     if (t < 2 || t > 17) return fail(PIL2GL_EINVAL, "BN128 Poseidon takes 1..16 inputs (t=%d)", t);
     std::lock_guard<std::mutex> lk(g_mu);
@@ -195,12 +240,26 @@ int get_params(int t, const Params **out) {
         Vec all;
         auto put = [&](const Vec &x) { size_t o = all.size(); all.insert(all.end(), x.begin(), x.end()); return o; };
         const size_t oC8 = put(C8), oM = put(M), oD = put(D), oS = put(S), oV = put(V), oW = put(W), oCd = put(C);
-        (void)n;
         u32 *d = nullptr;
         HIP_TRY(hipMalloc((void **)&d, all.size() * 32));
         HIP_TRY(hipMemcpy(d, all.data(), all.size() * 32, hipMemcpyHostToDevice));
         P.base = d; P.C8 = d + oC8 * 8; P.M = d + oM * 8; P.D = d + oD * 8; P.S = d + oS * 8; P.V = d + oV * 8; P.W = d + oW * 8; P.Cd = d + oCd * 8;
         memcpy(P.m00, M[0].w, 32);
+        {
+            std::vector<int8_t> tm, td; Vec km, kd;
+            mfma_layer_tables(M, t, t, tm, km);
+            mfma_layer_tables(D, n, n, td, kd);
+            int8_t *dt = nullptr; u32 *dk = nullptr;
+            HIP_TRY(hipMalloc((void **)&dt, tm.size() + td.size() + 16 * 1024));      // + the spare tiles the read-ahead touches (MFMA_AHEAD)
+            HIP_TRY(hipMemset(dt, 0, tm.size() + td.size() + 16 * 1024));
+            HIP_TRY(hipMemcpy(dt, tm.data(), tm.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dt + tm.size(), td.data(), td.size(), hipMemcpyHostToDevice));
+            HIP_TRY(hipMalloc((void **)&dk, (km.size() + kd.size()) * 32));
+            HIP_TRY(hipMemcpy(dk, km.data(), km.size() * 32, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(dk + km.size() * 8, kd.data(), kd.size() * 32, hipMemcpyHostToDevice));
+            P.Mt = (const bnm::v4i *)dt; P.Dt = (const bnm::v4i *)(dt + tm.size());
+            P.MK = dk; P.DK = dk + km.size() * 8;
+        }
         P.rp = rp; P.t = t;
     }
     *out = &P;
@@ -208,7 +267,8 @@ int get_params(int t, const Params **out) {
 }
 
 // ------------------------------------------------------------------------------------------ device side
-struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8]; };
+struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8];
+                  const bnm::v4i *Mt, *Dt; const u32 *MK, *DK; int mfma; };
 
 // Where the state lives.  Elements [0, BN_LDS_ELEMS) in LDS as [element][limb][lane]; the elements above -- only the states
 // wider than BN_LDS_ELEMS have any: t = 10..17 -- in the lane's own private (scratch) memory, which the hardware swizzles so
@@ -318,6 +378,71 @@ __device__ __noinline__ void dense_mul(const St &st, int cur, const u32 *A, int 
     for (int i = 0; i < n; i++) lds_store(st, first + i, &nw[i * 8]);
 }
 
+// The same layer on the matrix cores (bn_mfma.cuh): the N operand pairs are made once and stay in registers, a row is N pairs of
+// MFMAs and one short finish; no 32x32 product of the state is left.  The operand tiles come from the L2 as ONE linear stream
+// (row after row, tile after tile) read MFMA_AHEAD tiles ahead of their use -- a load per tile and lane, the oldest awaited
+// alone -- so the table carries MFMA_AHEAD spare tiles after its last one.
+constexpr int MFMA_AHEAD = 8;
+template <int N>
+__device__ __noinline__ void dense_mfma_n(const St &st, const bnm::v4i *tiles, const u32 *kc, int first) {
+    bnm::v4i B0[N], B1[N];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        u32 x[8];
+        lds_load(st, first + j, x);
+        bnm::b_prep(x, B0[j], B1[j]);
+    }
+    const bnm::Sh sh = bnm::sh_init();
+    bnm::gtile tp = (bnm::gtile)tiles + st.lane;
+    bnm::v4i q[MFMA_AHEAD];
+#pragma unroll
+    for (int k = 0; k < MFMA_AHEAD; k++) q[k] = tp[(size_t)k * 64];
+    for (int i = 0; i < N; i++) {
+        bnm::v16i a0 = bnm::acc_init(), a1 = bnm::acc_init();
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const bnm::v4i a = q[0];
+#pragma unroll
+            for (int k = 0; k + 1 < MFMA_AHEAD; k++) q[k] = q[k + 1];
+            q[MFMA_AHEAD - 1] = tp[(size_t)(j + MFMA_AHEAD) * 64];
+            a0 = bnm::mfma(a, B0[j], a0);
+            a1 = bnm::mfma(a, B1[j], a1);
+        }
+        tp += (size_t)N * 64;
+        u32 k[8], o[8];
+        load_const<true>(kc, (size_t)i, k);
+        bnm::finish_row(a0, a1, k, o, sh);
+        lds_store(st, first + i, o);                 // the old state is in B0 / B1: the new row can go straight to its place
+    }
+}
+__device__ __forceinline__ void dense_mfma(const St &st, const bnm::v4i *tiles, const u32 *kc, int n, int first) {
+    switch (n) {
+    case 1: dense_mfma_n<1>(st, tiles, kc, first); break;
+    case 2: dense_mfma_n<2>(st, tiles, kc, first); break;
+    case 3: dense_mfma_n<3>(st, tiles, kc, first); break;
+    case 4: dense_mfma_n<4>(st, tiles, kc, first); break;
+    case 5: dense_mfma_n<5>(st, tiles, kc, first); break;
+    case 6: dense_mfma_n<6>(st, tiles, kc, first); break;
+    case 7: dense_mfma_n<7>(st, tiles, kc, first); break;
+    case 8: dense_mfma_n<8>(st, tiles, kc, first); break;
+    case 9: dense_mfma_n<9>(st, tiles, kc, first); break;
+    case 10: dense_mfma_n<10>(st, tiles, kc, first); break;
+    case 11: dense_mfma_n<11>(st, tiles, kc, first); break;
+    case 12: dense_mfma_n<12>(st, tiles, kc, first); break;
+    case 13: dense_mfma_n<13>(st, tiles, kc, first); break;
+    case 14: dense_mfma_n<14>(st, tiles, kc, first); break;
+    case 15: dense_mfma_n<15>(st, tiles, kc, first); break;
+    case 16: dense_mfma_n<16>(st, tiles, kc, first); break;
+    default: dense_mfma_n<17>(st, tiles, kc, first); break;
+    }
+}
+template <bool WIDE>
+__device__ __forceinline__ void dense_layer(const St &st, int cur, const PermArgs &A, bool closing) {
+    const int n = closing ? A.t - 1 : A.t;
+    if (A.mfma) dense_mfma(st, closing ? A.Dt : A.Mt, closing ? A.DK : A.MK, n, closing ? 1 : 0);
+    else dense_mul<WIDE>(st, cur, closing ? A.D : A.M, n, closing ? 1 : 0);
+}
+
 // partial rounds, sparse form, in place: element 0 stays in registers.  WIDE: the next term's requests are pinned ahead of
 // the current term's two products (see dense_mul)
 template <bool WIDE>
@@ -387,16 +512,13 @@ __device__ __noinline__ int bn_perm(const St &st, int cur, const PermArgs &A) {
     }
     for (int r = 0; r < 4; r++) {
         add_sbox<WIDE>(st, cur, t, A.C8, (size_t)r * t, t);
-        dense_mul<WIDE>(st, cur, A.M, t, 0);
+        dense_layer<WIDE>(st, cur, A, false);
     }
-    {
-        const int n = t - 1;
-        partial_rounds<WIDE>(st, cur, A);
-        dense_mul<WIDE>(st, cur, A.D, n, 1);    // diag(1, Mh^RP)
-    }
+    partial_rounds<WIDE>(st, cur, A);
+    dense_layer<WIDE>(st, cur, A, true);        // diag(1, Mh^RP)
     for (int r = 4; r < 8; r++) {
         add_sbox<WIDE>(st, cur, t, A.C8, (size_t)r * t, t);
-        dense_mul<WIDE>(st, cur, A.M, t, 0);
+        dense_layer<WIDE>(st, cur, A, false);
     }
     return cur;
 }
@@ -619,6 +741,9 @@ PermArgs perm_args(const Params *P) {
     a.C8 = P->C8; a.M = P->M; a.D = P->D; a.S = P->S; a.V = P->V; a.W = P->W; a.Cd = P->Cd; a.t = P->t; a.rp = P->rp;
     static const bool dense = getenv("PIL2GL_BN128_DENSE") && atoi(getenv("PIL2GL_BN128_DENSE"));
     a.dense = dense ? 1 : 0;
+    static const bool mfma = !(getenv("PIL2GL_BN128_MFMA") && !atoi(getenv("PIL2GL_BN128_MFMA")));   // =0: the layers on the vector ALU (A/B runs)
+    a.mfma = mfma ? 1 : 0;
+    a.Mt = P->Mt; a.Dt = P->Dt; a.MK = P->MK; a.DK = P->DK;
     memcpy(a.m00, P->m00, 32);
     return a;
 }

@@ -101,9 +101,10 @@ struct Grain {
 //   C8[8][t]  constants of the 4+4 full rounds (the first of the second half also carries what the partial rounds pushed out)
 //   M[t][t]   dense MDS;  D[t-1][t-1] = Mhat^RP;  S[RP] scalar constants;  V[RP][t-1], W[RP][t-1] sparse rows / columns
 //   Cd[(8+RP)][t] the original constants, for the dense (test) form
-//   Mt / Dt   the same two dense layers as matrix-core operand tiles (bn_mfma.cuh), MK / DK their per-row constants
+//   Mt / Dt   the same two dense layers as matrix-core operand tiles (bn_mfma.cuh), MK / DK their per-row constants;
+//   Pt        the tile stream of the blocked partial rounds, KR / KU its row constants (mfma_partial_tables)
 struct Params { int t = 0, rp = 0; u32 *base = nullptr, *C8, *M, *D, *S, *V, *W, *Cd; u32 m00[8];
-                const bnm::v4i *Mt = nullptr, *Dt = nullptr; const u32 *MK = nullptr, *DK = nullptr; };
+                const bnm::v4i *Mt = nullptr, *Dt = nullptr, *Pt = nullptr; const u32 *MK = nullptr, *DK = nullptr, *KR = nullptr, *KU = nullptr; };
 Params g_params[18];
 std::mutex g_mu;
 
@@ -182,45 +183,89 @@ int derive_sparse(int t, int rp, const Vec &C, const Vec &M, Vec &C8, Vec &D, Ve
     return PIL2GL_OK;
 }
 
-// Operand tiles and row constants of one constant layer for the matrix cores (layout and derivation: bn_mfma.cuh).
-// A: rows x cols entries in Montgomery form.  tiles: rows*cols KB in lane order; K: rows plain integers mod r.
-void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &tiles, Vec &K) {
+// Operand tiles and row constants for the matrix cores (layout and derivation: bn_mfma.cuh).
+struct MfmaConsts {
     U256 P[32];                                      // 2^(8b+32) mod r, plain
-    {
+    U256 off;                                        // sum_k 2^25 256^k mod r
+    MfmaConsts() {
         U256 v = { { 1, 0, 0, 0 } };
         for (int e = 0; e < 32; e++) v = h_addmod(v, v);
         for (int b = 0; b < 32; b++) { P[b] = v; for (int e = 0; e < 8; e++) v = h_addmod(v, v); }
-    }
-    U256 off = { { 0, 0, 0, 0 } };                   // sum_k 2^25 256^k mod r
-    {
-        U256 v = { { (u64)bnm::ACC_BIAS, 0, 0, 0 } };
+        off = U256{ { 0, 0, 0, 0 } };
+        v = U256{ { (u64)bnm::ACC_BIAS, 0, 0, 0 } };
         for (int k = 0; k < 32; k++) { off = h_addmod(off, v); for (int e = 0; e < 8; e++) v = h_addmod(v, v); }
     }
+};
+// one tile (1 KB, lane order) of the coefficient a (Montgomery form); tot += the sum of its 32 constants
+void mfma_tile(const MfmaConsts &mc, const U256 &a, int8_t *tile, U256 &tot) {
+    for (int b = 0; b < 32; b++) {
+        const U256 c = h_mont(a, mc.P[b]);           // a 2^(8b+32) mod r as a plain integer
+        tot = h_addmod(tot, c);
+        int d[32], carry = 0;
+        for (int k = 0; k < 32; k++) {
+            int v = (int)((c.w[k / 8] >> (8 * (k % 8))) & 255) + carry;
+            carry = v >= 128;
+            d[k] = carry ? v - 256 : v;
+        }                                             // c < 2^254: the top digit takes the last carry
+        const int g = b / 16, sl = b % 16;
+        for (int m = 0; m < 32; m++) {
+            const int pos = 16 * ((m / 4) % 2) + 4 * (m / 8) + m % 4;
+            tile[(size_t)(g * 32 + m) * 16 + sl] = (int8_t)d[pos];
+        }
+    }
+}
+// the row constant: (128 tot - nAcc sum_k 2^25 256^k) / 2^32 + fold mod r   (nAcc accumulations started at the bias make up the row)
+U256 mfma_row_const(const MfmaConsts &mc, U256 tot, int nAcc, const U256 &fold) {
     const U256 inv32 = { { 0, 0, 0, 1ull << 32 } };  // 2^224: h_mont(a, 2^224) = a / 2^32
+    for (int e = 0; e < 7; e++) tot = h_addmod(tot, tot);
+    for (int e = 0; e < nAcc; e++) tot = h_submod(tot, mc.off);
+    return h_addmod(h_mont(tot, inv32), fold);
+}
+// A: rows x cols entries in Montgomery form.  tiles: rows*cols KB; K: rows plain integers mod r.
+void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &tiles, Vec &K) {
+    const MfmaConsts mc;
+    const U256 zero = { { 0, 0, 0, 0 } };
     tiles.assign((size_t)rows * cols * 1024, 0);
     K.resize((size_t)rows);
     for (int i = 0; i < rows; i++) {
-        U256 tot = { { 0, 0, 0, 0 } };
-        for (int j = 0; j < cols; j++) {
-            int8_t *tile = tiles.data() + ((size_t)i * cols + j) * 1024;
-            for (int b = 0; b < 32; b++) {
-                const U256 c = h_mont(A[(size_t)i * cols + j], P[b]);        // A_ij 2^(8b+32) mod r as a plain integer
-                tot = h_addmod(tot, c);
-                int d[32], carry = 0;
-                for (int k = 0; k < 32; k++) {
-                    int v = (int)((c.w[k / 8] >> (8 * (k % 8))) & 255) + carry;
-                    carry = v >= 128;
-                    d[k] = carry ? v - 256 : v;
-                }                                     // c < 2^254: the top digit takes the last carry
-                const int g = b / 16, sl = b % 16;
-                for (int m = 0; m < 32; m++) {
-                    const int pos = 16 * ((m / 4) % 2) + 4 * (m / 8) + m % 4;
-                    tile[(size_t)(g * 32 + m) * 16 + sl] = (int8_t)d[pos];
-                }
+        U256 tot = zero;
+        for (int j = 0; j < cols; j++) mfma_tile(mc, A[(size_t)i * cols + j], tiles.data() + ((size_t)i * cols + j) * 1024, tot);
+        K[i] = mfma_row_const(mc, tot, 1, zero);
+    }
+}
+// The partial rounds four to a block (partial_rounds_mfma): the tile stream in the order the kernel consumes it and the row constants.
+// Block b (rounds k0 = 4b .. k0+3), y = elements 1..n at the block's start, z_i = the S-box output of round k0+i:
+//   x0 after round k0+i = m00 z_i + sum_j V[k0+i][j] y_j + sum_{i'<i} (V[k0+i] . W[k0+i']) z_i';   y_j after the block = y_j + sum_i W[k0+i][j] z_i.
+// Stream per block: n x 4 tiles V[k0+i][j] (j outer);  4 x 4 tiles of the cross terms (round i, slot s holds z_(i+s-3): zero
+// tiles where that is before the block);  n x 5 tiles (1, W[k0+s][j]).  KR[k]: round k's row constant with S[k+1] folded in while
+// round k+1 is one of these; KU[b][j]: the column constants.
+void mfma_partial_tables(int t, int rp, const Vec &S, const Vec &V, const Vec &W, const U256 &m00, std::vector<int8_t> &tiles, Vec &KR, Vec &KU) {
+    const MfmaConsts mc;
+    const U256 zero = { { 0, 0, 0, 0 } }, one = h_to_mont(U256{ { 1, 0, 0, 0 } });
+    const int n = t - 1, nb = rp / 4;
+    tiles.assign((size_t)nb * (9 * n + 16) * 1024, 0);
+    KR.assign((size_t)nb * 4, zero); KU.assign((size_t)nb * n, zero);
+    int8_t *tp = tiles.data();
+    for (int b = 0; b < nb; b++) {
+        const int k0 = 4 * b;
+        U256 tot[4] = { zero, zero, zero, zero };
+        for (int j = 0; j < n; j++) for (int i = 0; i < 4; i++, tp += 1024) mfma_tile(mc, V[(size_t)(k0 + i) * n + j], tp, tot[i]);
+        for (int i = 0; i < 4; i++) {
+            for (int s = 0; s < 4; s++, tp += 1024) {
+                const int ip = i + s - 3;
+                if (ip < 0) continue;
+                U256 c = m00;
+                if (ip < i) { c = zero; for (int j = 0; j < n; j++) c = h_addmod(c, h_mont(V[(size_t)(k0 + i) * n + j], W[(size_t)(k0 + ip) * n + j])); }
+                mfma_tile(mc, c, tp, tot[i]);
             }
+            KR[(size_t)k0 + i] = mfma_row_const(mc, tot[i], 2, k0 + i + 1 < 4 * nb ? S[(size_t)k0 + i + 1] : zero);
         }
-        for (int e = 0; e < 7; e++) tot = h_addmod(tot, tot);
-        K[i] = h_mont(h_submod(tot, off), inv32);
+        for (int j = 0; j < n; j++) {
+            U256 tu = zero;
+            mfma_tile(mc, one, tp, tu); tp += 1024;
+            for (int s = 0; s < 4; s++, tp += 1024) mfma_tile(mc, W[(size_t)(k0 + s) * n + j], tp, tu);
+            KU[(size_t)b * n + j] = mfma_row_const(mc, tu, 1, zero);
+        }
     }
 }
 
@@ -246,19 +291,24 @@ int get_params(int t, const Params **out) {
         P.base = d; P.C8 = d + oC8 * 8; P.M = d + oM * 8; P.D = d + oD * 8; P.S = d + oS * 8; P.V = d + oV * 8; P.W = d + oW * 8; P.Cd = d + oCd * 8;
         memcpy(P.m00, M[0].w, 32);
         {
-            std::vector<int8_t> tm, td; Vec km, kd;
+            std::vector<int8_t> tm, td, tpr; Vec km, kd, kr, ku;
             mfma_layer_tables(M, t, t, tm, km);
             mfma_layer_tables(D, n, n, td, kd);
+            mfma_partial_tables(t, rp, S, V, W, M[0], tpr, kr, ku);
+            const size_t spare = 16 * 1024;          // the tiles the read-ahead touches past the end of a table (MFMA_AHEAD)
             int8_t *dt = nullptr; u32 *dk = nullptr;
-            HIP_TRY(hipMalloc((void **)&dt, tm.size() + td.size() + 16 * 1024));      // + the spare tiles the read-ahead touches (MFMA_AHEAD)
-            HIP_TRY(hipMemset(dt, 0, tm.size() + td.size() + 16 * 1024));
+            HIP_TRY(hipMalloc((void **)&dt, tm.size() + td.size() + tpr.size() + 3 * spare));
+            HIP_TRY(hipMemset(dt, 0, tm.size() + td.size() + tpr.size() + 3 * spare));
             HIP_TRY(hipMemcpy(dt, tm.data(), tm.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(dt + tm.size(), td.data(), td.size(), hipMemcpyHostToDevice));
-            HIP_TRY(hipMalloc((void **)&dk, (km.size() + kd.size()) * 32));
-            HIP_TRY(hipMemcpy(dk, km.data(), km.size() * 32, hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(dk + km.size() * 8, kd.data(), kd.size() * 32, hipMemcpyHostToDevice));
-            P.Mt = (const bnm::v4i *)dt; P.Dt = (const bnm::v4i *)(dt + tm.size());
-            P.MK = dk; P.DK = dk + km.size() * 8;
+            HIP_TRY(hipMemcpy(dt + tm.size() + spare, td.data(), td.size(), hipMemcpyHostToDevice));
+            if (!tpr.empty()) HIP_TRY(hipMemcpy(dt + tm.size() + td.size() + 2 * spare, tpr.data(), tpr.size(), hipMemcpyHostToDevice));
+            Vec kall;
+            kall.insert(kall.end(), km.begin(), km.end()); kall.insert(kall.end(), kd.begin(), kd.end());
+            kall.insert(kall.end(), kr.begin(), kr.end()); kall.insert(kall.end(), ku.begin(), ku.end());
+            HIP_TRY(hipMalloc((void **)&dk, kall.size() * 32));
+            HIP_TRY(hipMemcpy(dk, kall.data(), kall.size() * 32, hipMemcpyHostToDevice));
+            P.Mt = (const bnm::v4i *)dt; P.Dt = (const bnm::v4i *)(dt + tm.size() + spare); P.Pt = (const bnm::v4i *)(dt + tm.size() + td.size() + 2 * spare);
+            P.MK = dk; P.DK = dk + km.size() * 8; P.KR = P.DK + kd.size() * 8; P.KU = P.KR + kr.size() * 8;
         }
         P.rp = rp; P.t = t;
     }
@@ -268,7 +318,7 @@ int get_params(int t, const Params **out) {
 
 // ------------------------------------------------------------------------------------------ device side
 struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8];
-                  const bnm::v4i *Mt, *Dt; const u32 *MK, *DK; int mfma; };
+                  const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma; };
 
 // Where the state lives.  Elements [0, BN_LDS_ELEMS) in LDS as [element][limb][lane]; the elements above -- only the states
 // wider than BN_LDS_ELEMS have any: t = 10..17 -- in the lane's own private (scratch) memory, which the hardware swizzles so
@@ -446,14 +496,14 @@ __device__ __forceinline__ void dense_layer(const St &st, int cur, const PermArg
 // partial rounds, sparse form, in place: element 0 stays in registers.  WIDE: the next term's requests are pinned ahead of
 // the current term's two products (see dense_mul)
 template <bool WIDE>
-__device__ __noinline__ void partial_rounds(const St &st, int cur, const PermArgs &A) {
+__device__ __noinline__ void partial_rounds(const St &st, int cur, const PermArgs &A, int kFirst) {
     const int t = A.t;
     u32 x0[8], m00[8];
     lds_load(st, 0, x0);
 #pragma unroll
     for (int l = 0; l < 8; l++) m00[l] = A.m00[l];
     const int n = t - 1;
-    for (int k = 0; k < A.rp; k++) {
+    for (int k = kFirst; k < A.rp; k++) {
         u32 c[8];
         load_const<WIDE>(A.S, (size_t)k, c);
         bn::fr_add(x0, c);
@@ -498,6 +548,108 @@ __device__ __noinline__ void partial_rounds(const St &st, int cur, const PermArg
     lds_store(st, 0, x0);
 }
 
+// The partial rounds on the matrix cores, four to a block (tables: mfma_partial_tables).  Per block: the four rows' parts on y
+// (n x 4 pairs of MFMAs, carried to ten words each), then the four rounds -- S-box on the vector ALU, its output z_i made an
+// operand, the cross terms of row i (<= 4 pairs) added to the row's stored part, one short finish = the next x0 -- then the n
+// columns y_j + sum_i W z_i (5 pairs and one finish each).  No 32x32 product is left but the S-box's.  The tiles are ONE linear
+// stream in consumption order, read PR_AHEAD tiles ahead.
+constexpr int PR_AHEAD = 6;
+struct TileStream {
+    bnm::gtile p;
+    bnm::v4i q[PR_AHEAD];
+    __device__ __forceinline__ void start(const bnm::v4i *tiles, int lane) {
+        p = (bnm::gtile)tiles + lane;
+#pragma unroll
+        for (int k = 0; k < PR_AHEAD; k++) q[k] = p[(size_t)k * 64];
+    }
+    __device__ __forceinline__ bnm::v4i next() {
+        const bnm::v4i a = q[0];
+#pragma unroll
+        for (int k = 0; k + 1 < PR_AHEAD; k++) q[k] = q[k + 1];
+        q[PR_AHEAD - 1] = p[(size_t)PR_AHEAD * 64];
+        p += 64;
+        return a;
+    }
+};
+__device__ __noinline__ void partial_rounds_mfma(const St &st, const PermArgs &A) {
+    const int n = A.t - 1, nb = A.rp / 4;
+    const bnm::Sh sh = bnm::sh_init();
+    TileStream ts;
+    ts.start(A.Pt, st.lane);
+    u32 x0[8];
+    lds_load(st, 0, x0);
+    {
+        u32 c[8];
+        load_const<true>(A.S, 0, c);
+        bn::fr_add(x0, c);
+    }
+    for (int b = 0; b < nb; b++) {
+        u32 pc[4][10];
+        {
+            bnm::v16i P0[4], P1[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { P0[i] = bnm::acc_init(); P1[i] = bnm::acc_init(); }
+            for (int j = 0; j < n; j++) {
+                u32 y[8];
+                lds_load(st, 1 + j, y);
+                bnm::v4i b0, b1;
+                bnm::b_prep(y, b0, b1);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bnm::v4i a = ts.next();
+                    P0[i] = bnm::mfma(a, b0, P0[i]);
+                    P1[i] = bnm::mfma(a, b1, P1[i]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) bnm::carry_pair(P0[i], P1[i], pc[i], sh);
+        }
+        bnm::v4i zb0[4], zb1[4];                      // the operands of z_(i-3) .. z_i; before the block's first: anything (zero tiles)
+#pragma unroll
+        for (int s = 0; s < 4; s++) { zb0[s] = bnm::v4i{ 0, 0, 0, 0 }; zb1[s] = bnm::v4i{ 0, 0, 0, 0 }; }
+        for (int i = 0; i < 4; i++) {
+            pow5(x0);
+#pragma unroll
+            for (int s = 0; s < 3; s++) { zb0[s] = zb0[s + 1]; zb1[s] = zb1[s + 1]; }
+            bnm::b_prep(x0, zb0[3], zb1[3]);
+            bnm::v16i c0 = bnm::acc_init(), c1 = bnm::acc_init();
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                const bnm::v4i a = ts.next();
+                c0 = bnm::mfma(a, zb0[s], c0);
+                c1 = bnm::mfma(a, zb1[s], c1);
+            }
+            u32 w[10], k[8];
+            bnm::carry_pair(c0, c1, w, sh);
+            bnm::add_pair(w, pc[0]);
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int l = 0; l < 10; l++) pc[r][l] = pc[r + 1][l];
+            load_const<true>(A.KR, (size_t)(4 * b + i), k);
+            bnm::finish_words(w, k, x0);
+        }
+        for (int j = 0; j < n; j++) {
+            u32 y[8], k[8];
+            lds_load(st, 1 + j, y);
+            bnm::v4i b0, b1;
+            bnm::b_prep(y, b0, b1);
+            bnm::v4i a = ts.next();
+            bnm::v16i c0 = bnm::mfma(a, b0, bnm::acc_init()), c1 = bnm::mfma(a, b1, bnm::acc_init());
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                a = ts.next();
+                c0 = bnm::mfma(a, zb0[s], c0);
+                c1 = bnm::mfma(a, zb1[s], c1);
+            }
+            load_const<true>(A.KU, (size_t)b * n + j, k);
+            bnm::finish_row(c0, c1, k, y, sh);
+            lds_store(st, 1 + j, y);
+        }
+    }
+    lds_store(st, 0, x0);
+}
+
 // permutation of the t elements in buffer `cur`; returns the buffer holding the result
 template <bool WIDE>
 __device__ __noinline__ int bn_perm(const St &st, int cur, const PermArgs &A) {
@@ -514,7 +666,10 @@ __device__ __noinline__ int bn_perm(const St &st, int cur, const PermArgs &A) {
         add_sbox<WIDE>(st, cur, t, A.C8, (size_t)r * t, t);
         dense_layer<WIDE>(st, cur, A, false);
     }
-    partial_rounds<WIDE>(st, cur, A);
+    if (A.mfma) {
+        partial_rounds_mfma(st, A);
+        if (A.rp % 4) partial_rounds<WIDE>(st, cur, A, A.rp & ~3);   // the rounds left over, one by one
+    } else partial_rounds<WIDE>(st, cur, A, 0);
     dense_layer<WIDE>(st, cur, A, true);        // diag(1, Mh^RP)
     for (int r = 4; r < 8; r++) {
         add_sbox<WIDE>(st, cur, t, A.C8, (size_t)r * t, t);
@@ -743,7 +898,7 @@ PermArgs perm_args(const Params *P) {
     a.dense = dense ? 1 : 0;
     static const bool mfma = !(getenv("PIL2GL_BN128_MFMA") && !atoi(getenv("PIL2GL_BN128_MFMA")));   // =0: the layers on the vector ALU (A/B runs)
     a.mfma = mfma ? 1 : 0;
-    a.Mt = P->Mt; a.Dt = P->Dt; a.MK = P->MK; a.DK = P->DK;
+    a.Mt = P->Mt; a.Dt = P->Dt; a.Pt = P->Pt; a.MK = P->MK; a.DK = P->DK; a.KR = P->KR; a.KU = P->KU;
     memcpy(a.m00, P->m00, 32);
     return a;
 }

@@ -77,11 +77,23 @@ __device__ __forceinline__ void carry5(const v16i &a, u32 w[5], const Sh &sh) {
     w[4] = (u32)acc;
 }
 
-// the two tiles' accumulators of one row -> this lane's (permutation's) canonical out_i.  kc: the row's K_i, 8 limbs, wave-uniform.
-__device__ __forceinline__ void finish_row(const v16i &a0, const v16i &a1, const u32 *kc, u32 out[8], const Sh &sh) {
-    u32 w0[5], w1[5];
-    carry5(a0, w0, sh);
-    carry5(a1, w1, sh);
+// Both tiles' accumulators of one row -> ten words: w[0..4] / w[5..9] = this lane's 16 positions of tile 0 / tile 1 as 5-limb numbers
+__device__ __forceinline__ void carry_pair(const v16i &a0, const v16i &a1, u32 w[10], const Sh &sh) {
+    carry5(a0, w, sh);
+    carry5(a1, w + 5, sh);
+}
+// w += v as two 5-limb numbers (a row gathered in two accumulations, e.g. a partial round's row: the block's part and the cross terms)
+__device__ __forceinline__ void add_pair(u32 w[10], const u32 v[10]) {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        u64 c = 0;
+#pragma unroll
+        for (int l = 0; l < 5; l++) { c += (u64)w[5 * h + l] + v[5 * h + l]; w[5 * h + l] = (u32)c; c >>= 32; }
+    }
+}
+// the ten words of one row -> this lane's (permutation's) canonical out_i.  kc: the row's K_i, 8 limbs, wave-uniform.
+__device__ __forceinline__ void finish_words(u32 w[10], const u32 *kc, u32 out[8]) {
+    u32 *w0 = w, *w1 = w + 5;
 #pragma unroll
     for (int q = 0; q < 5; q++) {                     // afterwards w0 = low half (bits 0..159), w1 = high half (from bit 128) of the lane's own row
         const auto r = __builtin_amdgcn_permlane32_swap(w0[q], w1[q], false, false);
@@ -101,7 +113,7 @@ __device__ __forceinline__ void finish_row(const v16i &a0, const v16i &a1, const
     u32 o[9];
 #pragma unroll
     for (int l = 1; l < 8; l++) { v = (u64)m * bn::r_limb(l) + t[l] + (v >> 32); o[l - 1] = (u32)v; }
-    o[7] = t[8] + (u32)(v >> 32);                     // < 2^243 + r: eight limbs
+    o[7] = t[8] + (u32)(v >> 32);                     // < 2^244 + r: eight limbs
     // + K_i, then at most two subtractions of r
     u64 s = 0;
 #pragma unroll
@@ -111,6 +123,11 @@ __device__ __forceinline__ void finish_row(const v16i &a0, const v16i &a1, const
     bn::cond_sub_r(o);
 #pragma unroll
     for (int l = 0; l < 8; l++) out[l] = o[l];
+}
+__device__ __forceinline__ void finish_row(const v16i &a0, const v16i &a1, const u32 *kc, u32 out[8], const Sh &sh) {
+    u32 w[10];
+    carry_pair(a0, a1, w, sh);
+    finish_words(w, kc, out);
 }
 
 }  // namespace bnm

@@ -95,3 +95,141 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+# ------------------------------------------------------------------ the partial rounds, four to a block, rows as digit products
+def derive_sparse(t):
+    """bn128.hip::derive_sparse on plain integers: (C8[8][t], D[(t-1)^2], S[rp], V[rp][t-1], W[rp][t-1], m00)"""
+    C, M = O.poseidon_constants(t)
+    rp, n = O.N_ROUNDS_P[t - 2], t - 1
+    Mh = [[M[i + 1][j + 1] for j in range(n)] for i in range(n)]
+    v = [M[0][1 + j] for j in range(n)]
+    w = [M[i + 1][0] for i in range(n)]
+
+    def inv_mat(A):
+        A = [row[:] + [int(i == k) for k in range(n)] for i, row in enumerate(A)]
+        for c in range(n):
+            p = next(r for r in range(c, n) if A[r][c])
+            A[c], A[p] = A[p], A[c]
+            iv = pow(A[c][c], -1, R)
+            A[c] = [x * iv % R for x in A[c]]
+            for r in range(n):
+                if r != c and A[r][c]:
+                    f = A[r][c]
+                    A[r] = [(x - f * y) % R for x, y in zip(A[r], A[c])]
+        return [row[n:] for row in A]
+    Mhi = inv_mat(Mh)
+    mv = lambda A, x: [sum(a * b for a, b in zip(row, x)) % R for row in A]
+    S, V, W = [], [], []
+    e = C[4 * t:5 * t]
+    f = None
+    for k in range(rp):
+        S.append(e[0])
+        Me = mv(M, [0] + e[1:])
+        if k + 1 < rp:
+            e = [(C[(5 + k) * t + j] + Me[j]) % R for j in range(t)]
+        else:
+            f = Me
+    vk, wk = v, mv(Mhi, w)
+    for k in range(rp):
+        V.append(vk); W.append(wk)
+        vk = [sum(vk[i] * Mh[i][j] for i in range(n)) % R for j in range(n)]
+        wk = mv(Mhi, wk)
+    D = [[int(i == j) for j in range(n)] for i in range(n)]
+    for k in range(rp):
+        D = [[sum(Mh[i][q] * D[q][j] for q in range(n)) % R for j in range(n)] for i in range(n)]
+    C8 = [C[r * t:(r + 1) * t] for r in range(4)]
+    C8 += [[(C[(4 + rp) * t + j] + f[j]) % R for j in range(t)]] + [C[(4 + rp + r) * t:(5 + rp + r) * t] for r in range(1, 4)]
+    return C8, D, S, V, W, M[0][0], M
+
+
+def row_tables(coefs, n_acc=1, fold=0):
+    """one row: plain coefficients, one per operand -> (digits[j][b][k], K); fold: a Montgomery-form constant added to the row"""
+    dig = [[signed_digits(a * pow(256, b, R) * (1 << 32) % R) for b in range(32)] for a in coefs]
+    tot = sum(a * pow(256, b, R) * (1 << 32) % R for a in coefs for b in range(32))
+    K = ((128 * tot - n_acc * OFF) * pow(1 << 32, -1, R) + fold) % R
+    return dig, K
+
+
+def row_positions(dig, x):
+    S = [BIAS] * 32
+    for j, xj in enumerate(x):
+        assert 0 <= xj < MONT
+        for b in range(32):
+            s = ((xj >> (8 * b)) & 255) - 128
+            for k in range(32):
+                S[k] += dig[j][b][k] * s
+    assert all(0 < v < (1 << 26) for v in S)
+    return S
+
+
+def row_finish(pos_lists, K):
+    V = sum(sum(v << (8 * k) for k, v in enumerate(S)) for S in pos_lists)
+    m = (V % (1 << 32)) * N0INV % (1 << 32)
+    t = ((V + m * R) >> 32) + K
+    assert t < (1 << 255)
+    for _ in range(2):
+        if t >= R:
+            t -= R
+    assert t < R
+    return t
+
+
+def sbox(x):           # Montgomery form in and out
+    return pow(x, 5, R) * pow(MONT, -4, R) % R
+
+
+def partial_rounds_blocked(t, x, sp):
+    """x: Montgomery-form state entering the partial rounds -> state after them (before the closing D layer)"""
+    C8, D, S, V, W, m00, M = sp
+    rp, n = len(S), t - 1
+    toM = lambda a: a * MONT % R
+    nb = rp // 4
+    x0, y = x[0], x[1:]
+    x0 = (x0 + toM(S[0])) % R
+    for blk in range(nb):
+        k0 = 4 * blk
+        P = [row_positions(row_tables(V[k0 + i])[0], y) for i in range(4)]          # the block's rows on y at its start
+        z = []
+        for i in range(4):
+            z.append(sbox(x0))
+            coefs = [sum(V[k0 + i][j] * W[k0 + ip][j] for j in range(n)) % R for ip in range(i)] + [m00]
+            fold = toM(S[k0 + i + 1]) if k0 + i + 1 < 4 * nb else 0
+            dig, K = row_tables(coefs, 2, fold)
+            Kp = (K + 128 * sum(V[k0 + i][j] * pow(256, b, R) * (1 << 32) for j in range(n) for b in range(32)) * pow(1 << 32, -1, R)) % R
+            x0 = row_finish([P[i], row_positions(dig, z)], Kp)
+        for j in range(n):
+            dig, K = row_tables([1] + [W[k0 + i][j] for i in range(4)])
+            y[j] = row_finish([row_positions(dig, [y[j]] + z)], K)
+    for k in range(4 * nb, rp):                                                       # the rounds left over, as they are
+        x0 = (x0 + toM(S[k])) % R
+        zz = sbox(x0)
+        x0 = (m00 * zz + sum(V[k][j] * y[j] for j in range(n))) % R
+        y = [(y[j] + W[k][j] * zz) % R for j in range(n)]
+    return [x0] + y
+
+
+def check_blocked():
+    rnd = random.Random(9)
+    for t in (3, 6, 17):
+        sp = derive_sparse(t)
+        C8, D, S, V, W, m00, M = sp
+        n = t - 1
+        toM = lambda a: a * MONT % R
+        ins = [rnd.randrange(R) for _ in range(t)]
+        st = [toM(a) for a in ins]
+        for r in range(4):
+            st = [sbox((a + toM(c)) % R) for a, c in zip(st, C8[r])]
+            st = [sum(M[i][j] * st[j] for j in range(t)) % R for i in range(t)]
+        st = partial_rounds_blocked(t, st, sp)
+        st = [st[0]] + [sum(D[i][j] * st[1 + j] for j in range(n)) % R for i in range(n)]
+        for r in range(4, 8):
+            st = [sbox((a + toM(c)) % R) for a, c in zip(st, C8[r])]
+            st = [sum(M[i][j] * st[j] for j in range(t)) % R for i in range(t)]
+        got = [a * pow(MONT, -1, R) % R for a in st]
+        assert got == O.poseidon(ins[1:], ins[0], t), t
+        print("t = %2d: permutation with blocked partial rounds (rows as digit products) == oracle" % t)
+
+
+if __name__ == "__main__":
+    check_blocked()

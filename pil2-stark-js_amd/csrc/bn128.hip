@@ -221,7 +221,7 @@ U256 mfma_row_const(const MfmaConsts &mc, U256 tot, int nAcc, const U256 &fold) 
     for (int e = 0; e < nAcc; e++) tot = h_submod(tot, mc.off);
     return h_addmod(h_mont(tot, inv32), fold);
 }
-// A: rows x cols entries in Montgomery form.  tiles: rows*cols KB; K: rows plain integers mod r.
+// A: rows x cols entries in Montgomery form.  tiles: rows*cols KB; K: rows plain integers mod r (callers add what follows the layer).
 void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &tiles, Vec &K) {
     const MfmaConsts mc;
     const U256 zero = { { 0, 0, 0, 0 } };
@@ -291,10 +291,25 @@ int get_params(int t, const Params **out) {
         P.base = d; P.C8 = d + oC8 * 8; P.M = d + oM * 8; P.D = d + oD * 8; P.S = d + oS * 8; P.V = d + oV * 8; P.W = d + oW * 8; P.Cd = d + oCd * 8;
         memcpy(P.m00, M[0].w, 32);
         {
-            std::vector<int8_t> tm, td, tpr; Vec km, kd, kr, ku;
-            mfma_layer_tables(M, t, t, tm, km);
+            std::vector<int8_t> tm, td, tpr; Vec km0, km, kd, kr, ku;
+            mfma_layer_tables(M, t, t, tm, km0);
             mfma_layer_tables(D, n, n, td, kd);
             mfma_partial_tables(t, rp, S, V, W, M[0], tpr, kr, ku);
+            // What follows a layer is added by its row constants (the values in between are lazy representatives, no other addition
+            // is left): the next full round's constants C8; after the fourth full round S[0] on element 0; after the closing layer
+            // C8[4] on elements 1..n -- element 0 gets C8[4][0] from the last partial round's row when that round is one of the
+            // blocked ones (rp % 4 == 0), from the vector code otherwise.  MK: one set per dense layer of the permutation, 8 x t.
+            km.resize((size_t)8 * t);
+            const bool nofold = getenv("PIL2GL_BN128_NOFOLD") && atoi(getenv("PIL2GL_BN128_NOFOLD"));
+            for (int inst = 0; inst < 8; inst++) for (int i = 0; i < t; i++) {
+                U256 f = { { 0, 0, 0, 0 } };
+                if (nofold) {}
+                else if (inst == 3) { if (i == 0) f = S[0]; }
+                else if (inst < 7) f = C8[(size_t)(inst + 1) * t + i];
+                km[(size_t)inst * t + i] = h_addmod(km0[i], f);
+            }
+            if (!nofold) for (int i = 0; i < n; i++) kd[i] = h_addmod(kd[i], C8[(size_t)4 * t + 1 + i]);
+            if (!nofold && rp % 4 == 0 && rp >= 4) kr[(size_t)rp - 1] = h_addmod(kr[(size_t)rp - 1], C8[(size_t)4 * t]);
             const size_t spare = 16 * 1024;          // the tiles the read-ahead touches past the end of a table (MFMA_AHEAD)
             int8_t *dt = nullptr; u32 *dk = nullptr;
             HIP_TRY(hipMalloc((void **)&dt, tm.size() + td.size() + tpr.size() + 3 * spare));
@@ -318,7 +333,7 @@ int get_params(int t, const Params **out) {
 
 // ------------------------------------------------------------------------------------------ device side
 struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8];
-                  const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma; };
+                  const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma, nofold; };
 
 // Where the state lives.  Elements [0, BN_LDS_ELEMS) in LDS as [element][limb][lane]; the elements above -- only the states
 // wider than BN_LDS_ELEMS have any: t = 10..17 -- in the lane's own private (scratch) memory, which the hardware swizzles so
@@ -330,10 +345,11 @@ struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 
 #define BN_LDS_ELEMS 9
 #endif
 typedef u32 __attribute__((address_space(5))) *priv_u32;
-struct St { u32 *S; priv_u32 hi; int tmax, lane; };
+typedef u32 __attribute__((address_space(3))) *lds_u32;
+struct St { lds_u32 S; priv_u32 hi; int tmax, lane; };
 #define S_LDS(st, j, l) (st).S[(((j) * 8 + (l)) * BN_BLOCK) + (st).lane]
 
-__device__ __forceinline__ void lds_load(const St &st, int j, u32 x[8]) {
+__device__ __forceinline__ void lds_load(const St st, int j, u32 x[8]) {
     if (j < BN_LDS_ELEMS) {
 #pragma unroll
         for (int l = 0; l < 8; l++) x[l] = S_LDS(st, j, l);
@@ -342,7 +358,7 @@ __device__ __forceinline__ void lds_load(const St &st, int j, u32 x[8]) {
         for (int l = 0; l < 8; l++) x[l] = st.hi[(j - BN_LDS_ELEMS) * 8 + l];
     }
 }
-__device__ __forceinline__ void lds_store(const St &st, int j, const u32 x[8]) {
+__device__ __forceinline__ void lds_store(const St st, int j, const u32 x[8]) {
     if (j < BN_LDS_ELEMS) {
 #pragma unroll
         for (int l = 0; l < 8; l++) S_LDS(st, j, l) = x[l];
@@ -370,11 +386,42 @@ __device__ __forceinline__ void pow5(u32 x[8]) {
     u32 x2[8], x4[8];
     bn::fr_mul(x2, x, x); bn::fr_mul(x4, x2, x2); bn::fr_mul(x, x4, x);
 }
+// the same on lazy representatives: x < 0.69 * 2^256 in (a layer's output < 2^255, plus a round constant at most), x^5 < 0.63 * 2^256
+// out -- any 256-bit value will do for the matrix operand that reads it (bn_field.cuh fr_mul_nr)
+__device__ __forceinline__ void pow5_lazy(u32 x[8]) {
+    u32 x2[8], x4[8];
+    bn::fr_mul_nr(x2, x, x); bn::fr_mul_nr(x4, x2, x2); bn::fr_mul_nr(x, x4, x);
+}
+// x + c for a lazy x < 2^255 and a constant c < r: < 0.69 * 2^256, left as it is (the S-box that follows takes it, pow5_lazy)
+__device__ __forceinline__ void add_lazy(u32 x[8], const u32 c[8]) { bnm::add_chain8(x, c); }
+// The S-box layer of a full round in the matrix-core pipeline: the round's constants arrive with the previous layer's rows
+// (except the first round's, C != nullptr); lazy in, lazy out
+__device__ __noinline__ void sbox_lazy(const St st, int t, const u32 *C) {
+    for (int j = 0; j < t; j++) {
+        u32 x[8];
+        lds_load(st, j, x);
+        if (C) {
+            u32 c[8];
+            load_const<true>(C, (size_t)j, c);
+            add_lazy(x, c);
+        }
+        pow5_lazy(x);
+        lds_store(st, j, x);
+    }
+}
+__device__ __noinline__ void canon_state(const St st, int t) {
+    for (int j = 0; j < t; j++) {
+        u32 x[8];
+        lds_load(st, j, x);
+        bnm::canon(x);
+        lds_store(st, j, x);
+    }
+}
 
 // x^5 on elements [0, nSbox) after adding constants C[0..t), then the dense n x n matrix A applied to elements
 // [first, first+n) of buffer cur into buffer cur^1 (elements below `first` are copied)
 template <bool WIDE>
-__device__ __noinline__ void add_sbox(const St &st, int cur, int t, const u32 *C, size_t cOff, int nSbox) {
+__device__ __noinline__ void add_sbox(const St st, int cur, int t, const u32 *C, size_t cOff, int nSbox) {
     for (int j = 0; j < t; j++) {
         u32 x[8], c[8];
         lds_load(st, j, x);
@@ -388,7 +435,7 @@ __device__ __noinline__ void add_sbox(const St &st, int cur, int t, const u32 *C
 // 17 x 32 B, a few KB of traffic per permutation against ~10^5 multiply steps) until all rows are done; one LDS buffer per
 // wave then suffices (4 waves per CU at t = 17 instead of 2).
 template <bool WIDE>
-__device__ __noinline__ void dense_mul(const St &st, int cur, const u32 *A, int n, int first) {
+__device__ __noinline__ void dense_mul(const St st, int cur, const u32 *A, int n, int first) {
     u32 nw[17 * 8];
     for (int i = 0; i < n; i++) {
         u32 acc[17];
@@ -434,7 +481,7 @@ __device__ __noinline__ void dense_mul(const St &st, int cur, const u32 *A, int 
 // alone -- so the table carries MFMA_AHEAD spare tiles after its last one.
 constexpr int MFMA_AHEAD = 8;
 template <int N>
-__device__ __noinline__ void dense_mfma_n(const St &st, const bnm::v4i *tiles, const u32 *kc, int first) {
+__device__ __noinline__ void dense_mfma_n(const St st, const bnm::v4i *tiles, const u32 *kc, int first) {
     bnm::v4i B0[N], B1[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -465,7 +512,7 @@ __device__ __noinline__ void dense_mfma_n(const St &st, const bnm::v4i *tiles, c
         lds_store(st, first + i, o);                 // the old state is in B0 / B1: the new row can go straight to its place
     }
 }
-__device__ __forceinline__ void dense_mfma(const St &st, const bnm::v4i *tiles, const u32 *kc, int n, int first) {
+__device__ __forceinline__ void dense_mfma(const St st, const bnm::v4i *tiles, const u32 *kc, int n, int first) {
     switch (n) {
     case 1: dense_mfma_n<1>(st, tiles, kc, first); break;
     case 2: dense_mfma_n<2>(st, tiles, kc, first); break;
@@ -486,17 +533,11 @@ __device__ __forceinline__ void dense_mfma(const St &st, const bnm::v4i *tiles, 
     default: dense_mfma_n<17>(st, tiles, kc, first); break;
     }
 }
-template <bool WIDE>
-__device__ __forceinline__ void dense_layer(const St &st, int cur, const PermArgs &A, bool closing) {
-    const int n = closing ? A.t - 1 : A.t;
-    if (A.mfma) dense_mfma(st, closing ? A.Dt : A.Mt, closing ? A.DK : A.MK, n, closing ? 1 : 0);
-    else dense_mul<WIDE>(st, cur, closing ? A.D : A.M, n, closing ? 1 : 0);
-}
 
 // partial rounds, sparse form, in place: element 0 stays in registers.  WIDE: the next term's requests are pinned ahead of
 // the current term's two products (see dense_mul)
 template <bool WIDE>
-__device__ __noinline__ void partial_rounds(const St &st, int cur, const PermArgs &A, int kFirst) {
+__device__ __noinline__ void partial_rounds(const St st, int cur, const PermArgs &A, int kFirst) {
     const int t = A.t;
     u32 x0[8], m00[8];
     lds_load(st, 0, x0);
@@ -571,18 +612,13 @@ struct TileStream {
         return a;
     }
 };
-__device__ __noinline__ void partial_rounds_mfma(const St &st, const PermArgs &A) {
+__device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A) {
     const int n = A.t - 1, nb = A.rp / 4;
     const bnm::Sh sh = bnm::sh_init();
     TileStream ts;
     ts.start(A.Pt, st.lane);
     u32 x0[8];
-    lds_load(st, 0, x0);
-    {
-        u32 c[8];
-        load_const<true>(A.S, 0, c);
-        bn::fr_add(x0, c);
-    }
+    lds_load(st, 0, x0);                              // S[0] came with the row of the layer before
     for (int b = 0; b < nb; b++) {
         u32 pc[4][10];
         {
@@ -608,7 +644,7 @@ __device__ __noinline__ void partial_rounds_mfma(const St &st, const PermArgs &A
 #pragma unroll
         for (int s = 0; s < 4; s++) { zb0[s] = bnm::v4i{ 0, 0, 0, 0 }; zb1[s] = bnm::v4i{ 0, 0, 0, 0 }; }
         for (int i = 0; i < 4; i++) {
-            pow5(x0);
+            pow5_lazy(x0);
 #pragma unroll
             for (int s = 0; s < 3; s++) { zb0[s] = zb0[s + 1]; zb1[s] = zb1[s + 1]; }
             bnm::b_prep(x0, zb0[3], zb1[3]);
@@ -652,7 +688,7 @@ __device__ __noinline__ void partial_rounds_mfma(const St &st, const PermArgs &A
 
 // permutation of the t elements in buffer `cur`; returns the buffer holding the result
 template <bool WIDE>
-__device__ __noinline__ int bn_perm(const St &st, int cur, const PermArgs &A) {
+__device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
     const int t = A.t;
     if (A.dense) {                                   // poseidon.circom:22-44 as written (tests)
         for (int r = 0; r < N_ROUNDS_F + A.rp; r++) {
@@ -662,23 +698,47 @@ __device__ __noinline__ int bn_perm(const St &st, int cur, const PermArgs &A) {
         }
         return cur;
     }
+    if (A.mfma) {
+        // the linear layers on the matrix cores (bn_mfma.cuh); between them the state is lazy (< 2^255), every constant but the first
+        // round's arrives with a layer's rows, and the only 32x32 products left are the S-boxes'
+        for (int r = 0; r < 4; r++) {
+            sbox_lazy(st, t, r == 0 || A.nofold ? A.C8 + (size_t)r * t * 8 : nullptr);
+            dense_mfma(st, A.Mt, A.MK + (size_t)r * t * 8, t, 0);
+        }
+        if (A.nofold) { u32 x[8], c[8]; lds_load(st, 0, x); load_const<true>(A.S, 0, c); add_lazy(x, c); lds_store(st, 0, x); }
+        if (A.rp >= 4) partial_rounds_mfma(st, A);
+        if (A.rp % 4 || A.rp < 4) {                  // the rounds left over, one by one on canonical values
+            canon_state(st, t);
+            partial_rounds<WIDE>(st, cur, A, A.rp & ~3);
+            if (!A.nofold) {
+                u32 x[8], c[8];
+                lds_load(st, 0, x);
+                load_const<true>(A.C8, (size_t)4 * t, c);
+                bn::fr_add(x, c);
+                lds_store(st, 0, x);
+            }
+        }
+        dense_mfma(st, A.Dt, A.DK, t - 1, 1);        // diag(1, Mh^RP)
+        for (int r = 4; r < 8; r++) {
+            sbox_lazy(st, t, A.nofold ? A.C8 + (size_t)r * t * 8 : nullptr);
+            dense_mfma(st, A.Mt, A.MK + (size_t)r * t * 8, t, 0);
+        }
+        return cur;
+    }
     for (int r = 0; r < 4; r++) {
         add_sbox<WIDE>(st, cur, t, A.C8, (size_t)r * t, t);
-        dense_layer<WIDE>(st, cur, A, false);
+        dense_mul<WIDE>(st, cur, A.M, t, 0);
     }
-    if (A.mfma) {
-        partial_rounds_mfma(st, A);
-        if (A.rp % 4) partial_rounds<WIDE>(st, cur, A, A.rp & ~3);   // the rounds left over, one by one
-    } else partial_rounds<WIDE>(st, cur, A, 0);
-    dense_layer<WIDE>(st, cur, A, true);        // diag(1, Mh^RP)
+    partial_rounds<WIDE>(st, cur, A, 0);
+    dense_mul<WIDE>(st, cur, A.D, t - 1, 1);         // diag(1, Mh^RP)
     for (int r = 4; r < 8; r++) {
         add_sbox<WIDE>(st, cur, t, A.C8, (size_t)r * t, t);
-        dense_layer<WIDE>(st, cur, A, false);
+        dense_mul<WIDE>(st, cur, A.M, t, 0);
     }
     return cur;
 }
 
-__device__ __forceinline__ void to_mont_store(const St &st, int j, const u64 w[4]) {
+__device__ __forceinline__ void to_mont_store(const St st, int j, const u64 w[4]) {
     u32 x[8], r2[8], o[8];
 #pragma unroll
     for (int k = 0; k < 4; k++) { x[2 * k] = (u32)w[k]; x[2 * k + 1] = (u32)(w[k] >> 32); }
@@ -687,13 +747,14 @@ __device__ __forceinline__ void to_mont_store(const St &st, int j, const u64 w[4
     bn::fr_mul(o, x, r2);                            // frm_toMontgomery: x * 2^256 mod r (x < 2^256)
     lds_store(st, j, o);
 }
-__device__ __forceinline__ void zero_store(const St &st, int j) {
+__device__ __forceinline__ void zero_store(const St st, int j) {
     const u32 z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     lds_store(st, j, z);
 }
-__device__ __forceinline__ void digest_out(const St &st, int j, u64 *o) {
+__device__ __forceinline__ void digest_out(const St st, int j, u64 *o) {
     u32 x[8];
     lds_load(st, j, x);
+    bnm::canon(x);                                   // the matrix-core pipeline leaves lazy representatives
 #pragma unroll
     for (int k = 0; k < 4; k++) o[k] = (u64)x[2 * k] | ((u64)x[2 * k + 1] << 32);
 }
@@ -705,7 +766,7 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
     extern __shared__ u32 S[];
     const int lane = threadIdx.x, tmax = arity + 1;
     u32 hi_arr[(17 - BN_LDS_ELEMS) * 8];
-    const St st = { S, (priv_u32)hi_arr, tmax, lane };
+    const St st = { (lds_u32)S, (priv_u32)hi_arr, tmax, lane };
     const u64 row0 = (u64)blockIdx.x * BN_BLOCK + lane;
     const bool live = row0 < height;
     const u64 *v = in + (live ? row0 : height - 1) * width;
@@ -742,7 +803,7 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
     extern __shared__ u32 S[];
     const int lane = threadIdx.x, tmax = arity + 1;
     u32 hi_arr[(17 - BN_LDS_ELEMS) * 8];
-    const St st = { S, (priv_u32)hi_arr, tmax, lane };
+    const St st = { (lds_u32)S, (priv_u32)hi_arr, tmax, lane };
     const u64 i0 = (u64)blockIdx.x * BN_BLOCK + lane;
     const bool live = i0 < nOps;
     const u64 *v = in + (live ? i0 : nOps - 1) * (u64)arity * 4;
@@ -764,7 +825,7 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
     extern __shared__ u32 S[];
     const int lane = threadIdx.x, tmax = nIn + 1;
     u32 hi_arr[(17 - BN_LDS_ELEMS) * 8];
-    const St st = { S, (priv_u32)hi_arr, tmax, lane };
+    const St st = { (lds_u32)S, (priv_u32)hi_arr, tmax, lane };
     const u64 i0 = (u64)blockIdx.x * BN_BLOCK + lane;
     const bool live = i0 < count;
     const u64 i = live ? i0 : count - 1;
@@ -898,6 +959,8 @@ PermArgs perm_args(const Params *P) {
     a.dense = dense ? 1 : 0;
     static const bool mfma = !(getenv("PIL2GL_BN128_MFMA") && !atoi(getenv("PIL2GL_BN128_MFMA")));   // =0: the layers on the vector ALU (A/B runs)
     a.mfma = mfma ? 1 : 0;
+    static const bool nofold = getenv("PIL2GL_BN128_NOFOLD") && atoi(getenv("PIL2GL_BN128_NOFOLD"));
+    a.nofold = nofold ? 1 : 0;
     a.Mt = P->Mt; a.Dt = P->Dt; a.Pt = P->Pt; a.MK = P->MK; a.DK = P->DK; a.KR = P->KR; a.KU = P->KU;
     memcpy(a.m00, P->m00, 32);
     return a;

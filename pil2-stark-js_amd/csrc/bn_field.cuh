@@ -168,6 +168,18 @@ __device__ __forceinline__ void fr_mul(u32 out[8], const u32 a[8], const u32 b[8
     for (int i = 0; i < 8; i++) out[i] = t[i];
 }
 
+// the same product WITHOUT the final subtraction: out = (ab + m r) / 2^256 < ab / 2^256 + r, which fits eight limbs whenever
+// a, b < 0.9 * 2^256 (and is < 2^255 for a, b < 2^255): the lazy representatives between the matrix-core layers (bn_mfma.cuh)
+__device__ __forceinline__ void fr_mul_nr(u32 out[8], const u32 a[8], const u32 b[8]) {
+    u32 m[8], t[9], rl[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rl[i] = r_limb(i);
+    u64 lo = 0; u32 hi = 0;
+    fr_mul_col<0>(lo, hi, a, b, m, rl, t);
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = t[i];
+}
+
 // operand-scanning (CIOS) form of the same product, compiler-generated carries (reference implementation for tests)
 __device__ __forceinline__ void fr_mul_os(u32 out[8], const u32 a[8], const u32 b[8]) {
     u32 t[10];

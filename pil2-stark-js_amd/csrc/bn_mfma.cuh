@@ -9,7 +9,7 @@
 // K_i = (128 sum_{j,b} c[i][j][b] - sum_k 2^25 256^k) / 2^32 mod r takes back the two offsets (operand bytes are fed as signed
 // u - 128; the accumulators start at 2^25, the instruction's inline constant, so that every S is positive).  The reduction mod r
 // is in the constants: ONE 32-bit Montgomery step per row is left of the 8-step reduction the vector form pays per row, and no
-// 32x32 product of the state at all.  out_i < 2^242.01 + 2r: two conditional subtractions make it canonical.
+// 32x32 product of the state at all.  out_i < 2^244 + 2r < 2^255 stays as it is (lazy) until the permutation's output is read.
 // Integer model of exactly these steps against the plain statement: tools/bn_mfma_model.py.
 //
 // Who holds what.  The kernels keep ONE PERMUTATION PER LANE (bn128.hip).  D(32x32) = A(32x32) * B(32x32) serves 32 permutations
@@ -44,6 +44,8 @@ __device__ __forceinline__ v16i acc_init() {
 }
 
 // the operands of both tiles from the lane's own eight limbs
+// (the swaps go through the builtin: hipcc pads a vector write against the swap that reads it -- two wait states -- itself;
+// their inputs must therefore come from compiler-generated instructions, not straight out of an asm statement)
 __device__ __forceinline__ void b_prep(const u32 x[8], v4i &b0, v4i &b1) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -55,26 +57,57 @@ __device__ __forceinline__ void b_prep(const u32 x[8], v4i &b0, v4i &b1) {
 
 __device__ __forceinline__ v16i mfma(v4i a, v4i b, v16i c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
 
-// sum_{k<16} 256^k a[k] (every a[k] < 2^26) -> five 32-bit words.  The shifts are multiply-adds by constants kept opaque in
-// scalar registers: x * 2^8 + acc stays ONE v_mad_u64_u32 instead of a 64-bit shift and a 64-bit add.
-struct Sh { u32 s8, s16, s24; };
+// ---- carry chains through vcc, one statement each (the compiler's 64-bit emulation costs two to three times the instructions)
+// a[0..N) += b[0..N), the carry out of the top limb is dropped (the callers' sums fit)
+#define BNM_ADDC(i, j) "v_addc_co_u32 %" #i ", vcc, %" #i ", %" #j ", vcc\n\t"
+__device__ __forceinline__ void add_chain5(u32 a[5], const u32 b[5]) {
+    asm("v_add_co_u32 %0, vcc, %0, %5\n\t" BNM_ADDC(1, 6) BNM_ADDC(2, 7) BNM_ADDC(3, 8) BNM_ADDC(4, 9)
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]) : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]) : "vcc");
+}
+__device__ __forceinline__ void add_chain8(u32 a[8], const u32 b[8]) {
+    asm("v_add_co_u32 %0, vcc, %0, %8\n\t" BNM_ADDC(1, 9) BNM_ADDC(2, 10) BNM_ADDC(3, 11) BNM_ADDC(4, 12) BNM_ADDC(5, 13) BNM_ADDC(6, 14) BNM_ADDC(7, 15)
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7])
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+}
+// a[0..9) += b[0..8) (the ninth limb takes the carry)
+__device__ __forceinline__ void add_chain9_8(u32 a[9], const u32 b[8]) {
+    asm("v_add_co_u32 %0, vcc, %0, %9\n\t" BNM_ADDC(1, 10) BNM_ADDC(2, 11) BNM_ADDC(3, 12) BNM_ADDC(4, 13) BNM_ADDC(5, 14) BNM_ADDC(6, 15) BNM_ADDC(7, 16)
+        "v_addc_co_u32 %8, vcc, 0, %8, vcc"
+        : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(a[8])
+        : "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]), "v"(b[5]), "v"(b[6]), "v"(b[7]) : "vcc");
+}
+// 32 x 32 -> 64 and multiply-add on a 64-bit accumulator, one v_mad_u64_u32 each; the constant operand sits in a scalar register
+__device__ __forceinline__ u64 mul_s(u32 x, u32 sc) { u64 d; asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(x), "s"(sc) : "vcc"); return d; }
+__device__ __forceinline__ u64 mad_s(u32 x, u32 sc, u64 acc) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(sc) : "vcc"); return acc; }
+
+// sum_{k<16} 256^k a[k] (every a[k] < 2^26) -> five 32-bit words.  Per limb the three shifted terms are ONE 64-bit value (three
+// multiply-adds by 2^8, 2^16, 2^24 held in scalar registers, no chain between limbs); the unshifted term and the previous limb's
+// overflow (< 2^19) add without carry in 32 bits; one five-limb chain joins them: 12 + 3 + 5 instructions.
+struct Sh { u32 s8, s16, s24; u64 zero; };
 __device__ __forceinline__ Sh sh_init() {
-    Sh s = { 1u << 8, 1u << 16, 1u << 24 };
-    asm volatile("" : "+s"(s.s8), "+s"(s.s16), "+s"(s.s24));
+    Sh s = { 1u << 8, 1u << 16, 1u << 24, 0 };
+    asm volatile("" : "+s"(s.s8), "+s"(s.s16), "+s"(s.s24), "+v"(s.zero));   // opaque: x * 2^8 + 0 stays one multiply-add
     return s;
 }
 __device__ __forceinline__ void carry5(const v16i &a, u32 w[5], const Sh &sh) {
-    u64 acc = 0;
+    // The accumulators are read by COMPILER-generated instructions only: hipcc pads a matrix instruction's result against its
+    // first reader (the hardware does not interlock it), but not against a reader inside an asm statement.
+    u64 L[4];
 #pragma unroll
     for (int l = 0; l < 4; l++) {
-        acc += (u32)a[4 * l];
-        acc = (u64)(u32)a[4 * l + 1] * sh.s8 + acc;
-        acc = (u64)(u32)a[4 * l + 2] * sh.s16 + acc;
-        acc = (u64)(u32)a[4 * l + 3] * sh.s24 + acc;
-        w[l] = (u32)acc;
-        acc >>= 32;
+        L[l] = (u64)(u32)a[4 * l + 1] * sh.s8 + sh.zero;
+        L[l] = (u64)(u32)a[4 * l + 2] * sh.s16 + L[l];
+        L[l] = (u64)(u32)a[4 * l + 3] * sh.s24 + L[l];
     }
-    w[4] = (u32)acc;
+    u32 e[5];
+    e[0] = (u32)a[0];
+#pragma unroll
+    for (int l = 1; l < 4; l++) e[l] = (u32)a[4 * l] + (u32)(L[l - 1] >> 32);
+    e[4] = 0;
+#pragma unroll
+    for (int l = 0; l < 4; l++) w[l] = (u32)L[l];
+    w[4] = (u32)(L[3] >> 32);
+    add_chain5(w, e);
 }
 
 // Both tiles' accumulators of one row -> ten words: w[0..4] / w[5..9] = this lane's 16 positions of tile 0 / tile 1 as 5-limb numbers
@@ -84,50 +117,82 @@ __device__ __forceinline__ void carry_pair(const v16i &a0, const v16i &a1, u32 w
 }
 // w += v as two 5-limb numbers (a row gathered in two accumulations, e.g. a partial round's row: the block's part and the cross terms)
 __device__ __forceinline__ void add_pair(u32 w[10], const u32 v[10]) {
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        u64 c = 0;
-#pragma unroll
-        for (int l = 0; l < 5; l++) { c += (u64)w[5 * h + l] + v[5 * h + l]; w[5 * h + l] = (u32)c; c >>= 32; }
-    }
+    add_chain5(w, v);
+    add_chain5(w + 5, v + 5);
 }
-// the ten words of one row -> this lane's (permutation's) canonical out_i.  kc: the row's K_i, 8 limbs, wave-uniform.
+// The ten words of one row -> this lane's (permutation's) out_i, LAZY: some representative below 2^255 (the values between the
+// layers are such: the matrix operands take ANY 256-bit representative, and the S-box's reduction-free products of operands below
+// 0.9 * 2^256 stay below 2^256 -- fr_mul_nr).
+// kc: the row's K_i, 8 limbs, wave-uniform.  V + 2^32 K + m r with m = -V/r mod 2^32, all three additions as carry chains.
 __device__ __forceinline__ void finish_words(u32 w[10], const u32 *kc, u32 out[8]) {
     u32 *w0 = w, *w1 = w + 5;
-#pragma unroll
-    for (int q = 0; q < 5; q++) {                     // afterwards w0 = low half (bits 0..159), w1 = high half (from bit 128) of the lane's own row
-        const auto r = __builtin_amdgcn_permlane32_swap(w0[q], w1[q], false, false);
-        w0[q] = r[0];
-        w1[q] = r[1];
-    }
-    u32 t[9];
+    // afterwards w0 = low half (bits 0..159), w1 = high half (from bit 128) of the lane's own row.  The words come out of asm
+    // statements (the carry chains), which hipcc does not pad against the swap: the two wait states are in the statement.
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %5\n\tv_permlane32_swap_b32 %1, %6\n\tv_permlane32_swap_b32 %2, %7\n\t"
+                 "v_permlane32_swap_b32 %3, %8\n\tv_permlane32_swap_b32 %4, %9"
+                 : "+v"(w0[0]), "+v"(w0[1]), "+v"(w0[2]), "+v"(w0[3]), "+v"(w0[4]), "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(w1[4]));
+    u32 t[9], z5[5] = { w0[4], 0, 0, 0, 0 };
 #pragma unroll
     for (int l = 0; l < 4; l++) t[l] = w0[l];
-    u64 c = (u64)w0[4] + w1[0];
-    t[4] = (u32)c; c >>= 32;
 #pragma unroll
-    for (int l = 1; l < 5; l++) { c += w1[l]; t[4 + l] = (u32)c; c >>= 32; }
-    // one Montgomery step: (V + m r) / 2^32
+    for (int l = 0; l < 5; l++) t[4 + l] = w1[l];
+    add_chain5(t + 4, z5);                            // V < 2^276: nine limbs
+    u32 k[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) k[l] = kc[l];
     const u32 m = t[0] * bn::N0INV;
-    u64 v = (u64)m * bn::r_limb(0) + t[0];
-    u32 o[9];
+    add_chain8(t + 1, k);                             // + 2^32 K (does not touch the limb m comes from)
+    u32 ul[8], uh[8], rl[8];
 #pragma unroll
-    for (int l = 1; l < 8; l++) { v = (u64)m * bn::r_limb(l) + t[l] + (v >> 32); o[l - 1] = (u32)v; }
-    o[7] = t[8] + (u32)(v >> 32);                     // < 2^244 + r: eight limbs
-    // + K_i, then at most two subtractions of r
-    u64 s = 0;
+    for (int l = 0; l < 8; l++) { rl[l] = bn::r_limb(l); asm volatile("" : "+s"(rl[l])); }   // r in scalar registers: one v_mad_u64_u32 per limb, no literal moves
+    u64 u[8];
+    asm("v_mad_u64_u32 %0, vcc, %8, %9, 0\n\tv_mad_u64_u32 %1, vcc, %8, %10, 0\n\tv_mad_u64_u32 %2, vcc, %8, %11, 0\n\tv_mad_u64_u32 %3, vcc, %8, %12, 0\n\t"
+        "v_mad_u64_u32 %4, vcc, %8, %13, 0\n\tv_mad_u64_u32 %5, vcc, %8, %14, 0\n\tv_mad_u64_u32 %6, vcc, %8, %15, 0\n\tv_mad_u64_u32 %7, vcc, %8, %16, 0"
+        : "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7])
+        : "v"(m), "s"(rl[0]), "s"(rl[1]), "s"(rl[2]), "s"(rl[3]), "s"(rl[4]), "s"(rl[5]), "s"(rl[6]), "s"(rl[7]) : "vcc");
 #pragma unroll
-    for (int l = 0; l < 8; l++) { s += (u64)o[l] + kc[l]; o[l] = (u32)s; s >>= 32; }
-    o[8] = 0;                                         // < 2^255
-    bn::cond_sub_r(o);
-    bn::cond_sub_r(o);
+    for (int l = 0; l < 8; l++) { ul[l] = (u32)u[l]; uh[l] = (u32)(u[l] >> 32); }
+    add_chain9_8(t, ul);                              // limb 0 becomes 0
+    add_chain8(t + 1, uh);                            // (V + m r) / 2^32 + K < 2^244 + 2r < 2^255
 #pragma unroll
-    for (int l = 0; l < 8; l++) out[l] = o[l];
+    for (int l = 0; l < 8; l++) out[l] = t[1 + l];
 }
 __device__ __forceinline__ void finish_row(const v16i &a0, const v16i &a1, const u32 *kc, u32 out[8], const Sh &sh) {
     u32 w[10];
     carry_pair(a0, a1, w, sh);
     finish_words(w, kc, out);
+}
+// t (nine limbs) -> t - r if t >= r, IN PLACE.  bn::cond_sub_r writes the differences to fresh registers and selects; when its
+// result is copied back over its input inside a loop, hipcc's coalescer has been seen to give a difference the register of the
+// limb it is selected against (v_cndmask v8, v8, v8: both outcomes the difference).  Here nothing but two scratch registers is
+// an output: the borrow of t - r becomes a mask, r AND the mask is subtracted in place.
+__device__ __forceinline__ void cond_sub_r_inplace(u32 t[9]) {
+    u32 scr, mask;
+    asm("v_sub_co_u32 %0, vcc, %2, %11\n\tv_subb_co_u32 %0, vcc, %3, %12, vcc\n\tv_subb_co_u32 %0, vcc, %4, %13, vcc\n\tv_subb_co_u32 %0, vcc, %5, %14, vcc\n\t"
+        "v_subb_co_u32 %0, vcc, %6, %15, vcc\n\tv_subb_co_u32 %0, vcc, %7, %16, vcc\n\tv_subb_co_u32 %0, vcc, %8, %17, vcc\n\tv_subb_co_u32 %0, vcc, %9, %18, vcc\n\t"
+        "v_subbrev_co_u32 %0, vcc, 0, %10, vcc\n\tv_cndmask_b32_e64 %1, -1, 0, vcc"
+        : "=&v"(scr), "=&v"(mask)
+        : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(t[8]),
+          "v"(bn::r_limb(0)), "v"(bn::r_limb(1)), "v"(bn::r_limb(2)), "v"(bn::r_limb(3)), "v"(bn::r_limb(4)), "v"(bn::r_limb(5)), "v"(bn::r_limb(6)), "v"(bn::r_limb(7)) : "vcc");
+    u32 rm[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) rm[l] = bn::r_limb(l) & mask;
+    asm("v_sub_co_u32 %0, vcc, %0, %9\n\tv_subb_co_u32 %1, vcc, %1, %10, vcc\n\tv_subb_co_u32 %2, vcc, %2, %11, vcc\n\tv_subb_co_u32 %3, vcc, %3, %12, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %4, %13, vcc\n\tv_subb_co_u32 %5, vcc, %5, %14, vcc\n\tv_subb_co_u32 %6, vcc, %6, %15, vcc\n\tv_subb_co_u32 %7, vcc, %7, %16, vcc\n\t"
+        "v_subbrev_co_u32 %8, vcc, 0, %8, vcc"
+        : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8])
+        : "v"(rm[0]), "v"(rm[1]), "v"(rm[2]), "v"(rm[3]), "v"(rm[4]), "v"(rm[5]), "v"(rm[6]), "v"(rm[7]) : "vcc");
+}
+// any representative below 2^255 (< 3r) -> the canonical one: two subtractions at most
+__device__ __forceinline__ void canon(u32 x[8]) {
+    u32 t[9];
+#pragma unroll
+    for (int l = 0; l < 8; l++) t[l] = x[l];
+    t[8] = 0;
+    cond_sub_r_inplace(t);
+    cond_sub_r_inplace(t);
+#pragma unroll
+    for (int l = 0; l < 8; l++) x[l] = t[l];
 }
 
 }  // namespace bnm

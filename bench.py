@@ -323,13 +323,24 @@ def lde_int_roofline(n_bits, n_cols, cosets, ms):
             "note": "the passes run at 94-100 % of their vector-ALU issue slots (profiles/r03_valu_utilisation.json): the distance to the floor is instruction count, not memory"}
 
 
-def bn128_mads(t):
-    """v_mad_u64_u32 steps of one BN254 Poseidon permutation of width t as bn128.hip computes it (Montgomery product 128,
-    an unreduced 64 per accumulated product + 64 per reduction), RF = 8, RP from poseidon.circom:7-9"""
+def bn128_work(t):
+    """(v_mad_u64_u32 steps, matrix instructions per 64 permutations) of one BN254 Poseidon permutation of width t as bn128.hip
+    computes it since round 5 (csrc/bn_mfma.cuh): every linear layer -- the dense MDS products, and the partial rounds four to a
+    block: rows, cross terms, column updates -- is a constant-tile product on v_mfma_i32_32x32x32_i8; the vector ALU keeps the
+    S-boxes (three Montgomery products of 128 steps each) and, per finished row, the 2 x 12 steps that carry the byte positions
+    plus the 8 of the one 32-bit Montgomery step.  RF = 8, RP from poseidon.circom:7-9; RP % 4 rounds run in the old vector form."""
     rp = [56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68][t - 2]
-    full = 8 * (t * 3 * 128 + t * (t * 64 + 64))
-    partial = rp * (3 * 128 + (t * 64 + 64) + (t - 1) * 128)
-    return full + partial
+    n, nb, tail = t - 1, rp // 4, rp % 4
+    sbox = (8 * t + rp) * 3 * 128
+    rows = 8 * t + n + 4 * nb + nb * n                                    # dense rows, closing layer, round rows, column updates
+    finish = rows * 32 + 4 * nb * 24                                      # + the block part of a round's row is carried on its own
+    valu_tail = tail * ((t * 64 + 64) + n * 128)
+    mfma = 2 * (8 * t * t + n * n) + nb * 2 * (4 * n + 16 + 5 * n)        # pairs: two 32-permutation tiles per wave
+    return sbox + finish + valu_tail, mfma
+
+
+def bn128_mads(t):
+    return bn128_work(t)[0]
 
 
 def start_watchdog(Progress):
@@ -632,8 +643,10 @@ def bench_bn128(args, dev, wl, n_bits, n_cols):
     while n > 1:
         n = (n - 1) // arity + 1; tree_perms += n
     mads = E * leaf_mads + tree_perms * bn128_mads(arity + 1)
+    mfmas = (E * sum(bn128_work(c + 1)[1] for c in chunks) + tree_perms * bn128_work(arity + 1)[1]) / 64.0    # per wave of 64 permutations
     floor_cyc = mads * CYC_MAD_U64_U32 / 64.0 / N_SIMD                              # chip-wide: a v_mad_u64_u32 serves 64 lanes of one of 1024 SIMDs
-    floor_ms = floor_cyc / CLOCK_HZ * 1e3
+    floor_mfma_cyc = mfmas * 32.0 / N_SIMD                                          # 32 cycles of a SIMD's matrix pipe per 32x32x32 i8 instruction
+    floor_ms = max(floor_cyc, floor_mfma_cyc) / CLOCK_HZ * 1e3                      # the two pipes run side by side (two waves per SIMD)
     alg = 8 * E * n_cols + 32 * (E + tree_perms)
     out = {"metric": "trace-cells/s, STARK commit step (extend + BN128 Poseidon Merkle tree, arity 16), blow-up 8",
            "value": N * n_cols / dt, "unit": "trace-cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
@@ -645,7 +658,9 @@ def bench_bn128(args, dev, wl, n_bits, n_cols):
                         "note": "BN254 Poseidon is integer-issue bound by three orders of magnitude; see roofline_int_issue"},
            "roofline_int_issue": {"bound": "int-issue", "kernel": "bn_linear_hash_kernel", "achieved": t_tree, "floor": floor_ms, "unit": "ms per tree at %.1f GHz" % (CLOCK_HZ / 1e9),
                                   "frac": floor_ms / t_tree, "v_mad_u64_u32_per_row": leaf_mads, "cycles_each": CYC_MAD_U64_U32,
-                                  "note": "floor = every 32x32 product of the Montgomery multiplications and reductions (bn128_mads) issued back to back at the measured 4.5 cycles, nothing else"},
+                                  "vector_floor_ms": floor_cyc / CLOCK_HZ * 1e3, "matrix_floor_ms": floor_mfma_cyc / CLOCK_HZ * 1e3,
+                                  "v_mfma_i32_32x32x32_i8_per_row": sum(bn128_work(c + 1)[1] for c in chunks) / 64.0, "matrix_cycles_each": 32,
+                                  "note": "floor = the larger of (a) every 32x32 product left on the vector ALU -- the S-boxes' Montgomery products and the rows' carry / reduction steps (bn128_work) -- issued back to back at the measured 4.5 cycles and (b) every matrix instruction of the linear layers at 32 cycles of its SIMD's matrix pipe; round 4's all-vector form needed 971 648 products per row (floor 3 847 ms)"},
            "kernels": [{"kernel": "BN128 merkelize (leaf hash + tree)", "ms": t_tree, "perms": leaf_perms + tree_perms, "Mperm_s": (leaf_perms + tree_perms) / t_tree / 1e3},
                        {"kernel": "interpolate", "ms": t_lde, "alg_bytes": 8 * N * n_cols * (1 + (1 << EXT_BITS)), "GBps": 8 * N * n_cols * 9 / t_lde / 1e6}],
            "root": hex(MH.root(tree))}

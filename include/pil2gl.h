@@ -224,6 +224,11 @@ int pil2gl_cols_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *w
 /* callCalculateExps / calculateExps: run the op-list on every row of the domain.  Section pointers in
  * ctx are DEVICE pointers; prog/ctx structs themselves are host memory (copied at launch). */
 int pil2gl_eval_program_dev(const glx_program *prog, const glx_ctx *ctx, void *stream);
+/* calculateExps with debug = true (prover_helpers.js:46-70: a constraint evaluated on the rows [first, last) of its boundary, stopping
+ * at the first row whose value is not zero): after the constraint's program has written its value to a column of `dim` (1 or 3) words
+ * per row, *hostRow = the smallest such row (UINT64_MAX if the constraint holds on the whole range) and hostVal[0..dim) its value.
+ * Blocks until the answer is on the host. */
+int pil2gl_first_nonzero_row_dev(const uint64_t *col, uint32_t dim, uint64_t first, uint64_t last, uint64_t *hostRow, uint64_t *hostVal, void *stream);
 
 /* ---- stage-2 witness hints (hints_helpers.js:91-114) ------------------------------------------------------------
  * calculateZ(F,num,den)  polutils.js:128-143: out[0] = 1, out[i] = out[i-1]*num[i-1]/den[i-1]   (num, den: n rows)

@@ -68,4 +68,6 @@ write("fib_flow_impols.json", False, False, True)
 # pil2 boundaries (everyFrame, firstRow, lastRow) instead of selector constants: one zerofier column of Zi_ext per boundary
 write("fib_flow_boundaries.json", False, False, True, True)
 # two witness stages: expressionsInfo.hintsInfo in the reference's shape, numerator / denominator as expressions (hints_helpers.js:21-33,102-113)
+# boundaries alone (no intermediate polynomials)
+write("fib_flow_boundaries_only.json", False, False, False, True)
 write("perm_flow_hints.json", False, perm_copies=2)

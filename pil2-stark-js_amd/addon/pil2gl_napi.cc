@@ -357,6 +357,17 @@ FN(EvalProgramDev) {
     P2(env, pil2gl_eval_program_dev(&prog, &ctx, nullptr)); return mk_undefined(env);
 }
 
+// (devCol, dim, first, last) -> [row, v0, v1, v2] as BigInt, row = 2^64-1 when the column is zero on [first, last)
+FN(FirstNonzeroRowDev) {
+    Args a(env, info); uint64_t col = a.u64(0), dim = a.u64(1), first = a.u64(2), last = a.u64(3);
+    if (!a.ok) return nullptr;
+    uint64_t out[4] = { 0, 0, 0, 0 };
+    P2(env, pil2gl_first_nonzero_row_dev((const uint64_t *)(uintptr_t)col, (uint32_t)dim, first, last, &out[0], &out[1], nullptr));
+    napi_value arr; NAPI_CALL(env, napi_create_array_with_length(env, 4, &arr));
+    for (uint32_t i = 0; i < 4; i++) { napi_value v; NAPI_CALL(env, napi_create_bigint_uint64(env, out[i], &v)); NAPI_CALL(env, napi_set_element(env, arr, i, v)); }
+    return arr;
+}
+
 static napi_value ModuleInit(napi_env env, napi_value exports) {
     struct { const char *name; napi_callback fn; } fns[] = {
         { "init", Init }, { "shutdown", Shutdown }, { "deviceInfo", DeviceInfo },
@@ -373,7 +384,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "buildLevDev", BuildLevDev }, { "computeEvalsDev", ComputeEvalsDev }, { "gprodDev", GprodDev }, { "gsumDev", GsumDev }, { "h1h2Dev", H1H2Dev },
         { "rowsDotExtDev", RowsDotExtDev }, { "rowsDotExtMultiDev", RowsDotExtMultiDev }, { "friCombineDev", FriCombineDev }, { "colsDotExtDev", ColsDotExtDev }, { "colsDotExtMultiDev", ColsDotExtMultiDev }, { "synthFibonacciDev", SynthFibonacciDev },
         { "friFoldDev", FriFoldDev }, { "friTransposeDev", FriTransposeDev },
-        { "friFold", FriFold }, { "friVerifyFold", FriVerifyFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev },
+        { "friFold", FriFold }, { "friVerifyFold", FriVerifyFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev }, { "firstNonzeroRowDev", FirstNonzeroRowDev },
     };
     for (auto &f : fns) {
         napi_value v;

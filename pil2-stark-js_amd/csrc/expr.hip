@@ -669,3 +669,37 @@ interpreter:
     HIP_TRY(hipStreamSynchronize(st));          // the staging copies above come from stack/heap buffers
     return PIL2GL_OK;
 }
+
+// ---- constraint checking (calculateExps with debug = true, prover_helpers.js:46-70) --------------------------------------------
+// The reference evaluates a constraint on the rows of its boundary, one after the other, and stops at the first row where the value
+// is not zero.  Here the program has run on the whole domain (pil2gl_eval_program_dev with the last destination sent to a column);
+// what is left is the smallest row of [first, last) whose value is non-zero: one atomic minimum per block that saw one.
+__global__ void first_nonzero_kernel(const u64 *__restrict__ col, u32 dim, u64 first, u64 last, unsigned long long *__restrict__ best) {
+    const u64 r = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    bool nz = false;
+    if (r < last) for (u32 k = 0; k < dim; k++) nz |= col[r * dim + k] != 0;
+    const u64 mask = __ballot(nz);
+    if (mask && (threadIdx.x & 63) == 0) atomicMin(best, (unsigned long long)(r + __builtin_ctzll(mask)));
+}
+extern "C" int pil2gl_first_nonzero_row_dev(const uint64_t *col, uint32_t dim, uint64_t first, uint64_t last, uint64_t *hostRow, uint64_t *hostVal, void *stream) {
+    P2_TRY(ensure_init());
+    if (!hostRow || !hostVal) return fail(PIL2GL_EINVAL, "null buffer");
+    if (dim != 1 && dim != 3) return fail(PIL2GL_EINVAL, "dim must be 1 or 3 (got %u)", dim);
+    if (last < first) return fail(PIL2GL_EINVAL, "empty range [%llu, %llu)", (unsigned long long)first, (unsigned long long)last);
+    *hostRow = ~0ull;
+    for (u32 k = 0; k < dim; k++) hostVal[k] = 0;
+    if (last == first) return PIL2GL_OK;
+    if (!col) return fail(PIL2GL_EINVAL, "null buffer");
+    const u64 blocks = (last - first + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
+    hipStream_t st = as_stream(stream);
+    u64 *d;
+    P2_TRY(scratch(4, 1, &d));
+    HIP_TRY(hipMemsetAsync(d, 0xff, 8, st));
+    first_nonzero_kernel<<<(unsigned)blocks, 256, 0, st>>>(col, dim, first, last, (unsigned long long *)d);
+    KERNEL_CHECK();
+    HIP_TRY(hipMemcpyAsync(hostRow, d, 8, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (*hostRow != ~0ull) HIP_TRY(hipMemcpy(hostVal, col + *hostRow * dim, (size_t)dim * 8, hipMemcpyDeviceToHost));
+    return PIL2GL_OK;
+}

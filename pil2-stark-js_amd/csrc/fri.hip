@@ -334,6 +334,7 @@ int pil2gl_geometric_dev(uint64_t first, uint64_t ratio, uint64_t n, uint64_t *o
     P2_TRY(ensure_init());
     if (n == 0) return PIL2GL_OK;
     if (!out || n > (1ull << 40)) return fail(PIL2GL_EINVAL, "bad geometric-sequence arguments");
+    if ((n + 255) / 256 > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");      // 2^39 elements and more: beyond one launch
     const u64 p = 0xFFFFFFFF00000001ull;
     GeomPow R;
     u64 cur = ratio % p;

@@ -99,7 +99,8 @@ function encode(code, dom, ctx, global) {
 // the domain -- an array of BigInt (dim 1) or of [a, b, c] (dim 3) -- which is how the hints read a numerator / denominator / lookup
 // column that is an expression rather than a committed polynomial (getHintField op "tmp", hints_helpers.js:32).  The last op's
 // destination is redirected to a scratch column on the device; nothing else of the program changes.
-function run(code, dom, ctx, global, ret) {
+// ret === "dev": the column stays in HBM and `onDev(devPtr, dim, rows)` reads what it needs of it (constraint checking).
+function run(code, dom, ctx, global, ret, onDev) {
     let ops = code.code, retDim = 0;
     if (ret) {
         if (!ops.length) throw new Error("calculateExps: an empty program returns nothing");
@@ -130,7 +131,8 @@ function run(code, dom, ctx, global, ret) {
         });
         addon.evalProgramDev(enc.ops, enc.nOps, enc.nTmp, nBits, dom === "n" ? 0 : ctx.extendBits, ptrs, widths, enc.scalars);
         enc.sections.forEach((s, i) => {
-            if (s.name === "$ret") {
+            if (s.name === "$ret" && ret === "dev") out = onDev(devs[i], retDim, rows);
+            else if (s.name === "$ret") {
                 const flat = new BigUint64Array(rows * retDim);
                 addon.devDownload(flat, devs[i], 0);
                 out = new Array(rows);
@@ -147,9 +149,43 @@ function run(code, dom, ctx, global, ret) {
     }
     return out;
 }
+// debug = true (prover_helpers.js:46-70): `code` is one constraint (expressionsInfo.constraints[i]: an op-list whose last op holds the
+// constraint's value, with its boundary and source line).  The reference walks the rows of the boundary and records the FIRST row whose
+// value is not zero; here the op-list runs on the whole domain on the device and pil2gl_first_nonzero_row_dev finds that row: the same
+// message lands in ctx.errors, and only the row index and its value cross PCIe.
+function checkConstraint(ctx, code, dom, global) {
+    const N = dom === "n" ? 2 ** ctx.nBits : 2 ** ctx.nBitsExt;
+    let first, last;
+    if (code.boundary === "everyRow") { first = 0; last = N; }
+    else if (code.boundary === "firstRow" || code.boundary === "finalProof") { first = 0; last = 1; }
+    else if (code.boundary === "lastRow") { first = N - 1; last = N; }
+    else if (code.boundary === "everyFrame") { first = code.offsetMin; last = N - code.offsetMax; }
+    else throw new Error("Invalid boundary: " + code.boundary);
+    if (!ctx.errors) ctx.errors = [];
+    if (last <= first) return;
+    const hit = run(code, dom, ctx, global, "dev", (dev, dim) => {
+        const [row, v0, v1, v2] = addon.firstNonzeroRowDev(dev, dim, first, last);
+        return row === 0xFFFFFFFFFFFFFFFFn ? null : { row, val: dim === 1 ? v0 : [v0, v1, v2] };
+    });
+    if (hit) ctx.errors.push(`${code.line}: identity does not match w=${hit.row} val=${dim1or3(hit.val)} `);
+}
+const dim1or3 = (v) => (Array.isArray(v) ? v.map((c) => c.toString(10)) : v.toString(10));     // F3g.toString, f3g.js:313-320
 module.exports.calculateExps = function calculateExps(ctx, code, dom, debug, ret, global) {
-    if (debug) throw new Error("debug (constraint checking) mode is not offloaded; use the reference evaluator");
+    if (debug) return checkConstraint(ctx, code, dom, !!global);
     return run(code, dom, ctx, !!global, !!ret);
+};
+// calculateExpAtPoint(ctx, code, i) (prover_helpers.js:74-80): the value of the op-list's last op at ONE row of the trace domain.  The
+// program runs on the whole domain (rows are independent on the device; one row is not cheaper) and one value is read back.
+module.exports.calculateExpAtPoint = function calculateExpAtPoint(ctx, code, i) {
+    return run(code, "n", ctx, false, "dev", (dev, dim) => {
+        const t = new BigUint64Array(dim);
+        addon.devDownload(t, dev, Number(i) * dim);
+        return dim === 1 ? t[0] : [t[0], t[1], t[2]];
+    });
+};
+module.exports.calculateExpressionAtRow = function calculateExpressionAtRow(ctx, expId, row) {       // prover_helpers.js:18-21
+    const expressionCode = ctx.expressionsInfo.expressionsCode.find((e) => e && e.expId === expId);
+    return module.exports.calculateExpAtPoint(ctx, expressionCode.code, row);
 };
 // calculateExpression(ctx, expId)   (prover_helpers.js:10-16): the expression's column on the trace domain
 module.exports.calculateExpression = function calculateExpression(ctx, expId, debug = false) {
@@ -205,7 +241,6 @@ module.exports.setPol = function setPol(ctx, idPol, pol, dom, options) {
 };
 
 module.exports.callCalculateExps = async function callCalculateExps(stage, code, dom, ctx, parallelExec, useThreads, debug, global = false) {
-    if (debug) throw new Error("debug (constraint checking) mode is not offloaded; use the reference evaluator");
-    run(code, dom, ctx, global, false);
+    module.exports.calculateExps(ctx, code, dom, debug, false, global);                            // prover_helpers.js:23-29 (no worker pool here)
 };
 module.exports.encode = encode;

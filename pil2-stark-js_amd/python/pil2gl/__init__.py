@@ -148,6 +148,14 @@ def calculateH1H2(f, t, dim=1):
     return h1, h2
 
 
+def firstNonZeroRow(col, dim, first, last):
+    """the device half of calculateExps(ctx, code, dom, debug = true) (prover_helpers.js:46-70): the first row of [first, last) where a
+    constraint's value column (dim 1 or 3 words per row, device buffer) is not zero -> (row, [value words]) or None"""
+    row = np.zeros(1, np.uint64); val = np.zeros(3, np.uint64)
+    call("pil2gl_first_nonzero_row_dev", _ptr(col), dim, first, last, _ptr(row), _ptr(val), _stream())
+    return None if int(row[0]) == 0xFFFFFFFFFFFFFFFF else (int(row[0]), [int(v) for v in val[:dim]])
+
+
 # ----------------------------------------------------------------------------- poseidon / linear hash
 def poseidon(inputs, capacity=None, nOuts=4):
     """hash/poseidon/poseidon.js:57 poseidon(inputs[8], capacity[4]?, nOuts=4) -> list of ints"""

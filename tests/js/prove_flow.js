@@ -29,6 +29,52 @@ function bigProof(p) {      // golden proof: decimal strings -> BigInt, everythi
     return typeof p === "string" ? BigInt(p) : p;
 }
 
+// computeStage for a witness stage (prover.js:193-214): the stage's hints (hints_helpers.js:81-123 restated on the drop-ins: calculateExpression
+// for fields that are expressions, calculateZ / calculateS, setPol), then the intermediate polynomials of the last witness stage
+// (:212-214: op-lists with destinations of type cm, trace domain)
+async function witnessStage(st, ctx) {
+    const pilInfo = ctx.pilInfo;
+    if (st > 1) {
+        for (const hint of ctx.expressionsInfo.hintsInfo || []) {
+            const fld = (name) => hint.fields.find((f) => f.name === name);
+            const ref = fld("reference");
+            if (!ref || pilInfo.cmPolsMap[ref.id].stage !== st) continue;
+            const col = (f) => (f.op === "cm" ? PH.getPol(ctx, f.id, "n") : f.op === "const" ? PH.getFixedPol(ctx, f.id) : f.op === "tmp" ? PH.calculateExpression(ctx, f.id) : BigInt(f.value));
+            if (hint.name === "gprod") PH.setPol(ctx, ref.id, await PU.calculateZ(null, col(fld("numerator")), col(fld("denominator"))), "n");
+            else if (hint.name === "gsum") PH.setPol(ctx, ref.id, await PU.calculateS(null, col(fld("numerator")), col(fld("denominator"))), "n");
+            else throw new Error("hint " + hint.name + " is not part of this flow");
+        }
+    }
+    const im = (ctx.expressionsInfo.imPolsCode || [])[st - 1];
+    if (st === pilInfo.nStages && im && im.code.length) await callCalculateExps(st, im, "n", ctx, false, false);
+}
+
+// The constraint check every reference integration test starts with (test/stark/helpers.js:23-33: starkGen with options.debug): the
+// witness stages are computed as in a proof but nothing is committed -- each stage's challenges are arbitrary (prover.js:65) -- and
+// after each stage its constraints are evaluated on the rows of their boundaries (computeStage, prover.js:223-230, through
+// callCalculateExps with debug = true).  -> ctx.errors, empty for a valid witness (proofGen returns true, prover.js:73-85).
+async function debugCheck(g, resident) {
+    const fromHost = (a) => (resident ? DevBuffer.from(a) : a);
+    const pilInfo = g.pilInfo, ss = pilInfo.starkStruct, N = 1 << ss.nBits;
+    const asBuf = (v) => fromHost(BigUint64Array.from(v, BigInt));
+    const ctx = { prover: "stark", pilInfo, expressionsInfo: g.expressionsInfo, nBits: ss.nBits, nBitsExt: ss.nBitsExt, extendBits: ss.nBitsExt - ss.nBits, N,
+        publics: g.publics.map(BigInt), challenges: [], evals: [], subproofValues: [], errors: [] };
+    for (let i = 0; i < pilInfo.nStages + 3; i++) ctx.challenges.push([]);
+    ctx.const_n = asBuf(g.consts);
+    ctx.cm1_n = asBuf(g.cm1);
+    for (let st = 2; st <= pilInfo.nStages; st++) { const n = pilInfo.mapSectionsN["cm" + st] * N; ctx["cm" + st + "_n"] = resident ? new DevBuffer(n) : new BigUint64Array(n); if (resident) ctx["cm" + st + "_n"].zero(); }
+    let seed = 0x9E3779B97F4A7C15n;
+    const rnd = () => { seed = (seed * 6364136223846793005n + 1442695040888963407n) & 0xFFFFFFFFFFFFFFFFn; return seed % 0xFFFFFFFF00000001n; };
+    for (let st = 1; st <= pilInfo.nStages; st++) {
+        ctx.challenges[st - 1] = pilInfo.challengesMap.filter((c) => c.stage === st).map(() => [rnd(), rnd(), rnd()]);
+        await witnessStage(st, ctx);
+        for (const constraint of (ctx.expressionsInfo.constraints || []).filter((c) => c.stage === st))
+            await callCalculateExps(st, constraint, "n", ctx, false, false, true);
+    }
+    if (resident) freeCtx(ctx);
+    return ctx.errors;
+}
+
 async function prove(g, resident) {
     // resident: every large buffer is a DevBuffer (HBM); the modules then work in place and only roots, evaluations,
     // the last FRI polynomial and the opened rows ever reach the JS heap
@@ -81,18 +127,8 @@ async function prove(g, resident) {
             const nCh = pilInfo.challengesMap.filter((c) => c.stage === st).length;
             ctx.challenges[st - 1] = [];
             for (let k = 0; k < nCh; k++) ctx.challenges[st - 1].push(transcript.getField());
-            for (const hint of ctx.expressionsInfo.hintsInfo || []) {
-                const fld = (name) => hint.fields.find((f) => f.name === name);
-                const ref = fld("reference");
-                if (!ref || pilInfo.cmPolsMap[ref.id].stage !== st) continue;
-                const col = (f) => (f.op === "cm" ? PH.getPol(ctx, f.id, "n") : f.op === "const" ? PH.getFixedPol(ctx, f.id) : f.op === "tmp" ? PH.calculateExpression(ctx, f.id) : BigInt(f.value));
-                if (hint.name === "gprod") PH.setPol(ctx, ref.id, await PU.calculateZ(null, col(fld("numerator")), col(fld("denominator"))), "n");
-                else if (hint.name === "gsum") PH.setPol(ctx, ref.id, await PU.calculateS(null, col(fld("numerator")), col(fld("denominator"))), "n");
-                else throw new Error("hint " + hint.name + " is not part of this flow");
-            }
         }
-        const im = (ctx.expressionsInfo.imPolsCode || [])[st - 1];
-        if (st === nStages && im && im.code.length) await callCalculateExps(st, im, "n", ctx, false, false);
+        await witnessStage(st, ctx);
         const w = pilInfo.mapSectionsN["cm" + st];
         await interpolate(ctx["cm" + st + "_n"], w, nBits, ctx["cm" + st + "_ext"], nBitsExt);
         ctx.trees[st] = await MH.merkelize(ctx["cm" + st + "_ext"], w, extN);
@@ -147,13 +183,15 @@ function freeCtx(ctx, keep = []) {
         for (const x of (Array.isArray(v) ? v : Object.values(v))) walk(x, depth + 1);
     })(ctx, 0);
 }
-module.exports = { prove, freeCtx };
+module.exports = { prove, freeCtx, debugCheck };
 
 if (require.main === module) (async () => {
-    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json", "fib_flow_impols.json", "fib_flow_boundaries.json", "perm_flow_hints.json"]) {
+    for (const name of ["fib_flow.json", "fib_flow_hashcommits.json", "fib_flow_prevrow.json", "fib_flow_impols.json", "fib_flow_boundaries.json", "fib_flow_boundaries_only.json", "perm_flow_hints.json"]) {
         const g = JSON.parse(fs.readFileSync(path.join(root, "tests/golden", name)));
-        await prove(g, false);
-        await prove(g, true);
+        for (const resident of [false, true]) {
+            assert.deepStrictEqual(await debugCheck(g, resident), [], name + ": the witness does not satisfy its constraints");    // options.debug pre-run, test/stark/helpers.js:23-33
+            await prove(g, resident);
+        }
     }
     console.log("prove flow OK");
 })().catch((e) => { console.error(e); process.exit(1); });

@@ -135,3 +135,23 @@ def test_constraint_program_compiles_with_hiprtc_and_fuses_horner():
         del os.environ["PIL2GL_EXPR_MULCALL"]
     assert rc == 0, lib.pil2gl_last_error()
     assert 1000 < nbytes.value < inlined
+
+
+def test_no_early_clobber_overlap_in_bn128_isa(tmp_path):
+    """hipcc's coalescer has been seen (round 5) to give an early-clobber asm output the register of an input it is later selected
+    against -- `v_cndmask_b32 v8, v8, v8, vcc` in bn::cond_sub_r when its result is copied back over its input inside a loop: both
+    outcomes of the select are then the difference, silently wrong for every value below r.  The pattern is searched for in the ISA of
+    the files that carry such asm statements (no GPU needed: hipcc cross-compiles)."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    pkg = os.path.join(ROOT, "pil2-stark-js_amd")
+    for src in ("bn128.hip",):
+        out = tmp_path / (src + ".s")
+        subprocess.check_call([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-ffp-contract=off", "-I" + os.path.join(pkg, "build"),
+                               "-S", "--cuda-device-only", os.path.join(pkg, "csrc", src), "-o", str(out)], stderr=subprocess.DEVNULL)
+        bad = re.findall(r"v_cndmask_b32 (v\d+), \1, \1, vcc", out.read_text())
+        assert not bad, "%s: a select between a register and itself (%d sites)" % (src, len(bad))

@@ -250,7 +250,9 @@ def test_bad_arguments_are_refused_before_any_launch(gl):
            ("pil2gl_fri_fold_dev", (ok, 5, 6, 1, gl._ptr(ch), ok, None)), ("pil2gl_fri_fold_dev", (ok, 31, 6, 1, gl._ptr(ch), ok, None)),
            ("pil2gl_fri_fold_dev", (ok, 5, 3, 1, None, ok, None)),
            ("pil2gl_build_x_dev", (32, 1, ok, None)), ("pil2gl_build_x_dev", (4, 1, None, None)),
-           ("pil2gl_geometric_dev", (1, 2, 8, None, None)),
+           ("pil2gl_geometric_dev", (1, 2, 8, None, None)), ("pil2gl_geometric_dev", (1, 2, 1 << 39, ok, None)), ("pil2gl_geometric_dev", (1, 2, 1 << 40, ok, None)),
+           ("pil2gl_first_nonzero_row_dev", (ok, 2, 0, 8, gl._ptr(ch), gl._ptr(ch), None)), ("pil2gl_first_nonzero_row_dev", (ok, 1, 9, 8, gl._ptr(ch), gl._ptr(ch), None)),
+           ("pil2gl_first_nonzero_row_dev", (None, 1, 0, 8, gl._ptr(ch), gl._ptr(ch), None)), ("pil2gl_first_nonzero_row_dev", (ok, 1, 0, 8, None, gl._ptr(ch), None)),
            ("pil2gl_build_zhinv_dev", (5, 4, ok, None)), ("pil2gl_build_zhinv_dev", (4, 6, None, None)),
            ("pil2gl_compute_q_split_dev", (ok, 4, 5, 3, 3, ok, None)),                        # qDeg * N > E
            ("pil2gl_compute_q_split_dev", (None, 4, 5, 3, 2, ok, None)),
@@ -264,6 +266,28 @@ def test_bad_arguments_are_refused_before_any_launch(gl):
             _lib.call(name, *args)
     torch.cuda.synchronize()
     assert int(d.sum()) == 0                      # and nothing was written
+
+
+def test_first_nonzero_row(gl):
+    """pil2gl_first_nonzero_row_dev (the device half of calculateExps' debug mode, prover_helpers.js:46-70): the smallest row of
+    [first, last) whose value is not zero, and that value; columns of dimension 1 and 3, ranges of every boundary kind"""
+    import torch
+    rng = np.random.default_rng(2)
+    for dim in (1, 3):
+        for n in (1, 7, 256, 1000, 70001):
+            col = np.zeros((n, dim), np.uint64)
+            assert gl.firstNonZeroRow(torch.from_numpy(col.view(np.int64)).cuda(), dim, 0, n) is None
+            hits = sorted(set(int(x) for x in rng.integers(0, n, 5)))
+            for r in hits:
+                col[r, int(rng.integers(0, dim))] = int(rng.integers(1, 1 << 63))
+            d = torch.from_numpy(col.view(np.int64)).cuda()
+            for first, last in ((0, n), (0, 1), (n - 1, n), (min(1, n - 1), max(n - 2, 1)), (hits[0] + 1, n), (hits[-1], hits[-1]), (0, hits[0])):
+                inside = [r for r in hits if first <= r < last]
+                got = gl.firstNonZeroRow(d, dim, first, last)
+                if not inside:
+                    assert got is None, (dim, n, first, last, got)
+                else:
+                    assert got == (inside[0], [int(v) for v in col[inside[0]]]), (dim, n, first, last, got)
 
 
 # ------------------------------------------------------------------ Poseidon / linear hash / Merkle

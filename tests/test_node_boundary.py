@@ -50,6 +50,85 @@ def test_config2_proof_from_node_device_resident():
     assert out.returncode == 0 and "prove c2 OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
 
 
+def _constraint_errors(g, flips, points=None):
+    """what calculateExps(ctx, constraint, "n", debug = true) of the reference leaves in ctx.errors for every stage-1 constraint of a
+    golden AIR (prover_helpers.js:46-70): rows of the boundary one after the other, F3g arithmetic on Python integers, the FIRST row
+    whose value is not zero"""
+    P_ = 0xFFFFFFFF00000001
+    info, N = g["pilInfo"], 1 << g["pilInfo"]["starkStruct"]["nBits"]
+    w, nc = info["mapSectionsN"]["cm1"], info["nConstants"]
+    cm = [int(v) for v in g["cm1"]]
+    for row, col, delta in flips:
+        cm[row * w + col] = (cm[row * w + col] + delta) % P_
+    consts, pub = [int(v) for v in g["consts"]], [int(v) for v in g["publics"]]
+    im = g["expressionsInfo"]["imPolsCode"][0]
+
+    def run(code, i, write):
+        tmp = {}
+
+        def get(r):
+            t = r["type"]
+            if t == "tmp": return tmp[r["id"]]
+            if t == "cm": return cm[((i + r.get("prime", 0)) % N) * w + info["cmPolsMap"][r["id"]]["stagePos"]]
+            if t == "const": return consts[((i + r.get("prime", 0)) % N) * nc + r["id"]]
+            if t == "number": return int(r["value"]) % P_
+            if t == "public": return pub[r["id"]]
+            raise AssertionError(t)
+        last = None
+        for c in code:
+            a = get(c["src"][0])
+            b = get(c["src"][1]) if c["op"] != "copy" else 0
+            last = {"add": (a + b) % P_, "sub": (a - b) % P_, "mul": a * b % P_, "copy": a}[c["op"]]
+            if c["dest"]["type"] == "tmp": tmp[c["dest"]["id"]] = last
+            elif write: cm[i * w + info["cmPolsMap"][c["dest"]["id"]]["stagePos"]] = last
+        return last
+    for i in range(N):                                  # the intermediate polynomials are the prover's own (prover.js:212-214)
+        run(im["code"], i, True)
+    errors = []
+    for c in g["expressionsInfo"]["constraints"]:
+        if c["stage"] != 1:
+            continue
+        b = c["boundary"]
+        first, last = {"everyRow": (0, N), "firstRow": (0, 1), "lastRow": (N - 1, N)}.get(b) or (c["offsetMin"], N - c["offsetMax"])
+        for i in range(first, last):
+            v = run(c["code"], i, False)
+            if v:
+                errors.append("%s: identity does not match w=%d val=%d " % (c["line"], i, v))
+                break
+    if points is not None:                              # calculateExpAtPoint: the first stage-1 constraint's value at the rows asked for
+        c0 = [c for c in g["expressionsInfo"]["constraints"] if c["stage"] == 1][0]
+        return errors, [str(run(c0["code"], i, False)) for i in points]
+    return errors
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(NODE is None, reason="node not installed")
+def test_constraint_check_debug_mode_from_node(tmp_path):
+    """calculateExps / callCalculateExps with debug = true and calculateExpAtPoint on the device (prover_helpers.js:46-80): a valid witness
+    leaves no error; one altered cell leaves the reference's message -- same constraint line, same first failing row, same value -- for
+    every boundary kind (everyRow on selector constants, everyFrame / firstRow / lastRow of pil2, an intermediate polynomial's identity)"""
+    import json
+    cases = {
+        # (row, column, delta): transitions, the public inputs' rows, the output's row, a cell that breaks two constraints at different rows
+        "fib_flow.json": [[], [[5, 0, 1]], [[0, 1, 7]], [[63, 0, 3]], [[0, 0, 1], [40, 3, 2]]],
+        "fib_flow_boundaries_only.json": [[], [[17, 1, 1]], [[0, 0, 5]], [[63, 0, 1]], [[62, 2, 9]], [[63, 3, 4]]],
+        "fib_flow_impols.json": [[], [[9, 2, 1]], [[30, 0, 1]]],
+        "fib_flow_prevrow.json": [[], [[1, 1, 1]]],
+    }
+    for golden, variants in cases.items():
+        g = json.load(open(os.path.join(ROOT, "tests", "golden", golden)))
+        job = tmp_path / (golden + ".job.json")
+        job.write_text(json.dumps({"golden": golden, "variants": [{"flips": f} for f in variants], "points": [0, 1, 63]}))
+        out = subprocess.run([NODE, os.path.join(ROOT, "tests", "js", "debug_flow.js"), str(job)], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "debug flow OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+        res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        for f, r in zip(variants, res["results"]):
+            want = _constraint_errors(g, f)
+            assert (not f) == (not want), (golden, f)                 # every altered cell above is caught by some constraint
+            assert r["host"] == want and r["dev"] == want, (golden, f, r, want)
+        assert res["at"] == _constraint_errors(g, [], [0, 1, 63])[1], (golden, res["at"])     # calculateExpAtPoint (an everyFrame identity need not vanish on the last row)
+
+
 def _canon(v):          # canonical text of a proof: decimal strings, no whitespace, keys in insertion order (= tests/js/prove_c3.js)
     if isinstance(v, dict):
         return "{" + ",".join('"%s":%s' % (k, _canon(x)) for k, x in v.items()) + "}"

@@ -611,6 +611,45 @@ def prove_from_host(dev, src, step_with, n_proofs=4):
         return {"error": str(e)[:300]}
 
 
+def node_driven_proof(info, exprs, setup, publics, start_row, res):
+    """The same proof once more with the JS ORCHESTRATION driving (north_star: "the JS orchestration keeps driving"): a fresh `node`
+    child process runs tests/js/prove_c3.js -- prover.js's stage order (src/prover/prover.js:7-127) over the JS drop-in modules, every
+    large buffer resident in HBM -- on the same AIR and witness, and reports its best proof time and the digest of its proof, which
+    must equal the digest of the proof this process made.  Outside `value`; PIL2GL_BENCH_NODE=0 skips it."""
+    import hashlib
+    import shutil
+    import subprocess
+    import tempfile
+    node = shutil.which("node")
+    if node is None:
+        return {"skipped": "node is not installed on this box"}
+
+    def canon(v):                                          # = tests/js/prove_c3.js canon(): decimal strings, keys in insertion order
+        if isinstance(v, dict):
+            return "{" + ",".join('"%s":%s' % (k, canon(x)) for k, x in v.items()) + "}"
+        if isinstance(v, (list, tuple)):
+            return "[" + ",".join(canon(x) for x in v) + "]"
+        return '"%d"' % int(v)
+    want = hashlib.sha256(canon(res["proof"]).encode()).hexdigest()
+    job = {"pilInfo": info, "expressionsInfo": exprs, "start": [str(v) for v in start_row], "publics": [str(v) for v in publics],
+           "constRoot": [str(v) for v in setup["constRoot"]], "queries": res["queries"]}
+    try:
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump(job, f)
+        t0 = time.perf_counter()
+        out = subprocess.run([node, os.path.join(ROOT, "tests", "js", "prove_c3.js"), f.name, "3"], capture_output=True, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        os.unlink(f.name)
+        if out.returncode != 0 or "prove c3 OK" not in out.stdout:
+            return {"error": (out.stdout[-300:] + out.stderr[-600:])}
+        line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+        return {"proof_seconds": line["proof_seconds"], "cells_per_s": line["cells_per_s"], "proofSha256_equal": line["proofSha256"] == want,
+                "proofSha256": line["proofSha256"], "child_wall_s": round(wall, 1),
+                "what": "node tests/js/prove_c3.js (best of 3): src/prover/prover.js:7-127's stage order over pil2-stark-js_amd/js, buffers in HBM, started as a fresh child process after this one's timed region"}
+    except Exception as e:  # pragma: no cover
+        return {"error": str(e)[:300]}
+
+
 def bench_bn128(args, dev, wl, n_bits, n_cols):
     """config 4: extendAndMerkelize with the BN128 MerkleHash (merklehash_bn128_p.js:47-129, arity 16, non-custom): the GL
     LDE of the 2^24 x 100 trace and the BN254-Poseidon linear hash + 16-ary tree over all 2^27 extended rows"""
@@ -850,8 +889,9 @@ def main():
         exchange["backend"] = backend + (" + HIP IPC windows (ranks share a GPU)" if exchange["mode"] == "ipc" else (" (RCCL over xGMI)" if backend == "nccl" else ""))
     # one more pass, outside the timed region, with a synchronisation after every stage (collective in the sharded mode: all ranks)
     stage_times = {}
+    last_proof = None
     if mode in ("prove", "prove-sharded") and (rank == 0 or mode == "prove-sharded"):
-        step(timings=stage_times); torch.cuda.synchronize()
+        last_proof = step(timings=stage_times); torch.cuda.synchronize()
 
     if rank == 0:
         # ---- per-kernel timing with HIP events on the launch stream (each call below is exactly one kernel, or one kernel
@@ -972,6 +1012,12 @@ def main():
             del dst, digests, lvl                               # (back to torch's allocator cache: the proofs below reuse the blocks)
             setup_, info_, exprs_, publics_ = prove_ctx
             out["prove_from_host"] = prove_from_host(dev, src, lambda buf: stark.stark_gen(be, buf, setup_, info_, exprs_, publics_))
+        if world == 1 and mode == "prove" and args.air != "perm" and last_proof is not None and os.environ.get("PIL2GL_BENCH_NODE", "1") != "0":
+            import numpy as _np2
+            start_row = [int(v) for v in src[:n_cols].cpu().numpy().view(_np2.uint64)]
+            dst = digests = lvl = None
+            gc.collect(); torch.cuda.empty_cache()             # the child needs its own 143 GB at config 3
+            out["node_driven"] = node_driven_proof(prove_ctx[1], prove_ctx[2], prove_ctx[0], prove_ctx[3], start_row, last_proof)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_prove(n_cols, args.split, args.air) if prove_ctx is not None else cpu_baseline_commit(n_cols, args.split)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]

@@ -219,6 +219,10 @@ int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
  * stage and the constants, stark_gen_helpers.js:233-264): hostOuts[k] receives nLev x widths[k] x 3. */
 int pil2gl_cols_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows, uint64_t rowStep,
                                   const uint64_t *const *levs, uint32_t nLev, uint64_t *const *hostOuts, void *stream);
+/* the same over the columns [colBegin[k], colBegin[k] + widths[k]) of matrices whose rows are strides[k] words long (colBegin null: from
+ * column 0): a rank of a coset-sharded proof evaluates its share of the columns, and only those cells are read. */
+int pil2gl_cols_dot_ext_range_dev(const uint64_t *const *bufs, const uint64_t *strides, const uint64_t *colBegin, const uint64_t *widths, uint32_t nBufs,
+                                  uint64_t nRows, uint64_t rowStep, const uint64_t *const *levs, uint32_t nLev, uint64_t *const *hostOuts, void *stream);
 
 /* ---- expression evaluator: src/prover/prover_helpers.js:23-259 ------------- */
 /* callCalculateExps / calculateExps: run the op-list on every row of the domain.  Section pointers in

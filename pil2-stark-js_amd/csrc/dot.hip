@@ -345,7 +345,7 @@ constexpr u32 CD_MAXSEG = 8;
 struct ColsDotParams {
     // columns of up to CD_MAXSEG matrices with the same rows, side by side: lane c of the launch belongs to the segment whose
     // [segC0, segC0 + segW) holds it (one sweep of the weights for all of them)
-    const u64 *segBuf[CD_MAXSEG]; u32 segW[CD_MAXSEG], segC0[CD_MAXSEG], nSeg;
+    const u64 *segBuf[CD_MAXSEG]; u32 segW[CD_MAXSEG], segC0[CD_MAXSEG], segStride[CD_MAXSEG], nSeg;   // segStride: words per matrix row (>= segW: a column range of a wider matrix)
     u64 width; u64 nRows; u64 rowStep;      // width: all segments together; rows k*rowStep, k < nRows
     const u32 *levLimbs;        // [nLev][nRows][3 comps][3 limbs]
     u32 nLev;
@@ -368,9 +368,9 @@ __global__ void __launch_bounds__(256) cols_dot_kernel(ColsDotParams P) {
             for (int i = 0; i < 6; i++) S[l][k][i] = 0;
     const bool valid = c < P.width;
     constexpr int RB = 8;                            // rows whose loads are in flight together
-    const u64 *buf = P.segBuf[0]; u64 sw = P.segW[0], cl = c;
+    const u64 *buf = P.segBuf[0]; u64 sw = P.segStride[0], cl = c;
 #pragma unroll
-    for (u32 k = 1; k < CD_MAXSEG; k++) if (k < P.nSeg && c >= P.segC0[k]) { buf = P.segBuf[k]; sw = P.segW[k]; cl = c - P.segC0[k]; }
+    for (u32 k = 1; k < CD_MAXSEG; k++) if (k < P.nSeg && c >= P.segC0[k]) { buf = P.segBuf[k]; sw = P.segStride[k]; cl = c - P.segC0[k]; }
     const u64 stride = P.rowStep * sw;
     for (u64 kb = k0; kb < k1; kb += RB) {
         u64 pv[RB];
@@ -626,11 +626,19 @@ int pil2gl_fri_combine_order_dev(const uint64_t *acc, const uint64_t *hostK, con
     return PIL2GL_OK;
 }
 
-// evaluations over several matrices with the same rows in ONE sweep of the weights: hostOuts[k] receives nLev x widths[k] x 3
+// evaluations over several matrices with the same rows in ONE sweep of the weights: hostOuts[k] receives nLev x widths[k] x 3.
+// The _range form takes columns [colBegin[k], colBegin[k] + widths[k]) of matrices whose rows are strides[k] words long (a rank of a
+// sharded proof evaluates its share of the columns: only those cells are read).
 int pil2gl_cols_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows, uint64_t rowStep,
                                   const uint64_t *const *levs, uint32_t nLev, uint64_t *const *hostOuts, void *stream) {
+    return pil2gl_cols_dot_ext_range_dev(bufs, widths, nullptr, widths, nBufs, nRows, rowStep, levs, nLev, hostOuts, stream);
+}
+int pil2gl_cols_dot_ext_range_dev(const uint64_t *const *bufs, const uint64_t *strides, const uint64_t *colBegin, const uint64_t *widths, uint32_t nBufs,
+                                  uint64_t nRows, uint64_t rowStep, const uint64_t *const *levs, uint32_t nLev, uint64_t *const *hostOuts, void *stream) {
     P2_TRY(ensure_init());
-    if (!bufs || !widths || !levs || !hostOuts || nBufs == 0) return fail(PIL2GL_EINVAL, "null buffer");
+    if (!bufs || !widths || !strides || !levs || !hostOuts || nBufs == 0) return fail(PIL2GL_EINVAL, "null buffer");
+    for (uint32_t k = 0; k < nBufs && k < CD_MAXSEG; k++)
+        if ((colBegin ? colBegin[k] : 0) + widths[k] > strides[k] || (strides[k] >> 31)) return fail(PIL2GL_EINVAL, "column range outside the matrix");
     if (nBufs > CD_MAXSEG) return fail(PIL2GL_EINVAL, "at most %u matrices per call", CD_MAXSEG);
     if (nLev < 1 || nLev > 4) return fail(PIL2GL_EINVAL, "nLev must be 1..4");
     u64 width = 0;
@@ -647,7 +655,10 @@ int pil2gl_cols_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *w
     for (u32 l = 0; l < nLev; l++) limbs_kernel<<<nblk(nRows * 3), 256, 0, st>>>(levs[l], nRows * 3, limbs + (u64)l * nRows * 9);
     ColsDotParams P;
     u32 c0 = 0;
-    for (u32 k = 0; k < CD_MAXSEG; k++) { P.segBuf[k] = k < nBufs ? bufs[k] : nullptr; P.segW[k] = k < nBufs ? (u32)widths[k] : 0; P.segC0[k] = c0; if (k < nBufs) c0 += (u32)widths[k]; }
+    for (u32 k = 0; k < CD_MAXSEG; k++) {
+        P.segBuf[k] = k < nBufs ? bufs[k] + (colBegin ? colBegin[k] : 0) : nullptr; P.segW[k] = k < nBufs ? (u32)widths[k] : 0; P.segStride[k] = k < nBufs ? (u32)strides[k] : 0;
+        P.segC0[k] = c0; if (k < nBufs) c0 += (u32)widths[k];
+    }
     P.nSeg = nBufs; P.width = width; P.nRows = nRows; P.rowStep = rowStep; P.levLimbs = limbs; P.nLev = nLev; P.partial = partial; P.rowsPerChunk = rpc;
     const u32 threads = (u32)std::min<u64>(256, (width + 63) / 64 * 64);
     dim3 grid((unsigned)nChunks, nblk(width, threads));

@@ -110,6 +110,7 @@ SIGNATURES = {
     "pil2gl_fri_combine_order_dev": (_I, [vp, vp, vp, vp, _U32, vp, _U64, vp, vp]),
     "pil2gl_cols_dot_ext_dev": (_I, [vp, _U64, _U64, _U64, C.POINTER(vp), _U32, vp, vp]),
     "pil2gl_cols_dot_ext_multi_dev": (_I, [vp, vp, _U32, _U64, _U64, vp, _U32, vp, vp]),
+    "pil2gl_cols_dot_ext_range_dev": (_I, [vp, vp, vp, vp, _U32, _U64, _U64, vp, _U32, vp, vp]),
     "pil2gl_eval_program_dev": (_I, [C.POINTER(GlxProgram), C.POINTER(GlxCtx), vp]),
     "pil2gl_first_nonzero_row_dev": (_I, [vp, _U32, _U64, _U64, vp, vp, vp]),
     "pil2gl_synth_fibonacci_dev": (_I, [_U32, _U32, vp, vp, vp]),

@@ -318,11 +318,17 @@ class ShardedTree:
         mine = torch.zeros(self.world * 4, dtype=torch.int64)
         mine[self.rank * 4:self.rank * 4 + 4] = torch.tensor(np.array(be.root({"nodes": self.sub}), dtype=np.uint64).view(np.int64))
         roots = comm.all_reduce_sum(mine) if comm.mode != "rehearse" else mine[:4].repeat(self.world)
-        cur = [[int(v) for v in roots[4 * r:4 * r + 4].numpy().view(np.uint64)] for r in range(self.world)]
+        cur = roots.numpy().view(np.uint64).reshape(self.world, 4).tolist()
         self.top = [cur]
-        while len(cur) > 1:                                     # merklehash_p.js:109-132 on w, w/2, ... nodes
-            cur = [[int(v) for v in be.poseidon(cur[2 * i] + cur[2 * i + 1], [0, 0, 0, 0], 4)] for i in range(len(cur) // 2)]
-            self.top.append(cur)
+        if self.world > 1 and hasattr(be, "merkelize_digests"):  # the log2(w) levels above the subtree roots in ONE device call (merklehash_p.js:109-132)
+            top = be.as_torch(be.merkelize_digests(be.from_torch(roots), self.world)).cpu().numpy().view(np.uint64).reshape(-1, 4)
+            o, n = self.world, self.world // 2
+            while n >= 1:
+                cur = top[o:o + n].tolist(); self.top.append(cur); o += n; n //= 2
+        else:
+            while len(cur) > 1:
+                cur = [[int(v) for v in be.poseidon(cur[2 * i] + cur[2 * i + 1], [0, 0, 0, 0], 4)] for i in range(len(cur) // 2)]
+                self.top.append(cur)
         self.root = cur[0]
 
     def siblings_local(self, idxs):
@@ -333,8 +339,7 @@ class ShardedTree:
         mine = [(q, i % self.block) for q, i in enumerate(idxs) if i // self.block == self.rank]
         if mine and low:
             sib = self.be.merkle_siblings(self.sub, self.block, [li for _, li in mine])
-            for (q, _), mp in zip(mine, sib):
-                t[q, :low] = torch.from_numpy(np.array(mp, dtype=np.uint64).view(np.int64))
+            t[torch.tensor([q for q, _ in mine]), :low] = torch.from_numpy(np.array(sib, dtype=np.uint64).view(np.int64).reshape(len(mine), low, 4))
         return t
 
     def siblings_finish(self, idxs, summed):
@@ -344,7 +349,7 @@ class ShardedTree:
         a = summed.numpy().view(np.uint64).reshape(len(idxs), max(low, 1), 4)
         out = []
         for q, i in enumerate(idxs):
-            mp = [[int(v) for v in a[q, l]] for l in range(low)]
+            mp = a[q, :low].tolist()
             b = i // self.block
             for level in self.top[:-1]:
                 mp.append(list(level[b ^ 1]))
@@ -454,6 +459,70 @@ def zhinv_slice(be, n_bits, ext_bits, cb, cc):
     return be.from_torch(be.as_torch(be.from_host(np.array(z, dtype=np.uint64))).repeat(1 << n_bits))     # tiled where the backend's memory is
 
 
+def zi_slice(be, boundary, n_bits, ext_bits, cb, cc, x_loc):
+    """the rows of cosets [cb, cb+cc) of one boundary's column of Zi_ext (stark_gen_helpers.js:146-160, polutils.js:39-102) in local-slice
+    order, built FROM THE RANK'S OWN ROWS: no table of 2^nBitsExt rows exists on the way.
+      everyRow   1 / (x^N - 1): depends on the coset only (zhinv_slice);
+      everyFrame prod (x - root_k): the evaluator over the rank's x rows;
+      firstRow / lastRow  (x^N - 1) / (x - root): x / (x - root) by the batched-inversion kernel of the FRI table
+                 (pil2gl_x_div_x_sub_xi_cosets_dev with the point (root, 0, 0)), times 1 / x -- a geometric sequence per coset -- times
+                 the coset's x^N - 1.
+    Backends without those operators (the CPU checker) slice the whole table."""
+    from . import stark as S
+    name = boundary["name"]
+    if name == "everyRow":
+        return zhinv_slice(be, n_bits, ext_bits, cb, cc)
+    N, lb = 1 << n_bits, _log2(cc)
+    if not (hasattr(be, "geometric") and hasattr(be, "x_div_x_sub_xi_cosets") and cc & (cc - 1) == 0):
+        return coset_slice(be, S.build_zi_table(be, boundary, n_bits, n_bits + ext_bits), n_bits, ext_bits, cb, cc, 1)
+    wN, wE = S.root_of_unity(n_bits), S.root_of_unity(n_bits + ext_bits)
+    out = be.empty(N * cc)
+    if name == "everyFrame":
+        roots = [pow(wN, i, S.P) for i in range(boundary["offsetMin"])] + [pow(wN, N - i - 1, S.P) for i in range(boundary["offsetMax"])]
+        if not roots:
+            return be.from_torch(torch.ones(N * cc, dtype=torch.int64, device=be.as_torch(out).device))
+        ops = []
+        for k in range(len(roots)):
+            ops.append((S.OPC["sub"], (S.TMP, 1, 0, 0, 1), (S.SEC, 1, 0, 0, 0), (S.SCALAR, 1, 0, 0, k)))
+            if k == 0:
+                ops.append((S.OPC["copy"], (S.TMP, 1, 0, 0, 0), (S.TMP, 1, 0, 0, 1), None))
+            else:
+                ops.append((S.OPC["mul"], (S.TMP, 1, 0, 0, 0), (S.TMP, 1, 0, 0, 0), (S.TMP, 1, 0, 0, 1)))
+        ops.append((S.OPC["copy"], (S.SEC, 1, 1, 0, 0), (S.TMP, 1, 0, 0, 0), None))
+        be.eval_program(ops, 2, [(x_loc, 1), (out, 1)], np.array(roots, dtype=np.uint64), n_bits + lb, 0)
+        return out
+    if name not in ("firstRow", "lastRow"):
+        raise ValueError("Boundary " + str(name) + " not supported")
+    root = 1 if name == "firstRow" else pow(wN, N - 1, S.P)
+    xdiv = be.x_div_x_sub_xi_cosets(n_bits + ext_bits, ext_bits, [[root, 0, 0]], cb, cc)        # [row][3]: x / (x - root), components 1, 2 zero
+    sN = pow(S.SHIFT, N, S.P)
+    wc = S.root_of_unity(ext_bits) if ext_bits else 1
+    cols = [be.geometric(S._inv(S.SHIFT * pow(wE, cb + jl, S.P) % S.P) * ((sN * pow(wc, cb + jl, S.P) - 1) % S.P) % S.P, S._inv(wN), N) for jl in range(cc)]
+    k = cols[0] if cc == 1 else be.from_torch(torch.stack([be.as_torch(c) for c in cols], dim=1).reshape(-1))    # (x^N - 1) / x, row by row
+    ops = [(S.OPC["mul"], (S.SEC, 1, 2, 0, 0), (S.SEC, 1, 0, 0, 0), (S.SEC, 1, 1, 0, 0))]
+    be.eval_program(ops, 1, [(xdiv, 3), (k, 1), (out, 1)], np.zeros(1, dtype=np.uint64), n_bits + lb, 0)
+    return out
+
+
+def shard_tables(be, setup, info, cb, cc):
+    """the rank's rows of the tables that depend on the setup and the coset range only -- the constants' extension, x, the zerofiers --,
+    built once per (setup, coset range) and kept with the setup: a prover that proves again and again with one setup (the bench, a
+    service) pays for them once (they were 8 % of a config-3 proof's rank share)"""
+    from . import stark as S
+    ss = info["starkStruct"]
+    nb, eb = ss["nBits"], ss["nBitsExt"] - ss["nBits"]
+    cache = setup.setdefault("_shardTables", {})
+    key = (cb, cc)
+    if key not in cache:
+        constShard, constTree = setup.get("constShard"), setup.get("constTree")
+        t = {"const_ext": constShard["local"] if constShard is not None else coset_slice(be, constTree["elements"], nb, eb, cb, cc, info["nConstants"]),
+             "x_ext": x_slice(be, nb, eb, cb, cc, S.SHIFT)}
+        for bi, boundary in enumerate(info.get("boundaries", [{"name": "everyRow"}])):
+            t["Zi_ext#%d" % bi] = zi_slice(be, boundary, nb, eb, cb, cc, t["x_ext"])
+        cache[key] = t
+    return dict(cache[key])
+
+
 def build_const_tree_sharded(be, consts, info, group=None, rehearse_world=None, comm=None):
     """buildConstTree (stark_buildConstTree.js:13-35) for a coset-sharded proof: every rank extends the constants on its own cosets
     and hashes its own leaves; the tree above them is split by leaf blocks (ShardedTree).  Same root as the single tree; no rank
@@ -535,6 +604,37 @@ def quotient_coefficients_sharded(be, q_loc, nb, eb, cb, cc, qDim, qDeg, comm):
     return be.from_torch(torch.cat([p_.reshape(-1) for p_ in comm.all_gather(be.as_torch(blk).reshape(-1))]))
 
 
+def _evals_by_opening(be, S, info, loc, widths, xis, nb, nbe, lb, cb, rank, world, comm, nC):
+    """the evaluations with the opening points dealt over the ranks (rank i mod world takes opening i on its own first coset, the
+    others contribute zeros, one all-reduce): the path of backends without column-range sums (the CPU checker)"""
+    n_ev = len(info["evMap"])
+    mine = [i for i in range(len(xis)) if i % world == rank]
+    ev_t = torch.zeros(n_ev * 3, dtype=torch.int64)
+    if mine:
+        g_inv = S._inv(S.SHIFT * pow(S.root_of_unity(nbe), cb, S.P) % S.P)          # 1 / (7 w_E^cb): this rank's first coset
+        levs = [be.build_lev(nb, S.ext_scale(xis[i], g_inv)) for i in mine]
+        sel = [k for k, ev in enumerate(info["evMap"]) if info["openingPoints"].index(ev["prime"]) in mine]
+        sub = dict(info); sub["evMap"] = [info["evMap"][k] for k in sel]; sub["openingPoints"] = [info["openingPoints"][i] for i in mine]
+        if hasattr(be, "evals_fast") and len(levs) <= 4:
+            evals = be.evals_fast(sub, loc, widths, nb, lb, levs)          # row k of the coset is local row k << log2(cc)
+        else:
+            descs = []
+            for ev in sub["evMap"]:
+                li = sub["openingPoints"].index(ev["prime"])
+                if ev["type"] == "const":
+                    descs.append((loc["const_ext"], nC, ev["id"], 1, li))
+                else:
+                    p = info["cmPolsMap"][ev["id"]]
+                    descs.append((loc["cm%d_ext" % p["stage"]], widths["cm%d_ext" % p["stage"]], p["stagePos"], p["dim"], li))
+            evals = be.compute_evals(descs, nb, lb, levs)
+        full = np.zeros((n_ev, 3), dtype=np.uint64)
+        full[sel] = np.array(evals, dtype=np.uint64).reshape(len(sel), 3)
+        ev_t = torch.from_numpy(full.reshape(-1).view(np.int64).copy())
+        del levs
+    ev_t = comm.all_reduce_sum(ev_t)                                      # every entry is non-zero on one rank only
+    return [[int(v) for v in r] for r in ev_t.numpy().view(np.uint64).reshape(n_ev, 3)]
+
+
 def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehearse_world=None, timings=None, comm=None, overwrite_trace=False, samples=None):
     """pil2gl.stark.stark_gen with every witness stage, the constraint evaluation and the FRI polynomial split by cosets over the
     ranks of `group`.  Every rank passes the same trace and setup and receives the same (complete) proof, identical to the
@@ -578,15 +678,11 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     transcript.put(setup["constRoot"])
 
     sl = lambda full, w: coset_slice(be, full, nb, eb, cb, cc, w)
-    # the rank's rows of the domain tables, built per coset: no buffer of this function has 2^nBitsExt rows
-    loc = {"const_ext": constShard["local"] if constShard is not None else sl(constTree["elements"], nC),
-           "x_ext": x_slice(be, nb, eb, cb, cc, S.SHIFT)}
+    # the rank's rows of the domain tables, built per coset (no buffer of this function has 2^nBitsExt rows) and once per setup
+    loc = shard_tables(be, setup, info, cb, cc)
     widths = {"const_n": nC, "const_ext": nC, "q_ext": qDim, "f_ext": 3, "x_ext": 1, "x_n": 1,
               "xDivXSubXi_ext": 3 * len(info["openingPoints"])}
-    for bi, boundary in enumerate(info.get("boundaries", [{"name": "everyRow"}])):
-        # everyRow's table depends on the coset only; the one-row and frame zerofiers are built whole and sliced (2^nBitsExt words
-        # for the moment of the slicing: AIRs that use those boundaries at config-5 size would want them built per coset too)
-        loc["Zi_ext#%d" % bi] = zhinv_slice(be, nb, eb, cb, cc) if boundary["name"] == "everyRow" else sl(S.build_zi_table(be, boundary, nb, nbe), 1)
+    for bi in range(len(info.get("boundaries", [{"name": "everyRow"}]))):
         widths["Zi_ext#%d" % bi] = 1
     for s_ in range(1, qStage + 1):
         widths["cm%d_n" % s_] = widths["cm%d_ext" % s_] = info["mapSectionsN"]["cm%d" % s_]
@@ -680,31 +776,37 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         if opening < 0:
             w = S._inv(w)
         xis.append(S.ext_scale(xi, w))
-    mine = [i for i in range(len(xis)) if i % world == rank]
-    ev_t = torch.zeros(n_ev * 3, dtype=torch.int64)
-    if mine:
+    if hasattr(be, "col_sums"):
+        # (opening, share of the columns) pairs dealt over the ranks: with w ranks and n openings each opening has w // n ranks, rank r takes
+        # opening r % n and the (r // n)-th share of every matrix's columns.  Its weights are LEv on ITS first coset (a closed form: one
+        # sweep, pil2gl_build_lev_dev), its cells the only ones it reads; the column sums of all ranks meet in one all-reduce
+        # (n x sum(widths) x 3 words) and every rank derives the evaluations from them
+        n_open = len(xis)
+        names = be.eval_matrices(info)
+        offs, tot = {}, 0
+        for nm in names:
+            offs[nm] = tot; tot += widths[nm]
+        sums_t = torch.zeros(n_open * tot * 3, dtype=torch.int64)
+        G = max(1, world // n_open)
+        tasks = [(rank % n_open, rank // n_open)] if world >= n_open else [(i, 0) for i in range(n_open) if i % world == rank]
         g_inv = S._inv(S.SHIFT * pow(S.root_of_unity(nbe), cb, S.P) % S.P)          # 1 / (7 w_E^cb): this rank's first coset
-        levs = [be.build_lev(nb, S.ext_scale(xis[i], g_inv)) for i in mine]
-        sel = [k for k, ev in enumerate(info["evMap"]) if info["openingPoints"].index(ev["prime"]) in mine]
-        sub = dict(info); sub["evMap"] = [info["evMap"][k] for k in sel]; sub["openingPoints"] = [info["openingPoints"][i] for i in mine]
-        if hasattr(be, "evals_fast") and len(levs) <= 4:
-            evals = be.evals_fast(sub, loc, widths, nb, lb, levs)          # row k of the coset is local row k << log2(cc)
-        else:
-            descs = []
-            for ev in sub["evMap"]:
-                li = sub["openingPoints"].index(ev["prime"])
-                if ev["type"] == "const":
-                    descs.append((loc["const_ext"], nC, ev["id"], 1, li))
-                else:
-                    p = info["cmPolsMap"][ev["id"]]
-                    descs.append((loc["cm%d_ext" % p["stage"]], widths["cm%d_ext" % p["stage"]], p["stagePos"], p["dim"], li))
-            evals = be.compute_evals(descs, nb, lb, levs)
-        full = np.zeros((n_ev, 3), dtype=np.uint64)
-        full[sel] = np.array(evals, dtype=np.uint64).reshape(len(sel), 3)
-        ev_t = torch.from_numpy(full.reshape(-1).view(np.int64).copy())
-        del levs
-    ev_t = comm.all_reduce_sum(ev_t)                                      # every entry is non-zero on one rank only
-    ctx["evals"] = [[int(v) for v in r] for r in ev_t.numpy().view(np.uint64).reshape(n_ev, 3)]
+        for o, c in tasks:
+            if c >= G:
+                continue
+            lev = be.build_lev(nb, S.ext_scale(xis[o], g_inv))
+            lap("evals_lev")
+            ranges = {nm: (widths[nm] * c // G, widths[nm] * (c + 1) // G) for nm in names}
+            part = be.col_sums(names, loc, widths, nb, lb, [lev], ranges)           # row k of the coset is local row k << log2(cc)
+            v = sums_t.numpy().view(np.uint64).reshape(n_open, tot, 3)
+            for nm in names:
+                v[o, offs[nm]:offs[nm] + widths[nm]] = part[nm][0]
+            del lev
+            lap("evals_dot")
+        sums_t = comm.all_reduce_sum(sums_t)                                          # every entry is non-zero on one rank only
+        v = sums_t.numpy().view(np.uint64).reshape(n_open, tot, 3)
+        ctx["evals"] = S.evals_from_col_sums(info, {nm: v[:, offs[nm]:offs[nm] + widths[nm]] for nm in names})
+    else:
+        ctx["evals"] = _evals_by_opening(be, S, info, loc, widths, xis, nb, nbe, lb, cb, rank, world, comm, nC)
     S.put_commit(be, transcript, ctx["evals"], hash_commits)
 
     lap("evals")
@@ -736,10 +838,19 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         f_cos = [be.from_torch(ft[:, jl, :].contiguous().reshape(-1)) if cc > 1 else loc["f_ext"] for jl in range(cc)]
         tbs = [be.fri_transpose(fj, nb, b1 - eb) for fj in f_cos]          # [gl_][nX*3]: row g' = the values of group 2^eb g' + j
         dig = torch.stack([be.as_torch(be.linear_hash_rows(tb, 3 * nX, gl_)).reshape(gl_, 4) for tb in tbs], dim=1)   # [gl_][cc][4]
-        parts = comm.all_gather(dig.reshape(-1).contiguous())
-        leaves = torch.stack([p_.reshape(gl_, cc * 4) for p_ in parts], dim=1).reshape(-1)      # leaf g = g' 2^eb + rank cc + jl
-        nodes1 = be.merkelize_digests(be.from_torch(leaves), 1 << b1)
-        root1 = be.root({"nodes": nodes1})
+        lap("fri_first_leaves")
+        stree1 = nodes1 = None
+        if gl_ % world == 0:
+            # the tree over the 2^b1 leaves split by leaf blocks like the stage trees: leaf g = g' 2^eb + coset is "position g', coset" of a
+            # 2^(b1-eb)-row matrix, so each rank receives its block's digests (all-to-all) and builds 1/w of the tree
+            stree1 = ShardedTree(be, None, gl_, cc, comm, block_parts=comm.all_to_all(dig.reshape(-1).contiguous()))
+            root1 = stree1.root
+        else:
+            parts = comm.all_gather(dig.reshape(-1).contiguous())
+            leaves = torch.stack([p_.reshape(gl_, cc * 4) for p_ in parts], dim=1).reshape(-1)      # leaf g = g' 2^eb + rank cc + jl
+            nodes1 = be.merkelize_digests(be.from_torch(leaves), 1 << b1)
+            root1 = be.root({"nodes": nodes1})
+        lap("fri_first_tree")
         transcript.put(root1)
         ch1 = transcript.getField()
         w_inv = S._inv(S.root_of_unity(b0))
@@ -750,9 +861,10 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         parts = comm.all_gather(fold.reshape(-1).contiguous())
         friPol = be.from_torch(torch.stack([p_.reshape(gl_, cc * 3) for p_ in parts], dim=1).reshape(-1))
         friTrees, friProof = [None] * len(steps), [{} for _ in range(len(steps) + 1)]
-        friTrees[1] = {"nodes": nodes1, "sharded_leaves": True}
+        friTrees[1] = {"nodes": nodes1, "sharded_leaves": True, "tree": stree1}
         friProof[1] = {"root": list(root1)}
-        fri_first = (tbs, 3 * nX, nodes1, 1 << b1)
+        fri_first = (tbs, 3 * nX, nodes1, 1 << b1, stree1)
+        lap("fri_first_fold")
         friTrees, friProof, challengesFRI = S.fri_commit_phase(be, ss, None, transcript, resume=(1, friPol, friTrees, friProof, [ch0, ch1]))
     else:
         f_ext = all_gather_rows(be, loc["f_ext"], nb, cc, 3, comm)
@@ -773,7 +885,9 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
         pieces.append(open_rows_local(be, constShard, queries, rank, world).cpu().reshape(-1) if not rehearse_world else torch.zeros(len(queries) * nC, dtype=torch.int64))
         pieces.append(constSTree.siblings_local(queries).reshape(-1))
     if fri_first is not None:                                          # the opened groups of the first FRI tree, from the cosets' owners
-        tbs, w1, nodes1, h1 = fri_first
+        tbs, w1, nodes1, h1, stree1 = fri_first
+        if stree1 is not None:
+            pieces.append(stree1.siblings_local(q1).reshape(-1))
         g1 = torch.zeros((len(q1), w1), dtype=torch.int64)
         own = [(k, (g >> eb), (g & ((1 << eb) - 1)) - cb) for k, g in enumerate(q1) if cb <= (g & ((1 << eb) - 1)) < cb + cc]
         for jl in range(cc):
@@ -782,6 +896,7 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
                 tt = be.as_torch(tbs[jl]).reshape(-1, w1)
                 g1[torch.tensor([k for k, _ in sel])] = tt[torch.tensor([gp for _, gp in sel], device=tt.device)].cpu()
         pieces.append(g1.reshape(-1))
+    lap("queries_gather")
     summed = comm.all_reduce_sum(torch.cat(pieces))
     parts, o = [], 0
     for p_ in pieces:
@@ -795,14 +910,15 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
                       constSTree.siblings_finish(queries, parts[2 * qStage + 1])))
     else:
         pc = be.group_proofs(constTree, queries)
-    friProof[0]["polQueries"] = [[[[int(v) for v in rows[i]], sib[i]] for rows, sib in opened] + [list(pc[i])] for i in range(len(queries))]
+    opened = [(rows.tolist(), sib) for rows, sib in opened]
+    friProof[0]["polQueries"] = [[[rows[i], sib[i]] for rows, sib in opened] + [list(pc[i])] for i in range(len(queries))]
     q = list(queries)
     for step in range(1, len(ss["steps"])):
         q = [qi % (1 << ss["steps"][step]["nBits"]) for qi in q]
         if step == 1 and fri_first is not None:
-            sib = be.merkle_siblings(nodes1, h1, q)
-            vals = parts[-1].numpy().view(np.uint64).reshape(len(q), w1)
-            friProof[step]["polQueries"] = [[[int(v) for v in vals[i]], sib[i]] for i in range(len(q))]
+            sib = stree1.siblings_finish(q, parts[-2]) if stree1 is not None else be.merkle_siblings(nodes1, h1, q)
+            vals = parts[-1].numpy().view(np.uint64).reshape(len(q), w1).tolist()
+            friProof[step]["polQueries"] = [[vals[i], sib[i]] for i in range(len(q))]
         else:
             friProof[step]["polQueries"] = [list(p_) for p_ in be.group_proofs(friTrees[step], q)]
     lap("queries")

@@ -105,6 +105,19 @@ def test_sharded_proof_over_rccl_one_rank(oracle):
     _launch(1, "--backend", "gpu", "--pg", "nccl", "--nbits", "16", "--pairs", "4", "--steps", "19,14,9,4", "--shardsetup", "1", worker=PROVE_WORKER)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_proof_with_boundaries_gpu_ranks(oracle, world):
+    """pil2 boundaries in the sharded proof: the rank's rows of the firstRow / lastRow / everyFrame zerofiers are built from its own
+    cosets (parallel.zi_slice: batched inversion over the rank's rows, the evaluator over its x rows), never sliced out of a
+    2^nBitsExt-row table; the tables are kept with the setup and a second proof reuses them"""
+    _launch(world, "--backend", "gpu", "--nbits", "10", "--pairs", "5", "--steps", "13,9,4", "--boundaries", "1", "--twice", "1", worker=PROVE_WORKER)
+
+
+def test_sharded_proof_with_boundaries_cpu(oracle):
+    _launch(2, "--backend", "oracle", "--boundaries", "1", "--twice", "1", worker=PROVE_WORKER)
+
+
 @pytest.mark.parametrize("steps", ["9,2", "9"])
 def test_sharded_proof_with_fri_groups_across_cosets_cpu(oracle, steps):
     """the first FRI tree's groups stay inside one coset only while steps[1].nBits >= the extension bits; below that (or

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--impols", type=int, default=0, help="fib: intermediate polynomials computed by the prover (fibonacci_air im_pols)")
     ap.add_argument("--boundaries", type=int, default=0, help="fib: constraints on pil2 boundaries (everyFrame / firstRow / lastRow) instead of selector constants")
     ap.add_argument("--shardsetup", type=int, default=0, help="1: the constant tree is split over the ranks too (parallel.build_const_tree_sharded)")
+    ap.add_argument("--twice", type=int, default=0, help="1: prove a second time with the same setup (cached tables)")
     a = ap.parse_args()
     if a.pg == "nccl":
         import torch
@@ -64,6 +65,10 @@ def main():
         setup_sh = parallel.build_const_tree_sharded(be, consts, info)
         assert list(setup_sh["constRoot"]) == list(setup["constRoot"]), "rank %d: sharded constant tree has another root" % rank
     got = parallel.stark_gen_sharded(be, be.from_host(cm), setup_sh, info, exprs, publics)
+    if a.twice:                                             # the rank's tables are kept with the setup (parallel.shard_tables): a second proof reuses them
+        assert "_shardTables" in setup_sh
+        again = parallel.stark_gen_sharded(be, be.from_host(cm), setup_sh, info, exprs, publics)
+        assert again["proof"] == got["proof"], "rank %d: the second proof with the same setup differs" % rank
     want = stark.stark_gen(be, be.from_host(cm), setup, info, exprs, publics)
     for k in ("challenges", "challengesFRISteps", "queries", "publics"):
         assert got[k] == want[k], "rank %d: %s differ" % (rank, k)

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE ONLY -- a restatement of the reference's chelpers encoder, to produce `.chelpers.bin` files for the
-product's reader (pil2gl.chelpers) to be tested against.  Only tests/ import this.
+reader in tests/chelpers_reader.py to be tested against.  Only tests/ import this.
 
 parity unpinned by execution: src/stark/chelpers/{getParserArgs,helpers,generateParser,binFile}.js need chai and
 @iden3/binfileutils, which are absent here, so the reference's own encoder cannot be run; the functions below

@@ -141,8 +141,18 @@ async function starkVerify(proof, publics, constRoot, challenges, starkInfo, ver
     const ctx = { evals: proof.evals, subproofValues: proof.subproofValues, publics, starkInfo, proof };
     const tr = challenges || await calculateTranscript(null, starkInfo, proof, publics, constRoot, options);
     ctx.challenges = tr.challenges; ctx.challengesFRISteps = tr.challengesFRISteps;
-    // (proofs of the older transcript layout draw the query positions from the main transcript: their caller passes them as challenges.friQueries)
-    ctx.friQueries = tr.friQueries ? tr.friQueries.slice() : await calculateFRIQueries(starkInfo, ctx.challengesFRISteps[ss.steps.length], options);
+    // The query positions ALWAYS come out of the last FRI challenge (stark_verify.js:93) -- positions handed in by the caller would not be
+    // bound to the transcript.  One exception, behind an explicit option: proofs of the older pil-stark transcript layout (the reference's
+    // test/final proof) draw them from the main transcript; options.legacyTranscriptQueries = true takes challenges.friQueries for those.
+    const derived = await calculateFRIQueries(starkInfo, ctx.challengesFRISteps[ss.steps.length], options);
+    if (options.legacyTranscriptQueries && tr.friQueries) ctx.friQueries = tr.friQueries.slice();
+    else {
+        if (tr.friQueries && (tr.friQueries.length !== derived.length || tr.friQueries.some((q, i) => Number(q) !== Number(derived[i])))) {
+            if (logger) logger.warn("Query positions do not follow from the FRI challenge");
+            return false;
+        }
+        ctx.friQueries = derived;
+    }
 
     // evaluations (:95-152)
     const xi = big(ctx.challenges[evalsStage][0]);
@@ -169,6 +179,12 @@ async function starkVerify(proof, publics, constRoot, challenges, starkInfo, ver
 
     // openings of every tree, all queries of a tree in one call (:165-178)
     const nQ = ss.nQueries, pq0 = proof.fri[0].polQueries, queries = ctx.friQueries;
+    // a proof whose openings are short (fewer queries than the struct asks for, a tree missing, fewer values than the section is wide) is
+    // an invalid proof, not an exception: the reference's paths all end in `return false`
+    const widthOf = (j) => (j < qStage ? (starkInfo.mapSectionsN["cm" + (j + 1)] || 0) : starkInfo.nConstants);
+    const wellFormed = Array.isArray(pq0) && pq0.length >= nQ && queries.length >= nQ && pq0.slice(0, nQ).every((q) => Array.isArray(q) && q.length >= qStage + 1 &&
+        q.slice(0, qStage + 1).every((o, j) => Array.isArray(o) && Array.isArray(o[0]) && Array.isArray(o[1]) && (o[0].length >= widthOf(j) || (o[0].length === 0 && o[1].length === 0))));
+    if (!wellFormed) { if (logger) logger.warn("Malformed openings"); return false; }
     const roots = [];
     for (let st = 1; st <= qStage; st++) roots.push(proof["root" + st]);
     roots.push(constRoot);
@@ -189,7 +205,7 @@ async function starkVerify(proof, publics, constRoot, challenges, starkInfo, ver
         const name = j < qStage ? "cm" + (j + 1) + "_ext" : "const_ext";
         const width = j < qStage ? (starkInfo.mapSectionsN["cm" + (j + 1)] || 0) : starkInfo.nConstants;
         const a = new BigUint64Array(Math.max(1, rows * width));
-        for (let i = 0; i < nQ; i++) { const v = pq0[i][j][0]; for (let c = 0; c < width; c++) a[i * width + c] = m(BigInt(v[c])); }
+        for (let i = 0; i < nQ; i++) { const v = pq0[i][j][0]; if (v.length < width) continue; for (let c = 0; c < width; c++) a[i * width + c] = m(BigInt(v[c])); }
         fake[name] = a;
     }
     const xdiv = new BigUint64Array(rows * 3 * nOpen);

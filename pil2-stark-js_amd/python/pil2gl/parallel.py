@@ -22,6 +22,9 @@ except Exception:  # pragma: no cover
     dist = None
 
 
+MAX_NTT_BITS = 30        # csrc/common.h PIL2GL_MAX_NTT_BITS: the largest single transform
+
+
 def coset_range(rank, world, ext_bits):
     """cosets [begin, begin+count) owned by `rank`; world must divide 2^ext_bits"""
     n = 1 << ext_bits
@@ -670,6 +673,14 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     qStage = nStages + 1
     nQ, nC = info["mapSectionsN"]["cm%d" % qStage], info["nConstants"]
     assert ss["steps"][0]["nBits"] == nbe
+    # the quotient's coefficients come by cosets and row blocks (no buffer of 2^nBitsExt rows) when the partition allows it; otherwise q is
+    # all-gathered and transformed whole on every rank -- which a domain beyond one transform, or beyond the memory for a replicated
+    # 2^nBitsExt x qDim buffer, cannot do: say so before any stage has been committed
+    import os
+    split_q = os.environ.get("PIL2GL_Q_GATHER", "0") != "1" and N % world == 0 and (N // world) >= 2 and cc & (cc - 1) == 0
+    if not split_q and nbe > MAX_NTT_BITS:
+        raise ValueError("sharded proof: 2^%d rows over %d ranks would all-gather the quotient and transform 2^%d rows on every rank (limit 2^%d); "
+                         "the coset-wise path needs world | N and a power-of-two coset count per rank" % (nb, world, nbe, MAX_NTT_BITS))
     ctx = {"pilInfo": info, "publics": list(publics), "challenges": [[] for _ in range(nStages + 3)], "evals": [], "subproofValues": [0] * info.get("nSubproofValues", 0)}
     constTree = setup.get("constTree")
     constShard, constSTree = setup.get("constShard"), setup.get("constTreeSharded")
@@ -736,8 +747,6 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
             t_ = be.as_torch(loc[k]).reshape(1 << nloc, -1)
             samples[k] = t_[ri.to(t_.device)].cpu().numpy().view(np.uint64)
     lap("q_expr")
-    import os
-    split_q = os.environ.get("PIL2GL_Q_GATHER", "0") != "1" and N % world == 0 and (N // world) >= 2 and cc & (cc - 1) == 0
     q_ext = None if split_q else all_gather_rows(be, loc["q_ext"], nb, cc, qDim, comm)
     # computeQStark (stark_gen_helpers.js:168-208): the coefficients of q by cosets and row blocks (quotient_coefficients_sharded;
     # PIL2GL_Q_GATHER=1: all-gather q and transform it everywhere); the split quotient has degree < N per column, so its

@@ -41,16 +41,27 @@ async function runCase(c, label) {
     const proof = bigProof(c.proof), publics = c.publics.map(BigInt), constRoot = bigProof(c.constRoot);
     const challenges = c.challenges ? bigProof(c.challenges) : undefined;
     if (challenges && challenges.friQueries) challenges.friQueries = challenges.friQueries.map(Number);
-    assert.strictEqual(await starkVerify(proof, publics, constRoot, challenges, c.starkInfo, c.verifierInfo), true, label + ": a valid proof is rejected");
+    // (the BN128 reference proof is of the older transcript layout: its query positions come from the main transcript, which the verifier
+    // accepts only when told so -- and refuses otherwise, since they do not follow from the FRI challenge)
+    const opts = challenges && challenges.friQueries ? { legacyTranscriptQueries: true } : {};
+    assert.strictEqual(await starkVerify(proof, publics, constRoot, challenges, c.starkInfo, c.verifierInfo, opts), true, label + ": a valid proof is rejected");
+    if (opts.legacyTranscriptQueries) assert.strictEqual(await starkVerify(proof, publics, constRoot, challenges, c.starkInfo, c.verifierInfo), false, label + ": caller-supplied query positions accepted without the option");
     let rejected = 0;
     if (challenges && challenges.friQueries) proof.__idx0 = challenges.friQueries[0];
     for (const [name, bad] of alterations(proof, bn)) {
         delete bad.__idx0;
         let ok;
-        try { ok = await starkVerify(bad, publics, constRoot, challenges, c.starkInfo, c.verifierInfo); } catch (e) { ok = false; }
+        try { ok = await starkVerify(bad, publics, constRoot, challenges, c.starkInfo, c.verifierInfo, opts); } catch (e) { ok = false; }
         // with the caller's challenges the transcript is not replayed: an altered root / evaluation is then caught by nothing but the
         // openings and the evaluation identity -- both of which bind them
         assert.strictEqual(ok, false, label + ": altered " + name + " accepted");
+        rejected++;
+    }
+    // malformed openings are an invalid proof, not an exception (the reference's paths end in `return false`)
+    for (const cut of ["queries", "tree", "values"]) {
+        const bad = bigProof(c.proof), q = bad.fri[0].polQueries;
+        if (cut === "queries") q.pop(); else if (cut === "tree") q[0].pop(); else q[1][q[1].length - 1][0].pop();
+        assert.strictEqual(await starkVerify(bad, publics, constRoot, challenges, c.starkInfo, c.verifierInfo, opts), false, label + ": openings short of " + cut + " accepted");
         rejected++;
     }
     if (publics.length && !challenges) {

@@ -1,7 +1,8 @@
 """the reference's expression bytecode (`.chelpers.bin`, src/stark/chelpers) read back into programs for
 the device evaluator.  The file is written by oracle/chelpers_ref.py, a line-by-line restatement of getParserArgs.js /
 helpers.js / generateParser.js / binFile.js (the reference's own encoder needs chai and @iden3/binfileutils, absent here:
-parity unpinned by execution for this row), and read by the product's pil2gl.chelpers."""
+parity unpinned by execution for this row), and read by tests/chelpers_reader.py.  Both writer and reader are this repository's: the pair
+proves nothing about the reference's files, so the reader does not travel with the product; the row stays closed."""
 import copy
 
 import pytest
@@ -19,7 +20,7 @@ def _airs():
 def _through_bytecode(info, exprs, tmp_path):
     """exprs with the constraint and FRI expressions' op-lists replaced by what comes back from the .chelpers.bin"""
     import chelpers_ref
-    from pil2gl import chelpers
+    import chelpers_reader as chelpers
     f = str(tmp_path / "air.chelpers.bin")
     chelpers_ref.write_chelpers(f, chelpers_ref.build_generic_bin_info(info, exprs))
     back = chelpers.read_chelpers_bin(f)
@@ -42,7 +43,7 @@ def _through_bytecode(info, exprs, tmp_path):
 
 def test_operation_table_and_container(tmp_path):
     import chelpers_ref
-    from pil2gl import chelpers
+    import chelpers_reader as chelpers
     t = chelpers.all_operations()
     assert len(t) == len(chelpers_ref.all_operations()) == 2 * 10 + 2 * (16 + 10 + 4) + 5 == 85     # generateParser.js:519-578
     assert t[0] == (None, "commit1", "commit1", "commit1") and t[-1] == (None, "tmp3", "commit3", "eval")

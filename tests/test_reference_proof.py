@@ -336,7 +336,7 @@ def test_final_proof_full_device_verification():
     proof = io.zkin2proof(z, info)
     publics = [int(v) for v in z["publics"]]
     tr = _final_transcript(be.new_transcript(), z, info)
-    ok, why = stark.stark_verify(be, proof, publics, root_c, info, None, vinfo, challenges=tr)
+    ok, why = stark.stark_verify(be, proof, publics, root_c, info, None, vinfo, challenges=tr, legacy_transcript_queries=True)
     assert ok, why
 
     def tampered(what):
@@ -360,10 +360,13 @@ def test_final_proof_full_device_verification():
         elif what == "root":
             bad["root3"] = int(bad["root3"]) + 1
         return bad
+    # positions handed in by the caller are not bound to the FRI challenge: refused unless the older layout is asked for by name
+    ok, why = stark.stark_verify(be, proof, publics, root_c, info, None, vinfo, challenges=tr)
+    assert not ok and "query positions" in why
     for what in ("eval", "opened value", "constant", "sibling", "fri layer value", "fri layer sibling", "last polynomial", "root"):
-        ok, why = stark.stark_verify(be, tampered(what), publics, root_c, info, None, vinfo, challenges=tr)
+        ok, why = stark.stark_verify(be, tampered(what), publics, root_c, info, None, vinfo, challenges=tr, legacy_transcript_queries=True)
         assert not ok, what
     # a challenge that is not the transcript's: the identity no longer holds
     bad_tr = dict(tr, challenges=[list(c) for c in tr["challenges"]]); bad_tr["challenges"][3] = [[1, 2, 3]]
-    ok, _ = stark.stark_verify(be, proof, publics, root_c, info, None, vinfo, challenges=bad_tr)
+    ok, _ = stark.stark_verify(be, proof, publics, root_c, info, None, vinfo, challenges=bad_tr, legacy_transcript_queries=True)
     assert not ok

@@ -18,6 +18,7 @@
 #include "common.h"
 #include "bn_field.cuh"
 #include "bn_mfma.cuh"
+#include "bn_field29.cuh"
 #include <mutex>
 #include <vector>
 #include <string.h>
@@ -26,6 +27,12 @@
 
 using namespace pil2gl;
 using bn::u32;
+
+// The S-box of the matrix-core pipeline in radix 2^29 (bn_field29.cuh: no carry instructions; its output is the state form times 2^-20,
+// which the tiles reading it take back).  -DBN_SBOX29=0: the 32-bit-limb products (A/B builds).
+#ifndef BN_SBOX29
+#define BN_SBOX29 1
+#endif
 
 namespace {
 
@@ -196,8 +203,10 @@ struct MfmaConsts {
         for (int k = 0; k < 32; k++) { off = h_addmod(off, v); for (int e = 0; e < 8; e++) v = h_addmod(v, v); }
     }
 };
-// one tile (1 KB, lane order) of the coefficient a (Montgomery form); tot += the sum of its 32 constants
-void mfma_tile(const MfmaConsts &mc, const U256 &a, int8_t *tile, U256 &tot) {
+// one tile (1 KB, lane order) of the coefficient a0 (Montgomery form); tot += the sum of its 32 constants.  sboxed: the operand this tile
+// multiplies comes straight out of the S-box, i.e. (bn_field29.cuh) carries a factor 2^-20: the coefficient takes it back
+void mfma_tile(const MfmaConsts &mc, const U256 &a0, int8_t *tile, U256 &tot, bool sboxed) {
+    const U256 a = sboxed && BN_SBOX29 ? h_mont(a0, h_to_mont(U256{ { 1ull << 20, 0, 0, 0 } })) : a0;
     for (int b = 0; b < 32; b++) {
         const U256 c = h_mont(a, mc.P[b]);           // a 2^(8b+32) mod r as a plain integer
         tot = h_addmod(tot, c);
@@ -222,14 +231,14 @@ U256 mfma_row_const(const MfmaConsts &mc, U256 tot, int nAcc, const U256 &fold) 
     return h_addmod(h_mont(tot, inv32), fold);
 }
 // A: rows x cols entries in Montgomery form.  tiles: rows*cols KB; K: rows plain integers mod r (callers add what follows the layer).
-void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &tiles, Vec &K) {
+void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &tiles, Vec &K, bool sboxed) {
     const MfmaConsts mc;
     const U256 zero = { { 0, 0, 0, 0 } };
     tiles.assign((size_t)rows * cols * 1024, 0);
     K.resize((size_t)rows);
     for (int i = 0; i < rows; i++) {
         U256 tot = zero;
-        for (int j = 0; j < cols; j++) mfma_tile(mc, A[(size_t)i * cols + j], tiles.data() + ((size_t)i * cols + j) * 1024, tot);
+        for (int j = 0; j < cols; j++) mfma_tile(mc, A[(size_t)i * cols + j], tiles.data() + ((size_t)i * cols + j) * 1024, tot, sboxed);
         K[i] = mfma_row_const(mc, tot, 1, zero);
     }
 }
@@ -249,21 +258,21 @@ void mfma_partial_tables(int t, int rp, const Vec &S, const Vec &V, const Vec &W
     for (int b = 0; b < nb; b++) {
         const int k0 = 4 * b;
         U256 tot[4] = { zero, zero, zero, zero };
-        for (int j = 0; j < n; j++) for (int i = 0; i < 4; i++, tp += 1024) mfma_tile(mc, V[(size_t)(k0 + i) * n + j], tp, tot[i]);
+        for (int j = 0; j < n; j++) for (int i = 0; i < 4; i++, tp += 1024) mfma_tile(mc, V[(size_t)(k0 + i) * n + j], tp, tot[i], false);
         for (int i = 0; i < 4; i++) {
             for (int s = 0; s < 4; s++, tp += 1024) {
                 const int ip = i + s - 3;
                 if (ip < 0) continue;
                 U256 c = m00;
                 if (ip < i) { c = zero; for (int j = 0; j < n; j++) c = h_addmod(c, h_mont(V[(size_t)(k0 + i) * n + j], W[(size_t)(k0 + ip) * n + j])); }
-                mfma_tile(mc, c, tp, tot[i]);
+                mfma_tile(mc, c, tp, tot[i], true);  // a z: the S-box's output
             }
             KR[(size_t)k0 + i] = mfma_row_const(mc, tot[i], 2, k0 + i + 1 < 4 * nb ? S[(size_t)k0 + i + 1] : zero);
         }
         for (int j = 0; j < n; j++) {
             U256 tu = zero;
-            mfma_tile(mc, one, tp, tu); tp += 1024;
-            for (int s = 0; s < 4; s++, tp += 1024) mfma_tile(mc, W[(size_t)(k0 + s) * n + j], tp, tu);
+            mfma_tile(mc, one, tp, tu, false); tp += 1024;
+            for (int s = 0; s < 4; s++, tp += 1024) mfma_tile(mc, W[(size_t)(k0 + s) * n + j], tp, tu, true);
             KU[(size_t)b * n + j] = mfma_row_const(mc, tu, 1, zero);
         }
     }
@@ -292,8 +301,8 @@ int get_params(int t, const Params **out) {
         memcpy(P.m00, M[0].w, 32);
         {
             std::vector<int8_t> tm, td, tpr; Vec km0, km, kd, kr, ku;
-            mfma_layer_tables(M, t, t, tm, km0);
-            mfma_layer_tables(D, n, n, td, kd);
+            mfma_layer_tables(M, t, t, tm, km0, true);     // every dense layer follows an S-box layer
+            mfma_layer_tables(D, n, n, td, kd, false);    // the closing layer reads the columns the blocks left
             mfma_partial_tables(t, rp, S, V, W, M[0], tpr, kr, ku);
             // What follows a layer is added by its row constants (the values in between are lazy representatives, no other addition
             // is left): the next full round's constants C8; after the fourth full round S[0] on element 0; after the closing layer
@@ -389,17 +398,30 @@ __device__ __forceinline__ void pow5(u32 x[8]) {
 // the same on lazy representatives: x < 0.69 * 2^256 in (a layer's output < 2^255, plus a round constant at most), x^5 < 0.63 * 2^256
 // out -- any 256-bit value will do for the matrix operand that reads it (bn_field.cuh fr_mul_nr)
 __device__ __forceinline__ void pow5_lazy(u32 x[8]) {
+#ifdef BN_ABLATE_SBOX
+    return;                                          // timing experiments only (tools): the S-box left out, results meaningless
+#endif
+#if BN_SBOX29
+    bn29::pow5(x);                                   // x^5 in the state's form times 2^-20 (the next layer's tiles carry 2^20)
+#else
     u32 x2[8], x4[8];
     bn::fr_mul_nr(x2, x, x); bn::fr_mul_nr(x4, x2, x2); bn::fr_mul_nr(x, x4, x);
+#endif
 }
 // x + c for a lazy x < 2^255 and a constant c < r: < 0.69 * 2^256, left as it is (the S-box that follows takes it, pow5_lazy)
 __device__ __forceinline__ void add_lazy(u32 x[8], const u32 c[8]) { bnm::add_chain8(x, c); }
 // The S-box layer of a full round in the matrix-core pipeline: the round's constants arrive with the previous layer's rows
 // (except the first round's, C != nullptr); lazy in, lazy out
+// (element j + 1 is requested before element j is worked on: more than half of a wide state lives in private memory, whose L2 latency --
+// a microsecond -- would otherwise be paid in full by every element; the same in the two loops of partial_rounds_mfma)
 __device__ __noinline__ void sbox_lazy(const St st, int t, const u32 *C) {
+    u32 xn[8];
+    lds_load(st, 0, xn);
     for (int j = 0; j < t; j++) {
         u32 x[8];
-        lds_load(st, j, x);
+#pragma unroll
+        for (int l = 0; l < 8; l++) x[l] = xn[l];
+        if (j + 1 < t) lds_load(st, j + 1, xn);
         if (C) {
             u32 c[8];
             load_const<true>(C, (size_t)j, c);
@@ -625,9 +647,13 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
             bnm::v16i P0[4], P1[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) { P0[i] = bnm::acc_init(); P1[i] = bnm::acc_init(); }
+            u32 yn[8];
+            lds_load(st, 1, yn);
             for (int j = 0; j < n; j++) {
                 u32 y[8];
-                lds_load(st, 1 + j, y);
+#pragma unroll
+                for (int l = 0; l < 8; l++) y[l] = yn[l];
+                if (j + 1 < n) lds_load(st, 2 + j, yn);               // the next column's words are on their way while this one's products run
                 bnm::v4i b0, b1;
                 bnm::b_prep(y, b0, b1);
 #pragma unroll
@@ -665,9 +691,14 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
             load_const<true>(A.KR, (size_t)(4 * b + i), k);
             bnm::finish_words(w, k, x0);
         }
+        u32 yn[8];
+        lds_load(st, 1, yn);
         for (int j = 0; j < n; j++) {
             u32 y[8], k[8];
-            lds_load(st, 1 + j, y);
+#pragma unroll
+            for (int l = 0; l < 8; l++) y[l] = yn[l];
+            if (j + 1 < n) lds_load(st, 2 + j, yn);
+            load_const<true>(A.KU, (size_t)b * n + j, k);             // (asked for early: used after the products)
             bnm::v4i b0, b1;
             bnm::b_prep(y, b0, b1);
             bnm::v4i a = ts.next();
@@ -678,7 +709,6 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
                 c0 = bnm::mfma(a, zb0[s], c0);
                 c1 = bnm::mfma(a, zb1[s], c1);
             }
-            load_const<true>(A.KU, (size_t)b * n + j, k);
             bnm::finish_row(c0, c1, k, y, sh);
             lds_store(st, 1 + j, y);
         }
@@ -950,7 +980,10 @@ __global__ void bn_convert_kernel(const u64 *__restrict__ in, u64 n, int toMont,
     for (int q = 0; q < 4; q++) out[4 * i + q] = (u64)o[2 * q] | ((u64)o[2 * q + 1] << 32);
 }
 
-size_t lds_bytes(int tmax) { return (size_t)(tmax < BN_LDS_ELEMS ? tmax : BN_LDS_ELEMS) * 8 * BN_BLOCK * 4; }   // the elements above live in private memory
+size_t lds_bytes(int tmax) {                         // the elements above BN_LDS_ELEMS live in private memory
+    static const size_t pad = getenv("PIL2GL_BN128_LDS_PAD") ? (size_t)atol(getenv("PIL2GL_BN128_LDS_PAD")) : 0;   // occupancy experiments: extra bytes per workgroup
+    return (size_t)(tmax < BN_LDS_ELEMS ? tmax : BN_LDS_ELEMS) * 8 * BN_BLOCK * 4 + pad;
+}
 
 PermArgs perm_args(const Params *P) {
     PermArgs a;

@@ -144,9 +144,11 @@ async function starkVerify(proof, publics, constRoot, challenges, starkInfo, ver
     // The query positions ALWAYS come out of the last FRI challenge (stark_verify.js:93) -- positions handed in by the caller would not be
     // bound to the transcript.  One exception, behind an explicit option: proofs of the older pil-stark transcript layout (the reference's
     // test/final proof) draw them from the main transcript; options.legacyTranscriptQueries = true takes challenges.friQueries for those.
-    const derived = await calculateFRIQueries(starkInfo, ctx.challengesFRISteps[ss.steps.length], options);
     if (options.legacyTranscriptQueries && tr.friQueries) ctx.friQueries = tr.friQueries.slice();
     else {
+        const seed = ctx.challengesFRISteps[ss.steps.length];
+        if (seed === undefined) { if (logger) logger.warn("No challenge to draw the query positions from"); return false; }
+        const derived = await calculateFRIQueries(starkInfo, seed, options);
         if (tr.friQueries && (tr.friQueries.length !== derived.length || tr.friQueries.some((q, i) => Number(q) !== Number(derived[i])))) {
             if (logger) logger.warn("Query positions do not follow from the FRI challenge");
             return false;

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include "bn_mfma.cuh"
+#include "bn_field29.cuh"
 using namespace bn;
 
 __device__ u32 rnd(u32 &s) { s = s * 1664525u + 1013904223u; return s ^ (s >> 15); }
@@ -93,6 +94,27 @@ __global__ void k_mul(int *bad, u32 seed, int mode) {
     if (bd) atomicAdd(bad, 1);
 }
 
+// the radix-2^29 S-box: x^5 / 2^1044 of a lazy x, i.e. the Montgomery (2^256) form of x^5 times 2^-20
+__global__ void k_pow29(int *bad, u32 seed, int mode) {
+    u32 s = seed * 257u + threadIdx.x * 7919u + blockIdx.x * 104729u;
+    u32 a[8];
+    for (int l = 0; l < 8; l++) a[l] = mode == 1 ? 0xffffffffu : rnd(s);
+    if (mode == 1) a[7] = 0xb0000000u; else if (mode == 2) a[7] = a[7] % 0xb0000000u; else a[7] &= 0x7fffffffu;      // below 0.69 * 2^256
+    u32 ac[8], y[8], want[8], x2[8], x4[8];
+    for (int l = 0; l < 8; l++) { ac[l] = a[l]; y[l] = a[l]; }
+    bnm::canon(ac); bnm::canon(ac);                       // up to 0.69 * 2^256 < 4r: a second pair of subtractions
+    fr_mul(x2, ac, ac); fr_mul(x4, x2, x2); fr_mul(want, x4, ac);
+    bn29::pow5(y);
+    int bd = y[7] >> 31;
+    u32 t20[8] = { 1u << 20, 0, 0, 0, 0, 0, 0, 0 }, r2[8], m20[8], got[8];
+    for (int l = 0; l < 8; l++) r2[l] = r2_limb(l);
+    fr_mul(m20, t20, r2);                                 // 2^20 in Montgomery form
+    bnm::canon(y);
+    fr_mul(got, y, m20);                                  // y * 2^20
+    for (int l = 0; l < 8; l++) bd |= want[l] != got[l];
+    if (bd) atomicAdd(bad, 1);
+}
+
 int main() {
     int *bad; (void)hipMalloc((void **)&bad, 4);
     for (int mode = 0; mode < 3; mode++) {
@@ -106,6 +128,12 @@ int main() {
         hipLaunchKernelGGL(k_mul, dim3(4096), dim3(64), 0, 0, bad, 777u + mode, mode);
         int h = -1; (void)hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
         printf("fr_mul_nr / x^5 on lazy operands vs canonical, mode %d: %d of %d lanes differ\n", mode, h, 4096 * 64);
+    }
+    for (int mode = 0; mode < 3; mode++) {
+        (void)hipMemset(bad, 0, 4);
+        hipLaunchKernelGGL(k_pow29, dim3(4096), dim3(64), 0, 0, bad, 4242u + mode, mode);
+        int h = -1; (void)hipMemcpy(&h, bad, 4, hipMemcpyDeviceToHost);
+        printf("radix-2^29 x^5 (times 2^20) vs the 32-bit-limb S-box, mode %d: %d of %d lanes differ\n", mode, h, 4096 * 64);
     }
     return 0;
 }

@@ -341,6 +341,21 @@ int get_params(int t, const Params **out) {
 }
 
 // ------------------------------------------------------------------------------------------ device side
+// -DBN_STAMPS: a diagnostic build that sums, per phase of the matrix-core permutation, the shader cycles a wave spends in it
+// (s_memtime around each phase, lane 0 adds into g_bn_stamps at the end of a permutation; pil2gl_bn128_debug_stamps reads them).
+// No stamp executes in the product build.
+#ifdef BN_STAMPS
+__device__ unsigned long long g_bn_stamps[16];
+__device__ __forceinline__ unsigned long long bn_now() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define BN_STAMP(slot, expr) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t0_ = bn_now(); __builtin_amdgcn_sched_barrier(0); expr; \
+    __builtin_amdgcn_sched_barrier(0); const unsigned long long t1_ = bn_now(); __builtin_amdgcn_sched_barrier(0); if (st.lane == 0) atomicAdd(&g_bn_stamps[slot], t1_ - t0_); }
+#else
+#define BN_STAMP(slot, expr) { expr; }
+#endif
 struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8];
                   const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma, nofold; };
 
@@ -517,24 +532,31 @@ __device__ __noinline__ void dense_mfma_n(const St st, const bnm::v4i *tiles, co
 #pragma unroll
     for (int k = 0; k < MFMA_AHEAD; k++) q[k] = tp[(size_t)k * 64];
     for (int i = 0; i < N; i++) {
+        u32 k[8], o[8];
+        load_const<true>(kc, (size_t)i, k);          // asked for ahead of the row's tiles: an in-order counter waits for everything older than what it wants
         bnm::v16i a0 = bnm::acc_init(), a1 = bnm::acc_init();
 #pragma unroll
         for (int j = 0; j < N; j++) {
             const bnm::v4i a = q[0];
 #pragma unroll
             for (int k = 0; k + 1 < MFMA_AHEAD; k++) q[k] = q[k + 1];
+#ifdef BN_ABLATE_TILEADDR
+            q[MFMA_AHEAD - 1] = ((bnm::gtile)tiles + st.lane)[(size_t)((j + MFMA_AHEAD) & 7) * 64];      // timing experiments only: every tile from one 8 KB window
+#else
             q[MFMA_AHEAD - 1] = tp[(size_t)(j + MFMA_AHEAD) * 64];
+#endif
             a0 = bnm::mfma(a, B0[j], a0);
             a1 = bnm::mfma(a, B1[j], a1);
         }
         tp += (size_t)N * 64;
-        u32 k[8], o[8];
-        load_const<true>(kc, (size_t)i, k);
         bnm::finish_row(a0, a1, k, o, sh);
         lds_store(st, first + i, o);                 // the old state is in B0 / B1: the new row can go straight to its place
     }
 }
 __device__ __forceinline__ void dense_mfma(const St st, const bnm::v4i *tiles, const u32 *kc, int n, int first) {
+#ifdef BN_ABLATE_DENSE
+    return;                                          // timing experiments only: the layer left out, results meaningless
+#endif
     switch (n) {
     case 1: dense_mfma_n<1>(st, tiles, kc, first); break;
     case 2: dense_mfma_n<2>(st, tiles, kc, first); break;
@@ -620,8 +642,14 @@ constexpr int PR_AHEAD = 6;
 struct TileStream {
     bnm::gtile p;
     bnm::v4i q[PR_AHEAD];
+#ifdef BN_ABLATE_TILEADDR
+    bnm::gtile base; unsigned cnt = 0;
+#endif
     __device__ __forceinline__ void start(const bnm::v4i *tiles, int lane) {
         p = (bnm::gtile)tiles + lane;
+#ifdef BN_ABLATE_TILEADDR
+        base = p;
+#endif
 #pragma unroll
         for (int k = 0; k < PR_AHEAD; k++) q[k] = p[(size_t)k * 64];
     }
@@ -629,7 +657,11 @@ struct TileStream {
         const bnm::v4i a = q[0];
 #pragma unroll
         for (int k = 0; k + 1 < PR_AHEAD; k++) q[k] = q[k + 1];
+#ifdef BN_ABLATE_TILEADDR
+        q[PR_AHEAD - 1] = base[(size_t)(cnt++ & 7) * 64];
+#else
         q[PR_AHEAD - 1] = p[(size_t)PR_AHEAD * 64];
+#endif
         p += 64;
         return a;
     }
@@ -643,33 +675,61 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
     lds_load(st, 0, x0);                              // S[0] came with the row of the layer before
     for (int b = 0; b < nb; b++) {
         u32 pc[4][10];
+#ifdef BN_STAMPS
+        unsigned long long tp0 = bn_now();
+#endif
         {
             bnm::v16i P0[4], P1[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) { P0[i] = bnm::acc_init(); P1[i] = bnm::acc_init(); }
             u32 yn[8];
             lds_load(st, 1, yn);
+#ifdef BN_STAMPS2
+            unsigned long long acc9 = 0, acc10 = 0, acc11 = 0;
+#endif
+#ifdef BN_ABLATE_P
+            for (int j = 0; j < n; j++) for (int i = 0; i < 4; i++) (void)ts.next();
+            if (false)
+#endif
             for (int j = 0; j < n; j++) {
                 u32 y[8];
 #pragma unroll
                 for (int l = 0; l < 8; l++) y[l] = yn[l];
+#ifdef BN_STAMPS2
+                __builtin_amdgcn_sched_barrier(0); const unsigned long long s0_ = bn_now(); __builtin_amdgcn_sched_barrier(0);
+#endif
                 if (j + 1 < n) lds_load(st, 2 + j, yn);               // the next column's words are on their way while this one's products run
                 bnm::v4i b0, b1;
                 bnm::b_prep(y, b0, b1);
+#ifdef BN_STAMPS2
+                __builtin_amdgcn_sched_barrier(0); const unsigned long long s1_ = bn_now(); __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     const bnm::v4i a = ts.next();
                     P0[i] = bnm::mfma(a, b0, P0[i]);
                     P1[i] = bnm::mfma(a, b1, P1[i]);
                 }
+#ifdef BN_STAMPS2
+                __builtin_amdgcn_sched_barrier(0); const unsigned long long s2_ = bn_now(); __builtin_amdgcn_sched_barrier(0);
+                acc9 += s1_ - s0_; acc10 += s2_ - s1_; acc11 += 1;
+#endif
             }
+#ifdef BN_STAMPS2
+            if (st.lane == 0) { atomicAdd(&g_bn_stamps[9], acc9); atomicAdd(&g_bn_stamps[10], acc10); atomicAdd(&g_bn_stamps[11], acc11); }
+#endif
 #pragma unroll
             for (int i = 0; i < 4; i++) bnm::carry_pair(P0[i], P1[i], pc[i], sh);
         }
+#ifdef BN_STAMPS
+        { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[3], t_ - tp0); tp0 = t_; }
+#endif
         bnm::v4i zb0[4], zb1[4];                      // the operands of z_(i-3) .. z_i; before the block's first: anything (zero tiles)
 #pragma unroll
         for (int s = 0; s < 4; s++) { zb0[s] = bnm::v4i{ 0, 0, 0, 0 }; zb1[s] = bnm::v4i{ 0, 0, 0, 0 }; }
         for (int i = 0; i < 4; i++) {
+            u32 k[8];
+            load_const<true>(A.KR, (size_t)(4 * b + i), k);           // (long before its use: the S-box hides it)
             pow5_lazy(x0);
 #pragma unroll
             for (int s = 0; s < 3; s++) { zb0[s] = zb0[s + 1]; zb1[s] = zb1[s + 1]; }
@@ -681,18 +741,24 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
                 c0 = bnm::mfma(a, zb0[s], c0);
                 c1 = bnm::mfma(a, zb1[s], c1);
             }
-            u32 w[10], k[8];
+            u32 w[10];
             bnm::carry_pair(c0, c1, w, sh);
             bnm::add_pair(w, pc[0]);
 #pragma unroll
             for (int r = 0; r < 3; r++)
 #pragma unroll
                 for (int l = 0; l < 10; l++) pc[r][l] = pc[r + 1][l];
-            load_const<true>(A.KR, (size_t)(4 * b + i), k);
             bnm::finish_words(w, k, x0);
         }
+#ifdef BN_STAMPS
+        { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[4], t_ - tp0); tp0 = t_; }
+#endif
         u32 yn[8];
         lds_load(st, 1, yn);
+#ifdef BN_ABLATE_U
+        for (int j = 0; j < n; j++) for (int s = 0; s < 5; s++) (void)ts.next();
+        if (false)
+#endif
         for (int j = 0; j < n; j++) {
             u32 y[8], k[8];
 #pragma unroll
@@ -712,6 +778,9 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
             bnm::finish_row(c0, c1, k, y, sh);
             lds_store(st, 1 + j, y);
         }
+#ifdef BN_STAMPS
+        { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[5], t_ - tp0); }
+#endif
     }
     lds_store(st, 0, x0);
 }
@@ -732,11 +801,11 @@ __device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
         // the linear layers on the matrix cores (bn_mfma.cuh); between them the state is lazy (< 2^255), every constant but the first
         // round's arrives with a layer's rows, and the only 32x32 products left are the S-boxes'
         for (int r = 0; r < 4; r++) {
-            sbox_lazy(st, t, r == 0 || A.nofold ? A.C8 + (size_t)r * t * 8 : nullptr);
-            dense_mfma(st, A.Mt, A.MK + (size_t)r * t * 8, t, 0);
+            BN_STAMP(0, sbox_lazy(st, t, r == 0 || A.nofold ? A.C8 + (size_t)r * t * 8 : nullptr));
+            BN_STAMP(1, dense_mfma(st, A.Mt, A.MK + (size_t)r * t * 8, t, 0));
         }
         if (A.nofold) { u32 x[8], c[8]; lds_load(st, 0, x); load_const<true>(A.S, 0, c); add_lazy(x, c); lds_store(st, 0, x); }
-        if (A.rp >= 4) partial_rounds_mfma(st, A);
+        if (A.rp >= 4) BN_STAMP(2, partial_rounds_mfma(st, A));
         if (A.rp % 4 || A.rp < 4) {                  // the rounds left over, one by one on canonical values
             canon_state(st, t);
             partial_rounds<WIDE>(st, cur, A, A.rp & ~3);
@@ -748,10 +817,10 @@ __device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
                 lds_store(st, 0, x);
             }
         }
-        dense_mfma(st, A.Dt, A.DK, t - 1, 1);        // diag(1, Mh^RP)
+        BN_STAMP(1, dense_mfma(st, A.Dt, A.DK, t - 1, 1));        // diag(1, Mh^RP)
         for (int r = 4; r < 8; r++) {
-            sbox_lazy(st, t, A.nofold ? A.C8 + (size_t)r * t * 8 : nullptr);
-            dense_mfma(st, A.Mt, A.MK + (size_t)r * t * 8, t, 0);
+            BN_STAMP(0, sbox_lazy(st, t, A.nofold ? A.C8 + (size_t)r * t * 8 : nullptr));
+            BN_STAMP(1, dense_mfma(st, A.Mt, A.MK + (size_t)r * t * 8, t, 0));
         }
         return cur;
     }
@@ -801,6 +870,9 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
     const bool live = row0 < height;
     const u64 *v = in + (live ? row0 : height - 1) * width;
     int cur = 0;
+#ifdef BN_STAMPS
+    const unsigned long long tk0 = bn_now();
+#endif
     if (width <= 4) {                                // :45-50: up to four words taken as one 256-bit integer
         u64 w[4] = { 0, 0, 0, 0 };
         for (u64 k = 0; k < width; k++) w[k] = v[k];
@@ -825,6 +897,9 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
         }
     }
     if (live) digest_out(st, 0, out + 4 * row0);
+#ifdef BN_STAMPS
+    if (lane == 0) { atomicAdd(&g_bn_stamps[7], bn_now() - tk0); atomicAdd(&g_bn_stamps[8], 1ull); }
+#endif
 }
 
 // parents (merklehash_bn128_worker.js:104-144): out[i] = Poseidon(0; in[arity*i .. arity*i+arity-1])[0]
@@ -1025,6 +1100,14 @@ int check_arity(uint32_t arity) {
 }  // namespace
 
 extern "C" {
+
+#ifdef BN_STAMPS
+int pil2gl_bn128_debug_stamps(uint64_t *host16, int reset) {
+    HIP_TRY(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_bn_stamps), 128));
+    if (reset) { uint64_t z[16] = { 0 }; HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_bn_stamps), z, 128)); }
+    return PIL2GL_OK;
+}
+#endif
 
 uint64_t pil2gl_bn128_merkle_num_nodes(uint64_t height, uint32_t arity) {      // merklehash_bn128_p.js:31-45, in nodes
     if (height == 0 || arity < 2) return 0;

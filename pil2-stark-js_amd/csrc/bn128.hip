@@ -242,38 +242,42 @@ void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &ti
         K[i] = mfma_row_const(mc, tot, 1, zero);
     }
 }
-// The partial rounds four to a block (partial_rounds_mfma): the tile stream in the order the kernel consumes it and the row constants.
-// Block b (rounds k0 = 4b .. k0+3), y = elements 1..n at the block's start, z_i = the S-box output of round k0+i:
-//   x0 after round k0+i = m00 z_i + sum_j V[k0+i][j] y_j + sum_{i'<i} (V[k0+i] . W[k0+i']) z_i';   y_j after the block = y_j + sum_i W[k0+i][j] z_i.
-// Stream per block: n x 4 tiles V[k0+i][j] (j outer);  4 x 4 tiles of the cross terms (round i, slot s holds z_(i+s-3): zero
-// tiles where that is before the block);  n x 5 tiles (1, W[k0+s][j]).  KR[k]: round k's row constant with S[k+1] folded in while
-// round k+1 is one of these; KU[b][j]: the column constants.
+// The partial rounds four to a block, blocks two to a SUPER-BLOCK (partial_rounds_mfma): the tile stream in the order the kernel consumes it and
+// the row constants.  Block b (rounds k0 = 4b .. k0+3), z_i = the S-box output of round k0+i, y = elements 1..n at the start of b's SUPER-BLOCK:
+//   x0 after round k0+i = m00 z_i + sum_j V[k0+i][j] y_j + sum_{i'<i} (V[k0+i] . W[k0+i']) z_i'  [+ for the second block of a super-block the same
+//   cross terms with the four z of the first];   y_j after the super-block = y_j + sum over its rounds of W[k][j] z_k  (one column update per 8 rounds).
+// Stream per block: n x 4 tiles V[k0+i][j] (j outer);  second block: 4 x 4 tiles (V[k0+i] . W[k0-4+s]);  4 x 4 tiles of the block's own cross terms
+// (round i, slot s holds z_(i+s-3): zero tiles where that is before the block).  Per super-block after its blocks: n x (1 + 4 halves) tiles (1, W[k][j]).
+// KR[k]: round k's row constant with S[k+1] folded in while round k+1 is one of these; KU[sb][j]: the column constants.
 void mfma_partial_tables(int t, int rp, const Vec &S, const Vec &V, const Vec &W, const U256 &m00, std::vector<int8_t> &tiles, Vec &KR, Vec &KU) {
     const MfmaConsts mc;
     const U256 zero = { { 0, 0, 0, 0 } }, one = h_to_mont(U256{ { 1, 0, 0, 0 } });
-    const int n = t - 1, nb = rp / 4;
-    tiles.assign((size_t)nb * (9 * n + 16) * 1024, 0);
-    KR.assign((size_t)nb * 4, zero); KU.assign((size_t)nb * n, zero);
+    const int n = t - 1, nb = rp / 4, nsb = (nb + 1) / 2;
+    tiles.assign(((size_t)nb * (9 * n + 16) + (size_t)(nb / 2) * 16) * 1024, 0);      // (a super-block of two: n tiles fewer than two blocks' updates, 16 more for the second block's rows)
+    KR.assign((size_t)nb * 4, zero); KU.assign((size_t)nsb * n, zero);
+    auto dot = [&](int ka, int kb) { U256 c = zero; for (int j = 0; j < n; j++) c = h_addmod(c, h_mont(V[(size_t)ka * n + j], W[(size_t)kb * n + j])); return c; };
     int8_t *tp = tiles.data();
-    for (int b = 0; b < nb; b++) {
-        const int k0 = 4 * b;
-        U256 tot[4] = { zero, zero, zero, zero };
-        for (int j = 0; j < n; j++) for (int i = 0; i < 4; i++, tp += 1024) mfma_tile(mc, V[(size_t)(k0 + i) * n + j], tp, tot[i], false);
-        for (int i = 0; i < 4; i++) {
-            for (int s = 0; s < 4; s++, tp += 1024) {
-                const int ip = i + s - 3;
-                if (ip < 0) continue;
-                U256 c = m00;
-                if (ip < i) { c = zero; for (int j = 0; j < n; j++) c = h_addmod(c, h_mont(V[(size_t)(k0 + i) * n + j], W[(size_t)(k0 + ip) * n + j])); }
-                mfma_tile(mc, c, tp, tot[i], true);  // a z: the S-box's output
+    for (int sb = 0; sb < nsb; sb++) {
+        const int halves = nb - 2 * sb >= 2 ? 2 : 1;
+        for (int h = 0; h < halves; h++) {
+            const int k0 = 4 * (2 * sb + h);
+            U256 tot[4] = { zero, zero, zero, zero };
+            for (int j = 0; j < n; j++) for (int i = 0; i < 4; i++, tp += 1024) mfma_tile(mc, V[(size_t)(k0 + i) * n + j], tp, tot[i], false);
+            if (h == 1) for (int i = 0; i < 4; i++) for (int s = 0; s < 4; s++, tp += 1024) mfma_tile(mc, dot(k0 + i, k0 - 4 + s), tp, tot[i], true);
+            for (int i = 0; i < 4; i++) {
+                for (int s = 0; s < 4; s++, tp += 1024) {
+                    const int ip = i + s - 3;
+                    if (ip < 0) continue;
+                    mfma_tile(mc, ip < i ? dot(k0 + i, k0 + ip) : m00, tp, tot[i], true);      // a z: the S-box's output
+                }
+                KR[(size_t)k0 + i] = mfma_row_const(mc, tot[i], 2, k0 + i + 1 < 4 * nb ? S[(size_t)k0 + i + 1] : zero);
             }
-            KR[(size_t)k0 + i] = mfma_row_const(mc, tot[i], 2, k0 + i + 1 < 4 * nb ? S[(size_t)k0 + i + 1] : zero);
         }
         for (int j = 0; j < n; j++) {
             U256 tu = zero;
             mfma_tile(mc, one, tp, tu, false); tp += 1024;
-            for (int s = 0; s < 4; s++, tp += 1024) mfma_tile(mc, W[(size_t)(k0 + s) * n + j], tp, tu, true);
-            KU[(size_t)b * n + j] = mfma_row_const(mc, tu, 1, zero);
+            for (int s = 0; s < 4 * halves; s++, tp += 1024) mfma_tile(mc, W[(size_t)(8 * sb + s) * n + j], tp, tu, true);
+            KU[(size_t)sb * n + j] = mfma_row_const(mc, tu, 1, zero);
         }
     }
 }
@@ -633,11 +637,12 @@ __device__ __noinline__ void partial_rounds(const St st, int cur, const PermArgs
     lds_store(st, 0, x0);
 }
 
-// The partial rounds on the matrix cores, four to a block (tables: mfma_partial_tables).  Per block: the four rows' parts on y
-// (n x 4 pairs of MFMAs, carried to ten words each), then the four rounds -- S-box on the vector ALU, its output z_i made an
-// operand, the cross terms of row i (<= 4 pairs) added to the row's stored part, one short finish = the next x0 -- then the n
-// columns y_j + sum_i W z_i (5 pairs and one finish each).  No 32x32 product is left but the S-box's.  The tiles are ONE linear
-// stream in consumption order, read PR_AHEAD tiles ahead.
+// The partial rounds on the matrix cores, four to a block, two blocks to a super-block (tables: mfma_partial_tables).  Per block: the four
+// rows' parts on y (n x 4 pairs of MFMAs -- for a super-block's second block on the y of the super-block's START, plus 16 pairs on the first
+// block's S-box outputs -- carried to ten words each), then the four rounds: S-box on the vector ALU, its output z_i made an operand, the
+// cross terms of row i (<= 4 pairs) added to the row's stored part, one short finish = the next x0.  Per super-block, once: the n columns
+// y_j + sum_k W z_k (1 + 8 pairs and one finish each -- the costliest phase, hence every eight rounds, not four).  No 32x32 product is left
+// but the S-box's.  The tiles are ONE linear stream in consumption order, read PR_AHEAD tiles ahead.
 constexpr int PR_AHEAD = 6;
 struct TileStream {
     bnm::gtile p;
@@ -667,108 +672,117 @@ struct TileStream {
     }
 };
 __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A) {
-    const int n = A.t - 1, nb = A.rp / 4;
+    const int n = A.t - 1, nb = A.rp / 4, nsb = (nb + 1) / 2;
     const bnm::Sh sh = bnm::sh_init();
     TileStream ts;
     ts.start(A.Pt, st.lane);
     u32 x0[8];
     lds_load(st, 0, x0);                              // S[0] came with the row of the layer before
-    for (int b = 0; b < nb; b++) {
-        u32 pc[4][10];
+    for (int sb = 0; sb < nsb; sb++) {
+        const int halves = nb - 2 * sb >= 2 ? 2 : 1;
+        bnm::v4i zbA0[4], zbA1[4];                    // the first block's z operands, for the second block's rows and the column update
+        bnm::v4i zb0[4], zb1[4];                      // the current block's: z_(i-3) .. z_i
+#pragma unroll
+        for (int s = 0; s < 4; s++) { zbA0[s] = bnm::v4i{ 0, 0, 0, 0 }; zbA1[s] = bnm::v4i{ 0, 0, 0, 0 }; }
+        for (int h = 0; h < halves; h++) {
+            const int b = 2 * sb + h;
+            u32 pc[4][10];
 #ifdef BN_STAMPS
-        unsigned long long tp0 = bn_now();
+            unsigned long long tp0 = bn_now();
 #endif
-        {
-            bnm::v16i P0[4], P1[4];
+            {
+                bnm::v16i P0[4], P1[4];
 #pragma unroll
-            for (int i = 0; i < 4; i++) { P0[i] = bnm::acc_init(); P1[i] = bnm::acc_init(); }
-            u32 yn[8];
-            lds_load(st, 1, yn);
-#ifdef BN_STAMPS2
-            unsigned long long acc9 = 0, acc10 = 0, acc11 = 0;
-#endif
-#ifdef BN_ABLATE_P
-            for (int j = 0; j < n; j++) for (int i = 0; i < 4; i++) (void)ts.next();
-            if (false)
-#endif
-            for (int j = 0; j < n; j++) {
-                u32 y[8];
+                for (int i = 0; i < 4; i++) { P0[i] = bnm::acc_init(); P1[i] = bnm::acc_init(); }
+                u32 yn[8];
+                lds_load(st, 1, yn);
+                for (int j = 0; j < n; j++) {
+                    u32 y[8];
 #pragma unroll
-                for (int l = 0; l < 8; l++) y[l] = yn[l];
-#ifdef BN_STAMPS2
-                __builtin_amdgcn_sched_barrier(0); const unsigned long long s0_ = bn_now(); __builtin_amdgcn_sched_barrier(0);
-#endif
-                if (j + 1 < n) lds_load(st, 2 + j, yn);               // the next column's words are on their way while this one's products run
-                bnm::v4i b0, b1;
-                bnm::b_prep(y, b0, b1);
-#ifdef BN_STAMPS2
-                __builtin_amdgcn_sched_barrier(0); const unsigned long long s1_ = bn_now(); __builtin_amdgcn_sched_barrier(0);
-#endif
+                    for (int l = 0; l < 8; l++) y[l] = yn[l];
+                    if (j + 1 < n) lds_load(st, 2 + j, yn);           // the next column's words are on their way while this one's products run
+                    bnm::v4i b0, b1;
+                    bnm::b_prep(y, b0, b1);
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const bnm::v4i a = ts.next();
-                    P0[i] = bnm::mfma(a, b0, P0[i]);
-                    P1[i] = bnm::mfma(a, b1, P1[i]);
+                    for (int i = 0; i < 4; i++) {
+                        const bnm::v4i a = ts.next();
+                        P0[i] = bnm::mfma(a, b0, P0[i]);
+                        P1[i] = bnm::mfma(a, b1, P1[i]);
+                    }
                 }
-#ifdef BN_STAMPS2
-                __builtin_amdgcn_sched_barrier(0); const unsigned long long s2_ = bn_now(); __builtin_amdgcn_sched_barrier(0);
-                acc9 += s1_ - s0_; acc10 += s2_ - s1_; acc11 += 1;
-#endif
+                if (h == 1) {                                     // the rows of the second block see the first block's z through cross terms of their own
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int s = 0; s < 4; s++) {
+                            const bnm::v4i a = ts.next();
+                            P0[i] = bnm::mfma(a, zbA0[s], P0[i]);
+                            P1[i] = bnm::mfma(a, zbA1[s], P1[i]);
+                        }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) bnm::carry_pair(P0[i], P1[i], pc[i], sh);
             }
-#ifdef BN_STAMPS2
-            if (st.lane == 0) { atomicAdd(&g_bn_stamps[9], acc9); atomicAdd(&g_bn_stamps[10], acc10); atomicAdd(&g_bn_stamps[11], acc11); }
+#ifdef BN_STAMPS
+            { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[3], t_ - tp0); tp0 = t_; }
 #endif
 #pragma unroll
-            for (int i = 0; i < 4; i++) bnm::carry_pair(P0[i], P1[i], pc[i], sh);
+            for (int s = 0; s < 4; s++) { zb0[s] = bnm::v4i{ 0, 0, 0, 0 }; zb1[s] = bnm::v4i{ 0, 0, 0, 0 }; }      // before the block's first z: anything (zero tiles)
+            for (int i = 0; i < 4; i++) {
+                u32 k[8];
+                load_const<true>(A.KR, (size_t)(4 * b + i), k);       // (long before its use: the S-box hides it)
+                pow5_lazy(x0);
+#pragma unroll
+                for (int s = 0; s < 3; s++) { zb0[s] = zb0[s + 1]; zb1[s] = zb1[s + 1]; }
+                bnm::b_prep(x0, zb0[3], zb1[3]);
+                bnm::v16i c0 = bnm::acc_init(), c1 = bnm::acc_init();
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    const bnm::v4i a = ts.next();
+                    c0 = bnm::mfma(a, zb0[s], c0);
+                    c1 = bnm::mfma(a, zb1[s], c1);
+                }
+                u32 w[10];
+                bnm::carry_pair(c0, c1, w, sh);
+                bnm::add_pair(w, pc[0]);
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int l = 0; l < 10; l++) pc[r][l] = pc[r + 1][l];
+                bnm::finish_words(w, k, x0);
+            }
+#ifdef BN_STAMPS
+            { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[4], t_ - tp0); }
+#endif
+            if (h == 0 && halves == 2) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) { zbA0[s] = zb0[s]; zbA1[s] = zb1[s]; }
+            }
         }
 #ifdef BN_STAMPS
-        { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[3], t_ - tp0); tp0 = t_; }
+        unsigned long long tu0 = bn_now();
 #endif
-        bnm::v4i zb0[4], zb1[4];                      // the operands of z_(i-3) .. z_i; before the block's first: anything (zero tiles)
-#pragma unroll
-        for (int s = 0; s < 4; s++) { zb0[s] = bnm::v4i{ 0, 0, 0, 0 }; zb1[s] = bnm::v4i{ 0, 0, 0, 0 }; }
-        for (int i = 0; i < 4; i++) {
-            u32 k[8];
-            load_const<true>(A.KR, (size_t)(4 * b + i), k);           // (long before its use: the S-box hides it)
-            pow5_lazy(x0);
-#pragma unroll
-            for (int s = 0; s < 3; s++) { zb0[s] = zb0[s + 1]; zb1[s] = zb1[s + 1]; }
-            bnm::b_prep(x0, zb0[3], zb1[3]);
-            bnm::v16i c0 = bnm::acc_init(), c1 = bnm::acc_init();
-#pragma unroll
-            for (int s = 0; s < 4; s++) {
-                const bnm::v4i a = ts.next();
-                c0 = bnm::mfma(a, zb0[s], c0);
-                c1 = bnm::mfma(a, zb1[s], c1);
-            }
-            u32 w[10];
-            bnm::carry_pair(c0, c1, w, sh);
-            bnm::add_pair(w, pc[0]);
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int l = 0; l < 10; l++) pc[r][l] = pc[r + 1][l];
-            bnm::finish_words(w, k, x0);
-        }
-#ifdef BN_STAMPS
-        { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[4], t_ - tp0); tp0 = t_; }
-#endif
+        // the columns, once per super-block: y_j + sum over its rounds of W z
         u32 yn[8];
         lds_load(st, 1, yn);
-#ifdef BN_ABLATE_U
-        for (int j = 0; j < n; j++) for (int s = 0; s < 5; s++) (void)ts.next();
-        if (false)
-#endif
         for (int j = 0; j < n; j++) {
             u32 y[8], k[8];
 #pragma unroll
             for (int l = 0; l < 8; l++) y[l] = yn[l];
             if (j + 1 < n) lds_load(st, 2 + j, yn);
-            load_const<true>(A.KU, (size_t)b * n + j, k);             // (asked for early: used after the products)
+            load_const<true>(A.KU, (size_t)sb * n + j, k);            // (asked for early: used after the products)
             bnm::v4i b0, b1;
             bnm::b_prep(y, b0, b1);
             bnm::v4i a = ts.next();
             bnm::v16i c0 = bnm::mfma(a, b0, bnm::acc_init()), c1 = bnm::mfma(a, b1, bnm::acc_init());
+            if (halves == 2) {
+#pragma unroll
+                for (int s = 0; s < 4; s++) {
+                    a = ts.next();
+                    c0 = bnm::mfma(a, zbA0[s], c0);
+                    c1 = bnm::mfma(a, zbA1[s], c1);
+                }
+            }
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 a = ts.next();
@@ -779,7 +793,7 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
             lds_store(st, 1 + j, y);
         }
 #ifdef BN_STAMPS
-        { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[5], t_ - tp0); }
+        { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[5], t_ - tu0); }
 #endif
     }
     lds_store(st, 0, x0);
@@ -871,7 +885,7 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
     const u64 *v = in + (live ? row0 : height - 1) * width;
     int cur = 0;
 #ifdef BN_STAMPS
-    const unsigned long long tk0 = bn_now();
+    const unsigned long long tk0 = bn_now(), tr0 = __builtin_amdgcn_s_memrealtime();
 #endif
     if (width <= 4) {                                // :45-50: up to four words taken as one 256-bit integer
         u64 w[4] = { 0, 0, 0, 0 };
@@ -898,7 +912,7 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
     }
     if (live) digest_out(st, 0, out + 4 * row0);
 #ifdef BN_STAMPS
-    if (lane == 0) { atomicAdd(&g_bn_stamps[7], bn_now() - tk0); atomicAdd(&g_bn_stamps[8], 1ull); }
+    if (lane == 0) { atomicAdd(&g_bn_stamps[7], bn_now() - tk0); atomicAdd(&g_bn_stamps[8], 1ull); atomicAdd(&g_bn_stamps[12], __builtin_amdgcn_s_memrealtime() - tr0); }
 #endif
 }
 

@@ -180,26 +180,37 @@ def sbox(x):           # Montgomery form in and out
 
 
 def partial_rounds_blocked(t, x, sp):
-    """x: Montgomery-form state entering the partial rounds -> state after them (before the closing D layer)"""
+    """x: Montgomery-form state entering the partial rounds -> state after them (before the closing D layer).
+    Blocks of four rounds in SUPER-BLOCKS of two: the columns y are updated once per super-block (eight rounds); the second block's rows are
+    taken on the y of the super-block's start and get the first block's S-box outputs through cross terms like their own."""
     C8, D, S, V, W, m00, M = sp
     rp, n = len(S), t - 1
     toM = lambda a: a * MONT % R
     nb = rp // 4
     x0, y = x[0], x[1:]
     x0 = (x0 + toM(S[0])) % R
-    for blk in range(nb):
-        k0 = 4 * blk
-        P = [row_positions(row_tables(V[k0 + i])[0], y) for i in range(4)]          # the block's rows on y at its start
+    inv32 = pow(1 << 32, -1, R)
+    for sb in range((nb + 1) // 2):
+        halves = min(2, nb - 2 * sb)
         z = []
-        for i in range(4):
-            z.append(sbox(x0))
-            coefs = [sum(V[k0 + i][j] * W[k0 + ip][j] for j in range(n)) % R for ip in range(i)] + [m00]
-            fold = toM(S[k0 + i + 1]) if k0 + i + 1 < 4 * nb else 0
-            dig, K = row_tables(coefs, 2, fold)
-            Kp = (K + 128 * sum(V[k0 + i][j] * pow(256, b, R) * (1 << 32) for j in range(n) for b in range(32)) * pow(1 << 32, -1, R)) % R
-            x0 = row_finish([P[i], row_positions(dig, z)], Kp)
+        for h in range(halves):
+            k0 = 4 * (2 * sb + h)
+            P, Ktile = [], []
+            for i in range(4):                                                           # the block's rows on y at the SUPER-BLOCK's start,
+                coefs = list(V[k0 + i]) + [sum(V[k0 + i][j] * W[k0 - 4 + ip][j] for j in range(n)) % R for ip in range(4 * h)]   # + the first block's z (second block)
+                dig, _ = row_tables(coefs)
+                P.append(row_positions(dig, y + z[:4 * h]))
+                Ktile.append(128 * sum(a * pow(256, b, R) * (1 << 32) % R for a in coefs for b in range(32)) * inv32 % R)
+            for i in range(4):
+                z.append(sbox(x0))
+                own = z[4 * h:]
+                coefs = [sum(V[k0 + i][j] * W[k0 + ip][j] for j in range(n)) % R for ip in range(i)] + [m00]
+                fold = toM(S[k0 + i + 1]) if k0 + i + 1 < 4 * nb else 0
+                dig, K = row_tables(coefs, 2, fold)
+                x0 = row_finish([P[i], row_positions(dig, own)], (K + Ktile[i]) % R)
+        k0 = 8 * sb
         for j in range(n):
-            dig, K = row_tables([1] + [W[k0 + i][j] for i in range(4)])
+            dig, K = row_tables([1] + [W[k0 + i][j] for i in range(4 * halves)])
             y[j] = row_finish([row_positions(dig, [y[j]] + z)], K)
     for k in range(4 * nb, rp):                                                       # the rounds left over, as they are
         x0 = (x0 + toM(S[k])) % R
@@ -211,7 +222,7 @@ def partial_rounds_blocked(t, x, sp):
 
 def check_blocked():
     rnd = random.Random(9)
-    for t in (3, 6, 17):
+    for t in (3, 6, 9, 17):                                # 57 = 14 blocks + 1 round; 60 = 15 blocks (odd: a half super-block); 63; 68 = 17 blocks
         sp = derive_sparse(t)
         C8, D, S, V, W, m00, M = sp
         n = t - 1

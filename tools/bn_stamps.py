@@ -29,5 +29,7 @@ for i, nm in enumerate(names):
     if nm and i != 8:
         print("%-42s %6.1f %%   %9.0f cycles per wave" % (nm, 100.0 * out[i] / tot, out[i] / out[8]))
 print("waves", out[8])
+if out[12]:
+    print("shader clock inside the kernel: %.2f GHz (s_memtime against the 100 MHz s_memrealtime)" % (out[7] / out[12] * 0.1))
 if out[11]:
     print("P loop per column: load+prep %.0f cycles, tiles+products issued %.0f cycles (%d columns)" % (out[9] / out[11], out[10] / out[11], out[11]))

@@ -332,10 +332,11 @@ def bn128_work(t):
     rp = [56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68][t - 2]
     n, nb, tail = t - 1, rp // 4, rp % 4
     sbox = (8 * t + rp) * 3 * 128
-    rows = 8 * t + n + 4 * nb + nb * n                                    # dense rows, closing layer, round rows, column updates
+    nsb = (nb + 1) // 2                                                   # blocks two to a super-block: one column update per eight rounds
+    rows = 8 * t + n + 4 * nb + nsb * n                                   # dense rows, closing layer, round rows, column updates
     finish = rows * 32 + 4 * nb * 24                                      # + the block part of a round's row is carried on its own
     valu_tail = tail * ((t * 64 + 64) + n * 128)
-    mfma = 2 * (8 * t * t + n * n) + nb * 2 * (4 * n + 16 + 5 * n)        # pairs: two 32-permutation tiles per wave
+    mfma = 2 * (8 * t * t + n * n) + 2 * (nb * (4 * n + 16) + (nb // 2) * 16 + nsb * n + 4 * nb * n)      # pairs: two 32-permutation tiles per wave
     return sbox + finish + valu_tail, mfma
 
 

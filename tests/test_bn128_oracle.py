@@ -151,3 +151,15 @@ def test_c_port_equals_python_oracle():
         assert b.c_merkelize(rows, ar, cu) == b.merkelize([[int(v) for v in r] for r in rows], ar, cu), (h, w, ar, cu)
     rows = np.full((3, 4), 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)                    # width <= 4: one 256-bit integer above r
     assert b.c_merkelize(rows, 16, False) == b.merkelize([[int(v) for v in r] for r in rows], 16, False)
+
+
+def test_matrix_core_layers_integer_model():
+    """tools/bn_mfma_model.py: the byte-digit form of the BN254 linear layers that csrc/bn_mfma.cuh runs on the matrix cores (constants folded mod r,
+    signed digits, accumulator bias, one 32-bit Montgomery step, blocks of four partial rounds two to a super-block) on Python integers against the
+    plain statement and against the oracle's permutation -- the arithmetic the device kernels were written from"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "bn_mfma_model.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-1500:]
+    assert out.stdout.count("== plain statement") == 3 and out.stdout.count("== oracle") == 4, out.stdout

@@ -249,3 +249,21 @@ def test_config4_shape_tree_opens(bn, hbits):
         assert orc.root_from_group_proof([[int(x) for x in l] for l in mp], idx, v, 16, False) == int(root)
     v[3] ^= 1
     assert not MH.verifyGroupProof(root, mp, idx, v)
+
+
+def test_matrix_core_unit_kernels(tmp_path):
+    """tools/bn_mfma_unit.hip on the device: the hand-scheduled carry / finish chains against a plain restatement (random, all-maximal and mixed byte
+    positions), the reduction-free products and the radix-2^29 S-box against the canonical 32-bit-limb arithmetic -- 262 144 lanes each"""
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "bn_mfma_unit")
+    subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-I", os.path.join(ROOT, "pil2-stark-js_amd", "csrc"), os.path.join(ROOT, "tools", "bn_mfma_unit.hip"), "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1000:]
+    lines = [l for l in out.stdout.splitlines() if "lanes differ" in l]
+    assert len(lines) == 8 and all(": 0 of " in l for l in lines), out.stdout

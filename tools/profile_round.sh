@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$tag
 mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_rocprof.json 2> $O/bench_rocprof.err || exit 1
+PIL2GL_BENCH_NODE=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o bench -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_rocprof.json 2> $O/bench_rocprof.err || exit 1
 echo "stats done"
 for c in FETCH_SIZE WRITE_SIZE; do
   PIL2GL_BENCH_FROM_HOST=0 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/$c -o p -- python3 $R/tools/probe_prove.py > $O/$c.log 2>&1 || exit 1

@@ -689,7 +689,8 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     transcript.put(setup["constRoot"])
 
     sl = lambda full, w: coset_slice(be, full, nb, eb, cb, cc, w)
-    # the rank's rows of the domain tables, built per coset (no buffer of this function has 2^nBitsExt rows) and once per setup
+    # the rank's rows of the domain tables, built per coset and once per setup.  With the HIP backend and a power-of-two coset count per rank
+    # no buffer of this function has 2^nBitsExt rows; the CPU checker (no per-coset operators) and odd partitions slice whole tables
     loc = shard_tables(be, setup, info, cb, cc)
     widths = {"const_n": nC, "const_ext": nC, "q_ext": qDim, "f_ext": 3, "x_ext": 1, "x_n": 1,
               "xDivXSubXi_ext": 3 * len(info["openingPoints"])}

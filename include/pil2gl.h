@@ -99,6 +99,13 @@ int pil2gl_fft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *ds
 int pil2gl_ifft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst);
 int pil2gl_fft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, void *stream);
 int pil2gl_ifft_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, void *stream);
+/* The reference's worker-level operators, for a caller that keeps fft_p.js's own block loop (pool.exec sites fft_p.js:93,162,166);
+ * the calls above replace that whole loop and are the product path.
+ * fft_block(buff,start_pos,nPols,nBits,s,blockBits,layers)  fft_worker.js:21-67: buf = the 2^blockBits x nPols block standing at
+ * row start_pos of a 2^nBits-row transform; `layers` butterfly stages ending at stage s, in place.  layers <= blockBits.
+ * interpolatePrepareBlock(buff,width,start,inc,st_i,st_n)  fft_worker.js:6-19: row i of the height x width block times start*inc^i. */
+int pil2gl_fft_block_dev(uint64_t *buf, uint64_t start_pos, uint64_t nPols, uint32_t nBits, uint32_t s, uint32_t blockBits, uint32_t layers, void *stream);
+int pil2gl_interpolate_prepare_block_dev(uint64_t *buf, uint64_t width, uint64_t height, uint64_t start, uint64_t inc, void *stream);
 
 /* ---- Poseidon / linear hash / Merkle tree -------------------------------- */
 /* WASM export poseidon(pIn,nIn,pCap,nCap,pOut,nOut)  src/helpers/glwasm.js:216-426;

@@ -368,6 +368,20 @@ FN(FirstNonzeroRowDev) {
     return arr;
 }
 
+// worker-level operators (fft_worker.js:6-67) on a device block, in place
+FN(FftBlockDev) {
+    Args a(env, info); uint64_t buf = a.u64(0), startPos = a.u64(1), nPols = a.u64(2), nBits = a.u64(3), s = a.u64(4), blockBits = a.u64(5), layers = a.u64(6);
+    if (!a.ok) return nullptr;
+    P2(env, pil2gl_fft_block_dev((uint64_t *)(uintptr_t)buf, startPos, nPols, (uint32_t)nBits, (uint32_t)s, (uint32_t)blockBits, (uint32_t)layers, a.stream(7)));
+    return mk_undefined(env);
+}
+FN(InterpolatePrepareBlockDev) {
+    Args a(env, info); uint64_t buf = a.u64(0), width = a.u64(1), height = a.u64(2), start = a.u64(3), inc = a.u64(4);
+    if (!a.ok) return nullptr;
+    P2(env, pil2gl_interpolate_prepare_block_dev((uint64_t *)(uintptr_t)buf, width, height, start, inc, a.stream(5)));
+    return mk_undefined(env);
+}
+
 static napi_value ModuleInit(napi_env env, napi_value exports) {
     struct { const char *name; napi_callback fn; } fns[] = {
         { "init", Init }, { "shutdown", Shutdown }, { "deviceInfo", DeviceInfo },
@@ -385,6 +399,7 @@ static napi_value ModuleInit(napi_env env, napi_value exports) {
         { "rowsDotExtDev", RowsDotExtDev }, { "rowsDotExtMultiDev", RowsDotExtMultiDev }, { "friCombineDev", FriCombineDev }, { "colsDotExtDev", ColsDotExtDev }, { "colsDotExtMultiDev", ColsDotExtMultiDev }, { "synthFibonacciDev", SynthFibonacciDev },
         { "friFoldDev", FriFoldDev }, { "friTransposeDev", FriTransposeDev },
         { "friFold", FriFold }, { "friVerifyFold", FriVerifyFold }, { "friTranspose", FriTranspose }, { "evalProgramDev", EvalProgramDev }, { "firstNonzeroRowDev", FirstNonzeroRowDev },
+        { "fftBlockDev", FftBlockDev }, { "interpolatePrepareBlockDev", InterpolatePrepareBlockDev },
     };
     for (auto &f : fns) {
         napi_value v;

@@ -537,6 +537,45 @@ static int check_ntt_args(const void *src, const void *dst, uint32_t nBits, uint
 }
 
 // a coset slice only ever indexes 2^nBits * cosetCount local rows: the full extension may be larger than one device holds
+// ---- the reference's worker-level operators (fft_worker.js:6-67), for a caller that keeps fft_p.js's own block loop ----------------
+// The product path never runs these (pil2gl_fft / _interpolate replace the whole loop: bit reversal, blocks and transposes); they
+// exist so that `pool.exec("fft_block", ...)` / `("interpolatePrepareBlock", ...)` have a device twin with the same arguments.
+// One launch per stage, twiddles straight from the pow256 table.
+//
+// _fft_block (fft_worker.js:21-60) on a buffer of 2^blockBits rows that sits at row start_pos of an n-row transform: the recursion
+// first cuts the block into pieces of 2^layers rows (:30-34), then runs a decimation-in-time transform of `layers` stages on each
+// piece (:35-38); stage l = 1..layers pairs rows 2^(l-1) apart inside sub-blocks of 2^l rows and is the recursion level whose
+// (s, blockBits, layers) are (s - layers + l, l, l).  Its twiddle for pair i of the sub-block at absolute row sp (:40-58):
+//   w = w0 * F.w[l]^i,   w0 = F.w[s - layers + l]^p  if s > layers, else 1,   width = 2^(s - layers), height = n / width,
+//   p = (sp % height) * width + floor(sp / height)
+// (s > layers and width are the same at every level: s and the level's block size fall together.)
+namespace {
+__global__ void fft_block_stage_kernel(u64 *__restrict__ buf, u64 startPos, u64 nPols, u32 nBits, u32 s, u32 layers, u32 l, u64 nPairs,
+                                       const u64 *__restrict__ powW) {
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nPairs * nPols) return;
+    const u64 g = idx / nPols, c = idx - g * nPols;
+    const u64 half = 1ull << (l - 1), i = g & (half - 1), rel = (g >> (l - 1)) << l;
+    u64 w = root_pow(powW, l, (u32)i);
+    if (s > layers) {
+        const u32 sl = s - layers + l, wBits = s - layers;               // sl <= s <= 32
+        const u64 sp = startPos + rel, hBits = nBits - wBits;             // height = 2^hBits rows
+        const u64 pe = ((sp & ((1ull << hBits) - 1)) << wBits) + (sp >> hBits);
+        w = mul(w, root_pow(powW, sl, (u32)(pe & ((1ull << sl) - 1))));   // the root has order 2^sl
+    }
+    u64 *a = buf + (rel + i) * nPols + c, *b = buf + (rel + half + i) * nPols + c;
+    const u64 u = canon(*a), t = mul(w, *b);
+    *a = add(u, t);
+    *b = sub(u, t);
+}
+// interpolatePrepareBlock (fft_worker.js:6-19): row i of the block times start * inc^i
+__global__ void interpolate_prepare_block_kernel(u64 *__restrict__ buf, u64 width, u64 height, u64 start, u64 inc) {
+    const u64 idx = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= width * height) return;
+    buf[idx] = mul(buf[idx], mul(start, pow(inc, idx / width)));
+}
+}  // namespace
+
 static int check_coset_args(const void *src, const void *dst, uint32_t nBits, uint32_t nBitsExt, uint32_t cosetBegin, uint32_t cosetCount) {
     if (!src || !dst) return fail(PIL2GL_EINVAL, "null buffer");
     if (nBitsExt < nBits) return fail(PIL2GL_EINVAL, "nBitsExt (%u) < nBits (%u)", nBitsExt, nBits);
@@ -619,5 +658,39 @@ static int host_wrap(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64
 int pil2gl_interpolate(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt) { return host_wrap(src, nPols, nBits, dst, nBitsExt, 0); }
 int pil2gl_fft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst) { return host_wrap(src, nPols, nBits, dst, nBits, 1); }
 int pil2gl_ifft(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst) { return host_wrap(src, nPols, nBits, dst, nBits, 2); }
+
+// fft_block(buff, start_pos, nPols, nBits, s, blockBits, layers)  fft_worker.js:62-67: buf = the 2^blockBits x nPols block, in place
+int pil2gl_fft_block_dev(uint64_t *buf, uint64_t start_pos, uint64_t nPols, uint32_t nBits, uint32_t s, uint32_t blockBits, uint32_t layers, void *stream) {
+    P2_TRY(ensure_init());
+    // (the reference checks nothing; what is refused here has no meaning there either: F.w has 33 entries, :30-38 never end for
+    // layers > blockBits, and n / width is not an integer for s - layers > nBits)
+    if (nBits > 32 || s > 32 || blockBits > 32) return fail(PIL2GL_EINVAL, "fft_block: nBits %u, s %u, blockBits %u", nBits, s, blockBits);
+    if (layers > blockBits) return fail(PIL2GL_EINVAL, "fft_block: %u layers in a block of 2^%u rows", layers, blockBits);
+    if (s > layers && s - layers > nBits) return fail(PIL2GL_EINVAL, "fft_block: stage %u with %u layers in a transform of 2^%u rows", s, layers, nBits);
+    if (layers == 0 || nPols == 0) return PIL2GL_OK;                      // (:30-34 cut the block down to single rows: nothing to pair)
+    if (!buf) return fail(PIL2GL_EINVAL, "null buffer");
+    const u64 nPairs = 1ull << (blockBits - 1);
+    if (nPols > (1ull << 40) / nPairs) return fail(PIL2GL_EINVAL, "fft_block: block too large");
+    const u64 blocks = (nPairs * nPols + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "fft_block: grid too large");
+    hipStream_t st = as_stream(stream);
+    for (u32 l = 1; l <= layers; l++) {
+        fft_block_stage_kernel<<<(unsigned)blocks, 256, 0, st>>>(buf, start_pos, nPols, nBits, s, layers, l, nPairs, tables().powW);
+        KERNEL_CHECK();
+    }
+    return PIL2GL_OK;
+}
+// interpolatePrepareBlock(buff, width, start, inc, st_i, st_n)  fft_worker.js:6-19: buf = height x width, in place
+int pil2gl_interpolate_prepare_block_dev(uint64_t *buf, uint64_t width, uint64_t height, uint64_t start, uint64_t inc, void *stream) {
+    P2_TRY(ensure_init());
+    if (width == 0 || height == 0) return PIL2GL_OK;
+    if (!buf) return fail(PIL2GL_EINVAL, "null buffer");
+    if (height > (1ull << 40) / width) return fail(PIL2GL_EINVAL, "interpolatePrepareBlock: block too large");
+    const u64 blocks = (width * height + 255) / 256;
+    if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "interpolatePrepareBlock: grid too large");
+    interpolate_prepare_block_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(buf, width, height, start % P, inc % P);
+    KERNEL_CHECK();
+    return PIL2GL_OK;
+}
 
 }  // extern "C"

@@ -4,6 +4,7 @@ module.exports = {
     native: require("./native.js").addon,
     DevBuffer: require("./native.js").DevBuffer,
     fft_p: require("./fft_p.js"),
+    fft_worker: require("./fft_worker.js"),
     buildMerkleHash: require("./merklehash_p.js"),
     buildPoseidon: require("./poseidon.js"),
     buildMerkleHashBN128: require("./merklehash_bn128_p.js"),

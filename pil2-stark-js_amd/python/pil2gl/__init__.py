@@ -117,6 +117,30 @@ def ifft(buffSrc, nPols, nBits, buffDst):
         call("pil2gl_ifft", _ptr(buffSrc), nPols, nBits, _ptr(buffDst))
 
 
+def _block_on_device(buff, fn):
+    """worker-level operators work in place on a block: a device tensor as it stands, a host array through a staging tensor"""
+    if _is_dev(buff):
+        fn(buff)
+        return buff
+    if buff.size:
+        d = torch.from_numpy(buff.view(np.int64)).cuda()
+        fn(d)
+        buff[...] = d.cpu().numpy().view(np.uint64).reshape(buff.shape)
+    return buff
+
+
+def fft_block(buff, start_pos, nPols, nBits, s, blockBits, layers):
+    """fft_worker.js:62 fft_block: `layers` butterfly stages ending at stage s on the 2^blockBits x nPols block at row start_pos"""
+    _check_len(buff, nPols << blockBits, "buff")
+    return _block_on_device(buff, lambda d: call("pil2gl_fft_block_dev", _ptr(d), start_pos, nPols, nBits, s, blockBits, layers, _stream()))
+
+
+def interpolatePrepareBlock(buff, width, start, inc, st_i=0, st_n=1):
+    """fft_worker.js:6 interpolatePrepareBlock: row i of the block times start * inc^i"""
+    height = int(np.prod(buff.shape)) // width
+    return _block_on_device(buff, lambda d: call("pil2gl_interpolate_prepare_block_dev", _ptr(d), width, height, int(start), int(inc), _stream()))
+
+
 # ----------------------------------------------------------------------------- stage-2 hints (polutils.js:128-164)
 def _hint(fn, num, den, dimNum, dimDen, out):
     n = int(np.prod(den.shape)) // dimDen

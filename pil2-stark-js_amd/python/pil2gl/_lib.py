@@ -113,6 +113,8 @@ SIGNATURES = {
     "pil2gl_cols_dot_ext_range_dev": (_I, [vp, vp, vp, vp, _U32, _U64, _U64, vp, _U32, vp, vp]),
     "pil2gl_eval_program_dev": (_I, [C.POINTER(GlxProgram), C.POINTER(GlxCtx), vp]),
     "pil2gl_first_nonzero_row_dev": (_I, [vp, _U32, _U64, _U64, vp, vp, vp]),
+    "pil2gl_fft_block_dev": (_I, [vp, _U64, _U64, _U32, _U32, _U32, _U32, vp]),
+    "pil2gl_interpolate_prepare_block_dev": (_I, [vp, _U64, _U64, _U64, _U64, vp]),
     "pil2gl_synth_fibonacci_dev": (_I, [_U32, _U32, vp, vp, vp]),
     "pil2gl_debug_compact_program": (_I, [C.POINTER(GlxProgram), C.POINTER(GlxOp), C.POINTER(_U32)]),
     "pil2gl_debug_jit_compile": (_I, [C.POINTER(GlxProgram), C.POINTER(GlxCtx), C.POINTER(_U64), C.POINTER(_U32)]),

@@ -46,6 +46,60 @@ class ChunkedBuffer {
             for (let j = 0; j < e.length; j++) assert.strictEqual(co.getElement(j * nPols), e[j], "interpolate(chunked) " + c.name);
         }
     }
+    // --- fft_worker: the reference's block loop (fft_p.js:114-176 _fft, :187-297 interpolate; bit reversal and transposes on the host as there)
+    //     over the device twins of fft_block / interpolatePrepareBlock, for several block sizes, against the same goldens
+    {
+        const { fft_block, interpolatePrepareBlock } = require(path.join(root, "pil2-stark-js_amd/js/fft_worker.js"));
+        const { DevBuffer } = require(path.join(root, "pil2-stark-js_amd/js/native.js"));
+        const Pm = 0xFFFFFFFF00000001n, SH = 7n;
+        const powm = (b, e) => { let r = 1n; b %= Pm; while (e > 0n) { if (e & 1n) r = r * b % Pm; b = b * b % Pm; e >>= 1n; } return r; };
+        const BR = (x, nb) => { let r = 0; for (let k = 0; k < nb; k++) r |= ((x >> k) & 1) << (nb - 1 - k); return r; };
+        const rounds = (a, nPols, nBits, blockBits, dev) => {
+            const n = 1 << nBits; blockBits = Math.min(nBits, blockBits); const bs = 1 << blockBits;
+            let b = new BigUint64Array(n * nPols);
+            for (let i = 0; i < nBits; i += blockBits) {
+                const sInc = Math.min(blockBits, nBits - i);
+                for (let j = 0; j < n / bs; j++) {
+                    let bb = a.slice(j * bs * nPols, (j + 1) * bs * nPols);
+                    if (dev) { const d = DevBuffer.from(bb); assert.strictEqual(fft_block(d, j * bs, nPols, nBits, i + sInc, blockBits, sInc), d); bb = d.toHost(); d.free(); }
+                    else bb = fft_block(bb, j * bs, nPols, nBits, i + sInc, blockBits, sInc);
+                    a.set(bb, j * bs * nPols);
+                }
+                if (sInc < nBits) {
+                    const w = 1 << sInc, h = n / w;
+                    for (let x = 0; x < w; x++) for (let y = 0; y < h; y++) b.set(a.subarray((y * w + x) * nPols, (y * w + x + 1) * nPols), (x * h + y) * nPols);
+                    [a, b] = [b, a];
+                }
+            }
+            return a;
+        };
+        for (const c of ntt.cases) {
+            if (c.nBits < 1 || c.nBits > 7) continue;
+            const n = 1 << c.nBits, nPols = 3, p = H(c.p), f = H(c.fft);
+            for (const [blockBits, dev] of [[12, false], [2, false], [3, true], [1, false]]) {
+                const a = new BigUint64Array(n * nPols);
+                for (let i = 0; i < n; i++) for (let k = 0; k < nPols; k++) a[i * nPols + k] = p[BR(i, c.nBits)];
+                const r = rounds(a, nPols, c.nBits, blockBits, dev);
+                for (let i = 0; i < n; i++) for (let k = 0; k < nPols; k++) assert.strictEqual(r[i * nPols + k], f[i], `fft over fft_block ${c.name} blockBits ${blockBits}`);
+                for (const eb of Object.keys(c.ext)) {
+                    const nbe = c.nBits + Number(eb), e = H(c.ext[eb]), invN = powm(BigInt(n), Pm - 2n);
+                    let q = new BigUint64Array(n * nPols);
+                    for (let i = 0; i < n; i++) for (let k = 0; k < nPols; k++) q[i * nPols + k] = p[(n - BR(i, c.nBits)) % n];
+                    q = rounds(q, nPols, c.nBits, blockBits, dev);
+                    const per = 3;
+                    for (let i = 0; i < n; i += per) {
+                        const cur = Math.min(per, n - i), bb = q.slice(i * nPols, (i + cur) * nPols);
+                        q.set(interpolatePrepareBlock(bb, nPols, invN * powm(SH, BigInt(i)) % Pm, SH, i / per, Math.floor(n / per)), i * nPols);
+                    }
+                    let x = new BigUint64Array((1 << nbe) * nPols);
+                    for (let i = 0; i < (1 << nbe); i++) { const ri = BR(i, nbe); if (ri < n) x.set(q.subarray(ri * nPols, (ri + 1) * nPols), i * nPols); }
+                    x = rounds(x, nPols, nbe, blockBits + 1, dev);
+                    for (let i = 0; i < (1 << nbe); i++) for (let k = 0; k < nPols; k++) assert.strictEqual(x[i * nPols + k], e[i], `interpolate over the worker operators ${c.name} ext ${eb}`);
+                }
+            }
+        }
+        assert.throws(() => fft_block(new BigUint64Array(8), 0, 1, 3, 3, 2, 3), /layers/);
+    }
     // --- poseidon KATs (test/poseidon.test.js)
     const poseidon = getPoseidon();
     for (const [inp, cap, out] of H(G("poseidon.json"))) assert.deepStrictEqual(poseidon(inp, cap, 12), out);

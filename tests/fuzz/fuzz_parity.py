@@ -69,6 +69,34 @@ def case_transform():
         check("interpolate_cosets", (got == want.reshape(1 << nb, 1 << eb, C)[:, cb:cb + cc, :]).all(), (nb, C, eb, cb, cc))
 
 
+def case_worker_ops():
+    """the reference's worker-level transform operators (fft_worker.js:6-67): random arguments against the restatement (small blocks),
+    and fft_p.js's block loop over them (numpy bit reversal / transposes) against the one-call transforms (any size)"""
+    import fft_worker_ref as R
+    nb = int(rng.integers(1, 10)); bb = int(rng.integers(0, min(nb, 5) + 1)); layers = int(rng.integers(0, bb + 1)); s_ = int(rng.integers(layers, nb + 1)); C = int(rng.integers(1, 5))
+    sp = int(rng.integers(0, (1 << nb) - (1 << bb) + 1))
+    buf = field((C << bb,))
+    got = buf.copy(); pil2gl.fft_block(got, sp, C, nb, s_, bb, layers)
+    want = [int(x) for x in buf] if layers == 0 else R.fft_block([int(x) for x in buf], sp, C, nb, s_, bb, layers)
+    check("fft_block", [int(x) for x in got] == want, (nb, s_, bb, layers, C, sp))
+    h = int(rng.integers(1, 40)); w = int(rng.integers(1, 9)); buf = field((h * w,)); st, inc = int(field((1,))[0]), int(field((1,))[0])
+    got = buf.copy(); pil2gl.interpolatePrepareBlock(got, w, st, inc)
+    check("interpolatePrepareBlock", [int(x) for x in got] == R.interpolatePrepareBlock([int(x) for x in buf], w, st, inc), (h, w))
+    nb = int(rng.integers(1, 13)); C = int(rng.choice([1, 2, 3, 8, 17, 33])); bb = int(rng.integers(1, nb + 1)); n = 1 << nb
+    a = field((n, C)); want = np.zeros_like(a); pil2gl.fft(a, C, nb, want)
+    br = np.array([int(format(i, "0%db" % nb)[::-1], 2) for i in range(n)])
+    cur = torch.from_numpy(a[br].copy().view(np.int64)).cuda()                      # bitReverse (fft_p.js:35-42), then the rounds of :153-173 on the device
+    i = 0
+    while i < nb:
+        sInc = min(bb, nb - i)
+        for j in range(n >> bb):
+            pil2gl.fft_block(cur[j << bb:(j + 1) << bb].reshape(-1), j << bb, C, nb, i + sInc, bb, sInc)
+        if sInc < nb:
+            cur = cur.reshape(n >> sInc, 1 << sInc, C).transpose(0, 1).contiguous().reshape(n, C)      # traspose (:20-32)
+        i += bb
+    check("fft over fft_block", (cur.cpu().numpy().view(np.uint64) == want).all(), (nb, C, bb))
+
+
 def case_hash_tree():
     w = int(rng.integers(0, 140)); h = int(rng.choice([1, 2, 3, 5, 31, 64, 65, 257, 1000, 4097])); split = bool(rng.integers(0, 2))
     if w == 0:
@@ -242,7 +270,7 @@ def case_proof_bn128():
 
 
 ONLY = os.environ.get("FUZZ_ONLY", "").split(",") if os.environ.get("FUZZ_ONLY") else None
-CASES = [(f, w) for f, w in [(case_transform, 4), (case_hash_tree, 4), (case_fri_fold, 2), (case_proof, 3), (case_evaluator, 3), (case_hints, 2), (case_rows_dot, 3), (case_bn128, 1), (case_proof_bn128, 1)]
+CASES = [(f, w) for f, w in [(case_transform, 4), (case_worker_ops, 1), (case_hash_tree, 4), (case_fri_fold, 2), (case_proof, 3), (case_evaluator, 3), (case_hints, 2), (case_rows_dot, 3), (case_bn128, 1), (case_proof_bn128, 1)]
          if ONLY is None or f.__name__[5:] in ONLY]
 t0 = time.time(); last = t0
 order = [f for f, w in CASES for _ in range(w)]

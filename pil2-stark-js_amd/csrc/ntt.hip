@@ -402,6 +402,11 @@ int launch_pass(const u64 *src, u64 *dst, u64 C, u32 n, u32 lo, u32 k, bool dit,
 // split `bits` into ceil(bits/kmax) nearly equal passes
 int split_bits(u32 bits, u32 kmax, u32 *ks) {
     if (bits == 0) return 0;
+    if (const char *e = getenv("PIL2GL_NTT_SPLIT")) {          // experiments: "8,8,2" is taken when it adds up to `bits`
+        u32 tot = 0; int np = 0; u32 tmp[32];
+        for (const char *q = e; *q && np < 32;) { tmp[np] = (u32)atoi(q); tot += tmp[np++]; while (*q && *q != ',') q++; if (*q) q++; }
+        if (tot == bits) { for (int i = 0; i < np; i++) ks[i] = tmp[i]; return np; }
+    }
     u32 np = (bits + kmax - 1) / kmax, base = bits / np, extra = bits % np;
     for (u32 i = 0; i < np; i++) ks[i] = base + (i < extra ? 1 : 0);
     return (int)np;
@@ -452,6 +457,15 @@ int lde_launch(const u64 *src, u64 C, u32 n, u64 *dst, u32 nExt, hipStream_t st,
     const u32 kmaxF = env_u32("PIL2GL_LDE_WIDEFWD", 1) ? std::max(kmax, pick_kmax(C * cosetCount)) : kmax;
     u32 nfp = (n + kmaxF - 1) / kmaxF;
     u32 kf = (n + nfp - 1) / nfp;       // bits done by the mid kernel (both directions)
+    // The balanced split gives the mid kernel 6 or 7 bits whenever n is not 8 * passes (n = 17..21, 25..29): its fixed-geometry form
+    // (8 bits, 15 / 16 slots, coefficients in registers over the cosets) is worth more than balance -- 8-17 % of an interpolate at
+    // 2^17..2^28 rows x 16 / 32 / 64 / 100 columns, full extensions and single cosets alike (profiles/r05_lde_mid8_planner.txt);
+    // widths whose tiles are not 15 or 16 slots keep the balanced split (20 columns lose 2-4 % with 8).  PIL2GL_LDE_KF: experiments.
+    if (kf < 8 && n > 8 && kmaxF == 8 && !env_u32("PIL2GL_NTT_GENERIC", 0)) {
+        const Geom g8 = make_geom(8, C, 1ull << (n - 8), env_u32("PIL2GL_LDE_TILE", 4096), std::min<u32>(LDE_MAXTHREADS, env_u32("PIL2GL_LDE_THREADS", 512)));
+        if ((g8.S == 15 || g8.S == 16) && g8.by == 16 && g8.nbT == 1) kf = 8;
+    }
+    if (const char *e = getenv("PIL2GL_LDE_KF")) { const u32 f = (u32)atoi(e); kf = f ? std::min(f, n) : (n + nfp - 1) / nfp; }      // 0: the balanced split
     // 1. iNTT, decimation in frequency, bits [kf, n) from the top down: src -> tmp, then in place
     const u64 *coef = src;
     if (n > kf && !coefIn) {

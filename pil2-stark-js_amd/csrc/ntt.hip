@@ -412,6 +412,23 @@ int split_bits(u32 bits, u32 kmax, u32 *ks) {
     return (int)np;
 }
 
+// passes of a standalone transform.  Where the 8-bit pass has its fixed-geometry kernel (tiles of 15 / 16 slots) as many passes as possible take
+// 8 bits and ONE takes the remainder, if that is at least 4 bits: 2^20 x 100 in 8,8,4 instead of 7,7,6 -17 %, 2^22 in 8,8,6 instead of 8,7,7 -5 %;
+// a remainder of 1..3 bits (a whole sweep for almost no arithmetic) stays balanced: 2^26 in 8,8,8,2 loses 8 % (profiles/r05_lde_mid8_planner.txt)
+int plan_passes(u32 n, u32 kmax, u64 C, u32 *ks) {
+    const u32 r = n & 7;
+    if (kmax == 8 && n > 16 && (r == 0 || r >= 4) && !getenv("PIL2GL_NTT_SPLIT") && !env_u32("PIL2GL_NTT_GENERIC", 0) && !env_u32("PIL2GL_NTT_BALANCED", 0)) {
+        const Geom g = make_geom(8, C, 1ull << (n - 8), env_u32("PIL2GL_NTT_TILE", 4096), std::min<u32>(NTT_MAXTHREADS, env_u32("PIL2GL_NTT_THREADS", 256)));
+        if ((g.S == 15 || g.S == 16) && g.by == 16 && g.nbT == 1 && g.Wc == g.S) {
+            int np = 0;
+            for (u32 i = 0; i < n / 8; i++) ks[np++] = 8;
+            if (r) ks[np++] = r;
+            return np;
+        }
+    }
+    return split_bits(n, kmax, ks);
+}
+
 }  // namespace
 
 namespace pil2gl {
@@ -425,7 +442,7 @@ int ntt_launch(const u64 *src, u64 C, u32 n, u64 *dst, bool inverse, hipStream_t
     }
     u32 kmax = pick_kmax(C);
     u32 ks[32];
-    int np = split_bits(n, kmax, ks);
+    int np = plan_passes(n, kmax, C, ks);
     u64 scale = inverse ? h_inv(N % 0xFFFFFFFF00000001ull) : 0;
     if (np == 1) return launch_pass(src, dst, C, n, 0, n, false, inverse, scale, true, true, st);
     u64 *tmp;

@@ -248,7 +248,11 @@ struct RowsDotMfmaParams {
     u32 kSteps;
 };
 
-template <int NT>
+// ODD: some segment has an odd number of columns.  Its rows then start on 8-byte boundaries only and its last 16-byte unit is half a
+// unit: the staged row carries a zero word after it (zero digits in the operand table), the loads of that segment are 8-byte aligned
+// and the half unit is one 8-byte load.  (The even form keeps its 16-byte aligned loads: config 3's matrices are 2, 100 and 6 wide.)
+typedef int v4i_a8 __attribute__((ext_vector_type(4), aligned(8)));
+template <int NT, bool ODD = false>
 __global__ void __launch_bounds__(512, 1) rows_dot_mfma_kernel(RowsDotMfmaParams P) {
     extern __shared__ u64 sm[];
     constexpr u32 NTH = 64 * MF_WAVES, NG = MF_ROWS / 32;
@@ -275,7 +279,15 @@ __global__ void __launch_bounds__(512, 1) rows_dot_mfma_kernel(RowsDotMfmaParams
             const u64 *sb = P.segBuf[0]; u32 sw = P.segW[0], su = 0;
 #pragma unroll
             for (u32 k = 1; k < MF_MAXSEG; k++) if (k < P.nSeg && c >= P.segU0[k]) { sb = P.segBuf[k]; sw = P.segW[k]; su = P.segU0[k]; }
-            nxt[i] = (NTH * i + tid < total && row0 + r < P.nRows) ? *(const v4i *)(sb + (row0 + r) * sw + 2 * (c - su)) : z;
+            if constexpr (!ODD) nxt[i] = (NTH * i + tid < total && row0 + r < P.nRows) ? *(const v4i *)(sb + (row0 + r) * sw + 2 * (c - su)) : z;
+            else {
+                nxt[i] = z;
+                if (NTH * i + tid < total && row0 + r < P.nRows) {
+                    const u64 *q = sb + (row0 + r) * sw + 2 * (c - su);
+                    if (2 * (c - su) + 1 < sw) nxt[i] = *(const v4i_a8 *)q;
+                    else { const u64 v = *q; nxt[i][0] = (int)(u32)v; nxt[i][1] = (int)(u32)(v >> 32); }      // the row's last word; the staged pad word stays 0
+                }
+            }
             c += dr; r += dq;
             if (c >= upr) { c -= upr; r++; }
         }
@@ -431,8 +443,8 @@ static bool rows_dot_mfma_fits(const uint64_t *const *bufs, const uint64_t *widt
     if ((sw && sw[0] == '0') || nOut < 1 || nOut > 2 || nBufs < 1 || nBufs > MF_MAXSEG) return false;
     u64 total = 0;
     for (u32 k = 0; k < nBufs; k++) {
-        if (widths[k] == 0 || widths[k] % 2 || ((uintptr_t)bufs[k] & 15)) return false;
-        total += widths[k];
+        if (widths[k] == 0 || ((uintptr_t)bufs[k] & 15)) return false;
+        total += widths[k] + (widths[k] & 1);               // an odd segment is staged with a zero word after each row
     }
     if (total < 32 || total > MF_MAXW) return false;
     // the kernel keeps a 64-row tile and the digit planes in up to ~144 KB of LDS: only where a workgroup may have that much
@@ -453,9 +465,10 @@ static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *wid
     const u64 Pm = 0xFFFFFFFF00000001ull;
     const int NT = nOut == 1 ? 2 : 3;
     const u32 nO = 3 * nOut;
-    u64 winWidth = 0;
-    for (u32 k = 0; k < nBufs; k++) winWidth += widths[k];
-    std::vector<signed char> dig((size_t)winWidth * nO * 9);
+    u64 winWidth = 0;                                           // columns of the staged row: every segment rounded up to an even count
+    bool odd = false;
+    for (u32 k = 0; k < nBufs; k++) { winWidth += widths[k] + (widths[k] & 1); odd |= (widths[k] & 1) != 0; }
+    std::vector<signed char> dig((size_t)winWidth * nO * 9, 0);
     std::vector<u64> bias(nO);
     unsigned __int128 k128 = 0, offs = 0;
     for (int i = 0; i < 8; i++) k128 += (unsigned __int128)128 << (8 * i);
@@ -466,7 +479,7 @@ static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *wid
     for (u32 o = 0; o < nO; o++) {
         unsigned __int128 sumw = 0;
         u64 c = 0;
-        for (u32 k = 0; k < nBufs; k++)
+        for (u32 k = 0; k < nBufs; k++, c += c & 1)             // (an odd segment's pad column keeps its zero digits)
             for (u64 cl = 0; cl < widths[k]; cl++, c++) {
                 u64 w = hostCoefs[k][((u64)(o / 3) * widths[k] + cl) * 3 + (o % 3)] % Pm;
                 sumw = (sumw + w) % Pm;
@@ -507,7 +520,7 @@ static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *wid
     u32 u0 = 0;
     for (u32 k = 0; k < MF_MAXSEG; k++) {
         P.segBuf[k] = k < nBufs ? bufs[k] : nullptr; P.segW[k] = k < nBufs ? (u32)widths[k] : 0; P.segU0[k] = u0;
-        if (k < nBufs) u0 += (u32)(widths[k] / 2);
+        if (k < nBufs) u0 += (u32)((widths[k] + 1) / 2);
     }
     P.nSeg = nBufs; P.nRows = nRows; P.width = (u32)winWidth; P.nOut = nOut; P.atab = (const v4i *)d; P.bias = d + atWords;
     P.acc = acc; P.accumulate = (u32)accumulate; P.nTiles = (nRows + MF_ROWS - 1) / MF_ROWS; P.kSteps = kSteps;
@@ -516,13 +529,11 @@ static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *wid
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const unsigned grid = (unsigned)std::min<u64>(P.nTiles, (u64)cus);
-    if (NT == 2) {
-        HIP_TRY(hipFuncSetAttribute((const void *)rows_dot_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((rows_dot_mfma_kernel<2>), dim3(grid), dim3(64 * MF_WAVES), lds, st, P);
-    } else {
-        HIP_TRY(hipFuncSetAttribute((const void *)rows_dot_mfma_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((rows_dot_mfma_kernel<3>), dim3(grid), dim3(64 * MF_WAVES), lds, st, P);
-    }
+#define RD_LAUNCH(NT_, ODD_) { HIP_TRY(hipFuncSetAttribute((const void *)rows_dot_mfma_kernel<NT_, ODD_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                              hipLaunchKernelGGL((rows_dot_mfma_kernel<NT_, ODD_>), dim3(grid), dim3(64 * MF_WAVES), lds, st, P); }
+    if (NT == 2) { if (odd) RD_LAUNCH(2, true) else RD_LAUNCH(2, false) }
+    else { if (odd) RD_LAUNCH(3, true) else RD_LAUNCH(3, false) }
+#undef RD_LAUNCH
     KERNEL_CHECK();
     HIP_TRY(hipStreamSynchronize(st));          // the tables are host temporaries in a shared scratch slot
     return PIL2GL_OK;

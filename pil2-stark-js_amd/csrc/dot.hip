@@ -239,7 +239,7 @@ constexpr u32 MF_MAXSEG = 4;
 struct RowsDotMfmaParams {
     // the K dimension is the concatenation of up to MF_MAXSEG matrices with the same rows (a stage's matrices side by side):
     // segment k holds segW[k] (even) columns and starts at 16-byte unit segU0[k] of the staged row
-    const u64 *segBuf[MF_MAXSEG]; u32 segW[MF_MAXSEG], segU0[MF_MAXSEG], nSeg;
+    const u64 *segBuf[MF_MAXSEG]; u32 segW[MF_MAXSEG], segPitch[MF_MAXSEG], segU0[MF_MAXSEG], nSeg;      // segBuf: the window's first column; segPitch: words per matrix row
     u64 nRows; u32 width, nOut;         // width: all segments together
     const v4i *atab;            // [kSteps][NT][64 lanes]: 16 digit bytes per lane
     const u64 *bias;            // [3*nOut] canonical
@@ -248,8 +248,8 @@ struct RowsDotMfmaParams {
     u32 kSteps;
 };
 
-// ODD: some segment has an odd number of columns.  Its rows then start on 8-byte boundaries only and its last 16-byte unit is half a
-// unit: the staged row carries a zero word after it (zero digits in the operand table), the loads of that segment are 8-byte aligned
+// ODD: some segment has an odd number of columns, an odd row pitch or an odd first column.  Its rows then start on 8-byte boundaries only and
+// (odd count) its last 16-byte unit is half a unit: the staged row carries a zero word after it (zero digits in the operand table), the loads of that segment are 8-byte aligned
 // and the half unit is one 8-byte load.  (The even form keeps its 16-byte aligned loads: config 3's matrices are 2, 100 and 6 wide.)
 typedef int v4i_a8 __attribute__((ext_vector_type(4), aligned(8)));
 template <int NT, bool ODD = false>
@@ -276,14 +276,14 @@ __global__ void __launch_bounds__(512, 1) rows_dot_mfma_kernel(RowsDotMfmaParams
 #pragma unroll
         for (u32 i = 0; i < NL; i++) {
             const v4i z = { 0, 0, 0, 0 };
-            const u64 *sb = P.segBuf[0]; u32 sw = P.segW[0], su = 0;
+            const u64 *sb = P.segBuf[0]; u32 sw = P.segW[0], sp = P.segPitch[0], su = 0;
 #pragma unroll
-            for (u32 k = 1; k < MF_MAXSEG; k++) if (k < P.nSeg && c >= P.segU0[k]) { sb = P.segBuf[k]; sw = P.segW[k]; su = P.segU0[k]; }
-            if constexpr (!ODD) nxt[i] = (NTH * i + tid < total && row0 + r < P.nRows) ? *(const v4i *)(sb + (row0 + r) * sw + 2 * (c - su)) : z;
+            for (u32 k = 1; k < MF_MAXSEG; k++) if (k < P.nSeg && c >= P.segU0[k]) { sb = P.segBuf[k]; sw = P.segW[k]; sp = P.segPitch[k]; su = P.segU0[k]; }
+            if constexpr (!ODD) nxt[i] = (NTH * i + tid < total && row0 + r < P.nRows) ? *(const v4i *)(sb + (row0 + r) * sp + 2 * (c - su)) : z;
             else {
                 nxt[i] = z;
                 if (NTH * i + tid < total && row0 + r < P.nRows) {
-                    const u64 *q = sb + (row0 + r) * sw + 2 * (c - su);
+                    const u64 *q = sb + (row0 + r) * sp + 2 * (c - su);
                     if (2 * (c - su) + 1 < sw) nxt[i] = *(const v4i_a8 *)q;
                     else { const u64 v = *q; nxt[i][0] = (int)(u32)v; nxt[i][1] = (int)(u32)(v >> 32); }      // the row's last word; the staged pad word stays 0
                 }
@@ -438,14 +438,15 @@ using namespace pil2gl;
 
 // host side of rows_dot_mfma_kernel: signed base-256 digits of the weights laid out as the MFMA's A operand, the constant per output.
 // Segment k: nRows x widths[k] matrix bufs[k] with weights hostCoefs[k] ([nOut][widths[k]][3]); out = sum over all segments' columns.
-static bool rows_dot_mfma_fits(const uint64_t *const *bufs, const uint64_t *widths, u32 nBufs, u32 nOut) {
+// a segment of the staged row: columns [col0, col0 + width) of an nRows x pitch matrix, with the weights of those columns
+struct MfSeg { const u64 *buf; u64 pitch, col0, width; const u64 *coef; };     // coef: [nOut][pitch][3], the whole matrix's
+static u64 mf_padded(const MfSeg *segs, u32 n) { u64 t = 0; for (u32 k = 0; k < n; k++) t += segs[k].width + (segs[k].width & 1); return t; }
+static bool rows_dot_mfma_fits(const MfSeg *segs, u32 nSeg, u32 nOut) {
     const char *sw = getenv("PIL2GL_ROWS_DOT_MFMA");
-    if ((sw && sw[0] == '0') || nOut < 1 || nOut > 2 || nBufs < 1 || nBufs > MF_MAXSEG) return false;
-    u64 total = 0;
-    for (u32 k = 0; k < nBufs; k++) {
-        if (widths[k] == 0 || ((uintptr_t)bufs[k] & 15)) return false;
-        total += widths[k] + (widths[k] & 1);               // an odd segment is staged with a zero word after each row
-    }
+    if ((sw && sw[0] == '0') || nOut < 1 || nOut > 2 || nSeg < 1 || nSeg > MF_MAXSEG) return false;
+    for (u32 k = 0; k < nSeg; k++)
+        if (segs[k].width == 0 || ((uintptr_t)segs[k].buf & 7) || (segs[k].pitch >> 31)) return false;
+    const u64 total = mf_padded(segs, nSeg);                    // an odd segment is staged with a zero word after each row
     if (total < 32 || total > MF_MAXW) return false;
     // the kernel keeps a 64-row tile and the digit planes in up to ~144 KB of LDS: only where a workgroup may have that much
     // (gfx950: 160 KB); elsewhere the streaming kernel takes the call
@@ -460,14 +461,13 @@ static bool rows_dot_mfma_fits(const uint64_t *const *bufs, const uint64_t *widt
     const size_t need = (size_t)MF_ROWS * (total * 8 + 16) + (size_t)kSteps * NT * 1024;
     return (size_t)ldsMax >= need;
 }
-static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *widths, u32 nBufs, u64 nRows, const uint64_t *const *hostCoefs,
-                                u32 nOut, u64 *acc, bool accumulate, hipStream_t st) {
+static int launch_rows_dot_mfma(const MfSeg *segs, u32 nBufs, u64 nRows, u32 nOut, u64 *acc, bool accumulate, hipStream_t st) {
     const u64 Pm = 0xFFFFFFFF00000001ull;
     const int NT = nOut == 1 ? 2 : 3;
     const u32 nO = 3 * nOut;
-    u64 winWidth = 0;                                           // columns of the staged row: every segment rounded up to an even count
-    bool odd = false;
-    for (u32 k = 0; k < nBufs; k++) { winWidth += widths[k] + (widths[k] & 1); odd |= (widths[k] & 1) != 0; }
+    const u64 winWidth = mf_padded(segs, nBufs);                // columns of the staged row: every segment rounded up to an even count
+    bool odd = false;                                           // rows of some segment start on 8-byte boundaries only
+    for (u32 k = 0; k < nBufs; k++) odd |= ((segs[k].width | segs[k].pitch | segs[k].col0) & 1) != 0 || ((uintptr_t)segs[k].buf & 15);
     std::vector<signed char> dig((size_t)winWidth * nO * 9, 0);
     std::vector<u64> bias(nO);
     unsigned __int128 k128 = 0, offs = 0;
@@ -480,8 +480,8 @@ static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *wid
         unsigned __int128 sumw = 0;
         u64 c = 0;
         for (u32 k = 0; k < nBufs; k++, c += c & 1)             // (an odd segment's pad column keeps its zero digits)
-            for (u64 cl = 0; cl < widths[k]; cl++, c++) {
-                u64 w = hostCoefs[k][((u64)(o / 3) * widths[k] + cl) * 3 + (o % 3)] % Pm;
+            for (u64 cl = 0; cl < segs[k].width; cl++, c++) {
+                u64 w = segs[k].coef[((u64)(o / 3) * segs[k].pitch + segs[k].col0 + cl) * 3 + (o % 3)] % Pm;
                 sumw = (sumw + w) % Pm;
                 int carry = 0;
                 for (int j = 0; j < 9; j++) {
@@ -519,8 +519,8 @@ static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *wid
     RowsDotMfmaParams P;
     u32 u0 = 0;
     for (u32 k = 0; k < MF_MAXSEG; k++) {
-        P.segBuf[k] = k < nBufs ? bufs[k] : nullptr; P.segW[k] = k < nBufs ? (u32)widths[k] : 0; P.segU0[k] = u0;
-        if (k < nBufs) u0 += (u32)((widths[k] + 1) / 2);
+        P.segBuf[k] = k < nBufs ? segs[k].buf + segs[k].col0 : nullptr; P.segW[k] = k < nBufs ? (u32)segs[k].width : 0; P.segPitch[k] = k < nBufs ? (u32)segs[k].pitch : 0; P.segU0[k] = u0;
+        if (k < nBufs) u0 += (u32)((segs[k].width + 1) / 2);
     }
     P.nSeg = nBufs; P.nRows = nRows; P.width = (u32)winWidth; P.nOut = nOut; P.atab = (const v4i *)d; P.bias = d + atWords;
     P.acc = acc; P.accumulate = (u32)accumulate; P.nTiles = (nRows + MF_ROWS - 1) / MF_ROWS; P.kSteps = kSteps;
@@ -539,17 +539,10 @@ static int launch_rows_dot_mfma(const uint64_t *const *bufs, const uint64_t *wid
     return PIL2GL_OK;
 }
 
-extern "C" {
-
-int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, const uint64_t *hostCoef, uint32_t nOut,
-                            uint64_t *acc, int accumulate, void *stream) {
-    P2_TRY(ensure_init());
-    if (!buf || !hostCoef || !acc) return fail(PIL2GL_EINVAL, "null buffer");
-    if (nOut < 1 || nOut > 4) return fail(PIL2GL_EINVAL, "nOut must be 1..4");
-    if (width == 0 || nRows == 0) return PIL2GL_OK;
+// the vector-ALU kernels (whole-row streaming tiles / column tiles): any shape
+static int rows_dot_ext_plain(const uint64_t *buf, uint64_t width, uint64_t nRows, const uint64_t *hostCoef, uint32_t nOut,
+                              uint64_t *acc, int accumulate, void *stream) {
     hipStream_t st = as_stream(stream);
-    if (rows_dot_mfma_fits(&buf, &width, 1, nOut))    // long even rows, one or two outputs: the matrix cores
-        return launch_rows_dot_mfma(&buf, &width, 1, nRows, &hostCoef, nOut, acc, accumulate != 0, st);
     const u64 nC = (u64)nOut * width * 3;
     std::vector<u32> limbs(nC * 3);
     for (u64 i = 0; i < nC; i++) {
@@ -597,6 +590,56 @@ int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows,
 // the same sums over several matrices with the same rows (the stage matrices the FRI polynomial reads: friPolinomial.js:26-50
 // walks cm1..cmQ and the constants): out[r][o] = sum_k sum_c bufs[k][r][c] * hostCoefs[k][o][c].  One pass over all of them
 // when they fit the matrix-core kernel side by side, else one call per matrix accumulating into acc.
+// The matrices of a call as launches of the matrix-core kernel: a matrix wider than the kernel's staged row (MF_MAXW columns) is cut into even
+// column windows, windows and narrow matrices are packed (largest first) into launches of at most MF_MAXSEG segments and MF_MAXW columns,
+// each launch after the first accumulating.  Matrices left in a launch of under 32 columns go to rows_dot_ext_dev one by one.
+// -> false: not for the matrix cores (more than two outputs, PIL2GL_ROWS_DOT_MFMA=0, no wide launch at all)
+static bool rows_dot_mfma_plan(const uint64_t *const *bufs, const uint64_t *widths, const uint64_t *const *hostCoefs, u32 nBufs, u32 nOut,
+                               std::vector<std::vector<MfSeg>> &launches, std::vector<u32> &leftovers) {
+    if (nOut > 2) return false;
+    std::vector<MfSeg> wins;
+    for (u32 k = 0; k < nBufs; k++) {
+        const u64 W = widths[k];
+        if (W == 0) continue;
+        const u64 n = (W + (W & 1) + MF_MAXW - 1) / MF_MAXW;
+        u64 per = (W + n - 1) / n; per += per & 1;
+        for (u64 c0 = 0; c0 < W; c0 += per) wins.push_back({ bufs[k], W, c0, std::min<u64>(per, W - c0), hostCoefs[k] });
+    }
+    std::stable_sort(wins.begin(), wins.end(), [](const MfSeg &a, const MfSeg &b) { return a.width > b.width; });
+    std::vector<u64> fill;
+    for (const MfSeg &w : wins) {
+        const u64 pw = w.width + (w.width & 1);
+        size_t b = 0;
+        while (b < launches.size() && (launches[b].size() >= MF_MAXSEG || fill[b] + pw > MF_MAXW)) b++;
+        if (b == launches.size()) { launches.emplace_back(); fill.push_back(0); }
+        launches[b].push_back(w); fill[b] += pw;
+    }
+    bool any = false;
+    for (size_t b = 0; b < launches.size();) {
+        if (rows_dot_mfma_fits(launches[b].data(), (u32)launches[b].size(), nOut)) { any = true; b++; continue; }
+        for (const MfSeg &w : launches[b]) {
+            if (w.width != w.pitch) return false;               // (a window of a wide matrix always fits: cannot happen)
+            for (u32 k = 0; k < nBufs; k++) if (bufs[k] == w.buf && hostCoefs[k] == w.coef) { leftovers.push_back(k); break; }
+        }
+        launches.erase(launches.begin() + b); fill.erase(fill.begin() + b);
+    }
+    return any;
+}
+
+extern "C" {
+
+int pil2gl_rows_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows,
+                                  const uint64_t *const *hostCoefs, uint32_t nOut, uint64_t *acc, int accumulate, void *stream);
+// one matrix: rows of 32 columns and more with one or two outputs go to the matrix cores (in windows when wider than the staged row)
+int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, const uint64_t *hostCoef, uint32_t nOut,
+                            uint64_t *acc, int accumulate, void *stream) {
+    P2_TRY(ensure_init());
+    if (!buf || !hostCoef || !acc) return fail(PIL2GL_EINVAL, "null buffer");
+    if (nOut < 1 || nOut > 4) return fail(PIL2GL_EINVAL, "nOut must be 1..4");
+    if (width == 0 || nRows == 0) return PIL2GL_OK;
+    return pil2gl_rows_dot_ext_multi_dev(&buf, &width, 1, nRows, &hostCoef, nOut, acc, accumulate, stream);
+}
+
 int pil2gl_rows_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows,
                                   const uint64_t *const *hostCoefs, uint32_t nOut, uint64_t *acc, int accumulate, void *stream) {
     P2_TRY(ensure_init());
@@ -604,10 +647,18 @@ int pil2gl_rows_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *w
     for (uint32_t k = 0; k < nBufs; k++) if (!bufs[k] || !hostCoefs[k]) return fail(PIL2GL_EINVAL, "null buffer");
     if (nOut < 1 || nOut > 4) return fail(PIL2GL_EINVAL, "nOut must be 1..4");
     if (nRows == 0) return PIL2GL_OK;
-    if (rows_dot_mfma_fits(bufs, widths, nBufs, nOut))
-        return launch_rows_dot_mfma(bufs, widths, nBufs, nRows, hostCoefs, nOut, acc, accumulate != 0, as_stream(stream));
-    for (uint32_t k = 0; k < nBufs; k++)
-        P2_TRY(pil2gl_rows_dot_ext_dev(bufs[k], widths[k], nRows, hostCoefs[k], nOut, acc, (accumulate != 0 || k > 0) ? 1 : 0, stream));
+    std::vector<std::vector<MfSeg>> launches;
+    std::vector<u32> leftovers;
+    bool acc1 = accumulate != 0;
+    if (rows_dot_mfma_plan(bufs, widths, hostCoefs, nBufs, nOut, launches, leftovers)) {
+        for (const auto &l : launches) { P2_TRY(launch_rows_dot_mfma(l.data(), (u32)l.size(), nRows, nOut, acc, acc1, as_stream(stream))); acc1 = true; }
+        for (u32 k : leftovers) { P2_TRY(rows_dot_ext_plain(bufs[k], widths[k], nRows, hostCoefs[k], nOut, acc, acc1 ? 1 : 0, stream)); acc1 = true; }
+        return PIL2GL_OK;
+    }
+    for (uint32_t k = 0; k < nBufs; k++) {
+        if (widths[k] == 0) continue;
+        P2_TRY(rows_dot_ext_plain(bufs[k], widths[k], nRows, hostCoefs[k], nOut, acc, acc1 ? 1 : 0, stream)); acc1 = true;
+    }
     return PIL2GL_OK;
 }
 

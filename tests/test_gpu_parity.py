@@ -1138,11 +1138,13 @@ def test_rows_dot_kernels_agree_on_many_tiles(gl, monkeypatch):
 
 @pytest.mark.parametrize("widths,n_out,n_rows", [((100, 6, 2), 2, 1000), ((100, 7, 2), 2, 333), ((40, 40, 30), 1, 129), ((34,), 2, 64),
                                                  ((2, 6, 100), 2, 4099), ((100, 6, 2, 2, 2), 2, 70), ((60, 60), 2, 200), ((100, 6, 2), 3, 100),
-                                                 ((2, 18, 81, 6), 2, 1000), ((81,), 1, 130), ((35, 35, 35), 2, 257), ((111,), 2, 65), ((1, 31), 2, 100), ((113,), 2, 64)])
+                                                 ((2, 18, 81, 6), 2, 1000), ((81,), 1, 130), ((35, 35, 35), 2, 257), ((111,), 2, 65), ((1, 31), 2, 100), ((113,), 2, 64),
+                                                 ((200, 6, 2), 2, 777), ((2, 255, 6), 1, 300), ((120, 120, 120, 4, 4, 4), 2, 129), ((500, 3), 2, 70), ((30, 1), 2, 64)])
 def test_rows_dot_over_several_matrices(gl, widths, n_out, n_rows):
     """pil2gl_rows_dot_ext_multi_dev: the stage matrices of the FRI polynomial side by side in one pass of the matrix-core kernel
     (<= 112 columns together with every odd width counted as the next even one -- an odd matrix is staged with a zero word after each row:
-    the two-stage permutation AIR's 2 + 18 + 81 + 6 --, <= 4 matrices, <= 2 outputs), anything else matrix by matrix: sum over all columns"""
+    the two-stage permutation AIR's 2 + 18 + 81 + 6 --, <= 4 matrices, <= 2 outputs); wider inputs go in column windows packed into several
+    accumulating launches (config 5's 200 + 6 + 2: two), what is left under 32 columns, or has more outputs, matrix by matrix: sum over all columns"""
     import ctypes as C
     import torch
     from pil2gl import _lib

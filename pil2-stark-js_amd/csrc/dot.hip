@@ -243,7 +243,7 @@ struct RowsDotMfmaParams {
     u64 nRows; u32 width, nOut;         // width: all segments together
     const v4i *atab;            // [kSteps][NT][64 lanes]: 16 digit bytes per lane
     const u64 *bias;            // [3*nOut] canonical
-    u64 *acc; u32 accumulate;
+    u64 *acc; u32 accumulate, accStride;      // acc: this launch's first output word of row 0; accStride: words per row of the caller's array
     u64 nTiles;
     u32 kSteps;
 };
@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(512, 1) rows_dot_mfma_kernel(RowsDotMfmaParams
                 // w0 + w1 2^32 + w2 2^64 + w3 2^96 = w0 + w1 2^32 + w2 (2^32 - 1) - w3   (mod p)
                 u64 v = add(add(w[0], mul(w[1], 1ull << 32)), mul(w[2], EPS));
                 v = add(sub(v, w[3]), P.bias[o]);
-                u64 *out = P.acc + row * (3ull * P.nOut) + o;
+                u64 *out = P.acc + row * (u64)P.accStride + o;
                 if (P.accumulate) v = add(v, *out);
                 *out = v;
             }
@@ -461,7 +461,7 @@ static bool rows_dot_mfma_fits(const MfSeg *segs, u32 nSeg, u32 nOut) {
     const size_t need = (size_t)MF_ROWS * (total * 8 + 16) + (size_t)kSteps * NT * 1024;
     return (size_t)ldsMax >= need;
 }
-static int launch_rows_dot_mfma(const MfSeg *segs, u32 nBufs, u64 nRows, u32 nOut, u64 *acc, bool accumulate, hipStream_t st) {
+static int launch_rows_dot_mfma(const MfSeg *segs, u32 nBufs, u64 nRows, u32 nOut, u64 *acc, u32 accStride, bool accumulate, hipStream_t st) {
     const u64 Pm = 0xFFFFFFFF00000001ull;
     const int NT = nOut == 1 ? 2 : 3;
     const u32 nO = 3 * nOut;
@@ -523,7 +523,7 @@ static int launch_rows_dot_mfma(const MfSeg *segs, u32 nBufs, u64 nRows, u32 nOu
         if (k < nBufs) u0 += (u32)((segs[k].width + 1) / 2);
     }
     P.nSeg = nBufs; P.nRows = nRows; P.width = (u32)winWidth; P.nOut = nOut; P.atab = (const v4i *)d; P.bias = d + atWords;
-    P.acc = acc; P.accumulate = (u32)accumulate; P.nTiles = (nRows + MF_ROWS - 1) / MF_ROWS; P.kSteps = kSteps;
+    P.acc = acc; P.accumulate = (u32)accumulate; P.accStride = accStride; P.nTiles = (nRows + MF_ROWS - 1) / MF_ROWS; P.kSteps = kSteps;
     const size_t lds = (size_t)MF_ROWS * (winWidth * 8 + 16) + atab.size();
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
@@ -596,7 +596,6 @@ static int rows_dot_ext_plain(const uint64_t *buf, uint64_t width, uint64_t nRow
 // -> false: not for the matrix cores (more than two outputs, PIL2GL_ROWS_DOT_MFMA=0, no wide launch at all)
 static bool rows_dot_mfma_plan(const uint64_t *const *bufs, const uint64_t *widths, const uint64_t *const *hostCoefs, u32 nBufs, u32 nOut,
                                std::vector<std::vector<MfSeg>> &launches, std::vector<u32> &leftovers) {
-    if (nOut > 2) return false;
     std::vector<MfSeg> wins;
     for (u32 k = 0; k < nBufs; k++) {
         const u64 W = widths[k];
@@ -616,7 +615,7 @@ static bool rows_dot_mfma_plan(const uint64_t *const *bufs, const uint64_t *widt
     }
     bool any = false;
     for (size_t b = 0; b < launches.size();) {
-        if (rows_dot_mfma_fits(launches[b].data(), (u32)launches[b].size(), nOut)) { any = true; b++; continue; }
+        if (rows_dot_mfma_fits(launches[b].data(), (u32)launches[b].size(), std::min<u32>(nOut, 2))) { any = true; b++; continue; }
         for (const MfSeg &w : launches[b]) {
             if (w.width != w.pitch) return false;               // (a window of a wide matrix always fits: cannot happen)
             for (u32 k = 0; k < nBufs; k++) if (bufs[k] == w.buf && hostCoefs[k] == w.coef) { leftovers.push_back(k); break; }
@@ -651,8 +650,19 @@ int pil2gl_rows_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *w
     std::vector<u32> leftovers;
     bool acc1 = accumulate != 0;
     if (rows_dot_mfma_plan(bufs, widths, hostCoefs, nBufs, nOut, launches, leftovers)) {
-        for (const auto &l : launches) { P2_TRY(launch_rows_dot_mfma(l.data(), (u32)l.size(), nRows, nOut, acc, acc1, as_stream(stream))); acc1 = true; }
-        for (u32 k : leftovers) { P2_TRY(rows_dot_ext_plain(bufs[k], widths[k], nRows, hostCoefs[k], nOut, acc, acc1 ? 1 : 0, stream)); acc1 = true; }
+        // the kernel produces one or two outputs per launch: three or four opening points take two sweeps of the same launches
+        // (outputs 0-1, then 2-3: HBM-bound passes against one vector-ALU-bound pass), writing their own words of the caller's rows
+        for (u32 o0 = 0; o0 < nOut; o0 += 2) {
+            const u32 no = std::min<u32>(2, nOut - o0);
+            bool accg = accumulate != 0;
+            for (auto l : launches) {
+                for (MfSeg &sg : l) sg.coef += (u64)o0 * sg.pitch * 3;
+                P2_TRY(launch_rows_dot_mfma(l.data(), (u32)l.size(), nRows, no, acc + 3 * o0, 3 * nOut, accg, as_stream(stream)));
+                accg = true;
+            }
+        }
+        acc1 = true;
+        for (u32 k : leftovers) P2_TRY(rows_dot_ext_plain(bufs[k], widths[k], nRows, hostCoefs[k], nOut, acc, 1, stream));
         return PIL2GL_OK;
     }
     for (uint32_t k = 0; k < nBufs; k++) {
@@ -702,10 +712,19 @@ int pil2gl_cols_dot_ext_range_dev(const uint64_t *const *bufs, const uint64_t *s
     for (uint32_t k = 0; k < nBufs && k < CD_MAXSEG; k++)
         if ((colBegin ? colBegin[k] : 0) + widths[k] > strides[k] || (strides[k] >> 31)) return fail(PIL2GL_EINVAL, "column range outside the matrix");
     if (nBufs > CD_MAXSEG) return fail(PIL2GL_EINVAL, "at most %u matrices per call", CD_MAXSEG);
-    if (nLev < 1 || nLev > 4) return fail(PIL2GL_EINVAL, "nLev must be 1..4");
+    if (nLev < 1 || nLev > 64) return fail(PIL2GL_EINVAL, "nLev must be 1..64");
     u64 width = 0;
     for (uint32_t k = 0; k < nBufs; k++) { if (!bufs[k] || !hostOuts[k]) return fail(PIL2GL_EINVAL, "null buffer"); if (widths[k] >> 31) return fail(PIL2GL_EINVAL, "matrix too wide"); width += widths[k]; }
+    for (uint32_t l = 0; l < nLev; l++) if (!levs[l]) return fail(PIL2GL_EINVAL, "null buffer");
     if (width == 0 || nRows == 0) return PIL2GL_OK;
+    if (nLev > 4) {                         // a sweep weighs four opening points: more of them take more sweeps (hostOuts[k] is [nLev][widths[k]][3])
+        for (uint32_t l0 = 0; l0 < nLev; l0 += 4) {
+            std::vector<uint64_t *> outs(nBufs);
+            for (uint32_t k = 0; k < nBufs; k++) outs[k] = hostOuts[k] + (u64)l0 * widths[k] * 3;
+            P2_TRY(pil2gl_cols_dot_ext_range_dev(bufs, strides, colBegin, widths, nBufs, nRows, rowStep, levs + l0, std::min<u32>(4, nLev - l0), outs.data(), stream));
+        }
+        return PIL2GL_OK;
+    }
     hipStream_t st = as_stream(stream);
     const u32 rpc = 1024;
     const u64 nChunks = (nRows + rpc - 1) / rpc, n = (u64)nLev * width * 3;

@@ -94,7 +94,7 @@ module.exports.computeEvalsStark = async function computeEvalsStark(ctx, options
         };
         const openIdx = (ev) => ctx.pilInfo.openingPoints.findIndex((p) => p === ev.prime);
         ctx.evals = [];
-        if (nOpen <= 4) {
+        if (nOpen <= 64) {                                     // (a sweep of the library weighs four opening points; more of them take more sweeps inside the call)
             // eval_e = sum_k v_e[k << b] LEv[k] (:250-264) for EVERY column of a section and every opening in one sweep of
             // the section (pil2gl_cols_dot_ext_dev); a dim-3 polynomial q0 + q1 x + q2 x^2 is assembled from its base columns
             const sums = new Map(), secs = [];

@@ -1139,12 +1139,14 @@ def test_rows_dot_kernels_agree_on_many_tiles(gl, monkeypatch):
 @pytest.mark.parametrize("widths,n_out,n_rows", [((100, 6, 2), 2, 1000), ((100, 7, 2), 2, 333), ((40, 40, 30), 1, 129), ((34,), 2, 64),
                                                  ((2, 6, 100), 2, 4099), ((100, 6, 2, 2, 2), 2, 70), ((60, 60), 2, 200), ((100, 6, 2), 3, 100),
                                                  ((2, 18, 81, 6), 2, 1000), ((81,), 1, 130), ((35, 35, 35), 2, 257), ((111,), 2, 65), ((1, 31), 2, 100), ((113,), 2, 64),
-                                                 ((200, 6, 2), 2, 777), ((2, 255, 6), 1, 300), ((120, 120, 120, 4, 4, 4), 2, 129), ((500, 3), 2, 70), ((30, 1), 2, 64)])
+                                                 ((200, 6, 2), 2, 777), ((2, 255, 6), 1, 300), ((120, 120, 120, 4, 4, 4), 2, 129), ((500, 3), 2, 70), ((30, 1), 2, 64),
+                                                 ((100, 6, 2), 4, 300), ((2, 18, 81, 6), 3, 257), ((200, 7), 3, 130), ((16, 8), 4, 64)])
 def test_rows_dot_over_several_matrices(gl, widths, n_out, n_rows):
     """pil2gl_rows_dot_ext_multi_dev: the stage matrices of the FRI polynomial side by side in one pass of the matrix-core kernel
     (<= 112 columns together with every odd width counted as the next even one -- an odd matrix is staged with a zero word after each row:
     the two-stage permutation AIR's 2 + 18 + 81 + 6 --, <= 4 matrices, <= 2 outputs); wider inputs go in column windows packed into several
-    accumulating launches (config 5's 200 + 6 + 2: two), what is left under 32 columns, or has more outputs, matrix by matrix: sum over all columns"""
+    accumulating launches (config 5's 200 + 6 + 2: two), three or four outputs in two sweeps of those launches, what is left under 32 columns
+    matrix by matrix on the vector kernels: sum over all columns"""
     import ctypes as C
     import torch
     from pil2gl import _lib
@@ -1223,6 +1225,18 @@ def test_rows_and_cols_dot_ext(gl, oracle, monkeypatch, mode):
     for a_, b_ in zip(single, multi):
         assert np.array_equal(a_, b_)
     assert single[1][2, 5].tolist() == oracle.eval_pol_at(mats[1], 5, 1, nb2, eb2, levs2[2]).tolist()
+    # six opening points in one call (a sweep weighs four: two sweeps inside the library) == the points three at a time
+    levs6 = dlevs2 + [torch.from_numpy(rand_field(rng, (1 << nb2, 3)).view(np.int64)).cuda() for _ in range(3)]
+    lv6 = (C.c_void_p * 6)(*[t.data_ptr() for t in levs6])
+    lvb = (C.c_void_p * 3)(*[t.data_ptr() for t in levs6[3:]])
+    six = [np.zeros((6, m.shape[1], 3), np.uint64) for m in mats]
+    outs6 = (C.c_void_p * len(mats))(*[o.ctypes.data for o in six])
+    _lib.call("pil2gl_cols_dot_ext_multi_dev", ptrs, C.c_void_p(ws.ctypes.data), len(mats), 1 << nb2, 1 << eb2, lv6, 6, outs6, None)
+    second = [np.zeros_like(o) for o in single]
+    outs3 = (C.c_void_p * len(mats))(*[o.ctypes.data for o in second])
+    _lib.call("pil2gl_cols_dot_ext_multi_dev", ptrs, C.c_void_p(ws.ctypes.data), len(mats), 1 << nb2, 1 << eb2, lvb, 3, outs3, None)
+    for a_, b_, c_ in zip(six, multi, second):
+        assert np.array_equal(a_[:3], b_) and np.array_equal(a_[3:], c_)
     # column sums against the oracle's per-column evaluation (stark_gen_helpers.js:250-264)
     nb, eb, width = 11, 3, 9
     buf = rand_field(rng, (1 << (nb + eb), width)); dbuf = torch.from_numpy(buf.view(np.int64)).cuda()

@@ -6,7 +6,7 @@ import numpy as np, torch
 import pil2gl
 from pil2gl import _lib
 pil2gl.init(0)
-n_rows, width, n_out = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 27, 100, 2
+n_rows, width, n_out = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 27, int(os.environ.get("NCOLS", 100)), int(os.environ.get("NOUT", 2))
 dm = torch.randint(0, 2 ** 62, (n_rows * width,), dtype=torch.int64, device="cuda")
 coef = np.random.default_rng(1).integers(0, 2 ** 63, (n_out, width, 3), dtype=np.uint64)
 acc = torch.zeros(n_rows * n_out * 3, dtype=torch.int64, device="cuda")

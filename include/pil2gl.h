@@ -204,8 +204,10 @@ int pil2gl_compute_evals_dev(const pil2gl_eval_desc *descs, uint32_t nEvals, uin
 int pil2gl_rows_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, const uint64_t *hostCoef, uint32_t nOut,
                             uint64_t *acc, int accumulate, void *stream);
 /* the same over nBufs matrices with the same rows -- the stage matrices and the constants the FRI polynomial walks
- * (friPolinomial.js:26-50): acc[r][o] (+)= sum_k sum_c bufs[k][r][c] * hostCoefs[k][o][c], in one pass over all of them when
- * their columns fit the matrix-core kernel side by side (<= 112 columns in all, even widths, nOut <= 2). */
+ * (friPolinomial.js:26-50): acc[r][o] (+)= sum_k sum_c bufs[k][r][c] * hostCoefs[k][o][c].  On the matrix cores: one pass over
+ * all of them when their columns fit the kernel's staged row side by side (<= 112 columns in all, an odd width counted as the
+ * next even one, <= 4 matrices); wider inputs in column windows packed into accumulating passes; three or four outputs as
+ * two sweeps of two; matrices left with under 32 columns, and PIL2GL_ROWS_DOT_MFMA=0, on the vector kernels.  nOut: 1..4. */
 int pil2gl_rows_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows,
                                   const uint64_t *const *hostCoefs, uint32_t nOut, uint64_t *acc, int accumulate, void *stream);
 /* f[r] = Horner in vf1 over the openings of (acc[r][o] - K_o) * xDivXSubXi[r][o]   (friPolinomial.js:38-50);
@@ -223,7 +225,8 @@ int pil2gl_fri_combine_order_dev(const uint64_t *acc, const uint64_t *hostK, con
 int pil2gl_cols_dot_ext_dev(const uint64_t *buf, uint64_t width, uint64_t nRows, uint64_t rowStep, const uint64_t *const *levs,
                             uint32_t nLev, uint64_t *hostOut, void *stream);
 /* the same over nBufs (<= 8) matrices with the same rows in one sweep of the weights (computeEvalsStark walks every committed
- * stage and the constants, stark_gen_helpers.js:233-264): hostOuts[k] receives nLev x widths[k] x 3. */
+ * stage and the constants, stark_gen_helpers.js:233-264): hostOuts[k] receives nLev x widths[k] x 3.  nLev: 1..64 (a sweep
+ * weighs four opening points; more of them take more sweeps inside the call). */
 int pil2gl_cols_dot_ext_multi_dev(const uint64_t *const *bufs, const uint64_t *widths, uint32_t nBufs, uint64_t nRows, uint64_t rowStep,
                                   const uint64_t *const *levs, uint32_t nLev, uint64_t *const *hostOuts, void *stream);
 /* the same over the columns [colBegin[k], colBegin[k] + widths[k]) of matrices whose rows are strides[k] words long (colBegin null: from

@@ -2,8 +2,8 @@
 //   calculateZ(F,num,den)  src/helpers/polutils.js:128-143   z[0] = 1, z[i] = z[i-1] * num[i-1] / den[i-1]
 //   calculateS(F,num,den)  src/helpers/polutils.js:145-164   s[i] = s[i-1] + num / den[i]        (num: one element)
 // called from resolveHint (src/prover/hints_helpers.js:91-114).  The reference walks the column serially with BigInt
-// arithmetic after one batch inversion; here every ratio gets its own extension-field inversion (ALU is free at this
-// size) and the running product / sum is a three-kernel scan: per-block inclusive scan + block totals, scan of the
+// arithmetic after one batch inversion; here a thread inverts its eight denominators together (one field inversion per
+// eight rows) and the running product / sum is a three-kernel scan: per-block inclusive scan + block totals, scan of the
 // totals, then the fix-up (for the product: shifted by one row, z[0] = 1).  Operands may be base (dim 1) or cubic
 // extension (dim 3) columns, row-major; the result is dim 3 if either operand is, else dim 1.
 #include "common.h"
@@ -49,13 +49,35 @@ __global__ void __launch_bounds__(SCAN_THREADS) hint_scan1(const u64 *__restrict
     E3 loc[SCAN_ITEMS];
     E3 run = ident<PROD>();
     const E3 numS = PROD ? ident<true>() : ld_dim(num, 0, dimNum);
+    // the thread's SCAN_ITEMS denominators are inverted together (Montgomery's trick, what the reference's F.batchInverse does for the whole
+    // column, polutils.js:134): ONE field inversion -- an exponentiation, ~130 products -- and three extension products per row instead
+    // of an inversion per row.  A zero denominator inverts to zero, as it does alone (0^(p-2)): it is kept out of the running product.
+    const E3 one = ident<true>();
+    u32 zero = 0;
+    E3 acc = one;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        const u64 i = base + k;
+        E3 d = i < n ? ld_dim(den, i, dimDen) : one;
+        if (!(d.v[0] | d.v[1] | d.v[2])) { zero |= 1u << k; d = one; }
+        loc[k] = acc;                                   // the product of the denominators before this one
+        acc = e3_mul(acc, d);
+    }
+    E3 ai = (acc.v[1] | acc.v[2]) ? e3_inv(acc) : E3{ { inv(acc.v[0]), 0, 0 } };
+#pragma unroll
+    for (int k = SCAN_ITEMS - 1; k >= 0; k--) {
+        const u64 i = base + k;
+        E3 d = i < n ? ld_dim(den, i, dimDen) : one;
+        if ((zero >> k) & 1) d = one;
+        const E3 di = e3_mul(ai, loc[k]);               // 1 / d_k
+        ai = e3_mul(ai, d);
+        loc[k] = ((zero >> k) & 1) ? E3{ { 0, 0, 0 } } : di;
+    }
 #pragma unroll
     for (int k = 0; k < SCAN_ITEMS; k++) {
         const u64 i = base + k;
         if (i < n) {
-            const E3 d = ld_dim(den, i, dimDen);
-            const E3 di = (d.v[1] | d.v[2]) ? e3_inv(d) : E3{ { inv(d.v[0]), 0, 0 } };
-            const E3 r = e3_mul(PROD ? ld_dim(num, i, dimNum) : numS, di);
+            const E3 r = e3_mul(PROD ? ld_dim(num, i, dimNum) : numS, loc[k]);
             run = comb<PROD>(run, r);
         }
         loc[k] = run;

@@ -1045,6 +1045,15 @@ def test_gprod_gsum_columns(gl, oracle, n, dimNum, dimDen):
     assert np.array_equal(z, oracle.gprod(num, den, dimNum, dimDen))
     s = gl.calculateS(dn[:dimNum].contiguous(), dd, dimNum, dimDen).cpu().numpy().view(np.uint64)
     assert np.array_equal(s, oracle.gsum(num[:dimNum], den, dimNum, dimDen))
+    if n >= 2048:
+        # zero denominators: a lane inverts its eight denominators together, and a zero among them (0^(p-2) = 0 when inverted alone, as
+        # the oracle does) must not reach that product -- one in a batch, a whole batch, the column's last row
+        dz = den.reshape(n, dimDen).copy()
+        dz[7] = 0; dz[1024:1032] = 0; dz[1033] = 0; dz[n - 1] = 0
+        dz = dz.reshape(-1)
+        ddz = torch.from_numpy(dz.view(np.int64)).cuda()
+        assert np.array_equal(gl.calculateZ(dn, ddz, dimNum, dimDen).cpu().numpy().view(np.uint64), oracle.gprod(num, dz, dimNum, dimDen))
+        assert np.array_equal(gl.calculateS(dn[:dimNum].contiguous(), ddz, dimNum, dimDen).cpu().numpy().view(np.uint64), oracle.gsum(num[:dimNum], dz, dimNum, dimDen))
     if dimNum == dimDen and n > 1:
         rot = np.roll(den.reshape(n, dimDen), 1, axis=0).reshape(-1).copy()
         z2 = gl.calculateZ(torch.from_numpy(rot.view(np.int64)).cuda(), dd, dimNum, dimDen).cpu().numpy().view(np.uint64).reshape(n, -1)

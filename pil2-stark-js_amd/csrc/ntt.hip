@@ -342,9 +342,11 @@ Geom make_geom(u32 k, u64 C, u64 totalGroups, u32 maxElems, u32 nThreads) {
     } else {
         u32 chunks = (u32)((C + smax - 1) / smax);
         g.Wc = (u32)((C + chunks - 1) / chunks);
-        // 8-stage tiles have fixed-geometry kernels for 15 and 16 slots only: the same number of chunks at one of those widths with a
-        // ragged last chunk beats evenly cut chunks on the any-geometry kernels (81 columns: 15 x 5 + 6 instead of 14 x 5 + 11)
-        if (k == 8 && smax == 16 && !env_u32("PIL2GL_NTT_EVEN_CHUNKS", 0)) g.Wc = (C + 14) / 15 == chunks ? 15 : 16;
+        // 8-stage tiles have fixed-geometry kernels for 15 and 16 slots only: chunks of 16 with a ragged last chunk beat evenly cut chunks
+        // on the any-geometry kernels (81 columns: 16 x 5 + 1 instead of 14 x 5 + 11: -11 %), and 16 beats 15 where both give the same
+        // number of chunks (100 columns, 16 x 6 + 4 against 15 x 6 + 10: 194.7 against 198.1 ms per config-3 interpolate, four same-box
+        // pairs; other widths +-1 %: profiles/r05_lde_chunks_15_16.txt).  PIL2GL_NTT_WC15=1: 15 where it fits, as rounds 2-4 had it.
+        if (k == 8 && smax == 16 && !env_u32("PIL2GL_NTT_EVEN_CHUNKS", 0)) g.Wc = ((C + 14) / 15 == chunks && env_u32("PIL2GL_NTT_WC15", 0)) ? 15 : 16;
         g.nbT = 1;
         g.nColChunks = (u32)((C + g.Wc - 1) / g.Wc);
     }

@@ -36,7 +36,19 @@ using bn::u32;
 
 namespace {
 
-constexpr int BN_BLOCK = 64;
+constexpr int BN_BLOCK = 64;                         // lanes of a wave = permutations a wave carries
+// Waves per workgroup.  Every wave works alone on its own 64 permutations and its own LDS slice; what the waves of a workgroup share is
+// TIME: a barrier at the start of every matrix phase (dense layer, rows on y, column update) keeps them on the same operand tiles, so that
+// of the workgroup's loads of a tile one goes to the L2 and the others hit the CU's L1.
+#ifndef BN_WG_WAVES
+#define BN_WG_WAVES 1
+#endif
+constexpr int BN_THREADS = BN_BLOCK * BN_WG_WAVES;
+#if BN_WG_WAVES > 1
+#define BN_SYNC() __syncthreads()
+#else
+#define BN_SYNC()
+#endif
 constexpr int N_ROUNDS_F = 8;
 const int N_ROUNDS_P[16] = { 56, 57, 56, 60, 60, 63, 64, 63, 60, 66, 60, 65, 70, 60, 64, 68 };   // poseidon.circom:8
 
@@ -360,6 +372,16 @@ __device__ __forceinline__ unsigned long long bn_now() {
 #else
 #define BN_STAMP(slot, expr) { expr; }
 #endif
+// -DBN_PRIO_MFMA=n: the wave raises its issue priority to n while it feeds the matrix pipe (dense layers, rows on y, column updates) and drops it
+// to 0 for its vector phases, so that of a SIMD's two waves the one in a matrix phase is served first (A/B builds; 0 = no s_setprio at all)
+#ifndef BN_PRIO_MFMA
+#define BN_PRIO_MFMA 0
+#endif
+#if BN_PRIO_MFMA
+#define BN_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define BN_PRIO(n)
+#endif
 struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8];
                   const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma, nofold; };
 
@@ -375,9 +397,13 @@ struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 
 typedef u32 __attribute__((address_space(5))) *priv_u32;
 typedef u32 __attribute__((address_space(3))) *lds_u32;
 struct St { lds_u32 S; priv_u32 hi; int tmax, lane; };
+__host__ __device__ constexpr int lds_words(int tmax) { return (tmax < BN_LDS_ELEMS ? tmax : BN_LDS_ELEMS) * 8 * BN_BLOCK; }   // one wave's slice
 #define S_LDS(st, j, l) (st).S[(((j) * 8 + (l)) * BN_BLOCK) + (st).lane]
 
 __device__ __forceinline__ void lds_load(const St st, int j, u32 x[8]) {
+#ifdef BN_ABLATE_SCRATCH
+    if (j >= BN_LDS_ELEMS) j -= 17 - BN_LDS_ELEMS;   // timing experiments only: the upper elements aliased onto LDS slots, results meaningless
+#endif
     if (j < BN_LDS_ELEMS) {
 #pragma unroll
         for (int l = 0; l < 8; l++) x[l] = S_LDS(st, j, l);
@@ -387,6 +413,9 @@ __device__ __forceinline__ void lds_load(const St st, int j, u32 x[8]) {
     }
 }
 __device__ __forceinline__ void lds_store(const St st, int j, const u32 x[8]) {
+#ifdef BN_ABLATE_SCRATCH
+    if (j >= BN_LDS_ELEMS) j -= 17 - BN_LDS_ELEMS;
+#endif
     if (j < BN_LDS_ELEMS) {
 #pragma unroll
         for (int l = 0; l < 8; l++) S_LDS(st, j, l) = x[l];
@@ -533,12 +562,20 @@ __device__ __noinline__ void dense_mfma_n(const St st, const bnm::v4i *tiles, co
     const bnm::Sh sh = bnm::sh_init();
     bnm::gtile tp = (bnm::gtile)tiles + st.lane;
     bnm::v4i q[MFMA_AHEAD];
+    BN_SYNC();                                       // the workgroup's waves start the layer's tile stream together
 #pragma unroll
     for (int k = 0; k < MFMA_AHEAD; k++) q[k] = tp[(size_t)k * 64];
+#ifdef BN_STAMPS
+    unsigned long long sBurst = 0, sCarry = 0, sFinish = 0;
+#endif
     for (int i = 0; i < N; i++) {
         u32 k[8], o[8];
+#ifdef BN_STAMPS
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long tr0 = bn_now(); __builtin_amdgcn_sched_barrier(0);
+#endif
         load_const<true>(kc, (size_t)i, k);          // asked for ahead of the row's tiles: an in-order counter waits for everything older than what it wants
         bnm::v16i a0 = bnm::acc_init(), a1 = bnm::acc_init();
+        BN_PRIO(BN_PRIO_MFMA);
 #pragma unroll
         for (int j = 0; j < N; j++) {
             const bnm::v4i a = q[0];
@@ -553,9 +590,25 @@ __device__ __noinline__ void dense_mfma_n(const St st, const bnm::v4i *tiles, co
             a1 = bnm::mfma(a, B1[j], a1);
         }
         tp += (size_t)N * 64;
+        BN_PRIO(0);
+#ifdef BN_STAMPS
+        // (the burst ends when the first accumulator can be read: the stamp after an instruction that depends on both)
+        u32 w[10];
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long tr1 = bn_now(); __builtin_amdgcn_sched_barrier(0);
+        bnm::carry_pair(a0, a1, w, sh);
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long tr2 = bn_now(); __builtin_amdgcn_sched_barrier(0);
+        bnm::finish_words(w, k, o);
+        lds_store(st, first + i, o);
+        __builtin_amdgcn_sched_barrier(0); const unsigned long long tr3 = bn_now(); __builtin_amdgcn_sched_barrier(0);
+        sBurst += tr1 - tr0; sCarry += tr2 - tr1; sFinish += tr3 - tr2;
+#else
         bnm::finish_row(a0, a1, k, o, sh);
         lds_store(st, first + i, o);                 // the old state is in B0 / B1: the new row can go straight to its place
+#endif
     }
+#ifdef BN_STAMPS
+    if (st.lane == 0) { atomicAdd(&g_bn_stamps[13], sBurst); atomicAdd(&g_bn_stamps[14], sCarry); atomicAdd(&g_bn_stamps[15], sFinish); atomicAdd(&g_bn_stamps[6], (unsigned long long)N); }
+#endif
 }
 __device__ __forceinline__ void dense_mfma(const St st, const bnm::v4i *tiles, const u32 *kc, int n, int first) {
 #ifdef BN_ABLATE_DENSE
@@ -675,6 +728,7 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
     const int n = A.t - 1, nb = A.rp / 4, nsb = (nb + 1) / 2;
     const bnm::Sh sh = bnm::sh_init();
     TileStream ts;
+    BN_SYNC();
     ts.start(A.Pt, st.lane);
     u32 x0[8];
     lds_load(st, 0, x0);                              // S[0] came with the row of the layer before
@@ -696,6 +750,8 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
                 for (int i = 0; i < 4; i++) { P0[i] = bnm::acc_init(); P1[i] = bnm::acc_init(); }
                 u32 yn[8];
                 lds_load(st, 1, yn);
+                BN_SYNC();
+                BN_PRIO(BN_PRIO_MFMA);
                 for (int j = 0; j < n; j++) {
                     u32 y[8];
 #pragma unroll
@@ -720,6 +776,7 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
                             P1[i] = bnm::mfma(a, zbA1[s], P1[i]);
                         }
                 }
+                BN_PRIO(0);
 #pragma unroll
                 for (int i = 0; i < 4; i++) bnm::carry_pair(P0[i], P1[i], pc[i], sh);
             }
@@ -765,6 +822,7 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
         // the columns, once per super-block: y_j + sum over its rounds of W z
         u32 yn[8];
         lds_load(st, 1, yn);
+        BN_SYNC();
         for (int j = 0; j < n; j++) {
             u32 y[8], k[8];
 #pragma unroll
@@ -773,6 +831,7 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
             load_const<true>(A.KU, (size_t)sb * n + j, k);            // (asked for early: used after the products)
             bnm::v4i b0, b1;
             bnm::b_prep(y, b0, b1);
+            BN_PRIO(BN_PRIO_MFMA);
             bnm::v4i a = ts.next();
             bnm::v16i c0 = bnm::mfma(a, b0, bnm::acc_init()), c1 = bnm::mfma(a, b1, bnm::acc_init());
             if (halves == 2) {
@@ -789,6 +848,7 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
                 c0 = bnm::mfma(a, zb0[s], c0);
                 c1 = bnm::mfma(a, zb1[s], c1);
             }
+            BN_PRIO(0);
             bnm::finish_row(c0, c1, k, y, sh);
             lds_store(st, 1 + j, y);
         }
@@ -874,13 +934,13 @@ __device__ __forceinline__ void digest_out(const St st, int j, u64 *o) {
 
 // leaf digests (merklehash_bn128_worker.js:42-98): one row per lane
 template <bool WIDE>
-__global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) bn_linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int arity, int custom,
+__global__ void __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(2))) bn_linear_hash_kernel(const u64 *__restrict__ in, u64 width, u64 height, int arity, int custom,
                                                                     PermArgs full, PermArgs last, u64 *__restrict__ out) {
     extern __shared__ u32 S[];
-    const int lane = threadIdx.x, tmax = arity + 1;
+    const int lane = threadIdx.x % BN_BLOCK, wv = threadIdx.x / BN_BLOCK, tmax = arity + 1;
     u32 hi_arr[(17 - BN_LDS_ELEMS) * 8];
-    const St st = { (lds_u32)S, (priv_u32)hi_arr, tmax, lane };
-    const u64 row0 = (u64)blockIdx.x * BN_BLOCK + lane;
+    const St st = { (lds_u32)S + wv * lds_words(tmax), (priv_u32)hi_arr, tmax, lane };
+    const u64 row0 = ((u64)blockIdx.x * BN_WG_WAVES + wv) * BN_BLOCK + lane;
     const bool live = row0 < height;
     const u64 *v = in + (live ? row0 : height - 1) * width;
     int cur = 0;
@@ -918,12 +978,12 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
 
 // parents (merklehash_bn128_worker.js:104-144): out[i] = Poseidon(0; in[arity*i .. arity*i+arity-1])[0]
 template <bool WIDE>
-__global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) bn_merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, int arity, PermArgs full, u64 *__restrict__ out) {
+__global__ void __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(2))) bn_merkle_level_kernel(const u64 *__restrict__ in, u64 nOps, int arity, PermArgs full, u64 *__restrict__ out) {
     extern __shared__ u32 S[];
-    const int lane = threadIdx.x, tmax = arity + 1;
+    const int lane = threadIdx.x % BN_BLOCK, wv = threadIdx.x / BN_BLOCK, tmax = arity + 1;
     u32 hi_arr[(17 - BN_LDS_ELEMS) * 8];
-    const St st = { (lds_u32)S, (priv_u32)hi_arr, tmax, lane };
-    const u64 i0 = (u64)blockIdx.x * BN_BLOCK + lane;
+    const St st = { (lds_u32)S + wv * lds_words(tmax), (priv_u32)hi_arr, tmax, lane };
+    const u64 i0 = ((u64)blockIdx.x * BN_WG_WAVES + wv) * BN_BLOCK + lane;
     const bool live = i0 < nOps;
     const u64 *v = in + (live ? i0 : nOps - 1) * (u64)arity * 4;
     zero_store(st, 0);
@@ -939,13 +999,13 @@ __global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2
 
 // circomlibjs poseidon(inputs, initState, nOut): normal-form words in and out (transcript, verification, tests)
 template <bool WIDE>
-__global__ void __launch_bounds__(BN_BLOCK) __attribute__((amdgpu_waves_per_eu(2))) bn_poseidon_kernel(const u64 *__restrict__ in, const u64 *__restrict__ init, u64 count, int nIn, int nOut,
+__global__ void __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(2))) bn_poseidon_kernel(const u64 *__restrict__ in, const u64 *__restrict__ init, u64 count, int nIn, int nOut,
                                                                  PermArgs full, u64 *__restrict__ out) {
     extern __shared__ u32 S[];
-    const int lane = threadIdx.x, tmax = nIn + 1;
+    const int lane = threadIdx.x % BN_BLOCK, wv = threadIdx.x / BN_BLOCK, tmax = nIn + 1;
     u32 hi_arr[(17 - BN_LDS_ELEMS) * 8];
-    const St st = { (lds_u32)S, (priv_u32)hi_arr, tmax, lane };
-    const u64 i0 = (u64)blockIdx.x * BN_BLOCK + lane;
+    const St st = { (lds_u32)S + wv * lds_words(tmax), (priv_u32)hi_arr, tmax, lane };
+    const u64 i0 = ((u64)blockIdx.x * BN_WG_WAVES + wv) * BN_BLOCK + lane;
     const bool live = i0 < count;
     const u64 i = live ? i0 : count - 1;
     u64 w[4] = { 0, 0, 0, 0 };
@@ -1071,7 +1131,7 @@ __global__ void bn_convert_kernel(const u64 *__restrict__ in, u64 n, int toMont,
 
 size_t lds_bytes(int tmax) {                         // the elements above BN_LDS_ELEMS live in private memory
     static const size_t pad = getenv("PIL2GL_BN128_LDS_PAD") ? (size_t)atol(getenv("PIL2GL_BN128_LDS_PAD")) : 0;   // occupancy experiments: extra bytes per workgroup
-    return (size_t)(tmax < BN_LDS_ELEMS ? tmax : BN_LDS_ELEMS) * 8 * BN_BLOCK * 4 + pad;
+    return (size_t)lds_words(tmax) * 4 * BN_WG_WAVES + pad;
 }
 
 PermArgs perm_args(const Params *P) {
@@ -1145,14 +1205,14 @@ int pil2gl_bn128_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64
     const uint64_t nEl = (width + 2) / 3, nLast = nEl % arity;
     if (width > 4 && !custom && nLast) P2_TRY(get_params((int)nLast + 1, &pl));
     const size_t lds = lds_bytes((int)arity + 1);
-    const uint64_t blocks = (height + BN_BLOCK - 1) / BN_BLOCK;
+    const uint64_t blocks = (height + BN_THREADS - 1) / BN_THREADS;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
     if (wide_state((int)arity + 1)) {
         P2_TRY(set_lds_attr(bn_linear_hash_kernel<true>, lds));
-        bn_linear_hash_kernel<true><<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
+        bn_linear_hash_kernel<true><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
     } else {
         P2_TRY(set_lds_attr(bn_linear_hash_kernel<false>, lds));
-        bn_linear_hash_kernel<false><<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
+        bn_linear_hash_kernel<false><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
     }
     KERNEL_CHECK();
     return PIL2GL_OK;
@@ -1170,7 +1230,7 @@ int pil2gl_bn128_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint32_t
     const Params *pf;
     P2_TRY(get_params((int)arity + 1, &pf));
     const size_t lds = lds_bytes((int)arity + 1);
-    const uint64_t blocks = (nOps + BN_BLOCK - 1) / BN_BLOCK;
+    const uint64_t blocks = (nOps + BN_THREADS - 1) / BN_THREADS;
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
     if ((long)nOps <= wave_per_perm_max()) {          // the levels near the root: a wave per parent (see pil2gl_bn128_poseidon_dev)
         bn_sponge_chain_kernel<<<(unsigned)nOps, 64, 0, as_stream(stream)>>>(in, 1, (int)arity, nullptr, perm_args(pf), 1, 1, out);
@@ -1179,10 +1239,10 @@ int pil2gl_bn128_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint32_t
     }
     if (wide_state((int)arity + 1)) {
         P2_TRY(set_lds_attr(bn_merkle_level_kernel<true>, lds));
-        bn_merkle_level_kernel<true><<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
+        bn_merkle_level_kernel<true><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
     } else {
         P2_TRY(set_lds_attr(bn_merkle_level_kernel<false>, lds));
-        bn_merkle_level_kernel<false><<<(unsigned)blocks, BN_BLOCK, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
+        bn_merkle_level_kernel<false><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
     }
     KERNEL_CHECK();
     return PIL2GL_OK;
@@ -1217,7 +1277,7 @@ int pil2gl_bn128_poseidon_dev(const uint64_t *in, const uint64_t *init, uint64_t
     const Params *pf;
     P2_TRY(get_params((int)nIn + 1, &pf));
     const size_t lds = lds_bytes((int)nIn + 1);
-    const unsigned pblocks = (unsigned)((count + BN_BLOCK - 1) / BN_BLOCK);
+    const unsigned pblocks = (unsigned)((count + BN_THREADS - 1) / BN_THREADS);
     // few permutations (a transcript squeeze, the levels of a handful of Merkle paths): a lane each would leave them at the
     // latency of one wave working alone (~3 ms at t = 17); a wave each runs them in ~0.5 ms while the SIMDs outnumber them
     if ((long)count <= wave_per_perm_max()) {
@@ -1227,10 +1287,10 @@ int pil2gl_bn128_poseidon_dev(const uint64_t *in, const uint64_t *init, uint64_t
     }
     if (wide_state((int)nIn + 1)) {
         P2_TRY(set_lds_attr(bn_poseidon_kernel<true>, lds));
-        bn_poseidon_kernel<true><<<pblocks, BN_BLOCK, lds, as_stream(stream)>>>(in, init, count, (int)nIn, (int)nOut, perm_args(pf), out);
+        bn_poseidon_kernel<true><<<pblocks, BN_THREADS, lds, as_stream(stream)>>>(in, init, count, (int)nIn, (int)nOut, perm_args(pf), out);
     } else {
         P2_TRY(set_lds_attr(bn_poseidon_kernel<false>, lds));
-        bn_poseidon_kernel<false><<<pblocks, BN_BLOCK, lds, as_stream(stream)>>>(in, init, count, (int)nIn, (int)nOut, perm_args(pf), out);
+        bn_poseidon_kernel<false><<<pblocks, BN_THREADS, lds, as_stream(stream)>>>(in, init, count, (int)nIn, (int)nOut, perm_args(pf), out);
     }
     KERNEL_CHECK();
     return PIL2GL_OK;

@@ -47,6 +47,11 @@ __device__ __forceinline__ void from29(const u32 a[9], u32 x[8]) {
     }
 }
 
+#ifndef BN29_COLUMNS_C
+#define BN29_COLUMNS_C 0
+#endif
+#if BN29_COLUMNS_C
+// (the columns as C templates, round 5: hipcc splits every column into two chains and pays six glue instructions for it -- kept for A/B builds only)
 // one column: acc += sum a_i b_(K-i) (or, SQR, sum_{i < K-i} a_i (2a)_(K-i) + a_(K/2)^2) + sum m_i r_(K-i) over the m already known
 template <int K, bool SQR>
 __device__ __forceinline__ void column(u64 &acc, const u32 a[9], const u32 b[9], const u32 m[9]) {
@@ -93,10 +98,36 @@ __device__ __forceinline__ void mont(u32 out[9], const u32 a[9], const u32 b[9])
     out[8] = (u32)acc;
 }
 
+#else
+// The limbs of r in scalar registers (one constant-bus operand per multiply-add), made opaque once per S-box.
+struct RLimbs { u32 r[9]; };
+__device__ __forceinline__ RLimbs r_limbs() {
+    RLimbs R;
+#pragma unroll
+    for (int i = 0; i < 9; i++) { R.r[i] = r29(i); asm volatile("" : "+s"(R.r[i])); }
+    return R;
+}
+// the reduction digit of a column: -lo / r mod 2^29 = lo (2^28 - 1) mod 2^29 (r = 1 mod 2^28), a shift and a subtraction
+__device__ __forceinline__ u32 digit(u32 lo) {
+    u32 sh = lo << 28;
+    asm("" : "+v"(sh));                                                   // opaque: hipcc would turn the two full-rate steps back into a multiplication
+    return (sh - lo) & MASK;
+}
+// The seventeen columns of a product / a squaring, straight-line (gen_bn29_columns.py): every column ONE chain of multiply-adds on one
+// 64-bit accumulator (a x b, then m x r over the digits already known), the digit, and one 64-bit shift.
+#include "bn_field29_columns.inc"
+template <bool SQR>
+__device__ __forceinline__ void mont(u32 out[9], const u32 a[9], const u32 b[9], const RLimbs &R) {
+    if constexpr (SQR) mont_sqr_columns(out, a, b, R);
+    else mont_mul_columns(out, a, b, R);
+}
+#endif
+
 // x (eight words, below 0.9 * 2^256) -> x^5 / 2^1044 (eight words, below 2^252 + r)
 __device__ __forceinline__ void pow5(u32 x[8]) {
     u32 a[9], d[9], s2[9], s4[9];
     to29(x, a);
+#if BN29_COLUMNS_C
 #pragma unroll
     for (int j = 0; j < 9; j++) d[j] = a[j] << 1;
     mont<true>(s2, a, d);
@@ -104,6 +135,16 @@ __device__ __forceinline__ void pow5(u32 x[8]) {
     for (int j = 0; j < 9; j++) d[j] = s2[j] << 1;
     mont<true>(s4, s2, d);
     mont<false>(s2, s4, a);
+#else
+    const RLimbs R = r_limbs();
+#pragma unroll
+    for (int j = 0; j < 9; j++) d[j] = a[j] << 1;
+    mont<true>(s2, a, d, R);
+#pragma unroll
+    for (int j = 0; j < 9; j++) d[j] = s2[j] << 1;
+    mont<true>(s4, s2, d, R);
+    mont<false>(s2, s4, a, R);
+#endif
     from29(s2, x);
 }
 

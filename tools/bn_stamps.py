@@ -31,5 +31,8 @@ for i, nm in enumerate(names):
 print("waves", out[8])
 if out[12]:
     print("shader clock inside the kernel: %.2f GHz (s_memtime against the 100 MHz s_memrealtime)" % (out[7] / out[12] * 0.1))
+if out[6]:
+    print("dense rows (%d per wave): tiles + products issued %.0f cycles per row, carry of both accumulators (incl. the wait for the last product) %.0f, finish + store %.0f"
+          % (out[6] / out[8], out[13] / out[6], out[14] / out[6], out[15] / out[6]))
 if out[11]:
     print("P loop per column: load+prep %.0f cycles, tiles+products issued %.0f cycles (%d columns)" % (out[9] / out[11], out[10] / out[11], out[11]))

@@ -1,0 +1,11 @@
+set -u; : "${GRAFT_REPO_ROOT:?run on the GPU box}"
+R=$GRAFT_REPO_ROOT; L=$R/pil2-stark-js_amd/lib_ab; O=$R/gpurun_out/r06_bn5; mkdir -p $O
+cd $R
+{
+for v in stamps s_noscr s_notile s_both; do echo "== stamps $v"; PIL2GL_LIB=$L/libpil2gl_$v.so python3 tools/bn_stamps.py 20; done
+for v in "" lds10 ""; do
+  echo "== bench ${v:-product}"
+  for i in 1 2; do if [ -z "$v" ]; then python3 tools/bench_bn128.py 20 100 16 | tail -n 1; else PIL2GL_LIB=$L/libpil2gl_$v.so python3 tools/bench_bn128.py 20 100 16 | tail -n 1; fi; done
+done
+} > $O/log.txt 2>&1
+echo done

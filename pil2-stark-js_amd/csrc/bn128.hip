@@ -24,6 +24,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 using namespace pil2gl;
 using bn::u32;
@@ -41,7 +42,7 @@ constexpr int BN_BLOCK = 64;                         // lanes of a wave = permut
 // TIME: a barrier at the start of every matrix phase (dense layer, rows on y, column update) keeps them on the same operand tiles, so that
 // of the workgroup's loads of a tile one goes to the L2 and the others hit the CU's L1.
 #ifndef BN_WG_WAVES
-#define BN_WG_WAVES 1
+#define BN_WG_WAVES 4
 #endif
 constexpr int BN_THREADS = BN_BLOCK * BN_WG_WAVES;
 #if BN_WG_WAVES > 1
@@ -258,14 +259,14 @@ void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &ti
 // the row constants.  Block b (rounds k0 = 4b .. k0+3), z_i = the S-box output of round k0+i, y = elements 1..n at the start of b's SUPER-BLOCK:
 //   x0 after round k0+i = m00 z_i + sum_j V[k0+i][j] y_j + sum_{i'<i} (V[k0+i] . W[k0+i']) z_i'  [+ for the second block of a super-block the same
 //   cross terms with the four z of the first];   y_j after the super-block = y_j + sum over its rounds of W[k][j] z_k  (one column update per 8 rounds).
-// Stream per block: n x 4 tiles V[k0+i][j] (j outer);  second block: 4 x 4 tiles (V[k0+i] . W[k0-4+s]);  4 x 4 tiles of the block's own cross terms
+// Stream per block, in two passes (rows 0-1, then rows 2-3): n x 2 tiles V[k0+i][j] (j outer), second block: 2 x 4 tiles (V[k0+i] . W[k0-4+s]);  then 4 x 4 tiles of the block's own cross terms
 // (round i, slot s holds z_(i+s-3): zero tiles where that is before the block).  Per super-block after its blocks: n x (1 + 4 halves) tiles (1, W[k][j]).
 // KR[k]: round k's row constant with S[k+1] folded in while round k+1 is one of these; KU[sb][j]: the column constants.
 void mfma_partial_tables(int t, int rp, const Vec &S, const Vec &V, const Vec &W, const U256 &m00, std::vector<int8_t> &tiles, Vec &KR, Vec &KU) {
     const MfmaConsts mc;
     const U256 zero = { { 0, 0, 0, 0 } }, one = h_to_mont(U256{ { 1, 0, 0, 0 } });
     const int n = t - 1, nb = rp / 4, nsb = (nb + 1) / 2;
-    tiles.assign(((size_t)nb * (9 * n + 16) + (size_t)(nb / 2) * 16) * 1024, 0);      // (a super-block of two: n tiles fewer than two blocks' updates, 16 more for the second block's rows)
+    tiles.assign(((size_t)nb * (4 * n + 16) + (size_t)nsb * 9 * n + (size_t)(nb / 2) * 16) * 1024, 0);      // per block its rows and rounds, per super-block the columns (1 + 8 tiles each), 16 more for a second block's rows
     KR.assign((size_t)nb * 4, zero); KU.assign((size_t)nsb * n, zero);
     auto dot = [&](int ka, int kb) { U256 c = zero; for (int j = 0; j < n; j++) c = h_addmod(c, h_mont(V[(size_t)ka * n + j], W[(size_t)kb * n + j])); return c; };
     int8_t *tp = tiles.data();
@@ -274,8 +275,10 @@ void mfma_partial_tables(int t, int rp, const Vec &S, const Vec &V, const Vec &W
         for (int h = 0; h < halves; h++) {
             const int k0 = 4 * (2 * sb + h);
             U256 tot[4] = { zero, zero, zero, zero };
-            for (int j = 0; j < n; j++) for (int i = 0; i < 4; i++, tp += 1024) mfma_tile(mc, V[(size_t)(k0 + i) * n + j], tp, tot[i], false);
-            if (h == 1) for (int i = 0; i < 4; i++) for (int s = 0; s < 4; s++, tp += 1024) mfma_tile(mc, dot(k0 + i, k0 - 4 + s), tp, tot[i], true);
+            for (int pass = 0; pass < 2; pass++) {   // the kernel takes the rows two at a time (partial_rounds_mfma_n)
+                for (int j = 0; j < n; j++) for (int i = 2 * pass; i < 2 * pass + 2; i++, tp += 1024) mfma_tile(mc, V[(size_t)(k0 + i) * n + j], tp, tot[i], false);
+                if (h == 1) for (int i = 2 * pass; i < 2 * pass + 2; i++) for (int s = 0; s < 4; s++, tp += 1024) mfma_tile(mc, dot(k0 + i, k0 - 4 + s), tp, tot[i], true);
+            }
             for (int i = 0; i < 4; i++) {
                 for (int s = 0; s < 4; s++, tp += 1024) {
                     const int ip = i + s - 3;
@@ -288,6 +291,7 @@ void mfma_partial_tables(int t, int rp, const Vec &S, const Vec &V, const Vec &W
         for (int j = 0; j < n; j++) {
             U256 tu = zero;
             mfma_tile(mc, one, tp, tu, false); tp += 1024;
+            if (halves == 1) tp += 4 * 1024;       // (zero tiles where the kernel multiplies the absent first block's operands: one form of the column)
             for (int s = 0; s < 4 * halves; s++, tp += 1024) mfma_tile(mc, W[(size_t)(8 * sb + s) * n + j], tp, tu, true);
             KU[(size_t)sb * n + j] = mfma_row_const(mc, tu, 1, zero);
         }
@@ -392,7 +396,7 @@ struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 
 // like every operand of the wide kernels, so its L1 / L2 latency hides behind a multiply-accumulate.  The element index is
 // wave-uniform: the branch costs a scalar compare.
 #ifndef BN_LDS_ELEMS
-#define BN_LDS_ELEMS 9
+#define BN_LDS_ELEMS 10
 #endif
 typedef u32 __attribute__((address_space(5))) *priv_u32;
 typedef u32 __attribute__((address_space(3))) *lds_u32;
@@ -408,8 +412,10 @@ __device__ __forceinline__ void lds_load(const St st, int j, u32 x[8]) {
 #pragma unroll
         for (int l = 0; l < 8; l++) x[l] = S_LDS(st, j, l);
     } else {
+        priv_u32 hp = st.hi;
+        asm volatile("" : "+v"(hp));                  // opaque: ONE address register and immediate offsets (hipcc would hoist an address per element into registers of its own)
 #pragma unroll
-        for (int l = 0; l < 8; l++) x[l] = st.hi[(j - BN_LDS_ELEMS) * 8 + l];
+        for (int l = 0; l < 8; l++) x[l] = hp[(j - BN_LDS_ELEMS) * 8 + l];
     }
 }
 __device__ __forceinline__ void lds_store(const St st, int j, const u32 x[8]) {
@@ -420,8 +426,10 @@ __device__ __forceinline__ void lds_store(const St st, int j, const u32 x[8]) {
 #pragma unroll
         for (int l = 0; l < 8; l++) S_LDS(st, j, l) = x[l];
     } else {
+        priv_u32 hp = st.hi;
+        asm volatile("" : "+v"(hp));
 #pragma unroll
-        for (int l = 0; l < 8; l++) st.hi[(j - BN_LDS_ELEMS) * 8 + l] = x[l];
+        for (int l = 0; l < 8; l++) hp[(j - BN_LDS_ELEMS) * 8 + l] = x[l];
     }
 }
 // wave-uniform address.  WIDE: the tables live in global memory; saying so (the pointers reach the out-of-line helpers as
@@ -462,7 +470,7 @@ __device__ __forceinline__ void add_lazy(u32 x[8], const u32 c[8]) { bnm::add_ch
 // (except the first round's, C != nullptr); lazy in, lazy out
 // (element j + 1 is requested before element j is worked on: more than half of a wide state lives in private memory, whose L2 latency --
 // a microsecond -- would otherwise be paid in full by every element; the same in the two loops of partial_rounds_mfma)
-__device__ __noinline__ void sbox_lazy(const St st, int t, const u32 *C) {
+__device__ __forceinline__ void sbox_lazy_impl(const St st, int t, const u32 *C) {
     u32 xn[8];
     lds_load(st, 0, xn);
     for (int j = 0; j < t; j++) {
@@ -479,6 +487,7 @@ __device__ __noinline__ void sbox_lazy(const St st, int t, const u32 *C) {
         lds_store(st, j, x);
     }
 }
+__device__ __noinline__ void sbox_lazy(const St st, int t, const u32 *C) { sbox_lazy_impl(st, t, C); }
 __device__ __noinline__ void canon_state(const St st, int t) {
     for (int j = 0; j < t; j++) {
         u32 x[8];
@@ -551,7 +560,7 @@ __device__ __noinline__ void dense_mul(const St st, int cur, const u32 *A, int n
 // alone -- so the table carries MFMA_AHEAD spare tiles after its last one.
 constexpr int MFMA_AHEAD = 8;
 template <int N>
-__device__ __noinline__ void dense_mfma_n(const St st, const bnm::v4i *tiles, const u32 *kc, int first) {
+__device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *tiles, const u32 *kc, int first) {
     bnm::v4i B0[N], B1[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -610,6 +619,8 @@ __device__ __noinline__ void dense_mfma_n(const St st, const bnm::v4i *tiles, co
     if (st.lane == 0) { atomicAdd(&g_bn_stamps[13], sBurst); atomicAdd(&g_bn_stamps[14], sCarry); atomicAdd(&g_bn_stamps[15], sFinish); atomicAdd(&g_bn_stamps[6], (unsigned long long)N); }
 #endif
 }
+template <int N>
+__device__ __noinline__ void dense_mfma_n(const St st, const bnm::v4i *tiles, const u32 *kc, int first) { dense_mfma_impl<N>(st, tiles, kc, first); }
 __device__ __forceinline__ void dense_mfma(const St st, const bnm::v4i *tiles, const u32 *kc, int n, int first) {
 #ifdef BN_ABLATE_DENSE
     return;                                          // timing experiments only: the layer left out, results meaningless
@@ -696,7 +707,13 @@ __device__ __noinline__ void partial_rounds(const St st, int cur, const PermArgs
 // cross terms of row i (<= 4 pairs) added to the row's stored part, one short finish = the next x0.  Per super-block, once: the n columns
 // y_j + sum_k W z_k (1 + 8 pairs and one finish each -- the costliest phase, hence every eight rounds, not four).  No 32x32 product is left
 // but the S-box's.  The tiles are ONE linear stream in consumption order, read PR_AHEAD tiles ahead.
-constexpr int PR_AHEAD = 6;
+#ifndef BN_KR_LATE
+#define BN_KR_LATE 0
+#endif
+#ifndef BN_PR_AHEAD
+#define BN_PR_AHEAD 6
+#endif
+constexpr int PR_AHEAD = BN_PR_AHEAD;
 struct TileStream {
     bnm::gtile p;
     bnm::v4i q[PR_AHEAD];
@@ -711,84 +728,124 @@ struct TileStream {
 #pragma unroll
         for (int k = 0; k < PR_AHEAD; k++) q[k] = p[(size_t)k * 64];
     }
+    // (the request for tile k + PR_AHEAD stays where tile k is taken: left to itself hipcc's scheduler, short of registers, sinks every request to
+    // just before its use and the ring is one or two tiles deep)
     __device__ __forceinline__ bnm::v4i next() {
         const bnm::v4i a = q[0];
 #pragma unroll
         for (int k = 0; k + 1 < PR_AHEAD; k++) q[k] = q[k + 1];
+        __builtin_amdgcn_sched_barrier(0);
 #ifdef BN_ABLATE_TILEADDR
         q[PR_AHEAD - 1] = base[(size_t)(cnt++ & 7) * 64];
 #else
         q[PR_AHEAD - 1] = p[(size_t)PR_AHEAD * 64];
 #endif
+        __builtin_amdgcn_sched_barrier(0);
         p += 64;
         return a;
     }
 };
-__device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A) {
-    const int n = A.t - 1, nb = A.rp / 4, nsb = (nb + 1) / 2;
+// N = t - 1 columns.  Everything that indexes the state is unrolled, so that which columns live in LDS (elements below BN_LDS_ELEMS) and which in
+// private memory is known statically, and NO private-memory access sits inside a loop that runs the tile ring: hipcc answers a mix of scratch and
+// global accesses in flight -- or a branch around one -- with `s_waitcnt vmcnt(0)`, which drains the ring on every column and exposes the L2
+// latency of every tile (round 5's form: 2 465 cycles per column of eight matrix instructions).  The upper columns are therefore fetched in ONE batch:
+// before the rows' pass as matrix operands (kept for both half-passes), before / after the column update as words.  The rows on y are taken two at
+// a time (two passes over the columns: four accumulators instead of eight leave the registers for the batch; the lower columns are read from LDS twice).
+template <int N>
+__device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm::v4i *Pt, const u32 *KR, const u32 *KU, int rp) {
+    constexpr int NLO = N + 1 <= BN_LDS_ELEMS ? N : BN_LDS_ELEMS - 1;     // columns j whose element 1 + j lives in LDS
+    constexpr int NHI = N - NLO, NHA = NHI ? NHI : 1;
+    const int nb = rp / 4, nsb = (nb + 1) / 2;
     const bnm::Sh sh = bnm::sh_init();
     TileStream ts;
     BN_SYNC();
-    ts.start(A.Pt, st.lane);
-    u32 x0[8];
-    lds_load(st, 0, x0);                              // S[0] came with the row of the layer before
+    ts.start(Pt, st.lane);
+    // x0 (S[0] came with the row of the layer before) stays in its LDS slot outside the rounds: the rows' pass and the columns need the registers
     for (int sb = 0; sb < nsb; sb++) {
         const int halves = nb - 2 * sb >= 2 ? 2 : 1;
         bnm::v4i zbA0[4], zbA1[4];                    // the first block's z operands, for the second block's rows and the column update
         bnm::v4i zb0[4], zb1[4];                      // the current block's: z_(i-3) .. z_i
 #pragma unroll
         for (int s = 0; s < 4; s++) { zbA0[s] = bnm::v4i{ 0, 0, 0, 0 }; zbA1[s] = bnm::v4i{ 0, 0, 0, 0 }; }
-        for (int h = 0; h < halves; h++) {
-            const int b = 2 * sb + h;
-            u32 pc[4][10];
-#ifdef BN_STAMPS
-            unsigned long long tp0 = bn_now();
-#endif
-            {
-                bnm::v16i P0[4], P1[4];
+        u32 pc[4][10];
+        // the four rows' parts on y of one block; H = 1: the second block of a super-block (two instances: no branch inside the ring's straight line)
+        auto rows = [&](auto Hc) {
+            constexpr int H = decltype(Hc)::value;
+            bnm::v4i hb0[NHA], hb1[NHA];              // the upper columns as operands, one batch of private-memory loads per block
 #pragma unroll
-                for (int i = 0; i < 4; i++) { P0[i] = bnm::acc_init(); P1[i] = bnm::acc_init(); }
+            for (int q = 0; q < NHI; q++) {
+                u32 y[8];
+                lds_load(st, 1 + NLO + q, y);
+                bnm::b_prep(y, hb0[q], hb1[q]);
+            }
+            BN_SYNC();
+            BN_PRIO(BN_PRIO_MFMA);
+#pragma unroll
+            for (int pass = 0; pass < 2; pass++) {
+                bnm::v16i P0[2], P1[2];
+#pragma unroll
+                for (int r = 0; r < 2; r++) { P0[r] = bnm::acc_init(); P1[r] = bnm::acc_init(); }
                 u32 yn[8];
-                lds_load(st, 1, yn);
-                BN_SYNC();
-                BN_PRIO(BN_PRIO_MFMA);
-                for (int j = 0; j < n; j++) {
-                    u32 y[8];
+                if (NLO) lds_load(st, 1, yn);
 #pragma unroll
-                    for (int l = 0; l < 8; l++) y[l] = yn[l];
-                    if (j + 1 < n) lds_load(st, 2 + j, yn);           // the next column's words are on their way while this one's products run
+                for (int j = 0; j < N; j++) {
                     bnm::v4i b0, b1;
-                    bnm::b_prep(y, b0, b1);
+                    if (j < NLO) {
+                        u32 y[8];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
+                        for (int l = 0; l < 8; l++) y[l] = yn[l];
+                        if (j + 1 < NLO) lds_load(st, 2 + j, yn);         // the next column's words are on their way while this one's products run
+                        bnm::b_prep(y, b0, b1);
+                    } else { b0 = hb0[j < NLO ? 0 : j - NLO]; b1 = hb1[j < NLO ? 0 : j - NLO]; }
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
                         const bnm::v4i a = ts.next();
-                        P0[i] = bnm::mfma(a, b0, P0[i]);
-                        P1[i] = bnm::mfma(a, b1, P1[i]);
+                        P0[r] = bnm::mfma(a, b0, P0[r]);
+                        P1[r] = bnm::mfma(a, b1, P1[r]);
                     }
                 }
-                if (h == 1) {                                     // the rows of the second block see the first block's z through cross terms of their own
+                if constexpr (H == 1) {                               // the rows of the second block see the first block's z through cross terms of their own
 #pragma unroll
-                    for (int i = 0; i < 4; i++)
+                    for (int r = 0; r < 2; r++)
 #pragma unroll
                         for (int s = 0; s < 4; s++) {
                             const bnm::v4i a = ts.next();
-                            P0[i] = bnm::mfma(a, zbA0[s], P0[i]);
-                            P1[i] = bnm::mfma(a, zbA1[s], P1[i]);
+                            P0[r] = bnm::mfma(a, zbA0[s], P0[r]);
+                            P1[r] = bnm::mfma(a, zbA1[s], P1[r]);
                         }
                 }
-                BN_PRIO(0);
 #pragma unroll
-                for (int i = 0; i < 4; i++) bnm::carry_pair(P0[i], P1[i], pc[i], sh);
+                for (int r = 0; r < 2; r++) bnm::carry_pair(P0[r], P1[r], pc[2 * pass + r], sh);
+            }
+            BN_PRIO(0);
+        };
+        for (int h = 0; h < halves; h++) {
+            const int b = 2 * sb + h;
+#ifdef BN_STAMPS
+            unsigned long long tp0 = bn_now();
+#endif
+            if (h == 0) rows(std::integral_constant<int, 0>{});
+            else {
+#pragma unroll
+                for (int s = 0; s < 4; s++) { zbA0[s] = zb0[s]; zbA1[s] = zb1[s]; }
+                rows(std::integral_constant<int, 1>{});
             }
 #ifdef BN_STAMPS
             { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[3], t_ - tp0); tp0 = t_; }
 #endif
 #pragma unroll
             for (int s = 0; s < 4; s++) { zb0[s] = bnm::v4i{ 0, 0, 0, 0 }; zb1[s] = bnm::v4i{ 0, 0, 0, 0 }; }      // before the block's first z: anything (zero tiles)
+            u32 x0[8];
+            lds_load(st, 0, x0);
             for (int i = 0; i < 4; i++) {
                 u32 k[8];
-                load_const<true>(A.KR, (size_t)(4 * b + i), k);       // (long before its use: the S-box hides it)
+#if !BN_KR_LATE
+                load_const<true>(KR, (size_t)(4 * b + i), k);         // (long before its use: the S-box hides it)
+#endif
                 pow5_lazy(x0);
+#if BN_KR_LATE
+                load_const<true>(KR, (size_t)(4 * b + i), k);         // (behind the S-box, whose registers it would otherwise take: the cross terms' products hide it)
+#endif
 #pragma unroll
                 for (int s = 0; s < 3; s++) { zb0[s] = zb0[s + 1]; zb1[s] = zb1[s + 1]; }
                 bnm::b_prep(x0, zb0[3], zb1[3]);
@@ -808,39 +865,29 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
                     for (int l = 0; l < 10; l++) pc[r][l] = pc[r + 1][l];
                 bnm::finish_words(w, k, x0);
             }
+            lds_store(st, 0, x0);
 #ifdef BN_STAMPS
             { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[4], t_ - tp0); }
 #endif
-            if (h == 0 && halves == 2) {
-#pragma unroll
-                for (int s = 0; s < 4; s++) { zbA0[s] = zb0[s]; zbA1[s] = zb1[s]; }
-            }
         }
 #ifdef BN_STAMPS
         unsigned long long tu0 = bn_now();
 #endif
-        // the columns, once per super-block: y_j + sum over its rounds of W z
-        u32 yn[8];
-        lds_load(st, 1, yn);
-        BN_SYNC();
-        for (int j = 0; j < n; j++) {
-            u32 y[8], k[8];
-#pragma unroll
-            for (int l = 0; l < 8; l++) y[l] = yn[l];
-            if (j + 1 < n) lds_load(st, 2 + j, yn);
-            load_const<true>(A.KU, (size_t)sb * n + j, k);            // (asked for early: used after the products)
+        // the columns, once per super-block: y_j + sum over its rounds of W z -- 1 + 8 tiles and one finish each (a last super-block of one block
+        // has four zero tiles for the first block's operands, which are zero: ONE form of the column, mfma_partial_tables)
+        auto column = [&](u32 y[8], int j) {
+            u32 k[8];
+            load_const<true>(KU, (size_t)sb * N + j, k);              // (asked for early: used after the products)
             bnm::v4i b0, b1;
             bnm::b_prep(y, b0, b1);
             BN_PRIO(BN_PRIO_MFMA);
             bnm::v4i a = ts.next();
             bnm::v16i c0 = bnm::mfma(a, b0, bnm::acc_init()), c1 = bnm::mfma(a, b1, bnm::acc_init());
-            if (halves == 2) {
 #pragma unroll
-                for (int s = 0; s < 4; s++) {
-                    a = ts.next();
-                    c0 = bnm::mfma(a, zbA0[s], c0);
-                    c1 = bnm::mfma(a, zbA1[s], c1);
-                }
+            for (int s = 0; s < 4; s++) {
+                a = ts.next();
+                c0 = bnm::mfma(a, zbA0[s], c0);
+                c1 = bnm::mfma(a, zbA1[s], c1);
             }
 #pragma unroll
             for (int s = 0; s < 4; s++) {
@@ -850,13 +897,60 @@ __device__ __noinline__ void partial_rounds_mfma(const St st, const PermArgs &A)
             }
             BN_PRIO(0);
             bnm::finish_row(c0, c1, k, y, sh);
-            lds_store(st, 1 + j, y);
+        };
+        if (halves == 1) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) { zbA0[s] = bnm::v4i{ 0, 0, 0, 0 }; zbA1[s] = bnm::v4i{ 0, 0, 0, 0 }; }
+        }
+        BN_SYNC();
+        if (NLO) {                                                    // the lower columns: a loop (LDS takes a run-time index; the ring turns by three tiles per column)
+            u32 yn[8];
+            lds_load(st, 1, yn);
+#pragma unroll 1
+            for (int j = 0; j < NLO; j++) {
+                u32 y[8];
+#pragma unroll
+                for (int l = 0; l < 8; l++) y[l] = yn[l];
+                if (j + 1 < NLO) lds_load(st, 2 + j, yn);
+                column(y, j);
+                lds_store(st, 1 + j, y);
+            }
+        }
+        {
+            u32 yh[NHA][8];                                           // the upper columns: one batch in, one batch out
+#pragma unroll
+            for (int q = 0; q < NHI; q++) lds_load(st, 1 + NLO + q, yh[q]);
+#pragma unroll
+            for (int q = 0; q < NHI; q++) column(yh[q], NLO + q);
+#pragma unroll
+            for (int q = 0; q < NHI; q++) lds_store(st, 1 + NLO + q, yh[q]);
         }
 #ifdef BN_STAMPS
         { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[5], t_ - tu0); }
 #endif
     }
-    lds_store(st, 0, x0);
+}
+template <int N>
+__device__ __noinline__ void partial_rounds_mfma_n(const St st, const bnm::v4i *Pt, const u32 *KR, const u32 *KU, int rp) { partial_rounds_mfma_impl<N>(st, Pt, KR, KU, rp); }
+__device__ __forceinline__ void partial_rounds_mfma(const St st, const PermArgs &A) {
+    switch (A.t - 1) {
+    case 1: partial_rounds_mfma_n<1>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 2: partial_rounds_mfma_n<2>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 3: partial_rounds_mfma_n<3>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 4: partial_rounds_mfma_n<4>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 5: partial_rounds_mfma_n<5>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 6: partial_rounds_mfma_n<6>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 7: partial_rounds_mfma_n<7>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 8: partial_rounds_mfma_n<8>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 9: partial_rounds_mfma_n<9>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 10: partial_rounds_mfma_n<10>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 11: partial_rounds_mfma_n<11>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 12: partial_rounds_mfma_n<12>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 13: partial_rounds_mfma_n<13>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 14: partial_rounds_mfma_n<14>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    case 15: partial_rounds_mfma_n<15>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    default: partial_rounds_mfma_n<16>(st, A.Pt, A.KR, A.KU, A.rp); break;
+    }
 }
 
 // permutation of the t elements in buffer `cur`; returns the buffer holding the result
@@ -868,6 +962,21 @@ __device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
             const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
             add_sbox<WIDE>(st, cur, t, A.Cd, (size_t)r * t, full ? t : 1);
             dense_mul<WIDE>(st, cur, A.M, t, 0);
+        }
+        return cur;
+    }
+    if (A.mfma && !A.nofold && t == 17) {
+        // The width of the arity-16 trees (config 4) in ONE function body: every phase called out of line saves and restores the callee-saved
+        // half of its 256 registers in private memory (92-112 words per lane and call, ~480 KB per wave and permutation -- a third of the
+        // kernel's private-memory traffic, which the chip pays for in power: tools/power_probe.py).  One copy of each phase: the partial rounds
+        // and the closing layer sit at the top of the fifth full round (rp = 68 = 17 blocks of four, nothing left over).
+        for (int r = 0; r < 8; r++) {
+            if (r == 4) {
+                BN_STAMP(2, partial_rounds_mfma_impl<16>(st, A.Pt, A.KR, A.KU, A.rp));
+                BN_STAMP(1, dense_mfma_impl<16>(st, A.Dt, A.DK, 1));          // diag(1, Mh^RP)
+            }
+            BN_STAMP(0, sbox_lazy_impl(st, 17, r == 0 ? A.C8 : nullptr));
+            BN_STAMP(1, dense_mfma_impl<17>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0));
         }
         return cur;
     }

@@ -612,35 +612,41 @@ def prove_from_host(dev, src, step_with, n_proofs=4):
         return {"error": str(e)[:300]}
 
 
+def proof_sha256(proof):
+    """sha256 over the proof in the canonical text of tests/js/prove_c3.js canon(): decimal strings, keys in insertion order"""
+    import hashlib
+
+    def canon(v):
+        if isinstance(v, dict):
+            return "{" + ",".join('"%s":%s' % (k, canon(x)) for k, x in v.items()) + "}"
+        if isinstance(v, (list, tuple)):
+            return "[" + ",".join(canon(x) for x in v) + "]"
+        return '"%d"' % int(v)
+    return hashlib.sha256(canon(proof).encode()).hexdigest()
+
+
 def node_driven_proof(info, exprs, setup, publics, start_row, res):
     """The same proof once more with the JS ORCHESTRATION driving (north_star: "the JS orchestration keeps driving"): a fresh `node`
     child process runs tests/js/prove_c3.js -- prover.js's stage order (src/prover/prover.js:7-127) over the JS drop-in modules, every
     large buffer resident in HBM -- on the same AIR and witness, and reports its best proof time and the digest of its proof, which
     must equal the digest of the proof this process made.  Outside `value`; PIL2GL_BENCH_NODE=0 skips it."""
-    import hashlib
     import shutil
     import subprocess
     import tempfile
     node = shutil.which("node")
     if node is None:
         return {"skipped": "node is not installed on this box"}
-
-    def canon(v):                                          # = tests/js/prove_c3.js canon(): decimal strings, keys in insertion order
-        if isinstance(v, dict):
-            return "{" + ",".join('"%s":%s' % (k, canon(x)) for k, x in v.items()) + "}"
-        if isinstance(v, (list, tuple)):
-            return "[" + ",".join(canon(x) for x in v) + "]"
-        return '"%d"' % int(v)
-    want = hashlib.sha256(canon(res["proof"]).encode()).hexdigest()
+    want = proof_sha256(res["proof"])
     job = {"pilInfo": info, "expressionsInfo": exprs, "start": [str(v) for v in start_row], "publics": [str(v) for v in publics],
            "constRoot": [str(v) for v in setup["constRoot"]], "queries": res["queries"]}
+    path = None
     try:
         with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            path = f.name
             json.dump(job, f)
         t0 = time.perf_counter()
-        out = subprocess.run([node, os.path.join(ROOT, "tests", "js", "prove_c3.js"), f.name, "3"], capture_output=True, text=True, timeout=900)
+        out = subprocess.run([node, os.path.join(ROOT, "tests", "js", "prove_c3.js"), path, "3"], capture_output=True, text=True, timeout=900)
         wall = time.perf_counter() - t0
-        os.unlink(f.name)
         if out.returncode != 0 or "prove c3 OK" not in out.stdout:
             return {"error": (out.stdout[-300:] + out.stderr[-600:])}
         line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
@@ -649,9 +655,12 @@ def node_driven_proof(info, exprs, setup, publics, start_row, res):
                 "what": "node tests/js/prove_c3.js (best of 3): src/prover/prover.js:7-127's stage order over pil2-stark-js_amd/js, buffers in HBM, started as a fresh child process after this one's timed region"}
     except Exception as e:  # pragma: no cover
         return {"error": str(e)[:300]}
+    finally:
+        if path is not None and os.path.exists(path):          # (the job file holds pilInfo / expressionsInfo: never left behind, whatever the child did)
+            os.unlink(path)
 
 
-def bench_bn128(args, dev, wl, n_bits, n_cols):
+def bn128_commit_line(dev, n_bits, n_cols, steps, warmup):
     """config 4: extendAndMerkelize with the BN128 MerkleHash (merklehash_bn128_p.js:47-129, arity 16, non-custom): the GL
     LDE of the 2^24 x 100 trace and the BN254-Poseidon linear hash + 16-ary tree over all 2^27 extended rows"""
     import pil2gl
@@ -662,17 +671,16 @@ def bench_bn128(args, dev, wl, n_bits, n_cols):
     dst = torch.empty(E * n_cols, dtype=torch.int64, device=dev)
     MH = bn128.buildMerkleHash(arity, False)
     MH.merkelize(src[:n_cols * 64], n_cols, 64); torch.cuda.synchronize()          # parameter generation
-    times = {}
 
     def step():
         pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS)
         return MH.merkelize(dst, n_cols, E)
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         tree = step()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
     t_lde = ev_time(lambda: pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS), 1)
     t_tree = ev_time(lambda: MH.merkelize(dst, n_cols, E), 1)
     n_el = (n_cols + 2) // 3
@@ -689,7 +697,7 @@ def bench_bn128(args, dev, wl, n_bits, n_cols):
     floor_ms = max(floor_cyc, floor_mfma_cyc) / CLOCK_HZ * 1e3                      # the two pipes run side by side (two waves per SIMD)
     alg = 8 * E * n_cols + 32 * (E + tree_perms)
     out = {"metric": "trace-cells/s, STARK commit step (extend + BN128 Poseidon Merkle tree, arity 16), blow-up 8",
-           "value": N * n_cols / dt, "unit": "trace-cells/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
+           "value": N * n_cols / dt, "unit": "trace-cells/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": dt * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 limbs (BN254 Fr, Montgomery) + u64 (Goldilocks LDE)", "data": "synthetic",
            "config": {"workload": "config 4: extendAndMerkelize 2^%d rows x %d cols -> 2^%d rows, BN128 Poseidon linear hash + %d-ary tree over all 2^%d extended rows" % (n_bits, n_cols, n_bits + EXT_BITS, arity, n_bits + EXT_BITS),
                       "mode": "commit", "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "BN128-Poseidon (t = 17, 17, 3 per row; t = 17 in the tree)", "parallelism": "single GPU"},
@@ -704,10 +712,102 @@ def bench_bn128(args, dev, wl, n_bits, n_cols):
            "kernels": [{"kernel": "BN128 merkelize (leaf hash + tree)", "ms": t_tree, "perms": leaf_perms + tree_perms, "Mperm_s": (leaf_perms + tree_perms) / t_tree / 1e3},
                        {"kernel": "interpolate", "ms": t_lde, "alg_bytes": 8 * N * n_cols * (1 + (1 << EXT_BITS)), "GBps": 8 * N * n_cols * 9 / t_lde / 1e6}],
            "root": hex(MH.root(tree))}
+    return out
+
+
+def bench_bn128(args, dev, wl, n_bits, n_cols):
+    out = bn128_commit_line(dev, n_bits, n_cols, args.steps, args.warmup)
     if not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline_bn128(n_cols, arity)
+        out["cpu_baseline"] = cpu_baseline_bn128(n_cols, 16)
         out["speedup_vs_cpu_port"] = out["value"] / out["cpu_baseline"]["value"]
     print(json.dumps(out), flush=True)
+
+
+def bench_bn128_prove(args, dev, n_bits, n_cols):
+    """`--workload c4 --mode prove`: a WHOLE proof with `verificationHashType: "BN128"` at config 4's size -- the stage loop of bench's default line
+    (Fibonacci AIR, FRI 27/22/17/12/7, 64 queries) with every tree a BN254-Poseidon arity-16 tree and the BN128 transcript
+    (stark_gen_helpers.js:93-101, 388-412; merklehash_bn128_p.js:47-129): GL LDE and evaluators as in config 3, commitments as in config 4."""
+    import pil2gl
+    from pil2gl import stark
+    pil2gl.init(dev.index or 0)
+    n_cols -= n_cols & 1
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + EXT_BITS, "nQueries": 64, "verificationHashType": "BN128", "merkleTreeArity": 16, "merkleTreeCustom": False,
+          "steps": [{"nBits": b} for b in fri_steps_for(n_bits + EXT_BITS)]}
+    info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
+    be = stark.GpuBackend(dev.index or 0, False, "BN128", 16, False)
+    src, consts, publics = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
+    t0 = time.perf_counter()
+    setup = stark.build_const_tree(be, consts, info)
+    torch.cuda.synchronize(); t_setup = time.perf_counter() - t0
+    for _ in range(max(1, args.warmup)):
+        stark.stark_gen(be, src, setup, info, exprs, publics)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = stark.stark_gen(be, src, setup, info, exprs, publics)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / args.steps
+    stages = {}
+    stark.stark_gen(be, src, setup, info, exprs, publics, timings=stages); torch.cuda.synchronize()
+    N = 1 << n_bits
+    out = {"metric": "STARK prove time (ms_per_step) and trace-cells/s, synthetic Fibonacci AIR, BN128 Poseidon (arity 16) Merkle trees and transcript + FRI, blow-up 8",
+           "value": N * n_cols / dt, "unit": "trace-cells/s", "n_gpus": 1, "steps": args.steps, "warmup": max(1, args.warmup), "ms_per_step": dt * 1e3,
+           "higher_is_better": True, "scaling": None, "vs_baseline": None, "dtype": "u64 (Goldilocks) + u32 limbs (BN254 Fr)", "data": "synthetic",
+           "config": {"workload": "full proof (commit, Q, evals, FRI %s, 64 queries) of 2^%d rows x %d cols -> 2^%d rows, verificationHashType BN128, 16-ary trees" % (
+                          "/".join(str(b) for b in fri_steps_for(n_bits + EXT_BITS)), n_bits, n_cols, n_bits + EXT_BITS),
+                      "mode": "prove", "config": "c4", "nBits": n_bits, "nCols": n_cols, "nBitsExt": n_bits + EXT_BITS, "hash": "BN128-Poseidon (arity 16)", "parallelism": "single GPU"},
+           "prove": {"seconds": dt, "stages_s": {k: round(v, 4) for k, v in stages.items()}, "const_tree_s": round(t_setup, 3)},
+           "root1": hex(res["proof"]["root1"]), "proofSha256": proof_sha256(res["proof"])}
+    print(json.dumps(out), flush=True)
+
+
+def other_configs(dev, be, main_wl, main_split):
+    """The BASELINE configurations the headline line does not time, measured by the SAME run after its timed region and per-kernel pass,
+    with every buffer of the headline workload freed first: config 2 (whole proof), config 3 with `splitLinearHash` leaves (whole proof),
+    config 4 (BN128 commit).  Outside `value`; each entry carries its proof digest / root so that a reader can check what was computed.
+    PIL2GL_BENCH_OTHER=0 skips it."""
+    import pil2gl
+    from pil2gl import stark
+    res = {}
+
+    def proof_line(n_bits, n_cols, split, steps):
+        ss = {"nBits": n_bits, "nBitsExt": n_bits + EXT_BITS, "nQueries": 64, "verificationHashType": "GL", "splitLinearHash": bool(split),
+              "steps": [{"nBits": b} for b in fri_steps_for(n_bits + EXT_BITS)]}
+        info, exprs, _ = stark.fibonacci_air(n_cols // 2, ss)
+        src, consts, publics = fibonacci_trace_gpu(dev, n_bits, n_cols // 2, 0)
+        be_ = stark.GpuBackend(dev.index or 0, bool(split))                         # (the leaf form is the backend's MerkleHash, not the starkStruct's flag)
+        setup = stark.build_const_tree(be_, consts, info)
+        stark.stark_gen(be_, src, setup, info, exprs, publics)                      # warm-up (run-time compiled evaluators, tables)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            r = stark.stark_gen(be_, src, setup, info, exprs, publics)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        return {"workload": "full proof of 2^%d rows x %d cols, blow-up 8, GL Poseidon %s linear hash, FRI %s, 64 queries" % (
+                    n_bits, n_cols, "split" if split else "plain", "/".join(str(b) for b in fri_steps_for(n_bits + EXT_BITS))),
+                "ms_per_proof": round(dt * 1e3, 2), "steps": steps, "cells_per_s": (1 << n_bits) * n_cols / dt, "proofSha256": proof_sha256(r["proof"])}
+
+    def guarded(name, fn):
+        t0 = time.perf_counter()
+        try:
+            res[name] = fn()
+        except Exception as e:  # pragma: no cover
+            res[name] = {"error": repr(e)[:300]}
+        res[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+        gc.collect(); torch.cuda.empty_cache()
+    free = torch.cuda.mem_get_info(dev)[0]
+    if main_wl != "c2":
+        guarded("config2_proof", lambda: proof_line(20, 8, False, 5))
+    if free >= 170e9:
+        if not (main_wl == "c3" and main_split):
+            guarded("config3_split_proof", lambda: proof_line(24, 100, True, 2))
+
+        def c4():
+            o = bn128_commit_line(dev, 24, 100, 1, 0)
+            t = o["kernels"][0]
+            return {"workload": o["config"]["workload"], "ms_per_commit": round(o["ms_per_step"], 1), "tree_ms": round(t["ms"], 1), "Mperm_s": round(t["Mperm_s"], 2),
+                    "roofline_int_issue": round(o["roofline_int_issue"]["frac"], 4), "root": o["root"], "cells_per_s": o["value"]}
+        guarded("config4_bn128_commit", c4)
+    else:
+        res["skipped"] = "configs 3 (split) and 4 need 170 GB free on the GPU (%.0f GB are)" % (free / 1e9)
+    return res
 
 
 def main():
@@ -779,6 +879,8 @@ def main():
     if wl == "c4":
         if world > 1:
             raise SystemExit("--workload c4 is a single-GPU line")
+        if args.mode == "prove":
+            return bench_bn128_prove(args, dev, n_bits, n_cols)
         return bench_bn128(args, dev, wl, n_bits, n_cols)
     if sharded_mode and (1 << EXT_BITS) % world:
         raise SystemExit("a sharded mode needs a world size dividing the %d cosets" % (1 << EXT_BITS))
@@ -1017,11 +1119,17 @@ def main():
             import numpy as _np2
             start_row = [int(v) for v in src[:n_cols].cpu().numpy().view(_np2.uint64)]
             dst = digests = lvl = None
-            gc.collect(); torch.cuda.empty_cache()             # the child needs its own 143 GB at config 3
+            gc.collect(); torch.cuda.empty_cache()             # the child needs its own 143 GB at config 3; this process keeps the witness and the constant tree (~25 GB): 168 of 288 GB
             out["node_driven"] = node_driven_proof(prove_ctx[1], prove_ctx[2], prove_ctx[0], prove_ctx[3], start_row, last_proof)
+            out["node_driven_ok"] = bool(out["node_driven"].get("proofSha256_equal")) or "skipped" in out["node_driven"]      # a failed child shows at the top level, not only inside its record
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_prove(n_cols, args.split, args.air) if prove_ctx is not None else cpu_baseline_commit(n_cols, args.split)
             out["speedup_vs_cpu_port"] = value / out["cpu_baseline"]["value"]
+        if world == 1 and mode == "prove" and args.air != "perm" and os.environ.get("PIL2GL_BENCH_OTHER", "1") != "0":
+            # the other BASELINE configurations, timed by this run too (outside `value`): everything of the headline workload goes first
+            src = dst = digests = lvl = nodes = last_proof = prove_ctx = setup = consts = ksrc = lde = None
+            gc.collect(); torch.cuda.empty_cache()
+            out["other_configs"] = other_configs(dev, be, wl, args.split)
         print(json.dumps(out), flush=True)
     if dist is not None:
         mark("closing")

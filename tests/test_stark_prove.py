@@ -361,6 +361,38 @@ def test_config3_size_proof_verifies(oracle):
 
 
 @pytest.mark.gpu
+def test_config4_size_bn128_proof_verifies(oracle):
+    """BASELINE config 4's size with `verificationHashType: "BN128"` (stark_gen_helpers.js:93-101, 388-412): 2^24 rows x 100 columns, every tree a
+    BN254-Poseidon arity-16 tree over 2^27 rows (merklehash_bn128_p.js:47-129), BN128 transcript, FRI 27/22/17/12/7, 64 queries -- the whole
+    proof (`bench.py --workload c4 --mode prove`) passes the restated verifier, whose paths go through the Python-integer oracle's rule"""
+    import gc
+    import torch
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    if not torch.cuda.is_available() or torch.cuda.mem_get_info()[0] < 200e9:
+        pytest.skip("needs ~190 GB of free device memory")
+    import stark_ref
+    import bench
+    from pil2gl import stark
+    n_bits, n_cols = 24, 100
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 64, "verificationHashType": "BN128", "merkleTreeArity": 16, "merkleTreeCustom": False,
+          "steps": [{"nBits": b} for b in (27, 22, 17, 12, 7)]}
+    info, exprs, vinfo = stark.fibonacci_air(n_cols // 2, ss)
+    gpu = stark.GpuBackend(0, False, "BN128", 16, False)
+    cm, consts, publics = bench.fibonacci_trace_gpu(torch.device("cuda", 0), n_bits, n_cols // 2, 0)
+    setup = stark.build_const_tree(gpu, consts, info)
+    res = stark.stark_gen(gpu, cm, setup, info, exprs, publics)
+    del cm
+    torch.cuda.empty_cache()
+    assert isinstance(res["proof"]["root1"], int) and len(res["proof"]["fri"][0]["polQueries"][0][0][1][0]) == 16
+    ok, why = stark_ref.stark_verify(res, setup["constRoot"], info, vinfo, hash_type="BN128", arity=16, custom=False)
+    assert ok, why
+    bad = {**res, "proof": {**res["proof"], "root2": res["proof"]["root2"] ^ 1}}
+    assert not stark_ref.stark_verify(bad, setup["constRoot"], info, vinfo, hash_type="BN128", arity=16, custom=False)[0]
+
+
+@pytest.mark.gpu
 def test_config3_size_two_stage_proof_verifies(oracle):
     """the two-stage workload of `bench.py --air perm` at config 3's size (2^24 rows, 9 permutation checks: 18 stage-1 and 81
     stage-2 base columns, nine grand-product hints resolved on the device, polutils.js:105-164): the proof passes the restated
@@ -396,7 +428,8 @@ def test_config3_size_two_stage_proof_verifies(oracle):
 
 def _bn_case(n_bits=5, pairs=1):
     from pil2gl import stark
-    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 4, "verificationHashType": "BN128", "steps": [{"nBits": n_bits + 3}, {"nBits": 4}]}
+    steps = [n_bits + 3, 4] if n_bits <= 8 else list(range(n_bits + 3, 4, -5))
+    ss = {"nBits": n_bits, "nBitsExt": n_bits + 3, "nQueries": 4, "verificationHashType": "BN128", "steps": [{"nBits": b} for b in steps]}
     info, exprs, vinfo = stark.fibonacci_air(pairs, ss)
     cm, consts, publics = stark.fibonacci_trace(n_bits, pairs)
     return stark, info, exprs, vinfo, cm, consts, publics
@@ -418,8 +451,11 @@ def test_bn128_proof_on_oracle_backend_verifies(oracle, arity, custom):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("arity,custom,n_bits,pairs", [(16, False, 5, 1), (4, True, 5, 1), (8, False, 6, 3)])
+@pytest.mark.parametrize("arity,custom,n_bits,pairs", [(16, False, 5, 1), (4, True, 5, 1), (8, False, 6, 3), (16, False, 13, 26)])
 def test_gpu_bn128_proof_is_identical_to_oracle_proof(oracle, arity, custom, n_bits, pairs):
+    """the last case (2^13 rows x 52 columns -> 2^16 extended rows: 18 field elements per leaf = a width-17 and a width-3 permutation, 4 096
+    parents in the first tree level) takes the lane-per-permutation matrix-core kernels for the leaves AND the tree levels (the wave-per-
+    permutation kernel serves up to 2 048 permutations per call, bn128.hip wave_per_perm_max); its oracle trees come from oracle/bn128_oracle.c"""
     import stark_ref
     stark, info, exprs, vinfo, cm, consts, publics = _bn_case(n_bits, pairs)
     gpu = stark.GpuBackend(0, False, "BN128", arity, custom)

@@ -88,6 +88,11 @@ int pil2gl_extend_cosets_unshifted_dev(const uint64_t *src, uint64_t nPols, uint
  * (pil2gl_compute_q_split_brev_dev writes that order); dst = fft(nBitsExt) of the zero-padded coefficient matrix, natural order
  * (stark_gen_helpers.js:192) -- without the padded 2^nBitsExt-row input and its first nBitsExt - nBits stages. */
 int pil2gl_extend_coefs_brev_dev(const uint64_t *coefBrev, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt, void *stream);
+/* The slice [cosetBegin, cosetBegin+cosetCount) of that extension, local-slice order (row (pos, j - cosetBegin) = row (pos << b) + j): how a
+ * rank of a coset-split proof extends its part of the split quotient from the coefficients every rank holds (stark_gen_helpers.js:179-192),
+ * without first turning them into evaluations and back. */
+int pil2gl_extend_coefs_brev_cosets_dev(const uint64_t *coefBrev, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
+                                        uint32_t cosetBegin, uint32_t cosetCount, void *stream);
 /* Same with a caller-provided workspace of 2^nBits x nPols words for the coefficient matrix instead of the library's own
  * scratch; workspace == src is allowed (src is then overwritten): at config 5 a rank holds the 107 GB trace and its
  * 107 GB coset slice and nothing else. */

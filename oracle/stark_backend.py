@@ -45,6 +45,13 @@ class OracleBackend:
         full = orc.fft_cols(pad, nbe).reshape(1 << nb, 1 << (nbe - nb), C)
         dst[:] = full[:, cb:cb + cc, :].reshape(-1)
 
+    def extend_coefs_brev_cosets(self, coef_brev, C, nb, dst, nbe, cb, cc):
+        n = 1 << nb
+        rev = np.array([int(format(i, "0%db" % nb)[::-1], 2) if nb else 0 for i in range(n)])
+        pad = np.zeros((1 << nbe, C), np.uint64); pad[:n] = coef_brev.reshape(n, C)[rev]      # row bitrev(m) holds coefficient m
+        full = orc.fft_cols(pad, nbe).reshape(n, 1 << (nbe - nb), C)
+        dst[:] = full[:, cb:cb + cc, :].reshape(-1)
+
     def linear_hash_rows(self, buf, w, h):
         return np.concatenate([orc.linear_hash(buf[i * w:(i + 1) * w], self.split) for i in range(h)])
 

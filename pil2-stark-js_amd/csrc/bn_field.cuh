@@ -45,33 +45,28 @@ __device__ __forceinline__ void sub_r(u32 *a) {
     }
 }
 
-// t (9 limbs, t < 2^288) -> t - r if t >= r, else t; only limbs 0..7 of the result are kept (callers guarantee < 2^256 then).
-// One borrow chain through vcc and eight selects instead of the compare-then-subtract the compiler generates.
+// t (9 limbs, t < 2^288) -> t - r if t >= r, else t, IN PLACE; only limbs 0..7 of the result matter (callers guarantee < 2^256 then).
+// One borrow chain through vcc tells whether t >= r; the borrow becomes a mask and r AND the mask is subtracted in place.  Nothing but two
+// scratch registers is an output of the first statement: the earlier form wrote the nine differences to early-clobber outputs and selected
+// them against the inputs, and hipcc's coalescer, inside a loop that copies the result back over the input, gave a difference the register
+// of the limb it was selected against (`v_cndmask_b32 v8, v8, v8`: silently wrong for every value below r -- round 5).
 __device__ __forceinline__ void cond_sub_r(u32 t[9]) {
-    u32 d0, d1, d2, d3, d4, d5, d6, d7, d8;
+    u32 scr, mask;
     // the limbs of r travel in VGPRs: a literal and the vcc borrow-in would both need the single constant-bus slot
-    asm("v_sub_co_u32 %0, vcc, %9, %18\n\t"
-        "v_subb_co_u32 %1, vcc, %10, %19, vcc\n\t"
-        "v_subb_co_u32 %2, vcc, %11, %20, vcc\n\t"
-        "v_subb_co_u32 %3, vcc, %12, %21, vcc\n\t"
-        "v_subb_co_u32 %4, vcc, %13, %22, vcc\n\t"
-        "v_subb_co_u32 %5, vcc, %14, %23, vcc\n\t"
-        "v_subb_co_u32 %6, vcc, %15, %24, vcc\n\t"
-        "v_subb_co_u32 %7, vcc, %16, %25, vcc\n\t"
-        "v_subbrev_co_u32 %8, vcc, 0, %17, vcc\n\t"          // final borrow in vcc: t < r
-        "v_cndmask_b32 %0, %0, %9, vcc\n\t"
-        "v_cndmask_b32 %1, %1, %10, vcc\n\t"
-        "v_cndmask_b32 %2, %2, %11, vcc\n\t"
-        "v_cndmask_b32 %3, %3, %12, vcc\n\t"
-        "v_cndmask_b32 %4, %4, %13, vcc\n\t"
-        "v_cndmask_b32 %5, %5, %14, vcc\n\t"
-        "v_cndmask_b32 %6, %6, %15, vcc\n\t"
-        "v_cndmask_b32 %7, %7, %16, vcc\n\t"
-        "v_cndmask_b32 %8, %8, %17, vcc"
-        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7), "=&v"(d8)
+    asm("v_sub_co_u32 %0, vcc, %2, %11\n\tv_subb_co_u32 %0, vcc, %3, %12, vcc\n\tv_subb_co_u32 %0, vcc, %4, %13, vcc\n\tv_subb_co_u32 %0, vcc, %5, %14, vcc\n\t"
+        "v_subb_co_u32 %0, vcc, %6, %15, vcc\n\tv_subb_co_u32 %0, vcc, %7, %16, vcc\n\tv_subb_co_u32 %0, vcc, %8, %17, vcc\n\tv_subb_co_u32 %0, vcc, %9, %18, vcc\n\t"
+        "v_subbrev_co_u32 %0, vcc, 0, %10, vcc\n\tv_cndmask_b32_e64 %1, -1, 0, vcc"
+        : "=&v"(scr), "=&v"(mask)
         : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(t[8]),
           "v"(r_limb(0)), "v"(r_limb(1)), "v"(r_limb(2)), "v"(r_limb(3)), "v"(r_limb(4)), "v"(r_limb(5)), "v"(r_limb(6)), "v"(r_limb(7)) : "vcc");
-    t[0] = d0; t[1] = d1; t[2] = d2; t[3] = d3; t[4] = d4; t[5] = d5; t[6] = d6; t[7] = d7; t[8] = d8;
+    u32 rm[8];
+#pragma unroll
+    for (int l = 0; l < 8; l++) rm[l] = r_limb(l) & mask;
+    asm("v_sub_co_u32 %0, vcc, %0, %9\n\tv_subb_co_u32 %1, vcc, %1, %10, vcc\n\tv_subb_co_u32 %2, vcc, %2, %11, vcc\n\tv_subb_co_u32 %3, vcc, %3, %12, vcc\n\t"
+        "v_subb_co_u32 %4, vcc, %4, %13, vcc\n\tv_subb_co_u32 %5, vcc, %5, %14, vcc\n\tv_subb_co_u32 %6, vcc, %6, %15, vcc\n\tv_subb_co_u32 %7, vcc, %7, %16, vcc\n\t"
+        "v_subbrev_co_u32 %8, vcc, 0, %8, vcc"
+        : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8])
+        : "v"(rm[0]), "v"(rm[1]), "v"(rm[2]), "v"(rm[3]), "v"(rm[4]), "v"(rm[5]), "v"(rm[6]), "v"(rm[7]) : "vcc");
 }
 
 // a = a + b mod r   (a, b < r)

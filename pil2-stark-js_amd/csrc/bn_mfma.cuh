@@ -162,35 +162,14 @@ __device__ __forceinline__ void finish_row(const v16i &a0, const v16i &a1, const
     carry_pair(a0, a1, w, sh);
     finish_words(w, kc, out);
 }
-// t (nine limbs) -> t - r if t >= r, IN PLACE.  bn::cond_sub_r writes the differences to fresh registers and selects; when its
-// result is copied back over its input inside a loop, hipcc's coalescer has been seen to give a difference the register of the
-// limb it is selected against (v_cndmask v8, v8, v8: both outcomes the difference).  Here nothing but two scratch registers is
-// an output: the borrow of t - r becomes a mask, r AND the mask is subtracted in place.
-__device__ __forceinline__ void cond_sub_r_inplace(u32 t[9]) {
-    u32 scr, mask;
-    asm("v_sub_co_u32 %0, vcc, %2, %11\n\tv_subb_co_u32 %0, vcc, %3, %12, vcc\n\tv_subb_co_u32 %0, vcc, %4, %13, vcc\n\tv_subb_co_u32 %0, vcc, %5, %14, vcc\n\t"
-        "v_subb_co_u32 %0, vcc, %6, %15, vcc\n\tv_subb_co_u32 %0, vcc, %7, %16, vcc\n\tv_subb_co_u32 %0, vcc, %8, %17, vcc\n\tv_subb_co_u32 %0, vcc, %9, %18, vcc\n\t"
-        "v_subbrev_co_u32 %0, vcc, 0, %10, vcc\n\tv_cndmask_b32_e64 %1, -1, 0, vcc"
-        : "=&v"(scr), "=&v"(mask)
-        : "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]), "v"(t[4]), "v"(t[5]), "v"(t[6]), "v"(t[7]), "v"(t[8]),
-          "v"(bn::r_limb(0)), "v"(bn::r_limb(1)), "v"(bn::r_limb(2)), "v"(bn::r_limb(3)), "v"(bn::r_limb(4)), "v"(bn::r_limb(5)), "v"(bn::r_limb(6)), "v"(bn::r_limb(7)) : "vcc");
-    u32 rm[8];
-#pragma unroll
-    for (int l = 0; l < 8; l++) rm[l] = bn::r_limb(l) & mask;
-    asm("v_sub_co_u32 %0, vcc, %0, %9\n\tv_subb_co_u32 %1, vcc, %1, %10, vcc\n\tv_subb_co_u32 %2, vcc, %2, %11, vcc\n\tv_subb_co_u32 %3, vcc, %3, %12, vcc\n\t"
-        "v_subb_co_u32 %4, vcc, %4, %13, vcc\n\tv_subb_co_u32 %5, vcc, %5, %14, vcc\n\tv_subb_co_u32 %6, vcc, %6, %15, vcc\n\tv_subb_co_u32 %7, vcc, %7, %16, vcc\n\t"
-        "v_subbrev_co_u32 %8, vcc, 0, %8, vcc"
-        : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8])
-        : "v"(rm[0]), "v"(rm[1]), "v"(rm[2]), "v"(rm[3]), "v"(rm[4]), "v"(rm[5]), "v"(rm[6]), "v"(rm[7]) : "vcc");
-}
 // any representative below 2^255 (< 3r) -> the canonical one: two subtractions at most
 __device__ __forceinline__ void canon(u32 x[8]) {
     u32 t[9];
 #pragma unroll
     for (int l = 0; l < 8; l++) t[l] = x[l];
     t[8] = 0;
-    cond_sub_r_inplace(t);
-    cond_sub_r_inplace(t);
+    bn::cond_sub_r(t);
+    bn::cond_sub_r(t);
 #pragma unroll
     for (int l = 0; l < 8; l++) x[l] = t[l];
 }

@@ -651,6 +651,12 @@ int pil2gl_extend_coefs_brev_dev(const uint64_t *coefBrev, uint64_t nPols, uint3
     P2_TRY(check_ntt_args(coefBrev, dst, nBits, nBitsExt));
     return lde_launch(coefBrev, nPols, nBits, dst, nBitsExt, as_stream(stream), 0, 0, nullptr, true, true);
 }
+int pil2gl_extend_coefs_brev_cosets_dev(const uint64_t *coefBrev, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
+                                        uint32_t cosetBegin, uint32_t cosetCount, void *stream) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_coset_args(coefBrev, dst, nBits, nBitsExt, cosetBegin, cosetCount));
+    return lde_launch(coefBrev, nPols, nBits, dst, nBitsExt, as_stream(stream), cosetBegin, cosetCount, nullptr, true, true);
+}
 int pil2gl_interpolate_cosets_ws_dev(const uint64_t *src, uint64_t nPols, uint32_t nBits, uint64_t *dst, uint32_t nBitsExt,
                                      uint32_t cosetBegin, uint32_t cosetCount, uint64_t *workspace, void *stream) {
     P2_TRY(ensure_init());

@@ -100,6 +100,7 @@ SIGNATURES = {
     "pil2gl_compute_q_split_dev": (_I, [vp, _U32, _U32, _U32, _U32, vp, vp]),
     "pil2gl_compute_q_split_brev_dev": (_I, [vp, _U32, _U32, _U32, _U32, vp, vp]),
     "pil2gl_extend_coefs_brev_dev": (_I, [vp, _U64, _U32, vp, _U32, vp]),
+    "pil2gl_extend_coefs_brev_cosets_dev": (_I, [vp, _U64, _U32, vp, _U32, _U32, _U32, vp]),
     "pil2gl_x_div_x_sub_xi_dev": (_I, [_U32, vp, _U64, _U64, vp, vp]),
     "pil2gl_x_div_x_sub_xi_cosets_dev": (_I, [_U32, _U32, vp, _U64, _U64, _U32, _U32, vp, vp]),
     "pil2gl_build_lev_dev": (_I, [_U32, vp, vp, vp]),

@@ -12,6 +12,7 @@ the rank that owns its coset (open_rows).
 `be` is a backend object (pil2gl.stark.GpuBackend in production; the tests pass their CPU checker) providing
 interpolate_cosets / linear_hash_rows / merkelize_digest_parts / as_torch.
 """
+import json
 import numpy as np
 
 try:
@@ -515,7 +516,10 @@ def shard_tables(be, setup, info, cb, cc):
     ss = info["starkStruct"]
     nb, eb = ss["nBits"], ss["nBitsExt"] - ss["nBits"]
     cache = setup.setdefault("_shardTables", {})
-    key = (cb, cc)
+    # the key names everything the tables depend on: the coset range, the backend that holds them (a CPU checker run after a GPU run with the
+    # same setup must not be handed device tensors) and the AIR's domain, constants and boundaries
+    key = (cb, cc, getattr(be, "name", type(be).__name__), str(getattr(be, "dev", "")), nb, eb, info["nConstants"],
+           json.dumps(info.get("boundaries", [{"name": "everyRow"}]), sort_keys=True))
     if key not in cache:
         constShard, constTree = setup.get("constShard"), setup.get("constTree")
         t = {"const_ext": constShard["local"] if constShard is not None else coset_slice(be, constTree["elements"], nb, eb, cb, cc, info["nConstants"]),
@@ -524,6 +528,23 @@ def shard_tables(be, setup, info, cb, cc):
             t["Zi_ext#%d" % bi] = zi_slice(be, boundary, nb, eb, cb, cc, t["x_ext"])
         cache[key] = t
     return dict(cache[key])
+
+
+def clear_shard_tables(setup):
+    """drops the tables shard_tables keeps with a setup (several GB of HBM per rank at config 5: x, every zerofier column and, without a
+    sharded constant tree, a copy of the constants' slice); the next proof builds them again"""
+    setup.pop("_shardTables", None)
+
+
+def shard_tables_bytes(be, setup):
+    """bytes the kept tables hold on this rank (for the peak-memory figures)"""
+    n = 0
+    for t in setup.get("_shardTables", {}).values():
+        for k, v in t.items():
+            if k == "const_ext" and setup.get("constShard") is not None:
+                continue                                      # the sharded constant tree's own slice, not a copy
+            n += int(be.as_torch(v).numel()) * 8
+    return n
 
 
 def build_const_tree_sharded(be, consts, info, group=None, rehearse_world=None, comm=None):
@@ -552,7 +573,7 @@ def all_gather_rows(be, local, n_bits, cc, width, comm):
     return be.from_torch(full)
 
 
-def quotient_coefficients_sharded(be, q_loc, nb, eb, cb, cc, qDim, qDeg, comm):
+def quotient_coefficients_sharded(be, q_loc, nb, eb, cb, cc, qDim, qDeg, comm, brev=False):
     """computeQStark's first half (stark_gen_helpers.js:168-190: qq1 = ifft over the extended domain of q, then the split into qDeg
     chunks of N coefficients scaled by shift^(-N p)) WITHOUT gathering q: -> [N][qDeg*qDim] on every rank, the first N rows of
     pil2gl_compute_q_split_dev's result.  With r = 2^eb pos + j the size-E inverse transform factors by cosets,
@@ -604,7 +625,30 @@ def quotient_coefficients_sharded(be, q_loc, nb, eb, cb, cc, qDim, qDeg, comm):
                 ops.append((S.OPC["copy"], (S.SEC, 1, 1, 0, p_ * qDim + k), (S.TMP, 1, 0, 0, 0), None))
     blk = be.empty(nblk * qDeg * qDim)
     be.eval_program(ops, 2, [(be.from_torch(G.reshape(-1)), nco * qDim), (blk, qDeg * qDim)], scal, _log2(nblk), 0)
-    return be.from_torch(torch.cat([p_.reshape(-1) for p_ in comm.all_gather(be.as_torch(blk).reshape(-1))]))
+    if not brev:
+        return be.from_torch(torch.cat([p_.reshape(-1) for p_ in comm.all_gather(be.as_torch(blk).reshape(-1))]))
+    # the same matrix with coefficient i at row bitrev(i) (what pil2gl_extend_coefs_brev_cosets_dev reads): row i = r nblk + l sits at
+    # bitrev(l) w + bitrev(r) -- each rank reverses its own block's rows, the gathered blocks interleave in reversed rank order
+    lb_, lw_ = _log2(nblk), _log2(w)
+    bt = be.as_torch(blk).reshape(nblk, qDeg * qDim)
+    parts = comm.all_gather(bt[_bitrev_index(lb_, bt.device)].reshape(-1).contiguous())
+    order = [int(format(r, "0%db" % lw_)[::-1], 2) if lw_ else 0 for r in range(w)]
+    return be.from_torch(torch.stack([parts[order[r]].reshape(nblk, qDeg * qDim) for r in range(w)], dim=1).reshape(-1).contiguous())
+
+
+_BITREV = {}
+
+
+def _bitrev_index(bits, device):
+    """bitrev(i) for i < 2^bits as an index tensor on `device` (kept: one per size and device)"""
+    key = (bits, str(device))
+    if key not in _BITREV:
+        i = torch.arange(1 << bits, dtype=torch.int64, device=device)
+        r = torch.zeros_like(i)
+        for b in range(bits):
+            r |= ((i >> b) & 1) << (bits - 1 - b)
+        _BITREV[key] = r
+    return _BITREV[key]
 
 
 def _evals_by_opening(be, S, info, loc, widths, xis, nb, nbe, lb, cb, rank, world, comm, nC):
@@ -753,20 +797,24 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     # PIL2GL_Q_GATHER=1: all-gather q and transform it everywhere); the split quotient has degree < N per column, so its
     # extension is again "one coset per rank": evaluations on the subgroup, then the unshifted coset extension of the own
     # cosets, own leaves, exchanged digests
-    if split_q:                                                # the coefficients without gathering q (by cosets, then by row blocks)
-        qq2 = quotient_coefficients_sharded(be, loc["q_ext"], nb, eb, cb, cc, qDim, qDeg, comm)
+    qname = "cm%d_ext" % qStage
+    if split_q:                                                # the coefficients without gathering q (by cosets, then by row blocks),
+        qq2 = quotient_coefficients_sharded(be, loc["q_ext"], nb, eb, cb, cc, qDim, qDeg, comm, brev=True)      # in the order the extension reads
+        del loc["q_ext"]
+        loc[qname] = be.empty(nQ << nloc)
+        be.extend_coefs_brev_cosets(qq2, nQ, nb, loc[qname], nbe, cb, cc)           # own cosets straight from the coefficients every rank holds
+        del qq2
     else:
         qq1 = be.empty(qDim << nbe)
         be.ifft(q_ext, qDim, nbe, qq1)
         qq2 = be.q_split(qq1, nb, nbe, qDim, qDeg)
         del qq1, q_ext
-    del loc["q_ext"]
-    q_sub = be.empty(nQ << nb)
-    be.fft(qq2[:nQ << nb], nQ, nb, q_sub)                    # rows >= N of qq2 are zero: these are all its coefficients
-    del qq2
-    qname = "cm%d_ext" % qStage
-    loc[qname] = be.empty(nQ << nloc)
-    be.extend_cosets_unshifted(q_sub, nQ, nb, loc[qname], nbe, cb, cc)
+        del loc["q_ext"]
+        q_sub = be.empty(nQ << nb)
+        be.fft(qq2[:nQ << nb], nQ, nb, q_sub)                # rows >= N of qq2 are zero: these are all its coefficients
+        del qq2
+        loc[qname] = be.empty(nQ << nloc)
+        be.extend_cosets_unshifted(q_sub, nQ, nb, loc[qname], nbe, cb, cc)
     lap("q_ntt")
     strees[qStage] = commit_local_slice(be, loc[qname], nQ, nb, cc, comm, split_tree=True)
     shards[qStage] = {"local": loc[qname], "width": nQ, "height": E, "cosetBegin": cb, "cosetCount": cc, "extBits": eb}

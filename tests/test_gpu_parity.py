@@ -1390,6 +1390,13 @@ def test_quotient_pieces_extended_from_their_coefficients(gl, oracle, nb, eb, qD
     assert (c.cpu().numpy().view(np.uint64).reshape(1 << nb, W)[br] == full).all()
     with pytest.raises(gl.Pil2glError):
         _lib.call("pil2gl_extend_coefs_brev_dev", gl._ptr(c), W, nb, gl._ptr(out), 40, None)
+    # coset slices of the same extension (a rank's part of the split quotient, pil2gl_extend_coefs_brev_cosets_dev): row (pos, j - cb) = row (pos << eb) + j
+    for cb, cc in {(0, 1), ((1 << eb) - 1, 1), (0, 1 << eb), ((1 << eb) // 2, (1 << eb) // 2)}:
+        sl = torch.zeros((W * cc) << nb, dtype=torch.int64, device="cuda")
+        _lib.call("pil2gl_extend_coefs_brev_cosets_dev", gl._ptr(c), W, nb, gl._ptr(sl), nbe, cb, cc, None)
+        assert (sl.cpu().numpy().view(np.uint64).reshape(1 << nb, cc, W) == want.reshape(1 << nb, 1 << eb, W)[:, cb:cb + cc]).all(), (cb, cc)
+    with pytest.raises(gl.Pil2glError):
+        _lib.call("pil2gl_extend_coefs_brev_cosets_dev", gl._ptr(c), W, nb, gl._ptr(out), nbe, 1 << eb, 1, None)
 
 
 @pytest.mark.parametrize("wide", ["1", "0"])

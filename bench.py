@@ -866,6 +866,11 @@ def main():
         import datetime
         coll_timeout = datetime.timedelta(seconds=float(os.environ.get("PIL2GL_DIST_TIMEOUT", "120")))
         if backend == "nccl":
+            # a collective whose peer is gone must END the job (non-zero exit of every rank), not hang it: the process group's watchdog aborts
+            # the process when a collective has been pending for `coll_timeout` -- also while the host sits in the device synchronisation
+            # behind it (all_reduce_sum's copy to the host); said explicitly, whatever this build's default is
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+            os.environ.setdefault("TORCH_NCCL_BLOCKING_WAIT", "0")
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=coll_timeout)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world, timeout=coll_timeout)

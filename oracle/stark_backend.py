@@ -55,6 +55,9 @@ class OracleBackend:
     def linear_hash_rows(self, buf, w, h):
         return np.concatenate([orc.linear_hash(buf[i * w:(i + 1) * w], self.split) for i in range(h)])
 
+    def linear_hash_rows_into(self, buf, w, h, out):
+        out[:4 * h] = self.linear_hash_rows(buf, w, h)
+
     def merkelize_digests(self, leaves, h):
         nodes = np.zeros(orc.merkle_num_nodes(h), np.uint64)
         nodes[:4 * h] = leaves[:4 * h]

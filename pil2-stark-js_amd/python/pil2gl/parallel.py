@@ -196,6 +196,12 @@ class Comm:
         if self.mode != "nccl" and x.is_cuda:                  # gloo with device data: through the host (slow; tests only)
             x = x.cpu()
         host_staged = x is not mine
+        if self.mode == "nccl" and outs is None:
+            # one output buffer, rank-major: RCCL writes every rank's part in place (a LIST of outputs is gathered into a buffer of the
+            # library's own first and copied out part by part)
+            flat = torch.empty(self.world * n, dtype=x.dtype, device=x.device)
+            work = dist.all_gather_into_tensor(flat, x.contiguous(), group=self.group, async_op=True)
+            return _Pending(work, list(flat.view(self.world, n)))
         parts = outs if (outs is not None and not host_staged) else [torch.empty_like(x) for _ in range(self.world)]
         if self.mode == "nccl":
             work = dist.all_gather(parts, x, group=self.group, async_op=True)
@@ -285,13 +291,15 @@ def commit_local_slice(be, local, width, n_bits, cc, comm, split_tree=False, chu
     else:
         mine = be.empty(rows * 4)
         gathered = [be.empty(rows * 4) for _ in range(comm.world)]
+        mt, gt = be.as_torch(mine), [be.as_torch(g) for g in gathered]      # (views of the same memory: the exchange layer speaks torch)
         pending = []
         for k in range(chunks):
             r0, r1 = rows * k // chunks, rows * (k + 1) // chunks
             be.linear_hash_rows_into(local[r0 * width:r1 * width], width, r1 - r0, mine[r0 * 4:r1 * 4])
-            pending.append(comm.all_gather_start(mine[r0 * 4:r1 * 4], [g[r0 * 4:r1 * 4] for g in gathered]))
+            pending.append(comm.all_gather_start(mt[r0 * 4:r1 * 4], [g[r0 * 4:r1 * 4] for g in gt]))
         for h in pending:
             h.wait()
+        gathered = gt
     # part r is [N][cc*4]; leaf index = pos*2^eb + r*cc + jl (natural row order of the extension), written straight into
     # the node array (no stacked / permuted copies: at config 5 the leaf level alone is 17 GB)
     if split_tree:

@@ -68,6 +68,13 @@ def main():
             want_sib.append([int(v) for v in want_nodes[off + 4 * (j ^ 1): off + 4 * (j ^ 1) + 4]])
             off += 4 * (n + (n & 1)); n = (n + 1) // 2; j //= 2
         assert [[int(v) for v in s_] for s_ in sib[k]] == want_sib, "rank %d: split-tree path of leaf %d differs" % (rank, i)
+    # the commit with the leaf hashing cut into four pieces, each piece's digests gathered while the next is hashed (the RCCL branch's
+    # overlap, commit_local_slice(chunks=4): here over gloo, where the pieces go one after the other): same node array
+    comm = parallel.Comm(None)
+    chunked = parallel.commit_local_slice(be, st["local"], C, nb, cc, comm, split_tree=False, chunks=4)
+    assert np.array_equal(be.to_host(chunked), want_nodes), "rank %d: chunked commit differs" % rank
+    chunked_split = parallel.commit_local_slice(be, st["local"], C, nb, cc, comm, split_tree=False, chunks=3)      # ragged pieces
+    assert np.array_equal(be.to_host(chunked_split), want_nodes), "rank %d: commit in three ragged pieces differs" % rank
     rows = parallel.open_rows(be, st, idxs)
     assert np.array_equal(rows, ext[idxs]), "rank %d: opened rows differ" % rank
     for i in idxs:

@@ -559,7 +559,12 @@ __device__ __noinline__ void dense_mul(const St st, int cur, const u32 *A, int n
 // (row after row, tile after tile) read MFMA_AHEAD tiles ahead of their use -- a load per tile and lane, the oldest awaited
 // alone -- so the table carries MFMA_AHEAD spare tiles after its last one.
 constexpr int MFMA_AHEAD = 8;
-template <int N>
+#ifndef BN_DENSE_AHEAD_SBOX
+#define BN_DENSE_AHEAD_SBOX 4
+#endif
+// SBOX: the NEXT round's S-box is applied to every finished row before it is stored (its constant came with the row): the separate S-box pass over
+// the state -- a load and a store of every element, seven of them in private memory -- disappears for that round.
+template <int N, bool SBOX = false>
 __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *tiles, const u32 *kc, int first) {
     bnm::v4i B0[N], B1[N];
 #pragma unroll
@@ -570,10 +575,11 @@ __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *til
     }
     const bnm::Sh sh = bnm::sh_init();
     bnm::gtile tp = (bnm::gtile)tiles + st.lane;
-    bnm::v4i q[MFMA_AHEAD];
+    constexpr int AHEAD = SBOX ? BN_DENSE_AHEAD_SBOX : MFMA_AHEAD;      // (the S-box in the row loop needs the registers of half the ring)
+    bnm::v4i q[AHEAD];
     BN_SYNC();                                       // the workgroup's waves start the layer's tile stream together
 #pragma unroll
-    for (int k = 0; k < MFMA_AHEAD; k++) q[k] = tp[(size_t)k * 64];
+    for (int k = 0; k < AHEAD; k++) q[k] = tp[(size_t)k * 64];
 #ifdef BN_STAMPS
     unsigned long long sBurst = 0, sCarry = 0, sFinish = 0;
 #endif
@@ -589,11 +595,11 @@ __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *til
         for (int j = 0; j < N; j++) {
             const bnm::v4i a = q[0];
 #pragma unroll
-            for (int k = 0; k + 1 < MFMA_AHEAD; k++) q[k] = q[k + 1];
+            for (int k = 0; k + 1 < AHEAD; k++) q[k] = q[k + 1];
 #ifdef BN_ABLATE_TILEADDR
-            q[MFMA_AHEAD - 1] = ((bnm::gtile)tiles + st.lane)[(size_t)((j + MFMA_AHEAD) & 7) * 64];      // timing experiments only: every tile from one 8 KB window
+            q[AHEAD - 1] = ((bnm::gtile)tiles + st.lane)[(size_t)((j + AHEAD) & 7) * 64];      // timing experiments only: every tile from one 8 KB window
 #else
-            q[MFMA_AHEAD - 1] = tp[(size_t)(j + MFMA_AHEAD) * 64];
+            q[AHEAD - 1] = tp[(size_t)(j + AHEAD) * 64];
 #endif
             a0 = bnm::mfma(a, B0[j], a0);
             a1 = bnm::mfma(a, B1[j], a1);
@@ -607,11 +613,13 @@ __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *til
         bnm::carry_pair(a0, a1, w, sh);
         __builtin_amdgcn_sched_barrier(0); const unsigned long long tr2 = bn_now(); __builtin_amdgcn_sched_barrier(0);
         bnm::finish_words(w, k, o);
+        if constexpr (SBOX) pow5_lazy(o);
         lds_store(st, first + i, o);
         __builtin_amdgcn_sched_barrier(0); const unsigned long long tr3 = bn_now(); __builtin_amdgcn_sched_barrier(0);
         sBurst += tr1 - tr0; sCarry += tr2 - tr1; sFinish += tr3 - tr2;
 #else
         bnm::finish_row(a0, a1, k, o, sh);
+        if constexpr (SBOX) pow5_lazy(o);
         lds_store(st, first + i, o);                 // the old state is in B0 / B1: the new row can go straight to its place
 #endif
     }
@@ -707,11 +715,14 @@ __device__ __noinline__ void partial_rounds(const St st, int cur, const PermArgs
 // cross terms of row i (<= 4 pairs) added to the row's stored part, one short finish = the next x0.  Per super-block, once: the n columns
 // y_j + sum_k W z_k (1 + 8 pairs and one finish each -- the costliest phase, hence every eight rounds, not four).  No 32x32 product is left
 // but the S-box's.  The tiles are ONE linear stream in consumption order, read PR_AHEAD tiles ahead.
+#ifndef BN_HI_BATCH
+#define BN_HI_BATCH 4
+#endif
 #ifndef BN_KR_LATE
 #define BN_KR_LATE 0
 #endif
 #ifndef BN_PR_AHEAD
-#define BN_PR_AHEAD 6
+#define BN_PR_AHEAD 4
 #endif
 constexpr int PR_AHEAD = BN_PR_AHEAD;
 struct TileStream {
@@ -771,17 +782,15 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
         // the four rows' parts on y of one block; H = 1: the second block of a super-block (two instances: no branch inside the ring's straight line)
         auto rows = [&](auto Hc) {
             constexpr int H = decltype(Hc)::value;
-            bnm::v4i hb0[NHA], hb1[NHA];              // the upper columns as operands, one batch of private-memory loads per block
-#pragma unroll
-            for (int q = 0; q < NHI; q++) {
-                u32 y[8];
-                lds_load(st, 1 + NLO + q, y);
-                bnm::b_prep(y, hb0[q], hb1[q]);
-            }
             BN_SYNC();
             BN_PRIO(BN_PRIO_MFMA);
 #pragma unroll
             for (int pass = 0; pass < 2; pass++) {
+                // the upper columns as operands: batches of at most BN_HI_BATCH private-memory elements, fetched just before their columns -- all seven
+                // kept across both passes (or even through one) do not fit beside the accumulators, and hipcc spills them: ~700 spill stores per wave
+                // of the leaf kernel, more than the state itself wrote (a spill is a store and a load where a second load does)
+                constexpr int HB = BN_HI_BATCH < NHA ? BN_HI_BATCH : NHA;
+                bnm::v4i hb0[HB], hb1[HB];
                 bnm::v16i P0[2], P1[2];
 #pragma unroll
                 for (int r = 0; r < 2; r++) { P0[r] = bnm::acc_init(); P1[r] = bnm::acc_init(); }
@@ -796,7 +805,19 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
                         for (int l = 0; l < 8; l++) y[l] = yn[l];
                         if (j + 1 < NLO) lds_load(st, 2 + j, yn);         // the next column's words are on their way while this one's products run
                         bnm::b_prep(y, b0, b1);
-                    } else { b0 = hb0[j < NLO ? 0 : j - NLO]; b1 = hb1[j < NLO ? 0 : j - NLO]; }
+                    } else {
+                        const int q = j < NLO ? 0 : j - NLO;                  // (static after unrolling)
+                        if (q % HB == 0) {
+#pragma unroll
+                            for (int e = 0; e < HB; e++)
+                                if (q + e < NHI) {
+                                    u32 y[8];
+                                    lds_load(st, 1 + NLO + q + e, y);
+                                    bnm::b_prep(y, hb0[e], hb1[e]);
+                                }
+                        }
+                        b0 = hb0[q % HB]; b1 = hb1[q % HB];
+                    }
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         const bnm::v4i a = ts.next();
@@ -970,13 +991,17 @@ __device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
         // half of its 256 registers in private memory (92-112 words per lane and call, ~480 KB per wave and permutation -- a third of the
         // kernel's private-memory traffic, which the chip pays for in power: tools/power_probe.py).  One copy of each phase: the partial rounds
         // and the closing layer sit at the top of the fifth full round (rp = 68 = 17 blocks of four, nothing left over).
-        for (int r = 0; r < 8; r++) {
-            if (r == 4) {
+        // The S-boxes of rounds 1-3 and 5-7 ride on the rows of the layer before them, round 4's on the closing layer's rows (its element 0, which comes
+        // out of the partial rounds, alone afterwards); only round 0's is a pass of its own.  Two copies of the wide layer (with / without the S-box).
+        BN_STAMP(0, sbox_lazy_impl(st, 17, A.C8));
+        for (int r = 0; r < 8; r++) {                                         // (one copy of each form of the layer)
+            if (r == 3 || r == 7) BN_STAMP(1, dense_mfma_impl<17>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0))
+            else BN_STAMP(1, (dense_mfma_impl<17, true>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0)))
+            if (r == 3) {
                 BN_STAMP(2, partial_rounds_mfma_impl<16>(st, A.Pt, A.KR, A.KU, A.rp));
-                BN_STAMP(1, dense_mfma_impl<16>(st, A.Dt, A.DK, 1));          // diag(1, Mh^RP)
+                BN_STAMP(1, (dense_mfma_impl<16, true>(st, A.Dt, A.DK, 1)));  // diag(1, Mh^RP), then round 4's S-box on elements 1..16
+                u32 x[8]; lds_load(st, 0, x); pow5_lazy(x); lds_store(st, 0, x);
             }
-            BN_STAMP(0, sbox_lazy_impl(st, 17, r == 0 ? A.C8 : nullptr));
-            BN_STAMP(1, dense_mfma_impl<17>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0));
         }
         return cur;
     }

@@ -206,7 +206,7 @@ int derive_sparse(int t, int rp, const Vec &C, const Vec &M, Vec &C8, Vec &D, Ve
 // Operand tiles and row constants for the matrix cores (layout and derivation: bn_mfma.cuh).
 struct MfmaConsts {
     U256 P[32];                                      // 2^(8b+32) mod r, plain
-    U256 off;                                        // sum_k 2^25 256^k mod r
+    U256 off;                                        // sum_k ACC_BIAS 256^k mod r
     MfmaConsts() {
         U256 v = { { 1, 0, 0, 0 } };
         for (int e = 0; e < 32; e++) v = h_addmod(v, v);
@@ -236,7 +236,7 @@ void mfma_tile(const MfmaConsts &mc, const U256 &a0, int8_t *tile, U256 &tot, bo
         }
     }
 }
-// the row constant: (128 tot - nAcc sum_k 2^25 256^k) / 2^32 + fold mod r   (nAcc accumulations started at the bias make up the row)
+// the row constant: (128 tot - nAcc sum_k ACC_BIAS 256^k) / 2^32 + fold mod r   (nAcc accumulations started at the bias make up the row)
 U256 mfma_row_const(const MfmaConsts &mc, U256 tot, int nAcc, const U256 &fold) {
     const U256 inv32 = { { 0, 0, 0, 1ull << 32 } };  // 2^224: h_mont(a, 2^224) = a / 2^32
     for (int e = 0; e < 7; e++) tot = h_addmod(tot, tot);
@@ -259,14 +259,15 @@ void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &ti
 // the row constants.  Block b (rounds k0 = 4b .. k0+3), z_i = the S-box output of round k0+i, y = elements 1..n at the start of b's SUPER-BLOCK:
 //   x0 after round k0+i = m00 z_i + sum_j V[k0+i][j] y_j + sum_{i'<i} (V[k0+i] . W[k0+i']) z_i'  [+ for the second block of a super-block the same
 //   cross terms with the four z of the first];   y_j after the super-block = y_j + sum over its rounds of W[k][j] z_k  (one column update per 8 rounds).
-// Stream per block, in two passes (rows 0-1, then rows 2-3): n x 2 tiles V[k0+i][j] (j outer), second block: 2 x 4 tiles (V[k0+i] . W[k0-4+s]);  then 4 x 4 tiles of the block's own cross terms
-// (round i, slot s holds z_(i+s-3): zero tiles where that is before the block).  Per super-block after its blocks: n x (1 + 4 halves) tiles (1, W[k][j]).
+// Stream per block, in two passes (rows 0-1, then rows 2-3): n x 2 tiles V[k0+i][j] (j outer), second block: 2 x 4 tiles (V[k0+i] . W[k0-4+s]);  then the block's own
+// cross terms, round i = 0..3: i + 1 tiles (z_0 .. z_i of the block; the last is m00).  Per super-block after its blocks: n x (1 + 8) tiles (1, W[k][j]; four zero tiles when
+// the super-block has one block).
 // KR[k]: round k's row constant with S[k+1] folded in while round k+1 is one of these; KU[sb][j]: the column constants.
 void mfma_partial_tables(int t, int rp, const Vec &S, const Vec &V, const Vec &W, const U256 &m00, std::vector<int8_t> &tiles, Vec &KR, Vec &KU) {
     const MfmaConsts mc;
     const U256 zero = { { 0, 0, 0, 0 } }, one = h_to_mont(U256{ { 1, 0, 0, 0 } });
     const int n = t - 1, nb = rp / 4, nsb = (nb + 1) / 2;
-    tiles.assign(((size_t)nb * (4 * n + 16) + (size_t)nsb * 9 * n + (size_t)(nb / 2) * 16) * 1024, 0);      // per block its rows and rounds, per super-block the columns (1 + 8 tiles each), 16 more for a second block's rows
+    tiles.assign(((size_t)nb * (4 * n + 10) + (size_t)nsb * 9 * n + (size_t)(nb / 2) * 16) * 1024, 0);      // per block its rows and rounds, per super-block the columns (1 + 8 tiles each), 16 more for a second block's rows
     KR.assign((size_t)nb * 4, zero); KU.assign((size_t)nsb * n, zero);
     auto dot = [&](int ka, int kb) { U256 c = zero; for (int j = 0; j < n; j++) c = h_addmod(c, h_mont(V[(size_t)ka * n + j], W[(size_t)kb * n + j])); return c; };
     int8_t *tp = tiles.data();
@@ -280,11 +281,8 @@ void mfma_partial_tables(int t, int rp, const Vec &S, const Vec &V, const Vec &W
                 if (h == 1) for (int i = 2 * pass; i < 2 * pass + 2; i++) for (int s = 0; s < 4; s++, tp += 1024) mfma_tile(mc, dot(k0 + i, k0 - 4 + s), tp, tot[i], true);
             }
             for (int i = 0; i < 4; i++) {
-                for (int s = 0; s < 4; s++, tp += 1024) {
-                    const int ip = i + s - 3;
-                    if (ip < 0) continue;
+                for (int ip = 0; ip <= i; ip++, tp += 1024)                                    // round i: its i + 1 cross terms, z_0 .. z_i of the block
                     mfma_tile(mc, ip < i ? dot(k0 + i, k0 + ip) : m00, tp, tot[i], true);      // a z: the S-box's output
-                }
                 KR[(size_t)k0 + i] = mfma_row_const(mc, tot[i], 2, k0 + i + 1 < 4 * nb ? S[(size_t)k0 + i + 1] : zero);
             }
         }
@@ -589,7 +587,7 @@ __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *til
         __builtin_amdgcn_sched_barrier(0); const unsigned long long tr0 = bn_now(); __builtin_amdgcn_sched_barrier(0);
 #endif
         load_const<true>(kc, (size_t)i, k);          // asked for ahead of the row's tiles: an in-order counter waits for everything older than what it wants
-        bnm::v16i a0 = bnm::acc_init(), a1 = bnm::acc_init();
+        bnm::v16i a0, a1;
         BN_PRIO(BN_PRIO_MFMA);
 #pragma unroll
         for (int j = 0; j < N; j++) {
@@ -601,8 +599,11 @@ __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *til
 #else
             q[AHEAD - 1] = tp[(size_t)(j + AHEAD) * 64];
 #endif
-            a0 = bnm::mfma(a, B0[j], a0);
-            a1 = bnm::mfma(a, B1[j], a1);
+            if (j == 0) bnm::mfma_first(a, B0[0], B1[0], a0, a1);
+            else {
+                a0 = bnm::mfma(a, B0[j], a0);
+                a1 = bnm::mfma(a, B1[j], a1);
+            }
         }
         tp += (size_t)N * 64;
         BN_PRIO(0);
@@ -792,8 +793,6 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
                 constexpr int HB = BN_HI_BATCH < NHA ? BN_HI_BATCH : NHA;
                 bnm::v4i hb0[HB], hb1[HB];
                 bnm::v16i P0[2], P1[2];
-#pragma unroll
-                for (int r = 0; r < 2; r++) { P0[r] = bnm::acc_init(); P1[r] = bnm::acc_init(); }
                 u32 yn[8];
                 if (NLO) lds_load(st, 1, yn);
 #pragma unroll
@@ -821,8 +820,11 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
                         const bnm::v4i a = ts.next();
-                        P0[r] = bnm::mfma(a, b0, P0[r]);
-                        P1[r] = bnm::mfma(a, b1, P1[r]);
+                        if (j == 0) bnm::mfma_first(a, b0, b1, P0[r], P1[r]);
+                        else {
+                            P0[r] = bnm::mfma(a, b0, P0[r]);
+                            P1[r] = bnm::mfma(a, b1, P1[r]);
+                        }
                     }
                 }
                 if constexpr (H == 1) {                               // the rows of the second block see the first block's z through cross terms of their own
@@ -854,10 +856,11 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
 #ifdef BN_STAMPS
             { const unsigned long long t_ = bn_now(); if (st.lane == 0) atomicAdd(&g_bn_stamps[3], t_ - tp0); tp0 = t_; }
 #endif
-#pragma unroll
-            for (int s = 0; s < 4; s++) { zb0[s] = bnm::v4i{ 0, 0, 0, 0 }; zb1[s] = bnm::v4i{ 0, 0, 0, 0 }; }      // before the block's first z: anything (zero tiles)
             u32 x0[8];
             lds_load(st, 0, x0);
+            // the four rounds, unrolled: round i's cross terms are i + 1 tiles (z_0 .. z_i of this block), its row's part pc[i] and its operand slot
+            // are static -- no zero tiles multiplied, no operand or row shifted along
+#pragma unroll
             for (int i = 0; i < 4; i++) {
                 u32 k[8];
 #if !BN_KR_LATE
@@ -867,23 +870,20 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
 #if BN_KR_LATE
                 load_const<true>(KR, (size_t)(4 * b + i), k);         // (behind the S-box, whose registers it would otherwise take: the cross terms' products hide it)
 #endif
+                bnm::b_prep(x0, zb0[i], zb1[i]);
+                bnm::v16i c0, c1;
 #pragma unroll
-                for (int s = 0; s < 3; s++) { zb0[s] = zb0[s + 1]; zb1[s] = zb1[s + 1]; }
-                bnm::b_prep(x0, zb0[3], zb1[3]);
-                bnm::v16i c0 = bnm::acc_init(), c1 = bnm::acc_init();
-#pragma unroll
-                for (int s = 0; s < 4; s++) {
+                for (int s = 0; s <= i; s++) {
                     const bnm::v4i a = ts.next();
-                    c0 = bnm::mfma(a, zb0[s], c0);
-                    c1 = bnm::mfma(a, zb1[s], c1);
+                    if (s == 0) bnm::mfma_first(a, zb0[0], zb1[0], c0, c1);
+                    else {
+                        c0 = bnm::mfma(a, zb0[s], c0);
+                        c1 = bnm::mfma(a, zb1[s], c1);
+                    }
                 }
                 u32 w[10];
                 bnm::carry_pair(c0, c1, w, sh);
-                bnm::add_pair(w, pc[0]);
-#pragma unroll
-                for (int r = 0; r < 3; r++)
-#pragma unroll
-                    for (int l = 0; l < 10; l++) pc[r][l] = pc[r + 1][l];
+                bnm::add_pair(w, pc[i]);
                 bnm::finish_words(w, k, x0);
             }
             lds_store(st, 0, x0);
@@ -903,7 +903,8 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
             bnm::b_prep(y, b0, b1);
             BN_PRIO(BN_PRIO_MFMA);
             bnm::v4i a = ts.next();
-            bnm::v16i c0 = bnm::mfma(a, b0, bnm::acc_init()), c1 = bnm::mfma(a, b1, bnm::acc_init());
+            bnm::v16i c0, c1;
+            bnm::mfma_first(a, b0, b1, c0, c1);
 #pragma unroll
             for (int s = 0; s < 4; s++) {
                 a = ts.next();

@@ -4,12 +4,12 @@
 // rows V_k, the columns W_k and the closing matrix) is out_i = sum_j A_ij x_j mod r with CONSTANT A.  On the vector ALU a term is
 // 64 32x32 products (two instructions each); here the constant goes into the matrix operand instead:
 //     c[i][j][b] = A_ij * 256^b * 2^32 mod r,  b < 32        plain integers < r, written in signed base-256 digits d_k, k < 32
-//     S[i][k]    = 2^25 + sum_{j,b} d_k(c[i][j][b]) * (byte_b(x_j) - 128)            an i8 x i8 -> i32 product, one value per byte position
-//     V_i        = sum_k 256^k S[i][k]  < 2^274.01;    out_i = (V_i + m r) / 2^32 + K_i,   m = -V_i / r mod 2^32
-// K_i = (128 sum_{j,b} c[i][j][b] - sum_k 2^25 256^k) / 2^32 mod r takes back the two offsets (operand bytes are fed as signed
-// u - 128; the accumulators start at 2^25, the instruction's inline constant, so that every S is positive).  The reduction mod r
+//     S[i][k]    = 2^30 + sum_{j,b} d_k(c[i][j][b]) * (byte_b(x_j) - 128)            an i8 x i8 -> i32 product, one value per byte position
+//     V_i        = sum_k 256^k S[i][k]  < 2^280;    out_i = (V_i + m r) / 2^32 + K_i,   m = -V_i / r mod 2^32
+// K_i = (128 sum_{j,b} c[i][j][b] - sum_k 2^30 256^k) / 2^32 mod r takes back the two offsets (operand bytes are fed as signed
+// u - 128; the accumulators start at 2^30 -- the bit pattern of 2.0f, an inline constant of the instruction -- so that every S is positive).  The reduction mod r
 // is in the constants: ONE 32-bit Montgomery step per row is left of the 8-step reduction the vector form pays per row, and no
-// 32x32 product of the state at all.  out_i < 2^244 + 2r < 2^255 stays as it is (lazy) until the permutation's output is read.
+// 32x32 product of the state at all.  out_i < 2^249 + 2r < 2^255 stays as it is (lazy) until the permutation's output is read.
 // Integer model of exactly these steps against the plain statement: tools/bn_mfma_model.py.
 //
 // Who holds what.  The kernels keep ONE PERMUTATION PER LANE (bn128.hip).  D(32x32) = A(32x32) * B(32x32) serves 32 permutations
@@ -34,7 +34,7 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef const v4i __attribute__((address_space(1))) *gtile;
 
-constexpr int ACC_BIAS = 1 << 25;
+constexpr int ACC_BIAS = 1 << 30;         // 2.0f's bit pattern: an inline constant of the matrix instruction (its C operand), no register set-up per accumulator
 
 __device__ __forceinline__ v16i acc_init() {
     v16i a;
@@ -56,6 +56,21 @@ __device__ __forceinline__ void b_prep(const u32 x[8], v4i &b0, v4i &b1) {
 }
 
 __device__ __forceinline__ v16i mfma(v4i a, v4i b, v16i c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
+// The FIRST products of a row's two accumulators, started at the bias as the instruction's inline constant (C = 2.0: the bit pattern 2^30) instead of
+// sixteen registers per accumulator set up first (hipcc has no way to say that: 16 v_mov_b64 per row).  One asm statement that keeps the hazards the
+// compiler keeps around the builtin: two wait states after the vector writes of the operands (the swaps of b_prep), and the 8-pass result's eleven
+// before anything but a matrix instruction accumulating on it may read it.  -DBN_ACC_INLINE=0: the builtin on acc_init() (A/B builds).
+#ifndef BN_ACC_INLINE
+#define BN_ACC_INLINE 1
+#endif
+__device__ __forceinline__ void mfma_first(v4i a, v4i b0, v4i b1, v16i &c0, v16i &c1) {
+#if BN_ACC_INLINE
+    asm("s_nop 1\n\tv_mfma_i32_32x32x32_i8 %0, %2, %3, 2.0\n\tv_mfma_i32_32x32x32_i8 %1, %2, %4, 2.0\n\ts_nop 10"
+        : "=&v"(c0), "=&v"(c1) : "v"(a), "v"(b0), "v"(b1));
+#else
+    c0 = mfma(a, b0, acc_init()); c1 = mfma(a, b1, acc_init());
+#endif
+}
 
 // ---- carry chains through vcc, one statement each (the compiler's 64-bit emulation costs two to three times the instructions)
 // a[0..N) += b[0..N), the carry out of the top limb is dropped (the callers' sums fit)
@@ -80,9 +95,9 @@ __device__ __forceinline__ void add_chain9_8(u32 a[9], const u32 b[8]) {
 __device__ __forceinline__ u64 mul_s(u32 x, u32 sc) { u64 d; asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(d) : "v"(x), "s"(sc) : "vcc"); return d; }
 __device__ __forceinline__ u64 mad_s(u32 x, u32 sc, u64 acc) { asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(sc) : "vcc"); return acc; }
 
-// sum_{k<16} 256^k a[k] (every a[k] < 2^26) -> five 32-bit words.  Per limb the three shifted terms are ONE 64-bit value (three
+// sum_{k<16} 256^k a[k] (every a[k] < 2^31) -> five 32-bit words.  Per limb the three shifted terms are ONE 64-bit value (three
 // multiply-adds by 2^8, 2^16, 2^24 held in scalar registers, no chain between limbs); the unshifted term and the previous limb's
-// overflow (< 2^19) add without carry in 32 bits; one five-limb chain joins them: 12 + 3 + 5 instructions.
+// overflow (< 2^24) add without carry in 32 bits; one five-limb chain joins them: 12 + 3 + 5 instructions.
 struct Sh { u32 s8, s16, s24; u64 zero; };
 __device__ __forceinline__ Sh sh_init() {
     Sh s = { 1u << 8, 1u << 16, 1u << 24, 0 };
@@ -136,7 +151,7 @@ __device__ __forceinline__ void finish_words(u32 w[10], const u32 *kc, u32 out[8
     for (int l = 0; l < 4; l++) t[l] = w0[l];
 #pragma unroll
     for (int l = 0; l < 5; l++) t[4 + l] = w1[l];
-    add_chain5(t + 4, z5);                            // V < 2^276: nine limbs
+    add_chain5(t + 4, z5);                            // V < 2^280: nine limbs
     u32 k[8];
 #pragma unroll
     for (int l = 0; l < 8; l++) k[l] = kc[l];
@@ -153,7 +168,7 @@ __device__ __forceinline__ void finish_words(u32 w[10], const u32 *kc, u32 out[8
 #pragma unroll
     for (int l = 0; l < 8; l++) { ul[l] = (u32)u[l]; uh[l] = (u32)(u[l] >> 32); }
     add_chain9_8(t, ul);                              // limb 0 becomes 0
-    add_chain8(t + 1, uh);                            // (V + m r) / 2^32 + K < 2^244 + 2r < 2^255
+    add_chain8(t + 1, uh);                            // (V + m r) / 2^32 + K < 2^249 + 2r < 2^255
 #pragma unroll
     for (int l = 0; l < 8; l++) out[l] = t[1 + l];
 }

@@ -19,7 +19,7 @@ import bn128_oracle as O
 R = O.R
 MONT = 1 << 256
 N0INV = (-pow(R, -1, 1 << 32)) % (1 << 32)
-BIAS = 1 << 25
+BIAS = 1 << 30
 OFF = sum(BIAS << (8 * k) for k in range(32))
 
 
@@ -60,7 +60,7 @@ def layer_apply(dig, K, x):
                 row = dig[i][j][b]
                 for k in range(32):
                     S[k] += row[k] * s
-        assert all(0 < v < (1 << 26) for v in S), (min(S), max(S))
+        assert all(0 < v < (1 << 31) for v in S), (min(S), max(S))
         V = sum(v << (8 * k) for k, v in enumerate(S))
         m = (V % (1 << 32)) * N0INV % (1 << 32)
         t = (V + m * R) >> 32
@@ -159,7 +159,7 @@ def row_positions(dig, x):
             s = ((xj >> (8 * b)) & 255) - 128
             for k in range(32):
                 S[k] += dig[j][b][k] * s
-    assert all(0 < v < (1 << 26) for v in S)
+    assert all(0 < v < (1 << 31) for v in S)
     return S
 
 

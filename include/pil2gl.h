@@ -22,7 +22,7 @@
  *    torch tensor.data_ptr()) plus a hipStream_t passed as void* (NULL = default
  *    stream), so buffers can stay resident in HBM across the prover's steps.
  *    Most of them only ENQUEUE work on that stream and return:
- *      interpolate / interpolate_cosets[_ws] / extend_cosets_unshifted / extend_coefs_brev / fft / ifft, linear_hash_rows, merkelize,
+ *      interpolate / interpolate_cosets[_ws] / extend_cosets_unshifted / extend_coefs_brev[_cosets] / fft / ifft, linear_hash_rows, merkelize,
  *      merkelize_level, merkelize_digests, poseidon, fri_fold, fri_verify_fold, fri_transpose, build_x, geometric,
  *      x_div_x_sub_xi[_cosets], gprod, gsum, dev_zero, and their bn128_ twins.
  *    The following _dev calls BLOCK until their work on the stream has finished, because they hand a result to the host or

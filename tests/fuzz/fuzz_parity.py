@@ -223,6 +223,8 @@ def case_bn128():
     import bn128_oracle as bo
     from pil2gl import bn128
     arity = int(rng.choice([2, 4, 8, 16])); custom = bool(rng.integers(0, 2)); w = int(rng.integers(1, 60)); h = int(rng.choice([1, 2, 3, 5, 16, 17, 33, 70]))
+    if rng.random() < 0.15:                                 # tall enough that the first tree level is a lane-per-permutation launch too (> 2 048 parents), ragged workgroups
+        h = int(rng.choice([2049 * arity + 3, 40000, 4099 * arity]))
     a = field((h, w))
     MH = bn128.buildMerkleHash(arity, custom)
     tree = MH.merkelize(a, w, h)

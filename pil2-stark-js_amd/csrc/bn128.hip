@@ -388,11 +388,12 @@ struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 
                   const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma, nofold; };
 
 // Where the state lives.  Elements [0, BN_LDS_ELEMS) in LDS as [element][limb][lane]; the elements above -- only the states
-// wider than BN_LDS_ELEMS have any: t = 10..17 -- in the lane's own private (scratch) memory, which the hardware swizzles so
-// that a wave's access to one word is one contiguous 256-byte piece.  9 elements = 18 KB of LDS per wave: EIGHT waves per CU
-// (two per SIMD) instead of the four that a 17-element state in LDS allows; the private half is read one term ahead of its use
-// like every operand of the wide kernels, so its L1 / L2 latency hides behind a multiply-accumulate.  The element index is
-// wave-uniform: the branch costs a scalar compare.
+// wider than BN_LDS_ELEMS have any: t = 11..17 -- in the lane's own private (scratch) memory, which the hardware swizzles so
+// that a wave's access to one word is one contiguous 256-byte piece.  10 elements = 20 KB of LDS per wave: EIGHT waves per CU
+// (two per SIMD: all 160 KB) instead of the four that a 17-element state in LDS allows.  The private half is the kernel's costliest
+// traffic (the per-XCD working set of 256 waves' private state plus the tile table passes the 4 MB L2: it travels through the fabric,
+// and the card is power-limited): every phase touches it as few times as its registers allow, and never inside a loop that runs a
+// tile ring (partial_rounds_mfma_impl).  The element index is static wherever that matters.
 #ifndef BN_LDS_ELEMS
 #define BN_LDS_ELEMS 10
 #endif

@@ -5,7 +5,7 @@
 // 32x32 product, 128 products per Montgomery multiplication).  With NINE limbs of 29 bits a product is below 2^58 and a whole column --
 // nine products of a x b and nine of m x r -- stays below 2^63: no carry instruction at all.  81 + 81 multiply-adds instead of
 // 128 + 128 instructions; a squaring needs 45 + 81 (the doubled operand 2 a_j still fits a 32-bit register); r = 1 mod 2^28 makes
-// -1/r mod 2^29 = 2^28 - 1, so the reduction digit is a shift and a subtraction, not a multiplication.
+// -1/r mod 2^29 = 2^28 - 1 (the reduction digit: one 32-bit multiplication by a constant and a mask).
 //
 // The Montgomery radix is 2^261 here, not the 2^256 of the state: M(a, b) = a b / 2^261.  x^5 through two squarings and a product comes
 // out as X^5 / 2^1044 for a state value X = x 2^256, i.e. the state form of x^5 times 2^-20.  The constant 2^20 is multiplied into the
@@ -47,6 +47,9 @@ __device__ __forceinline__ void from29(const u32 a[9], u32 x[8]) {
     }
 }
 
+#ifndef BN29_DIGIT_MUL
+#define BN29_DIGIT_MUL 1
+#endif
 #ifndef BN29_COLUMNS_C
 #define BN29_COLUMNS_C 0
 #endif
@@ -107,11 +110,18 @@ __device__ __forceinline__ RLimbs r_limbs() {
     for (int i = 0; i < 9; i++) { R.r[i] = r29(i); asm volatile("" : "+s"(R.r[i])); }
     return R;
 }
-// the reduction digit of a column: -lo / r mod 2^29 = lo (2^28 - 1) mod 2^29 (r = 1 mod 2^28), a shift and a subtraction
+// the reduction digit of a column: -lo / r mod 2^29 = lo (2^28 - 1) mod 2^29 (r = 1 mod 2^28): one multiplication and a mask (round 6: 27.3 against 27.5 ms
+// at 2^20 x 100 for the shift-and-subtract form, three instructions; BN29_DIGIT_MUL=0 keeps it for A/B builds)
 __device__ __forceinline__ u32 digit(u32 lo) {
+#if BN29_DIGIT_MUL
+    u32 k = (1u << 28) - 1;
+    asm("" : "+s"(k));
+    return (lo * k) & MASK;
+#else
     u32 sh = lo << 28;
     asm("" : "+v"(sh));                                                   // opaque: hipcc would turn the two full-rate steps back into a multiplication
     return (sh - lo) & MASK;
+#endif
 }
 // The seventeen columns of a product / a squaring, straight-line (gen_bn29_columns.py): every column ONE chain of multiply-adds on one
 // 64-bit accumulator (a x b, then m x r over the digits already known), the digit, and one 64-bit shift.

@@ -1,7 +1,7 @@
 set -u; : "${GRAFT_REPO_ROOT:?run on the GPU box}"
-R=$GRAFT_REPO_ROOT; L=$R/pil2-stark-js_amd/lib_ab; O=$R/gpurun_out/r06_bn20; mkdir -p $O
+R=$GRAFT_REPO_ROOT; L=$R/pil2-stark-js_amd/lib_ab; O=$R/gpurun_out/r06_bn22; mkdir -p $O
 cd $R
-VARIANTS="${VARIANTS:-v6 v7b v7}"
+VARIANTS="${VARIANTS:-v8 dmul}"
 {
 for v in $VARIANTS; do echo "== check $v"; PIL2GL_LIB=$L/libpil2gl_$v.so timeout 300 python3 tools/check_bn_mfma.py 2>&1 | tail -n 1; done
 for v in $VARIANTS $VARIANTS; do

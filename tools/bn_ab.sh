@@ -1,7 +1,9 @@
-set -u; : "${GRAFT_REPO_ROOT:?run on the GPU box}"
-R=$GRAFT_REPO_ROOT; L=$R/pil2-stark-js_amd/lib_ab; O=$R/gpurun_out/r06_bn22; mkdir -p $O
+set -u; : "${GRAFT_REPO_ROOT:?run on the GPU box: VARIANTS='a b' gpurun -- bash tools/bn_ab.sh}"
+# A/B of BN254 builds inside ONE call (boxes differ by 3-4 %): for every variant lib_ab/libpil2gl_<v>.so (tools/build_variant.sh) the width check against the
+# oracle, the 2^20 x 100 arity-16 commit twice over two rounds, and the leaf launch's L2 / fabric request counters.  -> gpurun_out/bn_ab/log.txt
+R=$GRAFT_REPO_ROOT; L=$R/pil2-stark-js_amd/lib_ab; O=$R/gpurun_out/bn_ab; mkdir -p $O
 cd $R
-VARIANTS="${VARIANTS:-v8 dmul}"
+VARIANTS="${VARIANTS:?names of lib_ab builds}"
 {
 for v in $VARIANTS; do echo "== check $v"; PIL2GL_LIB=$L/libpil2gl_$v.so timeout 300 python3 tools/check_bn_mfma.py 2>&1 | tail -n 1; done
 for v in $VARIANTS $VARIANTS; do

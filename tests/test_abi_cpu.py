@@ -156,3 +156,13 @@ def test_no_early_clobber_overlap_in_bn128_isa(tmp_path):
                                "-S", "--cuda-device-only", os.path.join(pkg, "csrc", src), "-o", str(out)], stderr=subprocess.DEVNULL)
         bad = re.findall(r"v_cndmask_b32(?:_e32|_e64)? v\d+, (v\d+), \1, (?:vcc|s\[\d+:\d+\])", out.read_text())     # ANY select whose two sources are one register
         assert not bad, "%s: a select between a register and itself (%d sites)" % (src, len(bad))
+
+
+def test_bn254_sbox_columns_model_and_generated_file():
+    """the S-box's seventeen columns per product (csrc/bn_field29_columns.inc): the generator's integer model of exactly those columns -- every
+    column sum below 2^64, result = a b / 2^261 mod r below 2^252 + r -- on random and edge operands, and the checked-in file is what the
+    generator writes (build() runs the same check)"""
+    import subprocess
+    import sys
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "pil2-stark-js_amd", "csrc", "gen_bn29_columns.py"), "--check"])
+

@@ -281,7 +281,7 @@ def clock_under_hash_load():
 
 
 def pmc_file():
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
             return name
     return "pmc_traffic.json"

@@ -287,6 +287,10 @@ int pil2gl_bn128_merkelize_dev(const uint64_t *elems, uint64_t width, uint64_t h
 /* MerkleHash.getGroupProof(tree,idx)  merklehash_bn128_p.js:142-182: hostVals[width], hostSiblings[nLevels][arity][4] (normal form) */
 int pil2gl_bn128_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height, uint32_t arity,
                                  uint64_t idx, uint64_t *hostVals, uint64_t *hostSiblings, uint32_t *nLevels);
+/* The same for a batch of rows in one launch (fri.js:83-105 opens every tree at every query): hostVals nIdx x width values, hostSiblings
+ * nIdx x levels x arity field elements (4 words each, normal form), *nLevels = levels. */
+int pil2gl_bn128_group_proofs_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height, uint32_t arity,
+                                  const uint64_t *hostIdxs, uint32_t nIdx, uint64_t *hostVals, uint64_t *hostSiblings, uint32_t *nLevels);
 /* n elements between normal and Montgomery form (F.e / F.toObject); the host form is plain host arithmetic */
 int pil2gl_bn128_convert(const uint64_t *in, uint64_t n, int toMontgomery, uint64_t *out);
 int pil2gl_bn128_convert_dev(const uint64_t *in, uint64_t n, int toMontgomery, uint64_t *out, void *stream);

@@ -1265,6 +1265,24 @@ __global__ void bn_convert_kernel(const u64 *__restrict__ in, u64 n, int toMont,
     for (int q = 0; q < 4; q++) out[4 * i + q] = (u64)o[2 * q] | ((u64)o[2 * q + 1] << 32);
 }
 
+// A batch of openings (fri.js:83-105 opens every tree at every query): block q gathers row idxs[q] and, per level, the `arity` nodes of its group
+// (Montgomery words as stored; nodes beyond the level's count read as zero, merklehash_bn128_p.js:165-170) into out[q] = [width values | levels x arity x 4 words]
+struct BnLevels { u64 off[40], n[40]; u32 levels; };
+__global__ void bn_group_proofs_kernel(const u64 *__restrict__ elems, const u64 *__restrict__ nodes, u64 width, int arity, int abits,
+                                       const u64 *__restrict__ idxs, BnLevels L, u64 *__restrict__ out) {
+    const u64 stride = width + (u64)L.levels * arity * 4;
+    u64 *o = out + blockIdx.x * stride;
+    const u64 idx = idxs[blockIdx.x];
+    for (u64 c = threadIdx.x; c < width; c += blockDim.x) o[c] = elems[idx * width + c];
+    u64 id = idx;
+    for (u32 l = 0; l < L.levels; l++) {
+        const u64 si = id ^ (id & (u64)(arity - 1));
+        for (u32 k = threadIdx.x; k < (u32)arity * 4; k += blockDim.x)
+            o[width + ((u64)l * arity) * 4 + k] = si + k / 4 < L.n[l] ? nodes[(L.off[l] + si) * 4 + k] : 0;
+        id >>= abits;
+    }
+}
+
 size_t lds_bytes(int tmax) {                         // the elements above BN_LDS_ELEMS live in private memory
     static const size_t pad = getenv("PIL2GL_BN128_LDS_PAD") ? (size_t)atol(getenv("PIL2GL_BN128_LDS_PAD")) : 0;   // occupancy experiments: extra bytes per workgroup
     return (size_t)lds_words(tmax) * 4 * BN_WG_WAVES + pad;
@@ -1466,6 +1484,47 @@ int pil2gl_bn128_group_proof_dev(const uint64_t *elems, const uint64_t *nodes, u
         memcpy(hostSiblings + 4 * k, v.w, 32);
     }
     *nLevels = lv;
+    return PIL2GL_OK;
+}
+
+// The same for a batch of rows in one launch and one copy each way (a proof opens 64 rows of every tree: one call per row is seven small
+// synchronous copies per row and tree).  hostVals: nIdx x width; hostSiblings: nIdx x levels x arity x 4 words, normal form.
+int pil2gl_bn128_group_proofs_dev(const uint64_t *elems, const uint64_t *nodes, uint64_t width, uint64_t height, uint32_t arity,
+                                  const uint64_t *hostIdxs, uint32_t nIdx, uint64_t *hostVals, uint64_t *hostSiblings, uint32_t *nLevels) {
+    P2_TRY(ensure_init());
+    P2_TRY(check_arity(arity));
+    if (!nIdx) return PIL2GL_OK;
+    if (!nodes || !hostIdxs || !hostSiblings || !nLevels || (width && (!elems || !hostVals))) return fail(PIL2GL_EINVAL, "null buffer");
+    for (uint32_t i = 0; i < nIdx; i++) if (hostIdxs[i] >= height) return fail(PIL2GL_EINVAL, "Out of range");       // merklehash_bn128_p.js:145
+    uint32_t nbits = 0; while ((1u << nbits) < arity) nbits++;
+    BnLevels L; L.levels = 0;
+    uint64_t offset = 0, n = height;
+    while (n > 1) {
+        if (L.levels >= 40) return fail(PIL2GL_EINVAL, "too many levels");
+        L.off[L.levels] = offset; L.n[L.levels] = n; L.levels++;
+        const uint64_t nextN = (n - 1) / arity + 1;
+        offset += nextN * arity; n = nextN;
+    }
+    const u64 stride = width + (u64)L.levels * arity * 4;
+    u64 *d;
+    P2_TRY(scratch(6, (u64)nIdx * (stride + 1), &d));
+    u64 *dIdx = d + (u64)nIdx * stride;
+    HIP_TRY(hipMemcpy(dIdx, hostIdxs, (u64)nIdx * 8, hipMemcpyHostToDevice));
+    bn_group_proofs_kernel<<<nIdx, 64>>>(elems, nodes, width, (int)arity, (int)nbits, dIdx, L, d);
+    KERNEL_CHECK();
+    std::vector<u64> h((size_t)nIdx * stride);
+    HIP_TRY(hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost));
+    const u64 per = (u64)L.levels * arity * 4;
+    for (uint32_t q = 0; q < nIdx; q++) {
+        if (width) memcpy(hostVals + (u64)q * width, h.data() + (u64)q * stride, width * 8);
+        for (u64 k = 0; k < per / 4; k++) {
+            const u64 *w = h.data() + (u64)q * stride + width + 4 * k;
+            U256 v = { { w[0], w[1], w[2], w[3] } };
+            v = h_from_mont(v);
+            memcpy(hostSiblings + (u64)q * per + 4 * k, v.w, 32);
+        }
+    }
+    *nLevels = L.levels;
     return PIL2GL_OK;
 }
 

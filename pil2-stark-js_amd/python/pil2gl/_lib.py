@@ -131,6 +131,7 @@ SIGNATURES = {
     "pil2gl_bn128_merkelize": (_I, [vp, _U64, _U64, _U32, _I, vp]),
     "pil2gl_bn128_merkelize_dev": (_I, [vp, _U64, _U64, _U32, _I, vp, vp]),
     "pil2gl_bn128_group_proof_dev": (_I, [vp, vp, _U64, _U64, _U32, _U64, vp, vp, vp]),
+    "pil2gl_bn128_group_proofs_dev": (_I, [vp, vp, _U64, _U64, _U32, vp, _U32, vp, vp, vp]),
     "pil2gl_bn128_convert": (_I, [vp, _U64, _I, vp]),
     "pil2gl_bn128_convert_dev": (_I, [vp, _U64, _I, vp, vp]),
     "pil2gl_selftest_field": (_I, [vp, vp, _U64, vp, vp, vp]),

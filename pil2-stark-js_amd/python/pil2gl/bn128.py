@@ -147,6 +147,24 @@ class MerkleHashBN128:
             offset += nxt * a; n = nxt; idx >>= nbits
         return v, mp
 
+    def getGroupProofs(self, tree, idxs):
+        """getGroupProof for a batch of rows of a device-resident tree in one launch (pil2gl_bn128_group_proofs_dev); host trees: one by one"""
+        idxs = [int(i) for i in idxs]
+        if not idxs or not _is_dev(tree["nodes"]):
+            return [self.getGroupProof(tree, i) for i in idxs]
+        width, height, a, n = tree["width"], tree["height"], self.arity, len(idxs)
+        if any(i < 0 or i >= height for i in idxs):
+            raise Pil2glError("Out of range")
+        ii = np.array(idxs, dtype=np.uint64)
+        vals = np.zeros((n, max(width, 1)), np.uint64); nl = C.c_uint32()
+        sib_flat = np.zeros(n * 40 * a * 4, np.uint64)
+        call("pil2gl_bn128_group_proofs_dev", _ptr(tree["elements"]), _ptr(tree["nodes"]), width, height, a, _ptr(ii), n,
+             _ptr(vals), _ptr(sib_flat), C.byref(nl))
+        lv = nl.value
+        v2 = vals.reshape(-1)[:n * width].reshape(n, width).tolist() if width else [[] for _ in range(n)]
+        s2 = sib_flat[:n * lv * a * 4].reshape(n, lv, a, 4)
+        return [(v2[q], [_ints(s2[q, l]) for l in range(lv)]) for q in range(n)]
+
     def calculateRootFromGroupProof(self, mp, idx, vals):
         value = self.lh.hash(vals)                              # merklehash_bn128_p.js:184-232
         nbits = (self.arity - 1).bit_length()

@@ -127,6 +127,11 @@ def test_merkle_tree_and_proofs(bn, orc, arity, custom, N, nPols, idx, tmp_path)
         assert MH.root(tree) == want[-1]
         v, mp = MH.getGroupProof(tree, idx)
         assert v == a[idx].tolist() and mp == orc.group_proof(want, N, arity, idx)
+        # the batch form (one launch per tree on the device): every row of a spread, repeats included, == the single openings
+        rows = sorted({0, idx, N - 1, N // 2, (7 * idx + 3) % N}) + [idx]
+        batch = MH.getGroupProofs(tree, rows)
+        assert [b[0] for b in batch] == [a[i].tolist() for i in rows]
+        assert [b[1] for b in batch] == [orc.group_proof(want, N, arity, i) for i in rows]
         if N > 1 and nPols != 4:
             assert MH.verifyGroupProof(MH.root(tree), mp, idx, v)
             bad = list(v); bad[0] ^= 1
@@ -137,6 +142,8 @@ def test_merkle_tree_and_proofs(bn, orc, arity, custom, N, nPols, idx, tmp_path)
     assert (t2["nodes"] == nodes).all() and (t2["elements"] == a.reshape(-1)).all()
     with pytest.raises(bn.Pil2glError):
         MH.getGroupProof(tree, N)
+    with pytest.raises(bn.Pil2glError):
+        MH.getGroupProofs(tree, [0, N])
 
 
 def test_reference_final_proof_through_gpu(bn):

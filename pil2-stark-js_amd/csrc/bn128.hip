@@ -431,6 +431,21 @@ __device__ __forceinline__ void lds_store(const St st, int j, const u32 x[8]) {
         for (int l = 0; l < 8; l++) hp[(j - BN_LDS_ELEMS) * 8 + l] = x[l];
     }
 }
+// An element kept in OPERAND form (the two v4i of bnm::b_prep: bytes signed, halves swapped between the wave's halves) in its usual slot: the y
+// of the partial rounds live so from the layer before them to the layer after them -- every rows' pass and column update then LOADS its operand
+// where it prepared it (twelve instructions per column and pass: 704 preparations per width-17 permutation become 160)
+__device__ __forceinline__ void lds_load_b(const St st, int j, bnm::v4i &b0, bnm::v4i &b1) {
+    u32 x[8];
+    lds_load(st, j, x);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { b0[q] = (int)x[q]; b1[q] = (int)x[4 + q]; }
+}
+__device__ __forceinline__ void lds_store_b(const St st, int j, const bnm::v4i &b0, const bnm::v4i &b1) {
+    u32 x[8];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { x[q] = (u32)b0[q]; x[4 + q] = (u32)b1[q]; }
+    lds_store(st, j, x);
+}
 // wave-uniform address.  WIDE: the tables live in global memory; saying so (the pointers reach the out-of-line helpers as
 // generic ones) turns the flat loads into global loads, whose counter is separate from the LDS one and in order, so that a
 // request for the next term can stay in flight across the current multiply
@@ -563,14 +578,18 @@ constexpr int MFMA_AHEAD = 8;
 #endif
 // SBOX: the NEXT round's S-box is applied to every finished row before it is stored (its constant came with the row): the separate S-box pass over
 // the state -- a load and a store of every element, seven of them in private memory -- disappears for that round.
-template <int N, bool SBOX = false>
+// STORE_B: the rows of elements 1.. are stored in operand form (the layer before the partial rounds); LOAD_B: the inputs are in that form (the layer after).
+template <int N, bool SBOX = false, bool STORE_B = false, bool LOAD_B = false>
 __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *tiles, const u32 *kc, int first) {
     bnm::v4i B0[N], B1[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
-        u32 x[8];
-        lds_load(st, first + j, x);
-        bnm::b_prep(x, B0[j], B1[j]);
+        if constexpr (LOAD_B) lds_load_b(st, first + j, B0[j], B1[j]);
+        else {
+            u32 x[8];
+            lds_load(st, first + j, x);
+            bnm::b_prep(x, B0[j], B1[j]);
+        }
     }
     const bnm::Sh sh = bnm::sh_init();
     bnm::gtile tp = (bnm::gtile)tiles + st.lane;
@@ -616,13 +635,15 @@ __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *til
         __builtin_amdgcn_sched_barrier(0); const unsigned long long tr2 = bn_now(); __builtin_amdgcn_sched_barrier(0);
         bnm::finish_words(w, k, o);
         if constexpr (SBOX) pow5_lazy(o);
-        lds_store(st, first + i, o);
+        if (STORE_B && first + i >= 1) { bnm::v4i ob0, ob1; bnm::b_prep(o, ob0, ob1); lds_store_b(st, first + i, ob0, ob1); }
+        else lds_store(st, first + i, o);
         __builtin_amdgcn_sched_barrier(0); const unsigned long long tr3 = bn_now(); __builtin_amdgcn_sched_barrier(0);
         sBurst += tr1 - tr0; sCarry += tr2 - tr1; sFinish += tr3 - tr2;
 #else
         bnm::finish_row(a0, a1, k, o, sh);
         if constexpr (SBOX) pow5_lazy(o);
-        lds_store(st, first + i, o);                 // the old state is in B0 / B1: the new row can go straight to its place
+        if (STORE_B && first + i >= 1) { bnm::v4i ob0, ob1; bnm::b_prep(o, ob0, ob1); lds_store_b(st, first + i, ob0, ob1); }
+        else lds_store(st, first + i, o);            // the old state is in B0 / B1: the new row can go straight to its place
 #endif
     }
 #ifdef BN_STAMPS
@@ -764,7 +785,8 @@ struct TileStream {
 // latency of every tile (round 5's form: 2 465 cycles per column of eight matrix instructions).  The upper columns are therefore fetched in ONE batch:
 // before the rows' pass as matrix operands (kept for both half-passes), before / after the column update as words.  The rows on y are taken two at
 // a time (two passes over the columns: four accumulators instead of eight leave the registers for the batch; the lower columns are read from LDS twice).
-template <int N>
+// BFORM: the y (elements 1..N) arrive, live and leave in operand form (lds_load_b): the fast path of the width-17 permutation.
+template <int N, bool BFORM = false>
 __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm::v4i *Pt, const u32 *KR, const u32 *KU, int rp) {
     constexpr int NLO = N + 1 <= BN_LDS_ELEMS ? N : BN_LDS_ELEMS - 1;     // columns j whose element 1 + j lives in LDS
     constexpr int NHI = N - NLO, NHA = NHI ? NHI : 1;
@@ -804,16 +826,22 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
 #pragma unroll
                         for (int l = 0; l < 8; l++) y[l] = yn[l];
                         if (j + 1 < NLO) lds_load(st, 2 + j, yn);         // the next column's words are on their way while this one's products run
-                        bnm::b_prep(y, b0, b1);
+                        if constexpr (BFORM) {
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; q4++) { b0[q4] = (int)y[q4]; b1[q4] = (int)y[4 + q4]; }
+                        } else bnm::b_prep(y, b0, b1);
                     } else {
                         const int q = j < NLO ? 0 : j - NLO;                  // (static after unrolling)
                         if (q % HB == 0) {
 #pragma unroll
                             for (int e = 0; e < HB; e++)
                                 if (q + e < NHI) {
-                                    u32 y[8];
-                                    lds_load(st, 1 + NLO + q + e, y);
-                                    bnm::b_prep(y, hb0[e], hb1[e]);
+                                    if constexpr (BFORM) lds_load_b(st, 1 + NLO + q + e, hb0[e], hb1[e]);
+                                    else {
+                                        u32 y[8];
+                                        lds_load(st, 1 + NLO + q + e, y);
+                                        bnm::b_prep(y, hb0[e], hb1[e]);
+                                    }
                                 }
                         }
                         b0 = hb0[q % HB]; b1 = hb1[q % HB];
@@ -901,7 +929,10 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
             u32 k[8];
             load_const<true>(KU, (size_t)sb * N + j, k);              // (asked for early: used after the products)
             bnm::v4i b0, b1;
-            bnm::b_prep(y, b0, b1);
+            if constexpr (BFORM) {
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) { b0[q4] = (int)y[q4]; b1[q4] = (int)y[4 + q4]; }
+            } else bnm::b_prep(y, b0, b1);
             BN_PRIO(BN_PRIO_MFMA);
             bnm::v4i a = ts.next();
             bnm::v16i c0, c1;
@@ -920,6 +951,12 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
             }
             BN_PRIO(0);
             bnm::finish_row(c0, c1, k, y, sh);
+            if constexpr (BFORM) {                                    // back to the form it is kept in
+                bnm::v4i nb0, nb1;
+                bnm::b_prep(y, nb0, nb1);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; q4++) { y[q4] = (u32)nb0[q4]; y[4 + q4] = (u32)nb1[q4]; }
+            }
         };
         if (halves == 1) {
 #pragma unroll
@@ -997,11 +1034,12 @@ __device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
         // out of the partial rounds, alone afterwards); only round 0's is a pass of its own.  Two copies of the wide layer (with / without the S-box).
         BN_STAMP(0, sbox_lazy_impl(st, 17, A.C8));
         for (int r = 0; r < 8; r++) {                                         // (one copy of each form of the layer)
-            if (r == 3 || r == 7) BN_STAMP(1, dense_mfma_impl<17>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0))
+            if (r == 3) BN_STAMP(1, (dense_mfma_impl<17, false, true>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0)))      // its rows 1..16: the partial rounds' y, in operand form
+            else if (r == 7) BN_STAMP(1, dense_mfma_impl<17>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0))
             else BN_STAMP(1, (dense_mfma_impl<17, true>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0)))
             if (r == 3) {
-                BN_STAMP(2, partial_rounds_mfma_impl<16>(st, A.Pt, A.KR, A.KU, A.rp));
-                BN_STAMP(1, (dense_mfma_impl<16, true>(st, A.Dt, A.DK, 1)));  // diag(1, Mh^RP), then round 4's S-box on elements 1..16
+                BN_STAMP(2, (partial_rounds_mfma_impl<16, true>(st, A.Pt, A.KR, A.KU, A.rp)));
+                BN_STAMP(1, (dense_mfma_impl<16, true, false, true>(st, A.Dt, A.DK, 1)));  // diag(1, Mh^RP) on the y as they are, then round 4's S-box on elements 1..16
                 u32 x[8]; lds_load(st, 0, x); pow5_lazy(x); lds_store(st, 0, x);
             }
         }

@@ -574,7 +574,7 @@ __device__ __noinline__ void dense_mul(const St st, int cur, const u32 *A, int n
 // alone -- so the table carries MFMA_AHEAD spare tiles after its last one.
 constexpr int MFMA_AHEAD = 8;
 #ifndef BN_DENSE_AHEAD_SBOX
-#define BN_DENSE_AHEAD_SBOX 4
+#define BN_DENSE_AHEAD_SBOX 6
 #endif
 // SBOX: the NEXT round's S-box is applied to every finished row before it is stored (its constant came with the row): the separate S-box pass over
 // the state -- a load and a store of every element, seven of them in private memory -- disappears for that round.
@@ -593,7 +593,7 @@ __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *til
     }
     const bnm::Sh sh = bnm::sh_init();
     bnm::gtile tp = (bnm::gtile)tiles + st.lane;
-    constexpr int AHEAD = SBOX ? BN_DENSE_AHEAD_SBOX : MFMA_AHEAD;      // (the S-box in the row loop needs the registers of half the ring)
+    constexpr int AHEAD = SBOX ? BN_DENSE_AHEAD_SBOX : MFMA_AHEAD;      // (the S-box in the row loop needs some of the ring's registers: 4 / 6 / 8 tiles 27.15 / 26.9 / 26.9 ms)
     bnm::v4i q[AHEAD];
     BN_SYNC();                                       // the workgroup's waves start the layer's tile stream together
 #pragma unroll

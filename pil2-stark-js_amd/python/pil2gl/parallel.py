@@ -803,8 +803,8 @@ def stark_gen_sharded(be, cm1_n, setup, info, exprs, publics, group=None, rehear
     q_ext = None if split_q else all_gather_rows(be, loc["q_ext"], nb, cc, qDim, comm)
     # computeQStark (stark_gen_helpers.js:168-208): the coefficients of q by cosets and row blocks (quotient_coefficients_sharded;
     # PIL2GL_Q_GATHER=1: all-gather q and transform it everywhere); the split quotient has degree < N per column, so its
-    # extension is again "one coset per rank": evaluations on the subgroup, then the unshifted coset extension of the own
-    # cosets, own leaves, exchanged digests
+    # extension is again "one coset per rank": the own cosets of the unshifted extension straight from the coefficients every rank
+    # holds (pil2gl_extend_coefs_brev_cosets_dev: no forward transform to the subgroup and back), own leaves, exchanged digests
     qname = "cm%d_ext" % qStage
     if split_q:                                                # the coefficients without gathering q (by cosets, then by row blocks),
         qq2 = quotient_coefficients_sharded(be, loc["q_ext"], nb, eb, cb, cc, qDim, qDeg, comm, brev=True)      # in the order the extension reads

@@ -478,13 +478,16 @@ def rehearse_shard(args):
     N = 1 << n_bits
     src = make_trace(N, n_cols, 0x5EED0000, dev)
     times = []
+    gc.collect(); gc.disable()                                 # (the cycle collector stays out of the measured passes, as in the main line)
     for i in range(args.warmup + args.steps):
+        gc.collect()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         st = parallel.extend_and_merkelize_sharded(be, src, n_cols, n_bits, n_bits + EXT_BITS, overwrite_src=True, rehearse_world=K, split_tree=not args.full_tree)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         if i >= args.warmup:
             times.append(dt)
         del st
+    gc.enable()
     dt = sum(times) / len(times)
     free, total = torch.cuda.mem_get_info()
     print(json.dumps({"metric": "per-GPU time of a %d-GPU coset-sharded commit (rank 0's share run alone; digests of the other ranks stood in)" % K,

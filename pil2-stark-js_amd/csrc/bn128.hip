@@ -34,6 +34,14 @@ using bn::u32;
 #ifndef BN_SBOX29
 #define BN_SBOX29 1
 #endif
+// State elements kept in LDS (the rest in private memory: "Where the state lives" below) and the batch in which the partial rounds fetch the others'
+// operands (partial_rounds_mfma_impl::rows): both shape the order of the tile stream the host writes (mfma_partial_tables).
+#ifndef BN_LDS_ELEMS
+#define BN_LDS_ELEMS 10
+#endif
+#ifndef BN_HI_BATCH
+#define BN_HI_BATCH 4
+#endif
 
 namespace {
 
@@ -276,8 +284,18 @@ void mfma_partial_tables(int t, int rp, const Vec &S, const Vec &V, const Vec &W
         for (int h = 0; h < halves; h++) {
             const int k0 = 4 * (2 * sb + h);
             U256 tot[4] = { zero, zero, zero, zero };
-            for (int pass = 0; pass < 2; pass++) {   // the kernel takes the rows two at a time (partial_rounds_mfma_n)
-                for (int j = 0; j < n; j++) for (int i = 2 * pass; i < 2 * pass + 2; i++, tp += 1024) mfma_tile(mc, V[(size_t)(k0 + i) * n + j], tp, tot[i], false);
+            // the kernel takes the rows two at a time (partial_rounds_mfma_impl::rows): the first pass walks the columns in order, the second starts with the last
+            // batch of the columns that live in private memory (still in its registers), then the first batch, then the columns in LDS
+            const int nlo = n + 1 <= BN_LDS_ELEMS ? n : BN_LDS_ELEMS - 1, nhi = n - nlo, hb2 = nhi < BN_HI_BATCH ? nhi : BN_HI_BATCH, spl = nhi - hb2;
+            for (int pass = 0; pass < 2; pass++) {
+                std::vector<int> order;
+                if (pass == 0) for (int j = 0; j < n; j++) order.push_back(j);
+                else {
+                    for (int q = spl; q < nhi; q++) order.push_back(nlo + q);
+                    for (int q = 0; q < spl; q++) order.push_back(nlo + q);
+                    for (int j = 0; j < nlo; j++) order.push_back(j);
+                }
+                for (int j : order) for (int i = 2 * pass; i < 2 * pass + 2; i++, tp += 1024) mfma_tile(mc, V[(size_t)(k0 + i) * n + j], tp, tot[i], false);
                 if (h == 1) for (int i = 2 * pass; i < 2 * pass + 2; i++) for (int s = 0; s < 4; s++, tp += 1024) mfma_tile(mc, dot(k0 + i, k0 - 4 + s), tp, tot[i], true);
             }
             for (int i = 0; i < 4; i++) {
@@ -394,9 +412,6 @@ struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 
 // traffic (the per-XCD working set of 256 waves' private state plus the tile table passes the 4 MB L2: it travels through the fabric,
 // and the card is power-limited): every phase touches it as few times as its registers allow, and never inside a loop that runs a
 // tile ring (partial_rounds_mfma_impl).  The element index is static wherever that matters.
-#ifndef BN_LDS_ELEMS
-#define BN_LDS_ELEMS 10
-#endif
 typedef u32 __attribute__((address_space(5))) *priv_u32;
 typedef u32 __attribute__((address_space(3))) *lds_u32;
 struct St { lds_u32 S; priv_u32 hi; int tmax, lane; };
@@ -738,9 +753,6 @@ __device__ __noinline__ void partial_rounds(const St st, int cur, const PermArgs
 // cross terms of row i (<= 4 pairs) added to the row's stored part, one short finish = the next x0.  Per super-block, once: the n columns
 // y_j + sum_k W z_k (1 + 8 pairs and one finish each -- the costliest phase, hence every eight rounds, not four).  No 32x32 product is left
 // but the S-box's.  The tiles are ONE linear stream in consumption order, read PR_AHEAD tiles ahead.
-#ifndef BN_HI_BATCH
-#define BN_HI_BATCH 4
-#endif
 #ifndef BN_KR_LATE
 #define BN_KR_LATE 0
 #endif
@@ -808,20 +820,47 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
             constexpr int H = decltype(Hc)::value;
             BN_SYNC();
             BN_PRIO(BN_PRIO_MFMA);
+            // The upper columns as operands, in at most two batches of private-memory elements fetched just before their columns (all seven kept through a
+            // pass do not fit beside the accumulators: hipcc spilled them, ~700 spill stores per wave).  The SECOND batch (columns SPL.., at most
+            // BN_HI_BATCH of them) is still in its registers when the second pass begins: that pass takes it first, re-reads only the first batch,
+            // and ends on the lower columns (mfma_partial_tables writes the tiles in this order).
+            constexpr int HB2 = NHI < BN_HI_BATCH ? NHI : BN_HI_BATCH, SPL = NHI - HB2, HBA = HB2 ? HB2 : 1;
+            static_assert(SPL <= HBA, "two batches of BN_HI_BATCH elements must cover the upper columns");
+            bnm::v4i hb0[HBA], hb1[HBA];
+            auto fetch = [&](int q0, int cnt) {
+#pragma unroll
+                for (int e = 0; e < HBA; e++)
+                    if (e < cnt) {
+                        if constexpr (BFORM) lds_load_b(st, 1 + NLO + q0 + e, hb0[e], hb1[e]);
+                        else {
+                            u32 y[8];
+                            lds_load(st, 1 + NLO + q0 + e, y);
+                            bnm::b_prep(y, hb0[e], hb1[e]);
+                        }
+                    }
+            };
 #pragma unroll
             for (int pass = 0; pass < 2; pass++) {
-                // the upper columns as operands: batches of at most BN_HI_BATCH private-memory elements, fetched just before their columns -- all seven
-                // kept across both passes (or even through one) do not fit beside the accumulators, and hipcc spills them: ~700 spill stores per wave
-                // of the leaf kernel, more than the state itself wrote (a spill is a store and a load where a second load does)
-                constexpr int HB = BN_HI_BATCH < NHA ? BN_HI_BATCH : NHA;
-                bnm::v4i hb0[HB], hb1[HB];
                 bnm::v16i P0[2], P1[2];
-                u32 yn[8];
-                if (NLO) lds_load(st, 1, yn);
+                bool first = true;
+                auto products = [&](const bnm::v4i &b0, const bnm::v4i &b1) {
 #pragma unroll
-                for (int j = 0; j < N; j++) {
-                    bnm::v4i b0, b1;
-                    if (j < NLO) {
+                    for (int r = 0; r < 2; r++) {
+                        const bnm::v4i a = ts.next();
+                        if (first) bnm::mfma_first(a, b0, b1, P0[r], P1[r]);
+                        else {
+                            P0[r] = bnm::mfma(a, b0, P0[r]);
+                            P1[r] = bnm::mfma(a, b1, P1[r]);
+                        }
+                    }
+                    first = false;
+                };
+                auto lower = [&]() {
+                    u32 yn[8];
+                    if (NLO) lds_load(st, 1, yn);
+#pragma unroll
+                    for (int j = 0; j < NLO; j++) {
+                        bnm::v4i b0, b1;
                         u32 y[8];
 #pragma unroll
                         for (int l = 0; l < 8; l++) y[l] = yn[l];
@@ -830,31 +869,22 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
 #pragma unroll
                             for (int q4 = 0; q4 < 4; q4++) { b0[q4] = (int)y[q4]; b1[q4] = (int)y[4 + q4]; }
                         } else bnm::b_prep(y, b0, b1);
-                    } else {
-                        const int q = j < NLO ? 0 : j - NLO;                  // (static after unrolling)
-                        if (q % HB == 0) {
-#pragma unroll
-                            for (int e = 0; e < HB; e++)
-                                if (q + e < NHI) {
-                                    if constexpr (BFORM) lds_load_b(st, 1 + NLO + q + e, hb0[e], hb1[e]);
-                                    else {
-                                        u32 y[8];
-                                        lds_load(st, 1 + NLO + q + e, y);
-                                        bnm::b_prep(y, hb0[e], hb1[e]);
-                                    }
-                                }
-                        }
-                        b0 = hb0[q % HB]; b1 = hb1[q % HB];
+                        products(b0, b1);
                     }
+                };
+                auto upper = [&](int q0, int cnt) {
 #pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        const bnm::v4i a = ts.next();
-                        if (j == 0) bnm::mfma_first(a, b0, b1, P0[r], P1[r]);
-                        else {
-                            P0[r] = bnm::mfma(a, b0, P0[r]);
-                            P1[r] = bnm::mfma(a, b1, P1[r]);
-                        }
-                    }
+                    for (int e = 0; e < HBA; e++)
+                        if (e < cnt) products(hb0[e], hb1[e]);
+                };
+                if (pass == 0) {
+                    lower();
+                    if (SPL) { fetch(0, SPL); upper(0, SPL); }
+                    if (HB2) { fetch(SPL, HB2); upper(SPL, HB2); }
+                } else {
+                    if (HB2) upper(SPL, HB2);                          // (in registers since the first pass)
+                    if (SPL) { fetch(0, SPL); upper(0, SPL); }
+                    lower();
                 }
                 if constexpr (H == 1) {                               // the rows of the second block see the first block's z through cross terms of their own
 #pragma unroll

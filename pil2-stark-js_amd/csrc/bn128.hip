@@ -808,6 +808,13 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
     BN_SYNC();
     ts.start(Pt, st.lane);
     // x0 (S[0] came with the row of the layer before) stays in its LDS slot outside the rounds: the rows' pass and the columns need the registers
+    // BFORM: the upper columns as the column update leaves them (operand form) stay in registers into the first rows' pass of the NEXT super-block
+    // (the update's own operands are dead by then): that pass reads no private memory at all
+    u32 yh[NHA][8];
+    if constexpr (BFORM) {
+#pragma unroll
+        for (int q = 0; q < NHI; q++) lds_load(st, 1 + NLO + q, yh[q]);
+    }
     for (int sb = 0; sb < nsb; sb++) {
         const int halves = nb - 2 * sb >= 2 ? 2 : 1;
         bnm::v4i zbA0[4], zbA1[4];                    // the first block's z operands, for the second block's rows and the column update
@@ -877,13 +884,30 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
                     for (int e = 0; e < HBA; e++)
                         if (e < cnt) products(hb0[e], hb1[e]);
                 };
+                auto carried = [&](int q0, int cnt) {                  // the upper columns the last column update left in registers
+#pragma unroll
+                    for (int q = 0; q < NHA; q++)
+                        if (q >= q0 && q < q0 + cnt) {
+                            bnm::v4i b0, b1;
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; q4++) { b0[q4] = (int)yh[q][q4]; b1[q4] = (int)yh[q][4 + q4]; }
+                            products(b0, b1);
+                        }
+                };
+                constexpr bool CARRIED = BFORM && H == 0;
                 if (pass == 0) {
                     lower();
-                    if (SPL) { fetch(0, SPL); upper(0, SPL); }
-                    if (HB2) { fetch(SPL, HB2); upper(SPL, HB2); }
+                    if constexpr (CARRIED) carried(0, NHI);
+                    else {
+                        if (SPL) { fetch(0, SPL); upper(0, SPL); }
+                        if (HB2) { fetch(SPL, HB2); upper(SPL, HB2); }
+                    }
                 } else {
-                    if (HB2) upper(SPL, HB2);                          // (in registers since the first pass)
-                    if (SPL) { fetch(0, SPL); upper(0, SPL); }
+                    if constexpr (CARRIED) { carried(SPL, HB2); carried(0, SPL); }
+                    else {
+                        if (HB2) upper(SPL, HB2);                      // (in registers since the first pass)
+                        if (SPL) { fetch(0, SPL); upper(0, SPL); }
+                    }
                     lower();
                 }
                 if constexpr (H == 1) {                               // the rows of the second block see the first block's z through cross terms of their own
@@ -901,13 +925,16 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
             }
             BN_PRIO(0);
         };
+#ifdef BN_STAMPS
+        unsigned long long tp0 = bn_now();
+#endif
+        rows(std::integral_constant<int, 0>{});          // (outside the loop over the blocks: the carried columns must not be live around its back edge)
         for (int h = 0; h < halves; h++) {
             const int b = 2 * sb + h;
+            if (h == 1) {
 #ifdef BN_STAMPS
-            unsigned long long tp0 = bn_now();
+                tp0 = bn_now();
 #endif
-            if (h == 0) rows(std::integral_constant<int, 0>{});
-            else {
 #pragma unroll
                 for (int s = 0; s < 4; s++) { zbA0[s] = zb0[s]; zbA1[s] = zb1[s]; }
                 rows(std::integral_constant<int, 1>{});
@@ -1006,8 +1033,7 @@ __device__ __forceinline__ void partial_rounds_mfma_impl(const St st, const bnm:
                 lds_store(st, 1 + j, y);
             }
         }
-        {
-            u32 yh[NHA][8];                                           // the upper columns: one batch in, one batch out
+        {                                                             // the upper columns: one batch in, one batch out (and kept: see above)
 #pragma unroll
             for (int q = 0; q < NHI; q++) lds_load(st, 1 + NLO + q, yh[q]);
 #pragma unroll

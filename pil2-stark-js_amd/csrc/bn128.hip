@@ -132,7 +132,8 @@ struct Grain {
 //   Mt / Dt   the same two dense layers as matrix-core operand tiles (bn_mfma.cuh), MK / DK their per-row constants;
 //   Pt        the tile stream of the blocked partial rounds, KR / KU its row constants (mfma_partial_tables)
 struct Params { int t = 0, rp = 0; u32 *base = nullptr, *C8, *M, *D, *S, *V, *W, *Cd; u32 m00[8];
-                const bnm::v4i *Mt = nullptr, *Dt = nullptr, *Pt = nullptr; const u32 *MK = nullptr, *DK = nullptr, *KR = nullptr, *KU = nullptr; };
+                const bnm::v4i *Mt = nullptr, *Dt = nullptr, *Pt = nullptr; const u32 *MK = nullptr, *DK = nullptr, *KR = nullptr, *KU = nullptr;
+                const bnm::v4i *Mt0 = nullptr; const u32 *MK0 = nullptr, *C0p = nullptr; };       // the first layer for inputs S-boxed as plain integers (plain_sbox_store)
 Params g_params[18];
 std::mutex g_mu;
 
@@ -226,8 +227,9 @@ struct MfmaConsts {
 };
 // one tile (1 KB, lane order) of the coefficient a0 (Montgomery form); tot += the sum of its 32 constants.  sboxed: the operand this tile
 // multiplies comes straight out of the S-box, i.e. (bn_field29.cuh) carries a factor 2^-20: the coefficient takes it back
-void mfma_tile(const MfmaConsts &mc, const U256 &a0, int8_t *tile, U256 &tot, bool sboxed) {
-    const U256 a = sboxed && BN_SBOX29 ? h_mont(a0, h_to_mont(U256{ { 1ull << 20, 0, 0, 0 } })) : a0;
+void mfma_tile(const MfmaConsts &mc, const U256 &a0, int8_t *tile, U256 &tot, bool sboxed, const U256 *extra = nullptr) {
+    U256 a = sboxed && BN_SBOX29 ? h_mont(a0, h_to_mont(U256{ { 1ull << 20, 0, 0, 0 } })) : a0;
+    if (extra) a = h_mont(a, *extra);                // (a further factor in Montgomery form: the plain-input first layer)
     for (int b = 0; b < 32; b++) {
         const U256 c = h_mont(a, mc.P[b]);           // a 2^(8b+32) mod r as a plain integer
         tot = h_addmod(tot, c);
@@ -252,14 +254,15 @@ U256 mfma_row_const(const MfmaConsts &mc, U256 tot, int nAcc, const U256 &fold) 
     return h_addmod(h_mont(tot, inv32), fold);
 }
 // A: rows x cols entries in Montgomery form.  tiles: rows*cols KB; K: rows plain integers mod r (callers add what follows the layer).
-void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &tiles, Vec &K, bool sboxed) {
+// colFactor: columns >= 1 carry this further factor (Montgomery form)
+void mfma_layer_tables(const Vec &A, int rows, int cols, std::vector<int8_t> &tiles, Vec &K, bool sboxed, const U256 *colFactor = nullptr) {
     const MfmaConsts mc;
     const U256 zero = { { 0, 0, 0, 0 } };
     tiles.assign((size_t)rows * cols * 1024, 0);
     K.resize((size_t)rows);
     for (int i = 0; i < rows; i++) {
         U256 tot = zero;
-        for (int j = 0; j < cols; j++) mfma_tile(mc, A[(size_t)i * cols + j], tiles.data() + ((size_t)i * cols + j) * 1024, tot, sboxed);
+        for (int j = 0; j < cols; j++) mfma_tile(mc, A[(size_t)i * cols + j], tiles.data() + ((size_t)i * cols + j) * 1024, tot, sboxed, j >= 1 ? colFactor : nullptr);
         K[i] = mfma_row_const(mc, tot, 1, zero);
     }
 }
@@ -336,8 +339,19 @@ int get_params(int t, const Params **out) {
         P.base = d; P.C8 = d + oC8 * 8; P.M = d + oM * 8; P.D = d + oD * 8; P.S = d + oS * 8; P.V = d + oV * 8; P.W = d + oW * 8; P.Cd = d + oCd * 8;
         memcpy(P.m00, M[0].w, 32);
         {
-            std::vector<int8_t> tm, td, tpr; Vec km0, km, kd, kr, ku;
+            std::vector<int8_t> tm, td, tpr, tm0; Vec km0, km, kd, kr, ku, km0p, c0p;
             mfma_layer_tables(M, t, t, tm, km0, true);     // every dense layer follows an S-box layer
+            // The first layer once more for inputs that went through the S-box as PLAIN integers (leaf kernel: v + c instead of (v + c) 2^256 mod r,
+            // no conversion product): bn29::pow5 then returns the state form's value times 2^-1280 (five missing factors 2^256), which columns 1..t-1 of
+            // this copy take back.  c0p: the first round's constants as plain integers.
+            {
+                U256 f = { { 1, 0, 0, 0 } };
+                for (int e = 0; e < 1280; e++) f = h_addmod(f, f);
+                const U256 fm = h_to_mont(f);
+                mfma_layer_tables(M, t, t, tm0, km0p, true, &fm);
+                c0p.resize((size_t)t);
+                for (int i = 0; i < t; i++) c0p[i] = h_mont(C8[i], U256{ { 1, 0, 0, 0 } });
+            }
             mfma_layer_tables(D, n, n, td, kd, false);    // the closing layer reads the columns the blocks left
             mfma_partial_tables(t, rp, S, V, W, M[0], tpr, kr, ku);
             // What follows a layer is added by its row constants (the values in between are lazy representatives, no other addition
@@ -353,22 +367,26 @@ int get_params(int t, const Params **out) {
                 else if (inst < 7) f = C8[(size_t)(inst + 1) * t + i];
                 km[(size_t)inst * t + i] = h_addmod(km0[i], f);
             }
+            for (int i = 0; i < t; i++) km0p[i] = h_addmod(km0p[i], C8[(size_t)t + i]);      // (used without PIL2GL_BN128_NOFOLD only)
             if (!nofold) for (int i = 0; i < n; i++) kd[i] = h_addmod(kd[i], C8[(size_t)4 * t + 1 + i]);
             if (!nofold && rp % 4 == 0 && rp >= 4) kr[(size_t)rp - 1] = h_addmod(kr[(size_t)rp - 1], C8[(size_t)4 * t]);
             const size_t spare = 16 * 1024;          // the tiles the read-ahead touches past the end of a table (MFMA_AHEAD)
             int8_t *dt = nullptr; u32 *dk = nullptr;
-            HIP_TRY(hipMalloc((void **)&dt, tm.size() + td.size() + tpr.size() + 3 * spare));
-            HIP_TRY(hipMemset(dt, 0, tm.size() + td.size() + tpr.size() + 3 * spare));
+            HIP_TRY(hipMalloc((void **)&dt, tm.size() + td.size() + tpr.size() + tm0.size() + 4 * spare));
+            HIP_TRY(hipMemset(dt, 0, tm.size() + td.size() + tpr.size() + tm0.size() + 4 * spare));
+            HIP_TRY(hipMemcpy(dt + tm.size() + td.size() + tpr.size() + 3 * spare, tm0.data(), tm0.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(dt, tm.data(), tm.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(dt + tm.size() + spare, td.data(), td.size(), hipMemcpyHostToDevice));
             if (!tpr.empty()) HIP_TRY(hipMemcpy(dt + tm.size() + td.size() + 2 * spare, tpr.data(), tpr.size(), hipMemcpyHostToDevice));
             Vec kall;
             kall.insert(kall.end(), km.begin(), km.end()); kall.insert(kall.end(), kd.begin(), kd.end());
             kall.insert(kall.end(), kr.begin(), kr.end()); kall.insert(kall.end(), ku.begin(), ku.end());
+            kall.insert(kall.end(), km0p.begin(), km0p.end()); kall.insert(kall.end(), c0p.begin(), c0p.end());
             HIP_TRY(hipMalloc((void **)&dk, kall.size() * 32));
             HIP_TRY(hipMemcpy(dk, kall.data(), kall.size() * 32, hipMemcpyHostToDevice));
             P.Mt = (const bnm::v4i *)dt; P.Dt = (const bnm::v4i *)(dt + tm.size() + spare); P.Pt = (const bnm::v4i *)(dt + tm.size() + td.size() + 2 * spare);
             P.MK = dk; P.DK = dk + km.size() * 8; P.KR = P.DK + kd.size() * 8; P.KU = P.KR + kr.size() * 8;
+            P.Mt0 = (const bnm::v4i *)(dt + tm.size() + td.size() + tpr.size() + 3 * spare); P.MK0 = P.KU + ku.size() * 8; P.C0p = P.MK0 + km0p.size() * 8;
         }
         P.rp = rp; P.t = t;
     }
@@ -403,7 +421,8 @@ __device__ __forceinline__ unsigned long long bn_now() {
 #define BN_PRIO(n)
 #endif
 struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8];
-                  const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma, nofold; };
+                  const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma, nofold;
+                  const bnm::v4i *Mt0; const u32 *MK0, *C0p; int plain; };      // plain: elements 1..t-1 arrive S-boxed from the absorb (leaf kernel, width 17)
 
 // Where the state lives.  Elements [0, BN_LDS_ELEMS) in LDS as [element][limb][lane]; the elements above -- only the states
 // wider than BN_LDS_ELEMS have any: t = 11..17 -- in the lane's own private (scratch) memory, which the hardware swizzles so
@@ -1088,11 +1107,16 @@ __device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
         // and the closing layer sit at the top of the fifth full round (rp = 68 = 17 blocks of four, nothing left over).
         // The S-boxes of rounds 1-3 and 5-7 ride on the rows of the layer before them, round 4's on the closing layer's rows (its element 0, which comes
         // out of the partial rounds, alone afterwards); only round 0's is a pass of its own.  Two copies of the wide layer (with / without the S-box).
-        BN_STAMP(0, sbox_lazy_impl(st, 17, A.C8));
+        // A.plain (leaf kernel): elements 1..16 went through round 0's S-box where they were absorbed, as plain integers (plain_sbox_store): only element 0 is left,
+        // and the first layer reads its own copy of the tiles
+        if (A.plain) { u32 x[8], c[8]; lds_load(st, 0, x); load_const<true>(A.C8, 0, c); add_lazy(x, c); pow5_lazy(x); lds_store(st, 0, x); }
+        else BN_STAMP(0, sbox_lazy_impl(st, 17, A.C8));
         for (int r = 0; r < 8; r++) {                                         // (one copy of each form of the layer)
-            if (r == 3) BN_STAMP(1, (dense_mfma_impl<17, false, true>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0)))      // its rows 1..16: the partial rounds' y, in operand form
-            else if (r == 7) BN_STAMP(1, dense_mfma_impl<17>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0))
-            else BN_STAMP(1, (dense_mfma_impl<17, true>(st, A.Mt, A.MK + (size_t)r * 17 * 8, 0)))
+            const bnm::v4i *Mt = r == 0 && A.plain ? A.Mt0 : A.Mt;
+            const u32 *MK = r == 0 && A.plain ? A.MK0 : A.MK + (size_t)r * 17 * 8;
+            if (r == 3) BN_STAMP(1, (dense_mfma_impl<17, false, true>(st, Mt, MK, 0)))      // its rows 1..16: the partial rounds' y, in operand form
+            else if (r == 7) BN_STAMP(1, dense_mfma_impl<17>(st, Mt, MK, 0))
+            else BN_STAMP(1, (dense_mfma_impl<17, true>(st, Mt, MK, 0)))
             if (r == 3) {
                 BN_STAMP(2, (partial_rounds_mfma_impl<16, true>(st, A.Pt, A.KR, A.KU, A.rp)));
                 BN_STAMP(1, (dense_mfma_impl<16, true, false, true>(st, A.Dt, A.DK, 1)));  // diag(1, Mh^RP) on the y as they are, then round 4's S-box on elements 1..16
@@ -1150,6 +1174,17 @@ __device__ __forceinline__ void to_mont_store(const St st, int j, const u64 w[4]
     bn::fr_mul(o, x, r2);                            // frm_toMontgomery: x * 2^256 mod r (x < 2^256)
     lds_store(st, j, o);
 }
+// the same input for a permutation with A.plain: round 0's S-box on the PLAIN integer x + c (c = the round constant as a plain integer; x < 2^192: no reduction,
+// no conversion product); bn29::pow5's result is then 2^-1280 times what the state's form would give, which the first layer's own tiles take back
+__device__ __forceinline__ void plain_sbox_store(const St st, int j, const u64 w[4], const u32 *C0p) {
+    u32 x[8], c[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { x[2 * k] = (u32)w[k]; x[2 * k + 1] = (u32)(w[k] >> 32); }
+    load_const<true>(C0p, (size_t)j, c);
+    bnm::add_chain8(x, c);
+    pow5_lazy(x);
+    lds_store(st, j, x);
+}
 __device__ __forceinline__ void zero_store(const St st, int j) {
     const u32 z[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     lds_store(st, j, z);
@@ -1187,14 +1222,17 @@ __global__ void __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu
         u64 e = 0;
         while (e < nEl) {
             const u64 n = nEl - e < (u64)arity ? nEl - e : (u64)arity;
+            const bool plain = full.plain && (n == (u64)arity || custom);      // the chunk goes to `full`, whose first S-box rides on the absorb
             for (u64 k = 0; k < n; k++) {
                 u64 w[4] = { 0, 0, 0, 0 };
                 for (int q = 0; q < 3; q++) { const u64 idx = 3 * (e + k) + q; if (idx < width) w[q] = v[idx]; }
-                to_mont_store(st, 1 + (int)k, w);
+                if (plain) plain_sbox_store(st, 1 + (int)k, w, full.C0p);
+                else to_mont_store(st, 1 + (int)k, w);
             }
             if (n == (u64)arity) cur = bn_perm<WIDE>(st, cur, full);
             else if (custom) {                       // :87-93: zero-pad the last chunk to `arity` inputs
-                for (u64 k = n; k < (u64)arity; k++) zero_store(st, 1 + (int)k);
+                const u64 z[4] = { 0, 0, 0, 0 };
+                for (u64 k = n; k < (u64)arity; k++) { if (plain) plain_sbox_store(st, 1 + (int)k, z, full.C0p); else zero_store(st, 1 + (int)k); }
                 cur = bn_perm<WIDE>(st, cur, full);
             } else cur = bn_perm<WIDE>(st, cur, last);      // :85-86: t = nLast + 1
             e += n;
@@ -1382,7 +1420,7 @@ size_t lds_bytes(int tmax) {                         // the elements above BN_LD
     return (size_t)lds_words(tmax) * 4 * BN_WG_WAVES + pad;
 }
 
-PermArgs perm_args(const Params *P) {
+PermArgs perm_args(const Params *P, bool plainInputs = false) {
     PermArgs a;
     a.C8 = P->C8; a.M = P->M; a.D = P->D; a.S = P->S; a.V = P->V; a.W = P->W; a.Cd = P->Cd; a.t = P->t; a.rp = P->rp;
     static const bool dense = getenv("PIL2GL_BN128_DENSE") && atoi(getenv("PIL2GL_BN128_DENSE"));
@@ -1393,6 +1431,9 @@ PermArgs perm_args(const Params *P) {
     a.nofold = nofold ? 1 : 0;
     a.Mt = P->Mt; a.Dt = P->Dt; a.Pt = P->Pt; a.MK = P->MK; a.DK = P->DK; a.KR = P->KR; a.KU = P->KU;
     memcpy(a.m00, P->m00, 32);
+    a.Mt0 = P->Mt0; a.MK0 = P->MK0; a.C0p = P->C0p;
+    static const bool noplain = getenv("PIL2GL_BN128_PLAIN") && !atoi(getenv("PIL2GL_BN128_PLAIN"));   // =0: inputs converted and S-boxed by the permutation (A/B runs)
+    a.plain = plainInputs && !noplain && a.mfma && !a.nofold && !a.dense && BN_SBOX29 && P->t == 17 ? 1 : 0;
     return a;
 }
 
@@ -1457,10 +1498,10 @@ int pil2gl_bn128_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
     if (wide_state((int)arity + 1)) {
         P2_TRY(set_lds_attr(bn_linear_hash_kernel<true>, lds));
-        bn_linear_hash_kernel<true><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
+        bn_linear_hash_kernel<true><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf, true), perm_args(pl), out);
     } else {
         P2_TRY(set_lds_attr(bn_linear_hash_kernel<false>, lds));
-        bn_linear_hash_kernel<false><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf), perm_args(pl), out);
+        bn_linear_hash_kernel<false><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf, true), perm_args(pl), out);
     }
     KERNEL_CHECK();
     return PIL2GL_OK;

@@ -280,6 +280,57 @@ def clock_under_hash_load():
         return None
 
 
+class BoardPower:
+    """board power (W) while the timed steps run: a thread reads the cards' hwmon power1_input every 50 ms (tools/power_probe.py, tools/energy_probe.hip;
+    DESIGN.md 6 and 10: the Poseidon kernels run at the power cap, and their time follows joules, not stalls).  The sensor with the largest mean is the
+    card under load.  Reported beside the line, never part of `value`; None when no sensor is readable."""
+
+    def __init__(self):
+        import glob
+        self.files = sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_input")) or sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*/power1_average"))
+        self.samples = [[] for _ in self.files]
+        self.stop = False
+        self.thread = None
+
+    def _run(self):
+        while not self.stop:
+            for k, f in enumerate(self.files):
+                try:
+                    with open(f) as fh:
+                        self.samples[k].append(int(fh.read().strip()) / 1e6)
+                except Exception:
+                    pass
+            time.sleep(0.05)
+
+    def start(self):
+        if self.files:
+            import threading
+            self.thread = threading.Thread(target=self._run, daemon=True)
+            self.thread.start()
+        return self
+
+    def finish(self):
+        if self.thread is None:
+            return None
+        self.stop = True
+        self.thread.join(timeout=2)
+        best = None
+        for k, v in enumerate(self.samples):
+            if len(v) >= 4 and (best is None or sum(v) / len(v) > sum(self.samples[best]) / len(self.samples[best])):
+                best = k
+        if best is None:
+            return None
+        v = sorted(self.samples[best])
+        cap = None
+        try:
+            with open(os.path.join(os.path.dirname(self.files[best]), "power1_cap")) as fh:
+                cap = int(fh.read().strip()) / 1e6
+        except Exception:
+            pass
+        return {"W_median": round(v[len(v) // 2], 1), "W_p5": round(v[len(v) // 20], 1), "W_p95": round(v[(len(v) * 19) // 20], 1), "cap_W": cap, "samples": len(v),
+                "what": "hwmon power1_input of the card under load, sampled every 50 ms over the timed steps"}
+
+
 def pmc_file():
     for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "pmc_traffic.json"):
         if os.path.exists(os.path.join(ROOT, "profiles", name)):
@@ -694,10 +745,12 @@ def bn128_commit_line(dev, n_bits, n_cols, steps, warmup):
         return MH.merkelize(dst, n_cols, E)
     for _ in range(warmup):
         step()
+    power = BoardPower().start() if os.environ.get("PIL2GL_BENCH_POWER", "1") != "0" else None
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(steps):
         tree = step()
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    board_power = power.finish() if power is not None else None
     t_lde = ev_time(lambda: pil2gl.interpolate(src, n_cols, n_bits, dst, n_bits + EXT_BITS), 1)
     t_tree = ev_time(lambda: MH.merkelize(dst, n_cols, E), 1)
     n_el = (n_cols + 2) // 3
@@ -729,6 +782,8 @@ def bn128_commit_line(dev, n_bits, n_cols, steps, warmup):
            "kernels": [{"kernel": "BN128 merkelize (leaf hash + tree)", "ms": t_tree, "perms": leaf_perms + tree_perms, "Mperm_s": (leaf_perms + tree_perms) / t_tree / 1e3},
                        {"kernel": "interpolate", "ms": t_lde, "alg_bytes": 8 * N * n_cols * (1 + (1 << EXT_BITS)), "GBps": 8 * N * n_cols * 9 / t_lde / 1e6}],
            "root": hex(MH.root(tree))}
+    if board_power is not None:
+        out["board_power"] = board_power
     return out
 
 
@@ -820,7 +875,8 @@ def other_configs(dev, be, main_wl, main_split):
             o = bn128_commit_line(dev, 24, 100, 1, 0)
             t = o["kernels"][0]
             return {"workload": o["config"]["workload"], "ms_per_commit": round(o["ms_per_step"], 1), "tree_ms": round(t["ms"], 1), "Mperm_s": round(t["Mperm_s"], 2),
-                    "roofline_int_issue": round(o["roofline_int_issue"]["frac"], 4), "root": o["root"], "cells_per_s": o["value"]}
+                    "roofline_int_issue": round(o["roofline_int_issue"]["frac"], 4), "root": o["root"], "cells_per_s": o["value"],
+                    "board_power_W_median": (o.get("board_power") or {}).get("W_median")}
         guarded("config4_bn128_commit", c4)
     else:
         res["skipped"] = "configs 3 (split) and 4 need 170 GB free on the GPU (%.0f GB are)" % (free / 1e9)
@@ -988,6 +1044,7 @@ def main():
     gc.collect(); gc.disable()
     if comm is not None:
         comm.reset_stats()
+    power = BoardPower().start() if rank == 0 and os.environ.get("PIL2GL_BENCH_POWER", "1") != "0" else None
     barrier()
     t0 = time.perf_counter()
     step_marks = []
@@ -999,6 +1056,7 @@ def main():
     mark("timed region done")
     dt = time.perf_counter() - t0
     gc.enable()
+    board_power = power.finish() if power is not None else None
     step_ms = [round((b - a) * 1e3, 2) for a, b in zip([t0] + step_marks[:-1], step_marks)]
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
@@ -1113,6 +1171,8 @@ def main():
             "roofline_int_issue_lde": lde_int_roofline(n_bits, n_cols, cc, kernels[1]["ms"]),
             "kernels": kernels,
         }
+        if board_power is not None:
+            out["board_power"] = board_power
         if t_leaf_other is not None:
             out["leaf_plain_ms" if args.split else "leaf_split_ms"] = t_leaf_other
         if dist is not None:

@@ -28,7 +28,7 @@ __device__ __forceinline__ void sponge(const u64 *__restrict__ v, u32 width, u64
         const u32 n = min(8u, width - i);
 #pragma unroll
         for (u32 j = 0; j < 8; j++) st[j] = j < n ? v[i + j] : 0;
-        poseidon_perm<0>(st, m);                    // lazy: only the digest is canonicalised, below
+        poseidon_perm<0, 4>(st, m);                 // lazy: only the digest is canonicalised, below; four outputs are read
         st[8] = st[0]; st[9] = st[1]; st[10] = st[2]; st[11] = st[3];
     }
     digest[0] = canon(st[8]); digest[1] = canon(st[9]); digest[2] = canon(st[10]); digest[3] = canon(st[11]);
@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(SPLIT_BLOCK, 4) linear_hash_split_kernel(const
                     st[8 + j] = b >= 2 ? park[4 + j][tid] : 0;
                 }
             }
-            poseidon_perm<0>(st, m);
+            poseidon_perm<0, 4>(st, m);
             st[8] = st[0]; st[9] = st[1]; st[10] = st[2]; st[11] = st[3];
         }
         if (!closes) {                                                          // an even batch with a partner to come: its digest waits in LDS
@@ -127,7 +127,7 @@ __global__ void __launch_bounds__(256, 4) merkle_level_kernel(const u64 *__restr
 #pragma unroll
     for (int j = 0; j < 8; j++) st[j] = in[8 * i + j];
     st[8] = st[9] = st[10] = st[11] = 0;
-    poseidon_perm<4>(st, m);
+    poseidon_perm<4, 4>(st, m);
     if (!live) return;
     u64 *o = out + 4 * i;
     o[0] = st[0]; o[1] = st[1]; o[2] = st[2]; o[3] = st[3];

@@ -115,7 +115,10 @@ __device__ __forceinline__ u64 blk_combine_exact(u64 X, u64 Y) {
 // layer).  Same values as mds_layer_mfma(), which keeps its operands in registers.
 // lc (biased form only): the twelve addends of whatever S-boxes come next (POSEIDON_BLK_LC), added here as two 64-bit additions
 // on X and Y -- inside the S-box the same addition is an add, an add of 2^32-1, a compare and two selects.
-template <bool EXACT>
+// NSETS: how many of the three row sets (outputs 0-3, 4-7, 8-11) are computed: a sponge and a tree node keep only the first four outputs of a
+// permutation (linearhash.js:29-40, glwasm.js:1220-1254), so its LAST layer needs one set -- six matrix instructions and four recombinations
+// instead of eighteen and twelve; outputs 4 * NSETS .. 11 are left as they were.
+template <bool EXACT, int NSETS = 3>
 __device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m, const u64 *__restrict__ lc = nullptr) {
     const v4i *__restrict__ A = m.blkA + POSEIDON_BLK_LAYER_OPERAND * 64;
     v4i Bl[3], Bh[3];
@@ -129,7 +132,7 @@ __device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m, cons
     const v4i a0 = A[0], a1 = A[64], a2 = A[128], a00 = A[192];
     u64 cm[12], any = 0;
 #pragma unroll
-    for (int s = 0; s < 3; s++) {
+    for (int s = 0; s < NSETS; s++) {
         v16i L, H;
         // row set s multiplies K group t by the circulant's block (t - s) mod 3; row 0's own block carries the diagonal's 8
         const v4i r0 = s == 0 ? a00 : (s == 1 ? a2 : a1), r1 = s == 0 ? a1 : (s == 1 ? a0 : a2), r2 = s == 0 ? a2 : (s == 1 ? a1 : a0);
@@ -167,7 +170,7 @@ __device__ __forceinline__ void mds_layer_lds(u64 st[12], const MdsMfma &m, cons
     }
     if (__builtin_expect(any != 0, 0)) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
+        for (int i = 0; i < 4 * NSETS; i++) {
             u32 e;
             asm("s_nop 1\n\tv_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(e) : "s"(cm[i]));
             st[i] += e;

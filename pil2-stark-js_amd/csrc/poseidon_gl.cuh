@@ -101,8 +101,11 @@ namespace gl {
 // Rounds 4..25 run four to a linear layer (poseidon_blocks.cuh), every layer but the last on biased accumulators whose
 // constants the generator folded into POSEIDON_BLK_RCF / POSEIDON_BLK_C0; `m` comes from poseidon_init().
 // (forced inline: an outlined permutation passes its state through scratch, at a fifth of the rate)
-template <int NCANON = 12>
+// NOUT: how many leading outputs the caller reads (4: sponges and tree nodes -- the last layer then computes one row set; st[4..11] are stale afterwards)
+template <int NCANON = 12, int NOUT = 12>
 __device__ __forceinline__ void poseidon_perm(u64 st[12], const MdsMfma &m) {
+    static_assert(NOUT == 4 || NOUT == 8 || NOUT == 12, "row sets of four outputs");
+    static_assert(NCANON <= NOUT, "canonical outputs must be computed ones");
     const v4i *__restrict__ A = m.blkA;
     // every S-box's addend but round 0's is added by the layer (or block) before it: POSEIDON_BLK_LC[k] = what layer k adds
 #pragma unroll
@@ -125,7 +128,11 @@ __device__ __forceinline__ void poseidon_perm(u64 st[12], const MdsMfma &m) {
         mds_layer_lds<false>(st, m, &POSEIDON_BLK_LC[(r + 2) * 12]);
     }
     sbox_full(st, nullptr);
-    mds_layer_lds<true>(st, m);
+#ifdef PIL2GL_LAST_LAYER_FULL
+    mds_layer_lds<true, 3>(st, m);                  // (A/B builds: every permutation's last layer whole)
+#else
+    mds_layer_lds<true, NOUT / 4>(st, m);
+#endif
 #pragma unroll
     for (int i = 0; i < NCANON; i++) st[i] = canon(st[i]);
 }

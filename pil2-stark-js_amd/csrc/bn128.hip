@@ -422,7 +422,8 @@ __device__ __forceinline__ unsigned long long bn_now() {
 #endif
 struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8];
                   const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma, nofold;
-                  const bnm::v4i *Mt0; const u32 *MK0, *C0p; int plain; };      // plain: elements 1..t-1 arrive S-boxed from the absorb (leaf kernel, width 17)
+                  const bnm::v4i *Mt0; const u32 *MK0, *C0p; int plain;
+                  int nout1; };      // nout1: the caller reads element 0 of the result only (sponges, tree nodes): the last layer computes ONE row      // plain: elements 1..t-1 arrive S-boxed from the absorb (leaf kernel, width 17)
 
 // Where the state lives.  Elements [0, BN_LDS_ELEMS) in LDS as [element][limb][lane]; the elements above -- only the states
 // wider than BN_LDS_ELEMS have any: t = 11..17 -- in the lane's own private (scratch) memory, which the hardware swizzles so
@@ -613,8 +614,9 @@ constexpr int MFMA_AHEAD = 8;
 // SBOX: the NEXT round's S-box is applied to every finished row before it is stored (its constant came with the row): the separate S-box pass over
 // the state -- a load and a store of every element, seven of them in private memory -- disappears for that round.
 // STORE_B: the rows of elements 1.. are stored in operand form (the layer before the partial rounds); LOAD_B: the inputs are in that form (the layer after).
+// nrows: the leading rows that are computed (the permutation's last layer when only element 0 of the result is read: one of N)
 template <int N, bool SBOX = false, bool STORE_B = false, bool LOAD_B = false>
-__device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *tiles, const u32 *kc, int first) {
+__device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *tiles, const u32 *kc, int first, int nrows = N) {
     bnm::v4i B0[N], B1[N];
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -635,7 +637,7 @@ __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *til
 #ifdef BN_STAMPS
     unsigned long long sBurst = 0, sCarry = 0, sFinish = 0;
 #endif
-    for (int i = 0; i < N; i++) {
+    for (int i = 0; i < nrows; i++) {
         u32 k[8], o[8];
 #ifdef BN_STAMPS
         __builtin_amdgcn_sched_barrier(0); const unsigned long long tr0 = bn_now(); __builtin_amdgcn_sched_barrier(0);
@@ -681,33 +683,33 @@ __device__ __forceinline__ void dense_mfma_impl(const St st, const bnm::v4i *til
 #endif
     }
 #ifdef BN_STAMPS
-    if (st.lane == 0) { atomicAdd(&g_bn_stamps[13], sBurst); atomicAdd(&g_bn_stamps[14], sCarry); atomicAdd(&g_bn_stamps[15], sFinish); atomicAdd(&g_bn_stamps[6], (unsigned long long)N); }
+    if (st.lane == 0) { atomicAdd(&g_bn_stamps[13], sBurst); atomicAdd(&g_bn_stamps[14], sCarry); atomicAdd(&g_bn_stamps[15], sFinish); atomicAdd(&g_bn_stamps[6], (unsigned long long)nrows); }
 #endif
 }
 template <int N>
-__device__ __noinline__ void dense_mfma_n(const St st, const bnm::v4i *tiles, const u32 *kc, int first) { dense_mfma_impl<N>(st, tiles, kc, first); }
-__device__ __forceinline__ void dense_mfma(const St st, const bnm::v4i *tiles, const u32 *kc, int n, int first) {
+__device__ __noinline__ void dense_mfma_n(const St st, const bnm::v4i *tiles, const u32 *kc, int first, int nrows) { dense_mfma_impl<N>(st, tiles, kc, first, nrows < N ? nrows : N); }
+__device__ __forceinline__ void dense_mfma(const St st, const bnm::v4i *tiles, const u32 *kc, int n, int first, int nrows = 17) {
 #ifdef BN_ABLATE_DENSE
     return;                                          // timing experiments only: the layer left out, results meaningless
 #endif
     switch (n) {
-    case 1: dense_mfma_n<1>(st, tiles, kc, first); break;
-    case 2: dense_mfma_n<2>(st, tiles, kc, first); break;
-    case 3: dense_mfma_n<3>(st, tiles, kc, first); break;
-    case 4: dense_mfma_n<4>(st, tiles, kc, first); break;
-    case 5: dense_mfma_n<5>(st, tiles, kc, first); break;
-    case 6: dense_mfma_n<6>(st, tiles, kc, first); break;
-    case 7: dense_mfma_n<7>(st, tiles, kc, first); break;
-    case 8: dense_mfma_n<8>(st, tiles, kc, first); break;
-    case 9: dense_mfma_n<9>(st, tiles, kc, first); break;
-    case 10: dense_mfma_n<10>(st, tiles, kc, first); break;
-    case 11: dense_mfma_n<11>(st, tiles, kc, first); break;
-    case 12: dense_mfma_n<12>(st, tiles, kc, first); break;
-    case 13: dense_mfma_n<13>(st, tiles, kc, first); break;
-    case 14: dense_mfma_n<14>(st, tiles, kc, first); break;
-    case 15: dense_mfma_n<15>(st, tiles, kc, first); break;
-    case 16: dense_mfma_n<16>(st, tiles, kc, first); break;
-    default: dense_mfma_n<17>(st, tiles, kc, first); break;
+    case 1: dense_mfma_n<1>(st, tiles, kc, first, nrows); break;
+    case 2: dense_mfma_n<2>(st, tiles, kc, first, nrows); break;
+    case 3: dense_mfma_n<3>(st, tiles, kc, first, nrows); break;
+    case 4: dense_mfma_n<4>(st, tiles, kc, first, nrows); break;
+    case 5: dense_mfma_n<5>(st, tiles, kc, first, nrows); break;
+    case 6: dense_mfma_n<6>(st, tiles, kc, first, nrows); break;
+    case 7: dense_mfma_n<7>(st, tiles, kc, first, nrows); break;
+    case 8: dense_mfma_n<8>(st, tiles, kc, first, nrows); break;
+    case 9: dense_mfma_n<9>(st, tiles, kc, first, nrows); break;
+    case 10: dense_mfma_n<10>(st, tiles, kc, first, nrows); break;
+    case 11: dense_mfma_n<11>(st, tiles, kc, first, nrows); break;
+    case 12: dense_mfma_n<12>(st, tiles, kc, first, nrows); break;
+    case 13: dense_mfma_n<13>(st, tiles, kc, first, nrows); break;
+    case 14: dense_mfma_n<14>(st, tiles, kc, first, nrows); break;
+    case 15: dense_mfma_n<15>(st, tiles, kc, first, nrows); break;
+    case 16: dense_mfma_n<16>(st, tiles, kc, first, nrows); break;
+    default: dense_mfma_n<17>(st, tiles, kc, first, nrows); break;
     }
 }
 
@@ -1115,7 +1117,7 @@ __device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
             const bnm::v4i *Mt = r == 0 && A.plain ? A.Mt0 : A.Mt;
             const u32 *MK = r == 0 && A.plain ? A.MK0 : A.MK + (size_t)r * 17 * 8;
             if (r == 3) BN_STAMP(1, (dense_mfma_impl<17, false, true>(st, Mt, MK, 0)))      // its rows 1..16: the partial rounds' y, in operand form
-            else if (r == 7) BN_STAMP(1, dense_mfma_impl<17>(st, Mt, MK, 0))
+            else if (r == 7) BN_STAMP(1, dense_mfma_impl<17>(st, Mt, MK, 0, A.nout1 ? 1 : 17))
             else BN_STAMP(1, (dense_mfma_impl<17, true>(st, Mt, MK, 0)))
             if (r == 3) {
                 BN_STAMP(2, (partial_rounds_mfma_impl<16, true>(st, A.Pt, A.KR, A.KU, A.rp)));
@@ -1148,7 +1150,7 @@ __device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
         BN_STAMP(1, dense_mfma(st, A.Dt, A.DK, t - 1, 1));        // diag(1, Mh^RP)
         for (int r = 4; r < 8; r++) {
             BN_STAMP(0, sbox_lazy(st, t, A.nofold ? A.C8 + (size_t)r * t * 8 : nullptr));
-            BN_STAMP(1, dense_mfma(st, A.Mt, A.MK + (size_t)r * t * 8, t, 0));
+            BN_STAMP(1, dense_mfma(st, A.Mt, A.MK + (size_t)r * t * 8, t, 0, r == 7 && A.nout1 ? 1 : 17));
         }
         return cur;
     }
@@ -1420,7 +1422,7 @@ size_t lds_bytes(int tmax) {                         // the elements above BN_LD
     return (size_t)lds_words(tmax) * 4 * BN_WG_WAVES + pad;
 }
 
-PermArgs perm_args(const Params *P, bool plainInputs = false) {
+PermArgs perm_args(const Params *P, bool plainInputs = false, bool firstOnly = false) {
     PermArgs a;
     a.C8 = P->C8; a.M = P->M; a.D = P->D; a.S = P->S; a.V = P->V; a.W = P->W; a.Cd = P->Cd; a.t = P->t; a.rp = P->rp;
     static const bool dense = getenv("PIL2GL_BN128_DENSE") && atoi(getenv("PIL2GL_BN128_DENSE"));
@@ -1433,6 +1435,8 @@ PermArgs perm_args(const Params *P, bool plainInputs = false) {
     memcpy(a.m00, P->m00, 32);
     a.Mt0 = P->Mt0; a.MK0 = P->MK0; a.C0p = P->C0p;
     static const bool noplain = getenv("PIL2GL_BN128_PLAIN") && !atoi(getenv("PIL2GL_BN128_PLAIN"));   // =0: inputs converted and S-boxed by the permutation (A/B runs)
+    static const bool allrows = getenv("PIL2GL_BN128_ALLROWS") && atoi(getenv("PIL2GL_BN128_ALLROWS"));   // =1: every row of the last layer whatever the caller reads (A/B runs)
+    a.nout1 = firstOnly && !allrows ? 1 : 0;
     a.plain = plainInputs && !noplain && a.mfma && !a.nofold && !a.dense && BN_SBOX29 && P->t == 17 ? 1 : 0;
     return a;
 }
@@ -1498,10 +1502,10 @@ int pil2gl_bn128_linear_hash_rows_dev(const uint64_t *in, uint64_t width, uint64
     if (blocks > 0x7fffffffull) return fail(PIL2GL_EINVAL, "grid too large");
     if (wide_state((int)arity + 1)) {
         P2_TRY(set_lds_attr(bn_linear_hash_kernel<true>, lds));
-        bn_linear_hash_kernel<true><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf, true), perm_args(pl), out);
+        bn_linear_hash_kernel<true><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf, true, true), perm_args(pl, false, true), out);
     } else {
         P2_TRY(set_lds_attr(bn_linear_hash_kernel<false>, lds));
-        bn_linear_hash_kernel<false><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf, true), perm_args(pl), out);
+        bn_linear_hash_kernel<false><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, width, height, (int)arity, custom ? 1 : 0, perm_args(pf, true, true), perm_args(pl, false, true), out);
     }
     KERNEL_CHECK();
     return PIL2GL_OK;
@@ -1528,10 +1532,10 @@ int pil2gl_bn128_merkelize_level_dev(const uint64_t *in, uint64_t nOps, uint32_t
     }
     if (wide_state((int)arity + 1)) {
         P2_TRY(set_lds_attr(bn_merkle_level_kernel<true>, lds));
-        bn_merkle_level_kernel<true><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
+        bn_merkle_level_kernel<true><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf, false, true), out);
     } else {
         P2_TRY(set_lds_attr(bn_merkle_level_kernel<false>, lds));
-        bn_merkle_level_kernel<false><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf), out);
+        bn_merkle_level_kernel<false><<<(unsigned)blocks, BN_THREADS, lds, as_stream(stream)>>>(in, nOps, (int)arity, perm_args(pf, false, true), out);
     }
     KERNEL_CHECK();
     return PIL2GL_OK;

@@ -39,6 +39,9 @@ using bn::u32;
 #ifndef BN_LDS_ELEMS
 #define BN_LDS_ELEMS 10
 #endif
+#ifndef BN_SMALL_T
+#define BN_SMALL_T 4                    // widths up to this run the permutation round by round with the state and the layer's tiles in registers (perm_small)
+#endif
 #ifndef BN_HI_BATCH
 #define BN_HI_BATCH 4
 #endif
@@ -133,7 +136,8 @@ struct Grain {
 //   Pt        the tile stream of the blocked partial rounds, KR / KU its row constants (mfma_partial_tables)
 struct Params { int t = 0, rp = 0; u32 *base = nullptr, *C8, *M, *D, *S, *V, *W, *Cd; u32 m00[8];
                 const bnm::v4i *Mt = nullptr, *Dt = nullptr, *Pt = nullptr; const u32 *MK = nullptr, *DK = nullptr, *KR = nullptr, *KU = nullptr;
-                const bnm::v4i *Mt0 = nullptr; const u32 *MK0 = nullptr, *C0p = nullptr; };       // the first layer for inputs S-boxed as plain integers (plain_sbox_store)
+                const bnm::v4i *Mt0 = nullptr; const u32 *MK0 = nullptr, *C0p = nullptr;        // the first layer for inputs S-boxed as plain integers (plain_sbox_store)
+                const bnm::v4i *St = nullptr; const u32 *SK = nullptr; };                         // widths <= BN_SMALL_T: the round-by-round form in registers (perm_small)
 Params g_params[18];
 std::mutex g_mu;
 
@@ -370,10 +374,34 @@ int get_params(int t, const Params **out) {
             for (int i = 0; i < t; i++) km0p[i] = h_addmod(km0p[i], C8[(size_t)t + i]);      // (used without PIL2GL_BN128_NOFOLD only)
             if (!nofold) for (int i = 0; i < n; i++) kd[i] = h_addmod(kd[i], C8[(size_t)4 * t + 1 + i]);
             if (!nofold && rp % 4 == 0 && rp >= 4) kr[(size_t)rp - 1] = h_addmod(kr[(size_t)rp - 1], C8[(size_t)4 * t]);
+            // Small widths (t <= BN_SMALL_T): poseidon.circom:22-44 as written, every round one t x t layer of the SAME matrix -- two tile sets (after a full
+            // round every column comes out of the S-box, after a partial round only column 0) that stay in registers, and one row constant per round and row
+            // (the layer's own + the next round's constants).  No tile stream, no sparse blocks: a width-3 permutation is a chain of 65 short rounds whose
+            // latency, not its work, was the cost (perm_small).
+            std::vector<int8_t> ts; Vec sk;
+            if (t <= BN_SMALL_T) {
+                const MfmaConsts mc;
+                const U256 zero = { { 0, 0, 0, 0 } };
+                const int R = N_ROUNDS_F + rp;
+                ts.assign((size_t)2 * t * t * 1024, 0);
+                Vec kset[2]; kset[0].resize((size_t)t); kset[1].resize((size_t)t);
+                for (int set = 0; set < 2; set++)
+                    for (int i = 0; i < t; i++) {
+                        U256 tot = zero;
+                        for (int j = 0; j < t; j++) mfma_tile(mc, M[(size_t)i * t + j], ts.data() + ((size_t)(set * t + i) * t + j) * 1024, tot, set == 0 || j == 0);
+                        kset[set][i] = mfma_row_const(mc, tot, 1, zero);
+                    }
+                sk.resize((size_t)R * t);
+                for (int r = 0; r < R; r++) {
+                    const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + rp;
+                    for (int i = 0; i < t; i++) sk[(size_t)r * t + i] = h_addmod(kset[full ? 0 : 1][i], r + 1 < R ? C[(size_t)(r + 1) * t + i] : zero);
+                }
+            }
             const size_t spare = 16 * 1024;          // the tiles the read-ahead touches past the end of a table (MFMA_AHEAD)
             int8_t *dt = nullptr; u32 *dk = nullptr;
-            HIP_TRY(hipMalloc((void **)&dt, tm.size() + td.size() + tpr.size() + tm0.size() + 4 * spare));
-            HIP_TRY(hipMemset(dt, 0, tm.size() + td.size() + tpr.size() + tm0.size() + 4 * spare));
+            HIP_TRY(hipMalloc((void **)&dt, tm.size() + td.size() + tpr.size() + tm0.size() + ts.size() + 5 * spare));
+            HIP_TRY(hipMemset(dt, 0, tm.size() + td.size() + tpr.size() + tm0.size() + ts.size() + 5 * spare));
+            if (!ts.empty()) HIP_TRY(hipMemcpy(dt + tm.size() + td.size() + tpr.size() + tm0.size() + 4 * spare, ts.data(), ts.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(dt + tm.size() + td.size() + tpr.size() + 3 * spare, tm0.data(), tm0.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(dt, tm.data(), tm.size(), hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(dt + tm.size() + spare, td.data(), td.size(), hipMemcpyHostToDevice));
@@ -382,11 +410,13 @@ int get_params(int t, const Params **out) {
             kall.insert(kall.end(), km.begin(), km.end()); kall.insert(kall.end(), kd.begin(), kd.end());
             kall.insert(kall.end(), kr.begin(), kr.end()); kall.insert(kall.end(), ku.begin(), ku.end());
             kall.insert(kall.end(), km0p.begin(), km0p.end()); kall.insert(kall.end(), c0p.begin(), c0p.end());
+            kall.insert(kall.end(), sk.begin(), sk.end());
             HIP_TRY(hipMalloc((void **)&dk, kall.size() * 32));
             HIP_TRY(hipMemcpy(dk, kall.data(), kall.size() * 32, hipMemcpyHostToDevice));
             P.Mt = (const bnm::v4i *)dt; P.Dt = (const bnm::v4i *)(dt + tm.size() + spare); P.Pt = (const bnm::v4i *)(dt + tm.size() + td.size() + 2 * spare);
             P.MK = dk; P.DK = dk + km.size() * 8; P.KR = P.DK + kd.size() * 8; P.KU = P.KR + kr.size() * 8;
             P.Mt0 = (const bnm::v4i *)(dt + tm.size() + td.size() + tpr.size() + 3 * spare); P.MK0 = P.KU + ku.size() * 8; P.C0p = P.MK0 + km0p.size() * 8;
+            if (!ts.empty()) { P.St = (const bnm::v4i *)(dt + tm.size() + td.size() + tpr.size() + tm0.size() + 4 * spare); P.SK = P.C0p + c0p.size() * 8; }
         }
         P.rp = rp; P.t = t;
     }
@@ -423,7 +453,8 @@ __device__ __forceinline__ unsigned long long bn_now() {
 struct PermArgs { const u32 *C8, *M, *D, *S, *V, *W, *Cd; int t, rp, dense; u32 m00[8];
                   const bnm::v4i *Mt, *Dt, *Pt; const u32 *MK, *DK, *KR, *KU; int mfma, nofold;
                   const bnm::v4i *Mt0; const u32 *MK0, *C0p; int plain;
-                  int nout1; };      // nout1: the caller reads element 0 of the result only (sponges, tree nodes): the last layer computes ONE row      // plain: elements 1..t-1 arrive S-boxed from the absorb (leaf kernel, width 17)
+                  int nout1;         // nout1: the caller reads element 0 of the result only (sponges, tree nodes): the last layer computes ONE row
+                  const bnm::v4i *St; const u32 *SK; int small_; };      // small_: the width runs perm_small      // plain: elements 1..t-1 arrive S-boxed from the absorb (leaf kernel, width 17)
 
 // Where the state lives.  Elements [0, BN_LDS_ELEMS) in LDS as [element][limb][lane]; the elements above -- only the states
 // wider than BN_LDS_ELEMS have any: t = 11..17 -- in the lane's own private (scratch) memory, which the hardware swizzles so
@@ -1090,10 +1121,72 @@ __device__ __forceinline__ void partial_rounds_mfma(const St st, const PermArgs 
     }
 }
 
+// Widths up to BN_SMALL_T: the permutation round by round (poseidon.circom:22-44 as written) with the state, the layer's T x T tiles and the operands in
+// REGISTERS: every round adds its constants (they arrive with the previous layer's rows), takes the S-box (all elements / element 0) and multiplies by the
+// same matrix.  Two tile sets (which columns carry the S-box's 2^-20), swapped twice per permutation; nothing streams, nothing goes through LDS between
+// the rounds.  The blocked pipeline is built for seventeen elements: at three its phases are a few matrix instructions each and the wave spends its time
+// between them (a width-3 permutation took 1.08 M cycles per wave at an UNCAPPED 2.38 GHz, twice its S-boxes' issue time).
+template <int T>
+__device__ __noinline__ void perm_small(const St st, const PermArgs &A) {
+    u32 x[T][8];
+#pragma unroll
+    for (int j = 0; j < T; j++) {
+        u32 c[8];
+        lds_load(st, j, x[j]);
+        load_const<true>(A.Cd, (size_t)j, c);
+        add_lazy(x[j], c);
+    }
+    const bnm::Sh sh = bnm::sh_init();
+    const int R = N_ROUNDS_F + A.rp;
+    bnm::v4i tl[T * T];
+    bnm::gtile tp = (bnm::gtile)A.St + st.lane;
+#pragma unroll
+    for (int q = 0; q < T * T; q++) tl[q] = tp[(size_t)q * 64];
+#pragma unroll 1
+    for (int r = 0; r < R; r++) {
+        const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
+        if (r == N_ROUNDS_F / 2 || r == N_ROUNDS_F / 2 + A.rp) {          // the other tile set from here on
+            const size_t off = (size_t)(r == N_ROUNDS_F / 2 ? T * T : 0) * 64;
+#pragma unroll
+            for (int q = 0; q < T * T; q++) tl[q] = tp[off + (size_t)q * 64];
+        }
+        u32 k[T][8];
+#pragma unroll
+        for (int i = 0; i < T; i++) load_const<true>(A.SK, (size_t)r * T + i, k[i]);      // (asked for ahead of the S-boxes, which hide them)
+        pow5_lazy(x[0]);
+        if (full) {
+#pragma unroll
+            for (int j = 1; j < T; j++) pow5_lazy(x[j]);
+        }
+        bnm::v4i B0[T], B1[T];
+#pragma unroll
+        for (int j = 0; j < T; j++) bnm::b_prep(x[j], B0[j], B1[j]);
+        const int rows = r == R - 1 && A.nout1 ? 1 : T;
+#pragma unroll
+        for (int i = 0; i < T; i++) {
+            if (i < rows) {
+                bnm::v16i a0, a1;
+                bnm::mfma_first(tl[i * T], B0[0], B1[0], a0, a1);
+#pragma unroll
+                for (int j = 1; j < T; j++) { a0 = bnm::mfma(tl[i * T + j], B0[j], a0); a1 = bnm::mfma(tl[i * T + j], B1[j], a1); }
+                bnm::finish_row(a0, a1, k[i], x[i], sh);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < T; j++) lds_store(st, j, x[j]);
+}
+
 // permutation of the t elements in buffer `cur`; returns the buffer holding the result
 template <bool WIDE>
 __device__ __noinline__ int bn_perm(const St st, int cur, const PermArgs &A) {
     const int t = A.t;
+    if (A.small_) {
+        if (t == 2) perm_small<2>(st, A);
+        else if (t == 3) perm_small<3>(st, A);
+        else perm_small<4>(st, A);
+        return cur;
+    }
     if (A.dense) {                                   // poseidon.circom:22-44 as written (tests)
         for (int r = 0; r < N_ROUNDS_F + A.rp; r++) {
             const bool full = r < N_ROUNDS_F / 2 || r >= N_ROUNDS_F / 2 + A.rp;
@@ -1434,6 +1527,9 @@ PermArgs perm_args(const Params *P, bool plainInputs = false, bool firstOnly = f
     a.Mt = P->Mt; a.Dt = P->Dt; a.Pt = P->Pt; a.MK = P->MK; a.DK = P->DK; a.KR = P->KR; a.KU = P->KU;
     memcpy(a.m00, P->m00, 32);
     a.Mt0 = P->Mt0; a.MK0 = P->MK0; a.C0p = P->C0p;
+    a.St = P->St; a.SK = P->SK;
+    static const bool nosmall = getenv("PIL2GL_BN128_SMALL") && !atoi(getenv("PIL2GL_BN128_SMALL"));       // =0: small widths through the blocked pipeline as well (A/B runs)
+    a.small_ = P->St && !nosmall && a.mfma && !a.nofold && !a.dense && BN_SBOX29 ? 1 : 0;
     static const bool noplain = getenv("PIL2GL_BN128_PLAIN") && !atoi(getenv("PIL2GL_BN128_PLAIN"));   // =0: inputs converted and S-boxed by the permutation (A/B runs)
     static const bool allrows = getenv("PIL2GL_BN128_ALLROWS") && atoi(getenv("PIL2GL_BN128_ALLROWS"));   // =1: every row of the last layer whatever the caller reads (A/B runs)
     a.nout1 = firstOnly && !allrows ? 1 : 0;
